@@ -1,0 +1,214 @@
+/*
+ * sepr.h - C ABI of libsepr_hip.so: the SepReformer separator forward path for MI355X (gfx950).
+ *
+ * The reference (dmlguq456/SepReformer) is pure PyTorch Python: it has no FFI layer, every op below is
+ * reached there through torch.nn modules calling aten kernels.  This header is therefore the boundary
+ * the reference *would* bind if its modules dispatched to a native library: one entry point per fused
+ * block of the hot path, each citing the reference module it replaces (paths relative to
+ * /root/reference/models/SepReformer_Base_WSJ0/).  See INTEGRATION.md for the ctypes stubs.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, ints, a stream handle; no torch / C++ types cross the boundary;
+ *   - every function returns an int status: SEPR_OK (0) or a negative SEPR_E* code; nothing throws;
+ *   - no allocation inside: scratch is a caller-provided workspace (sepr_workspace_bytes tells how much);
+ *   - the library never frees or retains caller memory, holds no global mutable state besides the
+ *     opt-in profiler, and launches on the stream it is given (NULL = default stream): re-entrant
+ *     from several host threads, one per device, like torch.nn.parallel.data_parallel's replicas
+ *     (reference engine.py:64,98,130,167);
+ *   - all activations are fp32, *channel-last* rows: a tensor the reference holds as [b, C, T] is
+ *     [b, T, C] here (row = one frame); "rows" of a batch are (b, t) flattened;
+ *   - weights are fp32 in the layouts noted per struct ("packed" = re-laid-out once on the host by
+ *     sepreformer_amd/pack.py from the reference's state_dict tensors).
+ */
+#ifndef SEPR_H_
+#define SEPR_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEPR_VERSION 100 /* major*10000 + minor*100 + patch */
+
+#define SEPR_OK 0
+#define SEPR_EINVAL (-1)     /* bad shape / unsupported size / null pointer */
+#define SEPR_EWORKSPACE (-2) /* workspace too small */
+#define SEPR_EHIP (-3)       /* a HIP launch failed (see sepr_last_hip_error) */
+
+typedef void* sepr_stream_t; /* hipStream_t */
+
+/* ---- weight bundles (device pointers) --------------------------------------------------------- */
+
+/* GCFN, modules/network.py:46-66.  F -> 6F -> (dwconv3, GLU) 3F -> F */
+typedef struct {
+  const float* ln_g; /* [F]     net1.0.weight */
+  const float* ln_b; /* [F]     net1.0.bias */
+  const float* w1;   /* [6F,F]  net1.1.weight */
+  const float* b1;   /* [6F]    net1.1.bias */
+  const float* dw_w; /* [3,6F]  depthwise.weight, packed tap-major */
+  const float* dw_b; /* [6F]    depthwise.bias */
+  const float* w2;   /* [F,3F]  net2.2.weight */
+  const float* b2;   /* [F]     net2.2.bias */
+  const float* ls;   /* [F]     Layer_scale.layer_scale */
+} sepr_gcfn_w;
+
+/* CLA, modules/network.py:159-187 (eval-mode BatchNorm folded into w2/b2 by the packer) */
+typedef struct {
+  const float* ln_g; /* [F] */
+  const float* ln_b; /* [F] */
+  const float* w1;   /* [2F,F]  linear1.weight */
+  const float* b1;   /* [2F] */
+  const float* dw_w; /* [K,F]   dw_conv_1d.weight, packed tap-major (K = 65) */
+  const float* dw_b; /* [F] */
+  const float* w2;   /* [2F,F]  linear2.weight * bn_scale[row] */
+  const float* b2;   /* [2F]    (linear2.bias - running_mean) * bn_scale + BN.bias */
+  const float* w3;   /* [F,2F]  linear3.1.weight */
+  const float* b3;   /* [F] */
+  const float* ls;   /* [F] */
+} sepr_cla_w;
+
+/* MultiHeadAttention, modules/network.py:69-124 */
+typedef struct {
+  const float* ln_g; /* [F] */
+  const float* ln_b; /* [F] */
+  const float* wqkv; /* [3F,F]  linear_q / linear_k / linear_v weights stacked */
+  const float* bqkv; /* [3F] */
+  const float* wo;   /* [F,F]   linear_out.weight */
+  const float* bo;   /* [F] */
+  const float* ls;   /* [F] */
+} sepr_mha_w;
+
+/* EGA, modules/network.py:126-155 + the shared relative-position table, modules/module.py:42-57 */
+typedef struct {
+  sepr_mha_w attn;
+  const float* gate_ln_g; /* [F]   block.linear.0 */
+  const float* gate_ln_b; /* [F] */
+  const float* gate_w;    /* [F,F] block.linear.1 */
+  const float* gate_b;    /* [F] */
+  const float* pe_k;      /* [2*maxlen, F/H]  separator.pos_emb.pe_k.weight */
+  int maxlen;
+} sepr_ega_w;
+
+/* DownConvLayer, modules/module.py:63-78 (eval BN folded: y = gelu(conv_nobias * scale + shift)) */
+typedef struct {
+  const float* w;     /* [K,F] down_conv.weight packed tap-major (K = 5) */
+  const float* scale; /* [F] */
+  const float* shift; /* [F] */
+} sepr_down_w;
+
+/* SpkSplitStage, modules/module.py:110-125 */
+typedef struct {
+  const float* w1;   /* [4FS,F]   linear.0.weight */
+  const float* b1;   /* [4FS] */
+  const float* w2;   /* [FS,2FS]  linear.2.weight */
+  const float* b2;   /* [FS] */
+  const float* gn_g; /* [F]       norm.weight */
+  const float* gn_b; /* [F] */
+} sepr_split_w;
+
+/* OutputLayer + AudioDecoder, modules/module.py:237-283 */
+typedef struct {
+  const float* w1;   /* [4F,F]  end_conv1x1.0.weight */
+  const float* b1;   /* [4F] */
+  const float* w2;   /* [N,2F]  end_conv1x1.2.weight */
+  const float* b2;   /* [N] */
+  const float* wdec; /* [K,N]   ConvTranspose1d weight [N,1,K] packed tap-major */
+} sepr_out_w;
+
+/* ---- library ---------------------------------------------------------------------------------- */
+
+int sepr_version(void);
+const char* sepr_build_info(void);
+/* text of the last HIP error seen by the calling thread ("" if none) */
+const char* sepr_last_hip_error(void);
+
+/* ops for sepr_workspace_bytes */
+enum {
+  SEPR_OP_ENCODER = 0, SEPR_OP_GCFN, SEPR_OP_CLA, SEPR_OP_EGA, SEPR_OP_SPKATTN,
+  SEPR_OP_SPKSPLIT, SEPR_OP_OUTLAYER, SEPR_OP_COUNT
+};
+/* Scratch bytes op needs for n sequences of T frames (Tp = pooled frames for EGA, source frames for
+ * OUTLAYER; otherwise ignored), width F, encoder channels N, S speakers.  0 on bad arguments. */
+size_t sepr_workspace_bytes(int op, int n, int T, int Tp, int F, int N, int S);
+
+/* ---- hot path, in forward order ----------------------------------------------------------------- */
+
+/* AudioEncoder.forward, modules/module.py:19-23: Conv1d(1->N, K=16, stride, no bias) + exact GELU.
+ * wav [B,T] -> enc [B,L,N] (L = (T-K)/stride + 1); also the GroupNorm(1,N,eps) statistics of each
+ * sample of enc (mean, rstd) -> gn_stats [B,2] for sepr_projector_fwd.  w_enc is [K,N] (packed). */
+int sepr_encoder_fwd(const float* wav, int B, int T, const float* w_enc, int N, int K, int stride,
+                     float gn_eps, float* enc, float* gn_stats, void* ws, size_t ws_bytes,
+                     sepr_stream_t stream);
+
+/* FeatureProjector.forward + Separator.pad_signal, modules/module.py:32-35,220-234:
+ * GroupNorm(1,N) apply + 1x1 conv N->F (no bias); rows l >= L of out [B,Lp,F] are written as zeros. */
+int sepr_projector_fwd(const float* enc, int B, int L, int Lp, int N, int F, const float* gn_stats,
+                       const float* gn_g, const float* gn_b, const float* w, float* out,
+                       sepr_stream_t stream);
+
+/* GCFN.forward, modules/network.py:60-66.  x,y [n,T,F]; y may alias x. */
+int sepr_gcfn_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_w* w, void* ws,
+                  size_t ws_bytes, sepr_stream_t stream);
+
+/* CLA.forward (eval), modules/network.py:174-187.  x,y [n,T,F]; y may alias x. */
+int sepr_cla_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_cla_w* w, void* ws,
+                 size_t ws_bytes, sepr_stream_t stream);
+
+/* EGA.forward, modules/network.py:138-155 (with MultiHeadAttention.forward :90-124 and the relative
+ * position bias of modules/module.py:52-57,196-198 computed from pe_k without materialising pos_k).
+ * x,y [n,T,F], T = Tp * 2^k; y must NOT alias x. */
+int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const sepr_ega_w* w,
+                 void* ws, size_t ws_bytes, sepr_stream_t stream);
+
+/* SpkAttention.forward up to (excluding) its feed_forward GCFN, modules/network.py:233-247:
+ * attention across the S speakers of each frame + residual.  x,y [B*S,T,F] (row index b*S+s);
+ * y may alias x.  Follow with sepr_gcfn_fwd for :249. */
+int sepr_spkattn_fwd(const float* x, float* y, int nS, int S, int T, int F, int H,
+                     const sepr_mha_w* w, void* ws, size_t ws_bytes, sepr_stream_t stream);
+
+/* DownConvLayer.forward (eval), modules/module.py:72-78.  x [n,T,F] -> y [n,(T-1)/2+1,F]. */
+int sepr_downconv_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_down_w* w,
+                      sepr_stream_t stream);
+
+/* SpkSplitStage.forward, modules/module.py:120-125.  x [B,T,F] -> y [B*S,T,F] incl. GroupNorm(1,F). */
+int sepr_spksplit_fwd(const float* x, float* y, int B, int S, int T, int F, float gn_eps,
+                      const sepr_split_w* w, void* ws, size_t ws_bytes, sepr_stream_t stream);
+
+/* Decoder-side fusion, modules/module.py:212-214: nearest x2 upsample of lo [n,T/2,F], concat with
+ * skip [n,T,F] along channels, Conv1d(2F->F,k=1).  wf [F,2F], bf [F] -> y [n,T,F]. */
+int sepr_fuse_fwd(const float* lo, const float* skip, float* y, int n, int T, int F, const float* wf,
+                  const float* bf, sepr_stream_t stream);
+
+/* OutputLayer.forward (+Masking when enc != NULL) and AudioDecoder.forward, modules/module.py:249-283,
+ * modules/network.py:34-43, model.py:42-52.  x [nS,Tsrc,F]; frame l < L of the head reads source
+ * frame idx[l] (idx == NULL: l itself, i.e. the crop of :250; otherwise the nearest-upsample table of
+ * model.py:49).  enc [B,L,N] or NULL.  wav [S,B,Tout], Tout = (L-1)*stride + K. */
+int sepr_outlayer_decoder_fwd(const float* x, int nS, int S, int Tsrc, int L, const int* idx,
+                              const float* enc, int F, int N, int K, int stride, const sepr_out_w* w,
+                              float* wav, void* ws, size_t ws_bytes, sepr_stream_t stream);
+
+/* GroupNorm(1 group) statistics of x [n, count] -> stats [n,2] = (mean, rstd).  modules/module.py:28,117 */
+int sepr_groupnorm_stats(const float* x, int n, long long count, float eps, float* stats, void* ws,
+                         size_t ws_bytes, sepr_stream_t stream);
+
+/* y[M,N] = x[M,K] . w[N,K]^T + bias : the f32-MFMA projection core on its own (tests, roofline bench) */
+int sepr_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
+                    sepr_stream_t stream);
+
+/* ---- opt-in kernel timer (bench.py roofline) ------------------------------------------------- */
+/* Sites a projection launch can be attributed to. */
+enum {
+  SEPR_SITE_NONE = 0, SEPR_SITE_GCFN_UP, SEPR_SITE_GCFN_DOWN, SEPR_SITE_CLA, SEPR_SITE_ATTN_PROJ,
+  SEPR_SITE_EGA_GATE, SEPR_SITE_SPLIT, SEPR_SITE_FUSE, SEPR_SITE_OUT, SEPR_SITE_PROJECTOR,
+  SEPR_SITE_LINEAR, SEPR_SITE_COUNT
+};
+/* Start bracketing every launch of `site` with hipEvents on its own stream (up to max_launches). */
+int sepr_prof_start(int site, int max_launches);
+/* Synchronise the recorded events; returns launches, summed kernel ms and summed algorithmic FLOPs. */
+int sepr_prof_stop(long long* launches, double* total_ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEPR_H_ */

@@ -1,0 +1,350 @@
+// extern "C" entry points of libsepr_hip.so (declared in include/sepr.h): each fused block of the
+// separator is a short, fixed sequence of launches on the caller's stream.
+#include <string.h>
+
+#include "sepr_gemm.h"
+#include "sepr_pointwise.h"
+
+namespace sepr {
+
+static thread_local char g_err[256] = "";
+void set_hip_error(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+}
+
+static const float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default (network.py:50,81,133,162)
+
+// ---- workspace plans (floats unless noted) --------------------------------------------------------
+static size_t ws_gcfn(long long M, int F) {
+  return align_up(2 * M * 4) + align_up(6LL * F * M * 4) + align_up(3LL * F * M * 4) + 1024;
+}
+static size_t ws_cla(long long M, int F) {
+  return align_up(2 * M * 4) + 2 * align_up((long long)F * M * 4) + align_up(2LL * F * M * 4) + 1024;
+}
+static size_t ws_ega(long long M, long long Mp, int F) {
+  return align_up(2 * M * 4) + align_up(2 * Mp * 4) + 3 * align_up((long long)F * Mp * 4) + align_up(3LL * F * Mp * 4) + 2048;
+}
+static size_t ws_spk(long long M, int F) {
+  return align_up(2 * M * 4) + align_up(3LL * F * M * 4) + align_up((long long)F * M * 4) + 1024;
+}
+static size_t ws_split(long long M, int n_out, int T, int F, int S) {
+  return align_up(2LL * F * S * M * 4) + align_up((size_t)n_out * gn_chunks((long long)T * F) * 2 * 8) + align_up((size_t)n_out * 2 * 4) + 1024;
+}
+static size_t ws_out(long long M, int F, int N) {
+  return align_up(2LL * F * M * 4) + align_up((long long)N * M * 4) + 1024;
+}
+static size_t ws_enc(int B, int L) { return align_up((size_t)B * encoder_tiles(L) * 2 * 8) + 512; }
+
+}  // namespace sepr
+
+using namespace sepr;
+
+extern "C" int sepr_version(void) { return SEPR_VERSION; }
+extern "C" const char* sepr_build_info(void) {
+  return "libsepr_hip gfx950 f32-mfma(16x16x4) tile128x128x32 " __DATE__ " " __TIME__;
+}
+extern "C" const char* sepr_last_hip_error(void) { return g_err; }
+
+extern "C" size_t sepr_workspace_bytes(int op, int n, int T, int Tp, int F, int N, int S) {
+  if (n <= 0 || T <= 0 || F <= 0) return 0;
+  const long long M = (long long)n * T;
+  switch (op) {
+    case SEPR_OP_ENCODER: return ws_enc(n, T);  // T = encoder frames L
+    case SEPR_OP_GCFN: return ws_gcfn(M, F);
+    case SEPR_OP_CLA: return ws_cla(M, F);
+    case SEPR_OP_EGA: return Tp > 0 ? ws_ega(M, (long long)n * Tp, F) : 0;
+    case SEPR_OP_SPKATTN: return ws_spk(M, F);
+    case SEPR_OP_SPKSPLIT: return S > 0 ? ws_split(M, n * S, T, F, S) : 0;
+    case SEPR_OP_OUTLAYER: return N > 0 ? ws_out(M, F, N) : 0;  // T = output frames L
+    default: return 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int sepr_encoder_fwd(const float* wav, int B, int T, const float* w_enc, int N, int K, int stride, float gn_eps,
+                                float* enc, float* gn_stats, void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  if (!wav || !w_enc || !enc || !gn_stats || B <= 0 || T < K || stride <= 0) return SEPR_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int L = (T - K) / stride + 1;
+  Arena ar(ws, ws_bytes);
+  const int ntile = encoder_tiles(L);
+  double* part = ar.f64((size_t)B * ntile * 2);
+  if (!part) return SEPR_EWORKSPACE;
+  SEPR_TRY(launch_encoder(wav, B, T, L, w_enc, N, K, stride, enc, part, st));
+  SEPR_TRY(launch_gn_finalize(part, B, ntile, (long long)L * N, gn_eps, gn_stats, st));
+  return SEPR_OK;
+}
+
+extern "C" int sepr_projector_fwd(const float* enc, int B, int L, int Lp, int N, int F, const float* gn_stats,
+                                  const float* gn_g, const float* gn_b, const float* w, float* out, sepr_stream_t stream) {
+  if (!enc || !gn_stats || !gn_g || !gn_b || !w || !out || B <= 0 || L <= 0 || Lp < L) return SEPR_EINVAL;
+  GemmArgs a = gemm_args_zero();
+  a.M = B * Lp; a.N = F; a.K = N;
+  a.A = enc; a.lda = N;
+  a.rows_out = Lp; a.rows_src = L; a.rows_valid = L;
+  a.stats = gn_stats; a.stat_seq = 1; a.gamma = gn_g; a.beta = gn_b;
+  a.W = w; a.bias = nullptr;
+  a.Y = out; a.ldc = F;
+  return launch_gemm(PRO_NORM, EPI_STORE, a, SEPR_SITE_PROJECTOR, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int sepr_gcfn_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_w* w, void* ws, size_t ws_bytes,
+                             sepr_stream_t stream) {
+  if (!x || !y || !w || n <= 0 || T <= 0 || F <= 0 || F % 32 != 0) return SEPR_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long M = (long long)n * T;
+  if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
+  Arena ar(ws, ws_bytes);
+  float* stats = ar.f32(2 * M);
+  float* h = ar.f32(6LL * F * M);
+  float* g = ar.f32(3LL * F * M);
+  if (!ar.ok()) return SEPR_EWORKSPACE;
+  SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
+  {  // net1: LayerNorm -> Linear F->6F                                   (network.py:61)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = 6 * F; a.K = F;
+    a.A = x; a.lda = F; a.stats = stats; a.gamma = w->ln_g; a.beta = w->ln_b;
+    a.W = w->w1; a.bias = w->b1; a.Y = h; a.ldc = 6 * F;
+    SEPR_TRY(launch_gemm(PRO_NORM, EPI_STORE, a, SEPR_SITE_GCFN_UP, st));
+  }
+  SEPR_TRY(launch_dwglu(h, g, n, T, F, w->dw_w, w->dw_b, st));            // (network.py:62-65)
+  {  // net2 Linear 3F->F, LayerScale, residual                            (network.py:65-66)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = F; a.K = 3 * F;
+    a.A = g; a.lda = 3 * F; a.W = w->w2; a.bias = w->b2;
+    a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
+    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_RES, a, SEPR_SITE_GCFN_DOWN, st));
+  }
+  return SEPR_OK;
+}
+
+extern "C" int sepr_cla_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_cla_w* w, void* ws,
+                            size_t ws_bytes, sepr_stream_t stream) {
+  if (!x || !y || !w || n <= 0 || T <= 0 || F <= 0 || F % 64 != 0) return SEPR_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long M = (long long)n * T;
+  if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
+  Arena ar(ws, ws_bytes);
+  float* stats = ar.f32(2 * M);
+  float* u = ar.f32((long long)F * M);
+  float* c = ar.f32((long long)F * M);
+  float* d = ar.f32(2LL * F * M);
+  if (!ar.ok()) return SEPR_EWORKSPACE;
+  SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
+  {  // LayerNorm -> linear1 F->2F -> GLU                                  (network.py:175-177)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = 2 * F; a.K = F;
+    a.A = x; a.lda = F; a.stats = stats; a.gamma = w->ln_g; a.beta = w->ln_b;
+    a.W = w->w1; a.bias = w->b1; a.Y = u; a.ldc = F;
+    SEPR_TRY(launch_gemm(PRO_NORM, EPI_GLU, a, SEPR_SITE_CLA, st));
+  }
+  SEPR_TRY(launch_dwconv_same(u, c, n, T, F, K, w->dw_w, w->dw_b, st));   // (network.py:178-180)
+  {  // linear2 F->2F, eval BatchNorm (folded), GELU                       (network.py:181-185)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = 2 * F; a.K = F;
+    a.A = c; a.lda = F; a.W = w->w2; a.bias = w->b2; a.Y = d; a.ldc = 2 * F;
+    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_GELU, a, SEPR_SITE_CLA, st));
+  }
+  {  // linear3 2F->F, LayerScale, residual                                (network.py:185-187)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = F; a.K = 2 * F;
+    a.A = d; a.lda = 2 * F; a.W = w->w3; a.bias = w->b3;
+    a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
+    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_RES, a, SEPR_SITE_CLA, st));
+  }
+  return SEPR_OK;
+}
+
+extern "C" int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const sepr_ega_w* w, void* ws,
+                            size_t ws_bytes, sepr_stream_t stream) {
+  if (!x || !y || !w || x == y || n <= 0 || T <= 0 || Tp <= 0 || F <= 0 || F % 32 != 0 || T % Tp != 0) return SEPR_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int fac = T / Tp;
+  const long long M = (long long)n * T, Mp = (long long)n * Tp;
+  if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
+  Arena ar(ws, ws_bytes);
+  float* stats = ar.f32(2 * M);
+  float* stats_p = ar.f32(2 * Mp);
+  float* xd = ar.f32((long long)F * Mp);
+  float* qkv = ar.f32(3LL * F * Mp);
+  float* o = ar.f32((long long)F * Mp);
+  float* att = ar.f32((long long)F * Mp);
+  if (!ar.ok()) return SEPR_EWORKSPACE;
+  const float* xpool = x;
+  if (fac > 1) {  // adaptive_avg_pool1d                                    (network.py:146)
+    SEPR_TRY(launch_pool(x, xd, n, Tp, fac, F, st));
+    xpool = xd;
+  }
+  SEPR_TRY(launch_rowstats(xpool, stats_p, Mp, F, LN_EPS, st));
+  {  // MHA: LayerNorm -> q,k,v                                             (network.py:99-102)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)Mp; a.N = 3 * F; a.K = F;
+    a.A = xpool; a.lda = F; a.stats = stats_p; a.gamma = w->attn.ln_g; a.beta = w->attn.ln_b;
+    a.W = w->attn.wqkv; a.bias = w->attn.bqkv; a.Y = qkv; a.ldc = 3 * F;
+    SEPR_TRY(launch_gemm(PRO_NORM, EPI_STORE, a, SEPR_SITE_ATTN_PROJ, st));
+  }
+  SEPR_TRY(launch_relattn(qkv, o, n, Tp, F, H, w->pe_k, w->maxlen, st));   // (network.py:106-122)
+  {  // linear_out * LayerScale (no residual inside MHA)                    (network.py:124)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)Mp; a.N = F; a.K = F;
+    a.A = o; a.lda = F; a.W = w->attn.wo; a.bias = w->attn.bo;
+    a.Y = att; a.ldc = F; a.R = nullptr; a.ls = w->attn.ls;
+    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_RES, a, SEPR_SITE_ATTN_PROJ, st));
+  }
+  SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
+  {  // x + sigmoid(Linear(LayerNorm(x))) * upsample(att)                   (network.py:132-135,151-153)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = F; a.K = F;
+    a.A = x; a.lda = F; a.stats = stats; a.gamma = w->gate_ln_g; a.beta = w->gate_ln_b;
+    a.W = w->gate_w; a.bias = w->gate_b;
+    a.Y = y; a.ldc = F; a.R = x; a.aux = att; a.T = T; a.Tp = Tp; a.fac = fac;
+    SEPR_TRY(launch_gemm(PRO_NORM, EPI_GATE, a, SEPR_SITE_EGA_GATE, st));
+  }
+  return SEPR_OK;
+}
+
+extern "C" int sepr_spkattn_fwd(const float* x, float* y, int nS, int S, int T, int F, int H, const sepr_mha_w* w, void* ws,
+                                size_t ws_bytes, sepr_stream_t stream) {
+  if (!x || !y || !w || nS <= 0 || S <= 0 || nS % S != 0 || T <= 0 || F <= 0 || F % 32 != 0) return SEPR_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long M = (long long)nS * T;
+  if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
+  Arena ar(ws, ws_bytes);
+  float* stats = ar.f32(2 * M);
+  float* qkv = ar.f32(3LL * F * M);
+  float* o = ar.f32((long long)F * M);
+  if (!ar.ok()) return SEPR_EWORKSPACE;
+  SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
+  {
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = 3 * F; a.K = F;
+    a.A = x; a.lda = F; a.stats = stats; a.gamma = w->ln_g; a.beta = w->ln_b;
+    a.W = w->wqkv; a.bias = w->bqkv; a.Y = qkv; a.ldc = 3 * F;
+    SEPR_TRY(launch_gemm(PRO_NORM, EPI_STORE, a, SEPR_SITE_ATTN_PROJ, st));
+  }
+  SEPR_TRY(launch_spkmix(qkv, o, nS / S, S, T, F, H, st));
+  {  // x + LayerScale(linear_out(.))                                       (network.py:124,244)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = F; a.K = F;
+    a.A = o; a.lda = F; a.W = w->wo; a.bias = w->bo;
+    a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
+    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_RES, a, SEPR_SITE_ATTN_PROJ, st));
+  }
+  return SEPR_OK;
+}
+
+extern "C" int sepr_downconv_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_down_w* w,
+                                 sepr_stream_t stream) {
+  if (!x || !y || !w || n <= 0 || T <= 0) return SEPR_EINVAL;
+  const int pad = (K - 1) / 2;
+  const int To = (T + 2 * pad - K) / 2 + 1;
+  return launch_downconv(x, y, n, T, To, F, K, w->w, w->scale, w->shift, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int sepr_spksplit_fwd(const float* x, float* y, int B, int S, int T, int F, float gn_eps, const sepr_split_w* w,
+                                 void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  if (!x || !y || !w || B <= 0 || S <= 0 || T <= 0 || F <= 0 || F % 32 != 0) return SEPR_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long M = (long long)B * T;
+  if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
+  const int n_out = B * S;
+  const long long count = (long long)T * F;
+  const int nchunk = gn_chunks(count);
+  Arena ar(ws, ws_bytes);
+  float* z = ar.f32(2LL * F * S * M);
+  double* part = ar.f64((size_t)n_out * nchunk * 2);
+  float* stats = ar.f32((size_t)n_out * 2);
+  if (!ar.ok()) return SEPR_EWORKSPACE;
+  {  // Conv1d F->4FS (k=1) + GLU over the channel axis                     (module.py:114-115)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = 4 * F * S; a.K = F;
+    a.A = x; a.lda = F; a.W = w->w1; a.bias = w->b1; a.Y = z; a.ldc = 2 * F * S;
+    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_GLU, a, SEPR_SITE_SPLIT, st));
+  }
+  {  // Conv1d 2FS->FS (k=1), then view(B*S, F, T): channel s*F+f -> sequence b*S+s  (module.py:116,123)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = F * S; a.K = 2 * F * S;
+    a.A = z; a.lda = 2 * F * S; a.W = w->w2; a.bias = w->b2; a.Y = y; a.ldc = F;
+    a.T = T; a.S = S; a.Fs = F;
+    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_SPLIT, a, SEPR_SITE_SPLIT, st));
+  }
+  // GroupNorm(1, F) over (F, T) of every (b, s)                            (module.py:124)
+  SEPR_TRY(launch_gn_partial(y, part, n_out, count, nchunk, st));
+  SEPR_TRY(launch_gn_finalize(part, n_out, nchunk, count, gn_eps, stats, st));
+  SEPR_TRY(launch_gn_apply(y, stats, w->gn_g, w->gn_b, n_out, T, F, st));
+  return SEPR_OK;
+}
+
+extern "C" int sepr_fuse_fwd(const float* lo, const float* skip, float* y, int n, int T, int F, const float* wf,
+                             const float* bf, sepr_stream_t stream) {
+  if (!lo || !skip || !y || !wf || !bf || n <= 0 || T <= 0 || (T & 1) || F <= 0 || F % 32 != 0) return SEPR_EINVAL;
+  const long long M = (long long)n * T;
+  if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
+  GemmArgs a = gemm_args_zero();
+  a.M = (int)M; a.N = F; a.K = 2 * F;
+  a.A = lo; a.lda = F; a.A2 = skip; a.lda2 = F; a.ksplit = F;
+  a.rows_out = T; a.rows_src = T / 2; a.rows_valid = T; a.a_shift = 1;   // nearest x2: source frame t>>1
+  a.W = wf; a.bias = bf; a.Y = y; a.ldc = F;
+  return launch_gemm(PRO_CAT2, EPI_STORE, a, SEPR_SITE_FUSE, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int sepr_outlayer_decoder_fwd(const float* x, int nS, int S, int Tsrc, int L, const int* idx, const float* enc,
+                                         int F, int N, int K, int stride, const sepr_out_w* w, float* wav, void* ws,
+                                         size_t ws_bytes, sepr_stream_t stream) {
+  if (!x || !w || !wav || nS <= 0 || S <= 0 || nS % S != 0 || Tsrc <= 0 || L <= 0 || F % 32 != 0 || N % 4 != 0) return SEPR_EINVAL;
+  if (!idx && L > Tsrc) return SEPR_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long M = (long long)nS * L;
+  if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
+  Arena ar(ws, ws_bytes);
+  float* o1 = ar.f32(2LL * F * M);
+  float* o2 = ar.f32((long long)N * M);
+  if (!ar.ok()) return SEPR_EWORKSPACE;
+  {  // crop / upsample-gather rows, Linear F->4F, GLU                      (module.py:250-252, model.py:49)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = 4 * F; a.K = F;
+    a.A = x; a.lda = F; a.rows_out = L; a.rows_src = Tsrc; a.rows_valid = L; a.idx = idx;
+    a.W = w->w1; a.bias = w->b1; a.Y = o1; a.ldc = 2 * F;
+    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_GLU, a, SEPR_SITE_OUT, st));
+  }
+  {  // Linear 2F->N (+ ReLU(.) * encoder_output for the auxiliary heads)   (module.py:252-260, network.py:41)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = N; a.K = 2 * F;
+    a.A = o1; a.lda = 2 * F; a.W = w->w2; a.bias = w->b2; a.Y = o2; a.ldc = N;
+    a.rows_out = 0;
+    if (enc) {
+      a.aux = enc; a.S = S;
+      // EPI_MASK reads rows_out as the per-sequence frame count; keep the A-side map an identity
+      GemmArgs m = a;
+      m.rows_out = L; m.rows_src = L; m.rows_valid = L;
+      SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_MASK, m, SEPR_SITE_OUT, st));
+    } else {
+      SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_STORE, a, SEPR_SITE_OUT, st));
+    }
+  }
+  const int Tout = (L - 1) * stride + K;
+  SEPR_TRY(launch_decoder(o2, nS, S, L, N, K, stride, w->wdec, wav, Tout, st));   // (module.py:278-283)
+  return SEPR_OK;
+}
+
+extern "C" int sepr_groupnorm_stats(const float* x, int n, long long count, float eps, float* stats, void* ws, size_t ws_bytes,
+                                    sepr_stream_t stream) {
+  if (!x || !stats || n <= 0 || count <= 0 || count % 4 != 0) return SEPR_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nchunk = gn_chunks(count);
+  Arena ar(ws, ws_bytes);
+  double* part = ar.f64((size_t)n * nchunk * 2);
+  if (!part) return SEPR_EWORKSPACE;
+  SEPR_TRY(launch_gn_partial(x, part, n, count, nchunk, st));
+  SEPR_TRY(launch_gn_finalize(part, n, nchunk, count, eps, stats, st));
+  return SEPR_OK;
+}
+
+extern "C" int sepr_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
+                               sepr_stream_t stream) {
+  if (!x || !w || !y || M <= 0) return SEPR_EINVAL;
+  GemmArgs a = gemm_args_zero();
+  a.M = M; a.N = N; a.K = K;
+  a.A = x; a.lda = K; a.W = w; a.bias = bias; a.Y = y; a.ldc = N;
+  return launch_gemm(PRO_PLAIN, EPI_STORE, a, SEPR_SITE_LINEAR, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,72 @@
+// Shared device helpers and host-side launch plumbing for libsepr_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/sepr.h"
+
+namespace sepr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- math -----------------------------------------------------------------------------------------
+// exact-erf GELU (torch.nn.GELU() default, reference modules/module.py:17,70, modules/network.py:169)
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// butterfly sums over the lanes of a wave64
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+void set_hip_error(hipError_t e, const char* where);
+
+#define SEPR_CHECK_LAUNCH(where)                       \
+  do {                                                 \
+    hipError_t e__ = hipGetLastError();                \
+    if (e__ != hipSuccess) {                           \
+      ::sepr::set_hip_error(e__, where);               \
+      return SEPR_EHIP;                                \
+    }                                                  \
+  } while (0)
+
+#define SEPR_TRY(expr)                \
+  do {                                \
+    int rc__ = (expr);                \
+    if (rc__ != SEPR_OK) return rc__; \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// sequential carve-out of the caller's workspace
+struct Arena {
+  char* base;
+  size_t size, off;
+  Arena(void* p, size_t n) : base(static_cast<char*>(p)), size(n), off(0) {}
+  float* f32(size_t count) { return static_cast<float*>(take(count * sizeof(float))); }
+  double* f64(size_t count) { return static_cast<double*>(take(count * sizeof(double))); }
+  void* take(size_t bytes) {
+    size_t o = align_up(off);
+    off = o + bytes;
+    if (base == nullptr || off > size) return nullptr;
+    return base + o;
+  }
+  bool ok() const { return base != nullptr && off <= size; }
+};
+
+inline int cdiv(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }
+
+}  // namespace sepr

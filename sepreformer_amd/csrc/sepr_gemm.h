@@ -1,0 +1,320 @@
+// Row-projection core: Y = epilogue( prologue(X)[M,K] . W[N,K]^T + bias ) on the f32 MFMA pipe.
+//
+// Every dense contraction of the separator (94 % of its FLOPs) is a "tall" product:
+// M = batch x frames rows (up to 512 000), K and N in {F .. 8F}.  One workgroup (4 waves, 256 threads)
+// owns a 128-row x 128-column output tile; each wave a 64 x 64 sub-tile held as 4 x 4 accumulators of
+// v_mfma_f32_16x16x4_f32 (exact fp32 fmaf-chain numerics, 157 TFLOP/s chip peak).
+//
+// Operand roles are swapped on purpose: the MFMA "A" operand is the WEIGHT fragment (row index = output
+// column n) and "B" is the ACTIVATION fragment (column index = row m), so a lane ends up with four
+// consecutive output columns of one row (D[row = 4*(lane>>4) + r][col = lane&15]) and the epilogue
+// stores float4s.  Both fragments are "row, 4 consecutive k" 16-byte LDS reads; one K=16 step is four
+// MFMAs whose k-slots are {4g + r}: lane group g = lane>>4 supplies k = 16*kk + 4*g + r to MFMA r.
+//
+// The K loop is register-prefetched and LDS double-buffered (BK = 32, one barrier per K tile); two
+// workgroups fit a CU (72 KiB LDS each) so one's global latency hides under the other's MFMAs.
+// Prologues (LayerNorm / GroupNorm apply, row gather, two-source concat) run while staging A into LDS,
+// epilogues (bias, GLU, GELU, LayerScale + residual, sigmoid gate, speaker split, ReLU mask) on the
+// accumulators, so no normalised / activated intermediate ever goes to HBM.
+#pragma once
+#include "sepr_common.h"
+
+namespace sepr {
+
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_CAT2 = 2 };
+enum { EPI_STORE = 0, EPI_GLU = 1, EPI_GELU = 2, EPI_RES = 3, EPI_GATE = 4, EPI_SPLIT = 5, EPI_MASK = 6 };
+
+struct GemmArgs {
+  int M, N, K;
+  // ---- A side ----
+  const float* A;   // source rows, leading dimension lda
+  int lda;
+  const float* A2;  // PRO_CAT2: second source for k >= ksplit, leading dimension lda2
+  int lda2;
+  int ksplit;
+  // Row map.  rows_out == 0: source row = m.  Otherwise m -> (seq = m / rows_out, r = m % rows_out);
+  // the row is all-zero unless r < rows_valid; source row = seq*rows_src + (idx ? idx[r] : r) >> a_shift.
+  // (a_shift applies to A only, never to A2: the fusion conv reads lo at t>>1 and skip at t.)
+  int rows_out, rows_src, rows_valid, a_shift;
+  const int* idx;
+  // PRO_NORM: v = (a - mean) * rstd * gamma[k] + beta[k]; (mean, rstd) = stats[2*i], i = m (stat_seq == 0)
+  // or m / rows_out (stat_seq == 1)
+  const float* stats;
+  int stat_seq;
+  const float* gamma;
+  const float* beta;
+  // ---- W side ----
+  const float* W;     // [N][K] row-major (torch Linear / 1x1 Conv weight)
+  const float* bias;  // [N] or null
+  // ---- output ----
+  float* Y;
+  int ldc;
+  const float* R;    // EPI_RES: residual [M][ldc] or null.  EPI_GATE: x [M][ldc]
+  const float* ls;   // EPI_RES: per-column scale [N] or null
+  const float* aux;  // EPI_GATE: att [M/fac][N]; EPI_MASK: enc [(M/rows_out/S)*rows_out ...][N]
+  int T, Tp, fac;    // EPI_GATE: frames per sequence, pooled frames, T/Tp.  EPI_SPLIT: T
+  int S, Fs;         // EPI_SPLIT / EPI_MASK: speakers; EPI_SPLIT: F
+};
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_LDS_STRIDE = GEMM_BK + 4;
+constexpr int GEMM_THREADS = 256;
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
+  constexpr bool GLU = (EPI == EPI_GLU);
+  constexpr int LS = GEMM_LDS_STRIDE;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (GEMM_BM + GEMM_BN) * LS];
+  float* const As0 = smem;
+  float* const Bs0 = smem + 2 * GEMM_BM * LS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int fi = lane & 15, fg = lane >> 4;
+
+  // XCD-aware tile order: workgroup b runs on XCD b % 8; the NB column tiles of one row tile are made
+  // consecutive *on the same XCD* so the A rows they share are served by one L2.
+  const int NB = GLU ? (a.N / 2 + 63) / 64 : (a.N + GEMM_BN - 1) / GEMM_BN;
+  const int MB = (a.M + GEMM_BM - 1) / GEMM_BM;
+  const int xcd = blockIdx.x & 7;
+  const int q = blockIdx.x >> 3;
+  const int mb = (q / NB) * 8 + xcd;
+  const int nb = q % NB;
+  if (mb >= MB) return;
+  const int m0 = mb * GEMM_BM;
+
+  // ---- per-thread staging assignment: rows r0 + 32 i, float4 column c4 of the 32-wide K tile ----
+  const int c4 = tid & 7;
+  const int r0 = tid >> 3;
+  // Loads are unconditional (rows outside the problem point at row 0 and are zeroed by a select), so
+  // the K loop carries no divergent branches.
+  const float* pa[4];
+  const float* pa2[4];
+  bool va[4], vw[4];
+  float mean[4], rstd[4];
+  const float* pw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    pa[i] = a.A;
+    pa2[i] = (PRO == PRO_CAT2) ? a.A2 : a.A;
+    va[i] = false;
+    mean[i] = 0.f;
+    rstd[i] = 0.f;
+    if (m < a.M) {
+      long long src = m;
+      int seq = 0;
+      bool valid = true;
+      if (a.rows_out > 0) {
+        seq = m / a.rows_out;
+        const int r = m - seq * a.rows_out;
+        valid = r < a.rows_valid;
+        const int rr = valid ? (a.idx ? a.idx[r] : r) : 0;
+        src = (long long)seq * a.rows_src + (rr >> a.a_shift);
+      }
+      if (valid) {
+        va[i] = true;
+        pa[i] = a.A + src * a.lda;
+        if (PRO == PRO_CAT2) pa2[i] = a.A2 + (long long)m * a.lda2;
+        if (PRO == PRO_NORM) {
+          const long long si = a.stat_seq ? seq : m;
+          mean[i] = a.stats[2 * si];
+          rstd[i] = a.stats[2 * si + 1];
+        }
+      }
+    }
+    // weight rows of this tile: plain = 128 consecutive rows; GLU = 64 value rows then their 64 gate rows
+    const int rr = r0 + 32 * i;
+    int wrow;
+    if (GLU) {
+      const int c = nb * 64 + (rr & 63);
+      vw[i] = c < a.N / 2;
+      wrow = (rr < 64) ? c : a.N / 2 + c;
+    } else {
+      wrow = nb * GEMM_BN + rr;
+      vw[i] = wrow < a.N;
+    }
+    pw[i] = a.W + (vw[i] ? (long long)wrow * a.K : 0);
+  }
+
+  float4 ra[4], rb[4];
+  auto load_tile = [&](int kt) {
+    const int k = kt * GEMM_BK + 4 * c4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (PRO == PRO_CAT2) {
+        ra[i] = (k < a.ksplit) ? ld4(pa[i] + k) : ld4(pa2[i] + (k - a.ksplit));
+      } else {
+        ra[i] = ld4(pa[i] + k);
+      }
+      rb[i] = ld4(pw[i] + k);
+    }
+  };
+  auto store_tile = [&](int kt, int buf) {
+    float* As = As0 + buf * GEMM_BM * LS;
+    float* Bs = Bs0 + buf * GEMM_BN * LS;
+    float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = zero4();
+    if (PRO == PRO_NORM) {
+      const int k = kt * GEMM_BK + 4 * c4;
+      g4 = ld4(a.gamma + k);
+      b4 = ld4(a.beta + k);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = ra[i];
+      if (PRO == PRO_NORM) {
+        v.x = (v.x - mean[i]) * rstd[i] * g4.x + b4.x;
+        v.y = (v.y - mean[i]) * rstd[i] * g4.y + b4.y;
+        v.z = (v.z - mean[i]) * rstd[i] * g4.z + b4.z;
+        v.w = (v.w - mean[i]) * rstd[i] * g4.w + b4.w;
+      }
+      // rows outside the map are exactly zero (pad_signal semantics), also under PRO_NORM
+      st4(As + (r0 + 32 * i) * LS + 4 * c4, va[i] ? v : zero4());
+      st4(Bs + (r0 + 32 * i) * LS + 4 * c4, vw[i] ? rb[i] : zero4());
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // LDS row of the weight fragment nt of this wave
+  int brow[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+    brow[nt] = GLU ? ((nt >> 1) * 64 + wn * 32 + (nt & 1) * 16) : (wn * 64 + nt * 16);
+
+  const int nk = a.K / GEMM_BK;
+  load_tile(0);
+  store_tile(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const float* As = As0 + cur * GEMM_BM * LS;
+    const float* Bs = Bs0 + cur * GEMM_BN * LS;
+#pragma unroll
+    for (int kk = 0; kk < GEMM_BK / 16; ++kk) {
+      float4 wf[4], xf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        wf[t] = ld4(Bs + (brow[t] + fi) * LS + kk * 16 + 4 * fg);
+        xf[t] = ld4(As + (wm * 64 + t * 16 + fi) * LS + kk * 16 + 4 * fg);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].x, xf[mt].x, acc[nt][mt], 0, 0, 0);
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].y, xf[mt].y, acc[nt][mt], 0, 0, 0);
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].z, xf[mt].z, acc[nt][mt], 0, 0, 0);
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].w, xf[mt].w, acc[nt][mt], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) store_tile(kt + 1, cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds Y[m][ncol .. ncol+3] per (nt, mt) -----------------------------------
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + wm * 64 + mt * 16 + fi;
+    if (m >= a.M) continue;
+    long long out_row = m;   // row of Y (and of R)
+    long long aux_row = 0;
+    int split_b = 0, split_t = 0;
+    if (EPI == EPI_GATE) {
+      const int seq = m / a.T;
+      const int t = m - seq * a.T;
+      aux_row = (long long)seq * a.Tp + t / a.fac;
+    } else if (EPI == EPI_SPLIT) {
+      split_b = m / a.T;
+      split_t = m - split_b * a.T;
+    } else if (EPI == EPI_MASK) {
+      const int seq = m / a.rows_out;             // b*S + s
+      const int l = m - seq * a.rows_out;
+      aux_row = (long long)(seq / a.S) * a.rows_out + l;
+    }
+    if (GLU) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int ncol = nb * 64 + wn * 32 + nt * 16 + 4 * fg;
+        if (ncol >= a.N / 2) continue;
+        const float4 bv = ld4(a.bias + ncol), bg = ld4(a.bias + a.N / 2 + ncol);
+        const f32x4 v = acc[nt][mt], g = acc[nt + 2][mt];
+        float4 o;
+        o.x = (v[0] + bv.x) * sigmoid_f(g[0] + bg.x);
+        o.y = (v[1] + bv.y) * sigmoid_f(g[1] + bg.y);
+        o.z = (v[2] + bv.z) * sigmoid_f(g[2] + bg.z);
+        o.w = (v[3] + bv.w) * sigmoid_f(g[3] + bg.w);
+        st4(a.Y + out_row * a.ldc + ncol, o);
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int ncol = nb * GEMM_BN + wn * 64 + nt * 16 + 4 * fg;
+        if (ncol >= a.N) continue;
+        const f32x4 c = acc[nt][mt];
+        float4 v = make_float4(c[0], c[1], c[2], c[3]);
+        if (a.bias) {
+          const float4 b = ld4(a.bias + ncol);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (EPI == EPI_STORE) {
+          st4(a.Y + out_row * a.ldc + ncol, v);
+        } else if (EPI == EPI_GELU) {
+          v.x = gelu_exact(v.x); v.y = gelu_exact(v.y); v.z = gelu_exact(v.z); v.w = gelu_exact(v.w);
+          st4(a.Y + out_row * a.ldc + ncol, v);
+        } else if (EPI == EPI_RES) {
+          if (a.ls) {
+            const float4 s = ld4(a.ls + ncol);
+            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+          }
+          if (a.R) {
+            const float4 r = ld4(a.R + out_row * a.ldc + ncol);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          }
+          st4(a.Y + out_row * a.ldc + ncol, v);
+        } else if (EPI == EPI_GATE) {
+          const float4 x = ld4(a.R + out_row * a.ldc + ncol);
+          const float4 u = ld4(a.aux + aux_row * a.N + ncol);
+          v.x = x.x + sigmoid_f(v.x) * u.x;
+          v.y = x.y + sigmoid_f(v.y) * u.y;
+          v.z = x.z + sigmoid_f(v.z) * u.z;
+          v.w = x.w + sigmoid_f(v.w) * u.w;
+          st4(a.Y + out_row * a.ldc + ncol, v);
+        } else if (EPI == EPI_SPLIT) {
+          // column n = s*F + f  ->  Y[((b*S + s)*T + t)*F + f]   (reference module.py:123)
+          const int s = ncol / a.Fs;
+          const int f = ncol - s * a.Fs;
+          st4(a.Y + (((long long)split_b * a.S + s) * a.T + split_t) * a.Fs + f, v);
+        } else if (EPI == EPI_MASK) {
+          const float4 e = ld4(a.aux + aux_row * a.N + ncol);
+          v.x = fmaxf(v.x, 0.f) * e.x; v.y = fmaxf(v.y, 0.f) * e.y;
+          v.z = fmaxf(v.z, 0.f) * e.z; v.w = fmaxf(v.w, 0.f) * e.w;
+          st4(a.Y + out_row * a.ldc + ncol, v);
+        }
+      }
+    }
+  }
+}
+
+inline int gemm_grid(const GemmArgs& a, bool glu) {
+  const int NB = glu ? (a.N / 2 + 63) / 64 : (a.N + GEMM_BN - 1) / GEMM_BN;
+  const int MB = (a.M + GEMM_BM - 1) / GEMM_BM;
+  return ((MB + 7) / 8) * 8 * NB;
+}
+
+// host launcher (defined in sepr_gemm.hip): validates shapes, attributes the launch to a profiling site
+int launch_gemm(int pro, int epi, const GemmArgs& a, int site, hipStream_t stream);
+
+inline GemmArgs gemm_args_zero() {
+  GemmArgs a;
+  __builtin_memset(&a, 0, sizeof(a));
+  return a;
+}
+
+}  // namespace sepr

@@ -1,0 +1,219 @@
+"""Forward driver: walks the separator topology and calls one C-ABI entry point per fused block.
+
+Topology restated from reference ``modules/module.py:190-218`` (Separator.forward) and ``model.py:38-54``
+(Model.forward); every activation is a channel-last ``[sequences, frames, F]`` fp32 tensor on the HIP
+device and *stays* in that layout end to end - the reference's 471 ``permute().contiguous()`` copies per
+forward have no counterpart here.  PyTorch is used for the caching allocator and the
+current-stream handle only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .config import SepConfig
+from .pack import GN_EPS, PackedModel
+
+
+def nearest_index(src: int, dst: int) -> np.ndarray:
+    """Source frame of each output frame for ``F.upsample(mode='nearest')`` (reference model.py:49).
+
+    aten's ``nearest_idx``: identity when equal, ``>>1`` when exactly doubling, else
+    ``min(floor(dst_index * float32(src/dst)), src-1)`` evaluated in fp32 (checked against torch's own
+    tables in tests/golden/blocks_tiny.npz)."""
+    i = np.arange(dst, dtype=np.int64)
+    if dst == src:
+        return i.astype(np.int32)
+    if dst == 2 * src:
+        return (i >> 1).astype(np.int32)
+    scale = np.float32(src) / np.float32(dst)
+    idx = np.floor(i.astype(np.float32) * scale).astype(np.int64)
+    return np.minimum(idx, src - 1).astype(np.int32)
+
+
+class SeparatorEngine:
+    def __init__(self, cfg: SepConfig, packed: PackedModel, device: torch.device):
+        self.cfg = cfg
+        self.pk = packed
+        self.device = device
+        self.lib = L.load()
+        self._ws: Optional[torch.Tensor] = None
+        self._idx_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _workspace(self, nbytes: int) -> Tuple[int, int]:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws.data_ptr(), self._ws.numel()
+
+    def workspace_bytes(self, B: int, L_: int, Lp: int) -> int:
+        c, lib = self.cfg, self.lib
+        S, F, N = c.num_spks, c.feat, c.enc_channels
+        Tp = Lp >> c.num_stages
+        need = [lib.sepr_workspace_bytes(L.OP_ENCODER, B, L_, 0, F, N, S),
+                lib.sepr_workspace_bytes(L.OP_GCFN, B * S, Lp, 0, F, N, S),
+                lib.sepr_workspace_bytes(L.OP_CLA, B * S, Lp, 0, F, N, S),
+                lib.sepr_workspace_bytes(L.OP_EGA, B * S, Lp, Tp, F, N, S),
+                lib.sepr_workspace_bytes(L.OP_SPKATTN, B * S, Lp, 0, F, N, S),
+                lib.sepr_workspace_bytes(L.OP_SPKSPLIT, B, Lp, 0, F, N, S),
+                lib.sepr_workspace_bytes(L.OP_OUTLAYER, B * S, L_, 0, F, N, S)]
+        return int(max(need))
+
+    def prepare(self, B: int, L_: int, Lp: int) -> None:
+        """Bind the current stream and a workspace large enough for ``B`` utterances of ``Lp`` frames.
+        ``forward`` calls this itself; tests call it before driving single blocks."""
+        self._st = self._stream()
+        self._wsargs = self._workspace(self.workspace_bytes(B, L_, Lp))
+
+    def _new(self, *shape) -> torch.Tensor:
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _idx(self, src: int, dst: int) -> torch.Tensor:
+        key = (src, dst)
+        t = self._idx_cache.get(key)
+        if t is None:
+            t = torch.from_numpy(nearest_index(src, dst)).to(self.device)
+            self._idx_cache[key] = t
+        return t
+
+    # ---- blocks (each = one C-ABI call) --------------------------------------------------------------
+    def gcfn(self, x, w, n, T):
+        y = torch.empty_like(x)
+        L.check(self.lib.sepr_gcfn_fwd(x.data_ptr(), y.data_ptr(), n, T, self.cfg.feat, C.byref(w), *self._wsargs, self._st), "sepr_gcfn_fwd")
+        return y
+
+    def cla(self, x, w, n, T):
+        y = torch.empty_like(x)
+        L.check(self.lib.sepr_cla_fwd(x.data_ptr(), y.data_ptr(), n, T, self.cfg.feat, self.cfg.cla_kernel, C.byref(w), *self._wsargs, self._st), "sepr_cla_fwd")
+        return y
+
+    def ega(self, x, w, n, T, Tp):
+        y = torch.empty_like(x)
+        L.check(self.lib.sepr_ega_fwd(x.data_ptr(), y.data_ptr(), n, T, Tp, self.cfg.feat, self.cfg.heads, C.byref(w), *self._wsargs, self._st), "sepr_ega_fwd")
+        return y
+
+    def spkattn(self, x, w, n, T):
+        y = torch.empty_like(x)
+        L.check(self.lib.sepr_spkattn_fwd(x.data_ptr(), y.data_ptr(), n, self.cfg.num_spks, T, self.cfg.feat, self.cfg.heads, C.byref(w), *self._wsargs, self._st), "sepr_spkattn_fwd")
+        return y
+
+    def global_block(self, x, gw, n, T, Tp):       # reference modules/network.py:198-209
+        return self.gcfn(self.ega(x, gw[0], n, T, Tp), gw[1], n, T)
+
+    def local_block(self, x, lw, n, T):            # reference modules/network.py:220-224
+        return self.gcfn(self.cla(x, lw[0], n, T), lw[1], n, T)
+
+    def downconv(self, x, w, n, T):
+        K = self.cfg.down_kernel
+        To = (T + 2 * ((K - 1) // 2) - K) // 2 + 1
+        y = self._new(n, To, self.cfg.feat)
+        L.check(self.lib.sepr_downconv_fwd(x.data_ptr(), y.data_ptr(), n, T, self.cfg.feat, K, C.byref(w), self._st), "sepr_downconv_fwd")
+        return y, To
+
+    def spksplit(self, x, w, B, T):
+        S = self.cfg.num_spks
+        y = self._new(B * S, T, self.cfg.feat)
+        L.check(self.lib.sepr_spksplit_fwd(x.data_ptr(), y.data_ptr(), B, S, T, self.cfg.feat, GN_EPS, C.byref(w), *self._wsargs, self._st), "sepr_spksplit_fwd")
+        return y
+
+    def fuse(self, lo, skip, wb, n, T):
+        y = torch.empty_like(skip)
+        L.check(self.lib.sepr_fuse_fwd(lo.data_ptr(), skip.data_ptr(), y.data_ptr(), n, T, self.cfg.feat, wb[0], wb[1], self._st), "sepr_fuse_fwd")
+        return y
+
+    def head(self, x, w, nS, Tsrc, L_, idx, enc, B):
+        c = self.cfg
+        Tout = (L_ - 1) * c.enc_stride + c.enc_kernel
+        wav = self._new(c.num_spks, B, Tout)
+        L.check(self.lib.sepr_outlayer_decoder_fwd(
+            x.data_ptr(), nS, c.num_spks, Tsrc, L_, None if idx is None else idx.data_ptr(),
+            None if enc is None else enc.data_ptr(), c.feat, c.enc_channels, c.enc_kernel, c.enc_stride,
+            C.byref(w), wav.data_ptr(), *self._wsargs, self._st), "sepr_outlayer_decoder_fwd")
+        return wav
+
+    # ---- whole forward --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, with_aux: bool = True, taps: Optional[dict] = None):
+        """x ``[B,T]`` fp32 on the HIP device -> (wav ``[S,B,T']``, list of R aux ``[S,B,T']`` or ``[]``)."""
+        c, pk, lib = self.cfg, self.pk, self.lib
+        if x.dim() != 2:
+            raise RuntimeError("Input can only be 2 dimensional: [batch, samples]")
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise RuntimeError("separator input must be a float32 tensor on the HIP device")
+        x = x.contiguous()
+        B, T = x.shape
+        S, R, F, N = c.num_spks, c.num_stages, c.feat, c.enc_channels
+        if T < c.enc_kernel:
+            raise RuntimeError(f"input of {T} samples is shorter than the encoder kernel ({c.enc_kernel})")
+        L_ = c.frames(T)
+        Lp = c.padded_frames(L_)
+        Tp = Lp >> R
+        self.prepare(B, L_, Lp)
+
+        # AudioEncoder + FeatureProjector + pad_signal               (model.py:39-40, module.py:193)
+        enc = self._new(B, L_, N)
+        gn = self._new(B, 2)
+        L.check(lib.sepr_encoder_fwd(x.data_ptr(), B, T, pk.enc_w, N, c.enc_kernel, c.enc_stride, GN_EPS,
+                                     enc.data_ptr(), gn.data_ptr(), *self._wsargs, self._st), "sepr_encoder_fwd")
+        cur = self._new(B, Lp, F)
+        L.check(lib.sepr_projector_fwd(enc.data_ptr(), B, L_, Lp, N, F, gn.data_ptr(), pk.proj_g, pk.proj_b,
+                                       pk.proj_w, cur.data_ptr(), self._st), "sepr_projector_fwd")
+        if taps is not None:
+            taps["enc"], taps["proj"] = enc, cur
+
+        # temporal contracting part                                   (module.py:199-205)
+        skips: List[Tuple[torch.Tensor, int]] = []
+        Tc = Lp
+        for i in range(R):
+            st = pk.enc_stages[i]
+            for j in range(2):
+                cur = self.global_block(cur, st["g"][j], B, Tc, Tp)
+                cur = self.local_block(cur, st["l"][j], B, Tc)
+            if taps is not None:
+                taps[f"enc{i}.skip_pre_split"] = cur
+            skips.append((self.spksplit(cur, pk.splits[i], B, Tc), Tc))
+            cur, Tc = self.downconv(cur, st["down"], B, Tc)
+        if Tc != Tp:
+            raise RuntimeError(f"internal: bottleneck length {Tc} != pooled length {Tp}")
+        for j in range(2):
+            cur = self.global_block(cur, pk.bottleneck["g"][j], B, Tc, Tp)
+            cur = self.local_block(cur, pk.bottleneck["l"][j], B, Tc)
+        if taps is not None:
+            taps["bottleneck"] = cur
+        cur = self.spksplit(cur, pk.splits[R], B, Tc)
+
+        # temporal expanding part                                     (module.py:207-215)
+        nS = B * S
+        stage_outs: List[Tuple[torch.Tensor, int]] = []
+        for i in range(R):
+            stage_outs.append((cur, Tc))
+            skip, Ts = skips[R - 1 - i]
+            if Ts != 2 * Tc:
+                raise RuntimeError(f"internal: skip length {Ts} != 2 x {Tc}")
+            cur = self.fuse(cur, skip, pk.fuse[i], nS, Ts)
+            Tc = Ts
+            st = pk.dec_stages[i]
+            for j in range(3):
+                cur = self.global_block(cur, st["g"][j], nS, Tc, Tp)
+                cur = self.local_block(cur, st["l"][j], nS, Tc)
+                cur = self.spkattn(cur, st["spk"][j][0], nS, Tc)
+                cur = self.gcfn(cur, st["spk"][j][1], nS, Tc)
+            if taps is not None:
+                taps[f"dec{i}"] = cur
+        skips.clear()
+
+        # output layer + decoder, main and auxiliary heads            (model.py:42-52)
+        wav = self.head(cur, pk.out_main, nS, Tc, L_, None, None, B)
+        aux = []
+        if with_aux:
+            for i, (so, Ti) in enumerate(stage_outs):
+                aux.append(self.head(so, pk.out_aux[i], nS, Ti, L_, self._idx(Ti, L_), enc, B))
+        return wav, aux

@@ -1,0 +1,116 @@
+"""ctypes binding of ``libsepr_hip.so`` (C ABI declared in ``include/sepr.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``make -C sepreformer_amd/csrc``).  There is no
+fallback of any kind: if the shared object is missing or an entry point fails, this module raises.
+ctypes releases the GIL around every foreign call, so ``torch.nn.parallel.data_parallel`` replicas
+(one Python thread per device, reference ``engine.py:64``) can drive the library concurrently.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsepr_hip.so")
+
+SEPR_OK, SEPR_EINVAL, SEPR_EWORKSPACE, SEPR_EHIP = 0, -1, -2, -3
+_ERR = {SEPR_EINVAL: "SEPR_EINVAL (bad shape / unsupported size / null pointer)",
+        SEPR_EWORKSPACE: "SEPR_EWORKSPACE (workspace too small)",
+        SEPR_EHIP: "SEPR_EHIP (HIP launch failed)"}
+
+(OP_ENCODER, OP_GCFN, OP_CLA, OP_EGA, OP_SPKATTN, OP_SPKSPLIT, OP_OUTLAYER) = range(7)
+(SITE_NONE, SITE_GCFN_UP, SITE_GCFN_DOWN, SITE_CLA, SITE_ATTN_PROJ, SITE_EGA_GATE, SITE_SPLIT, SITE_FUSE,
+ SITE_OUT, SITE_PROJECTOR, SITE_LINEAR) = range(11)
+
+_fp = C.c_void_p  # device pointers travel as plain addresses
+
+
+def _struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": [(f, _fp) for f in fields]})
+
+
+GcfnW = _struct("GcfnW", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "ls"])
+ClaW = _struct("ClaW", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "w3", "b3", "ls"])
+MhaW = _struct("MhaW", ["ln_g", "ln_b", "wqkv", "bqkv", "wo", "bo", "ls"])
+
+
+class EgaW(C.Structure):
+    _fields_ = [("attn", MhaW), ("gate_ln_g", _fp), ("gate_ln_b", _fp), ("gate_w", _fp), ("gate_b", _fp),
+                ("pe_k", _fp), ("maxlen", C.c_int)]
+
+
+DownW = _struct("DownW", ["w", "scale", "shift"])
+SplitW = _struct("SplitW", ["w1", "b1", "w2", "b2", "gn_g", "gn_b"])
+OutW = _struct("OutW", ["w1", "b1", "w2", "b2", "wdec"])
+
+_i, _f, _sz, _ll = C.c_int, C.c_float, C.c_size_t, C.c_longlong
+
+# name -> (restype, argtypes); must list every symbol include/sepr.h declares (tests check this)
+SIGNATURES = {
+    "sepr_version": (_i, []),
+    "sepr_build_info": (C.c_char_p, []),
+    "sepr_last_hip_error": (C.c_char_p, []),
+    "sepr_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "sepr_encoder_fwd": (_i, [_fp, _i, _i, _fp, _i, _i, _i, _f, _fp, _fp, _fp, _sz, _fp]),
+    "sepr_projector_fwd": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "sepr_gcfn_fwd": (_i, [_fp, _fp, _i, _i, _i, C.POINTER(GcfnW), _fp, _sz, _fp]),
+    "sepr_cla_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, C.POINTER(ClaW), _fp, _sz, _fp]),
+    "sepr_ega_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _i, C.POINTER(EgaW), _fp, _sz, _fp]),
+    "sepr_spkattn_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _i, C.POINTER(MhaW), _fp, _sz, _fp]),
+    "sepr_downconv_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, C.POINTER(DownW), _fp]),
+    "sepr_spksplit_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _f, C.POINTER(SplitW), _fp, _sz, _fp]),
+    "sepr_fuse_fwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp]),
+    "sepr_outlayer_decoder_fwd": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, C.POINTER(OutW), _fp, _fp, _sz, _fp]),
+    "sepr_groupnorm_stats": (_i, [_fp, _i, _ll, _f, _fp, _fp, _sz, _fp]),
+    "sepr_linear_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
+    "sepr_prof_start": (_i, [_i, _i]),
+    "sepr_prof_stop": (_i, [C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib: Optional[C.CDLL] = None
+_lock = threading.Lock()
+
+
+class SeprLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the library once and type every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise SeprLibraryError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C sepreformer_amd/csrc`). "
+                "There is no CPU fallback for the separator path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError -> a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == SEPR_OK:
+        return
+    msg = _ERR.get(rc, f"status {rc}")
+    if rc == SEPR_EHIP:
+        msg += ": " + load().sepr_last_hip_error().decode(errors="replace")
+    raise RuntimeError(f"{what} failed: {msg}")
+
+
+def version() -> int:
+    return int(load().sepr_version())
+
+
+def build_info() -> str:
+    return load().sepr_build_info().decode()

@@ -1,0 +1,146 @@
+"""Host-side weight packing: reference ``state_dict`` tensors -> the layouts ``include/sepr.h`` documents.
+
+Done once per weight version on the device that owns the parameters (plain torch ops; weights are
+"PyTorch-owned storage", the kernels only read them).  What happens here:
+
+* depthwise-conv weights ``[C,1,K]`` become tap-major ``[K,C]`` so a wave reads contiguous channels;
+* q/k/v projections are stacked into one ``[3F,F]`` matrix (one launch instead of three);
+* eval-mode BatchNorm is folded: CLA's into ``linear2`` (reference ``modules/network.py:181-183``),
+  DownConv's into a per-channel scale/shift behind the depthwise conv (``modules/module.py:74-75``);
+  folding is done in fp64 and rounded once;
+* 1x1 ``Conv1d`` weights ``[O,I,1]`` are viewed ``[O,I]``; ``LayerScale`` ``[1,1,F]`` is viewed ``[F]``;
+* encoder / decoder kernels ``[N,1,K]`` become tap-major ``[K,N]``.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+
+from . import lib as L
+from .config import SepConfig
+
+BN_EPS = 1e-5      # torch.nn.BatchNorm1d default
+GN_EPS = 1e-8      # reference modules/module.py:28,117
+
+
+class Packed:
+    """Packed device tensors + the ctypes structs pointing at them (tensors are kept alive here)."""
+
+    def __init__(self):
+        self.keep: List[torch.Tensor] = []
+
+    def t(self, x: torch.Tensor) -> int:
+        x = x.detach().to(torch.float32).contiguous()
+        self.keep.append(x)
+        return x.data_ptr()
+
+
+def _tapmajor(w: torch.Tensor) -> torch.Tensor:
+    return w[:, 0, :].t().contiguous()          # [C,1,K] -> [K,C]
+
+
+def pack_gcfn(pk: Packed, sd: Dict[str, torch.Tensor], p: str) -> L.GcfnW:
+    return L.GcfnW(
+        ln_g=pk.t(sd[p + ".net1.0.weight"]), ln_b=pk.t(sd[p + ".net1.0.bias"]),
+        w1=pk.t(sd[p + ".net1.1.weight"]), b1=pk.t(sd[p + ".net1.1.bias"]),
+        dw_w=pk.t(_tapmajor(sd[p + ".depthwise.weight"])), dw_b=pk.t(sd[p + ".depthwise.bias"]),
+        w2=pk.t(sd[p + ".net2.2.weight"]), b2=pk.t(sd[p + ".net2.2.bias"]),
+        ls=pk.t(sd[p + ".Layer_scale.layer_scale"].reshape(-1)))
+
+
+def pack_cla(pk: Packed, sd, p: str) -> L.ClaW:
+    s = sd[p + ".BN.weight"].double() / torch.sqrt(sd[p + ".BN.running_var"].double() + BN_EPS)
+    w2 = (sd[p + ".linear2.weight"].double() * s[:, None]).float()
+    b2 = ((sd[p + ".linear2.bias"].double() - sd[p + ".BN.running_mean"].double()) * s + sd[p + ".BN.bias"].double()).float()
+    return L.ClaW(
+        ln_g=pk.t(sd[p + ".layer_norm.weight"]), ln_b=pk.t(sd[p + ".layer_norm.bias"]),
+        w1=pk.t(sd[p + ".linear1.weight"]), b1=pk.t(sd[p + ".linear1.bias"]),
+        dw_w=pk.t(_tapmajor(sd[p + ".dw_conv_1d.weight"])), dw_b=pk.t(sd[p + ".dw_conv_1d.bias"]),
+        w2=pk.t(w2), b2=pk.t(b2),
+        w3=pk.t(sd[p + ".linear3.1.weight"]), b3=pk.t(sd[p + ".linear3.1.bias"]),
+        ls=pk.t(sd[p + ".Layer_scale.layer_scale"].reshape(-1)))
+
+
+def pack_mha(pk: Packed, sd, p: str) -> L.MhaW:
+    wqkv = torch.cat([sd[f"{p}.linear_{n}.weight"] for n in "qkv"], dim=0)
+    bqkv = torch.cat([sd[f"{p}.linear_{n}.bias"] for n in "qkv"], dim=0)
+    return L.MhaW(
+        ln_g=pk.t(sd[p + ".layer_norm.weight"]), ln_b=pk.t(sd[p + ".layer_norm.bias"]),
+        wqkv=pk.t(wqkv), bqkv=pk.t(bqkv),
+        wo=pk.t(sd[p + ".linear_out.weight"]), bo=pk.t(sd[p + ".linear_out.bias"]),
+        ls=pk.t(sd[p + ".Layer_scale.layer_scale"].reshape(-1)))
+
+
+def pack_ega(pk: Packed, sd, p: str, pe_ptr: int, maxlen: int) -> L.EgaW:
+    return L.EgaW(
+        attn=pack_mha(pk, sd, p + ".block.self_attn"),
+        gate_ln_g=pk.t(sd[p + ".block.linear.0.weight"]), gate_ln_b=pk.t(sd[p + ".block.linear.0.bias"]),
+        gate_w=pk.t(sd[p + ".block.linear.1.weight"]), gate_b=pk.t(sd[p + ".block.linear.1.bias"]),
+        pe_k=pe_ptr, maxlen=maxlen)
+
+
+def pack_down(pk: Packed, sd, p: str) -> L.DownW:
+    s = sd[p + ".BN.weight"].double() / torch.sqrt(sd[p + ".BN.running_var"].double() + BN_EPS)
+    shift = (sd[p + ".down_conv.bias"].double() - sd[p + ".BN.running_mean"].double()) * s + sd[p + ".BN.bias"].double()
+    return L.DownW(w=pk.t(_tapmajor(sd[p + ".down_conv.weight"])), scale=pk.t(s.float()), shift=pk.t(shift.float()))
+
+
+def pack_split(pk: Packed, sd, p: str) -> L.SplitW:
+    return L.SplitW(
+        w1=pk.t(sd[p + ".linear.0.weight"][:, :, 0]), b1=pk.t(sd[p + ".linear.0.bias"]),
+        w2=pk.t(sd[p + ".linear.2.weight"][:, :, 0]), b2=pk.t(sd[p + ".linear.2.bias"]),
+        gn_g=pk.t(sd[p + ".norm.weight"]), gn_b=pk.t(sd[p + ".norm.bias"]))
+
+
+def pack_out(pk: Packed, sd, p: str, dec_weight: torch.Tensor) -> L.OutW:
+    return L.OutW(
+        w1=pk.t(sd[p + ".end_conv1x1.0.weight"]), b1=pk.t(sd[p + ".end_conv1x1.0.bias"]),
+        w2=pk.t(sd[p + ".end_conv1x1.2.weight"]), b2=pk.t(sd[p + ".end_conv1x1.2.bias"]),
+        wdec=pk.t(_tapmajor(dec_weight)))
+
+
+class PackedModel(Packed):
+    """All blocks of one model, addressed the way the forward driver walks them."""
+
+    def __init__(self, cfg: SepConfig, sd: Dict[str, torch.Tensor]):
+        super().__init__()
+        R = cfg.num_stages
+        self.cfg = cfg
+        self.enc_w = self.t(_tapmajor(sd["audio_encoder.conv1d.weight"]))
+        self.proj_g = self.t(sd["feature_projector.norm.weight"])
+        self.proj_b = self.t(sd["feature_projector.norm.bias"])
+        self.proj_w = self.t(sd["feature_projector.conv1d.weight"][:, :, 0])
+        pe = self.t(sd["separator.pos_emb.pe_k.weight"])
+
+        def glob(p):
+            return pack_ega(self, sd, p + ".block.ega", pe, cfg.maxlen), pack_gcfn(self, sd, p + ".block.gcfn")
+
+        def loc(p):
+            return pack_cla(self, sd, p + ".block.cla"), pack_gcfn(self, sd, p + ".block.gcfn")
+
+        def enc_stage(p, down):
+            st = {"g": [glob(f"{p}.g_block_{i}") for i in (1, 2)], "l": [loc(f"{p}.l_block_{i}") for i in (1, 2)]}
+            st["down"] = pack_down(self, sd, p + ".downconv") if down else None
+            return st
+
+        self.enc_stages = [enc_stage(f"separator.enc_stages.{i}", True) for i in range(R)]
+        self.bottleneck = enc_stage("separator.bottleneck_G", False)
+        if cfg.per_level_split:
+            self.splits = [pack_split(self, sd, f"separator.spk_split_blocks.{i}") for i in range(R + 1)]
+        else:
+            one = pack_split(self, sd, "separator.spk_split_block")
+            self.splits = [one] * (R + 1)
+        self.fuse = [(self.t(sd[f"separator.simple_fusion.{i}.weight"][:, :, 0]),
+                      self.t(sd[f"separator.simple_fusion.{i}.bias"])) for i in range(R)]
+        self.dec_stages = []
+        for i in range(R):
+            p = f"separator.dec_stages.{i}"
+            self.dec_stages.append({
+                "g": [glob(f"{p}.g_block_{j}") for j in (1, 2, 3)],
+                "l": [loc(f"{p}.l_block_{j}") for j in (1, 2, 3)],
+                "spk": [(pack_mha(self, sd, f"{p}.spk_attn_{j}.self_attn"),
+                         pack_gcfn(self, sd, f"{p}.spk_attn_{j}.feed_forward")) for j in (1, 2, 3)],
+            })
+        self.out_main = pack_out(self, sd, "out_layer", sd["audio_decoder.weight"])
+        self.out_aux = [pack_out(self, sd, f"out_layer_bn.{i}", sd[f"decoder_bn.{i}.weight"]) for i in range(R)]

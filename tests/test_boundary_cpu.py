@@ -1,0 +1,189 @@
+"""Host-side logic that needs no GPU: the state_dict contract, config flattening, weight packing
+(BatchNorm folding), the nearest-upsample table, the C-ABI export list, and 'fails loudly' behaviour."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sepreformer_oracle as orc
+from sepreformer_amd import lib as L
+from sepreformer_amd.config import SepConfig, VARIANTS, load_model_kwargs, variant_yaml
+from sepreformer_amd.engine import nearest_index
+from sepreformer_amd.model import Model
+from sepreformer_amd.params import count_parameters
+from sepreformer_amd.synth import synth_mixture, synth_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("variant", ["SepReformer_Base_WSJ0", "SepReformer_Large_DM_WHAMR", "SepReformer_Large_DM_WHAM"])
+def test_state_dict_contract(variant):
+    """Same keys, shapes, dtypes AND order as the reference module tree (listing generated from the
+    imported reference; SURVEY.md section 8b 'state_dict contract')."""
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")) as f:
+        want = json.load(f)[variant]
+    m = Model.from_config(VARIANTS[variant], init_seed=0)
+    got = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+    assert got == want
+    assert m.num_stages == 4 and m.num_spks == 2
+
+
+def test_parameter_counts():
+    # SURVEY.md section 2.2 probe numbers
+    assert count_parameters(VARIANTS["SepReformer_Base_WSJ0"]) == 14_691_584
+    assert count_parameters(VARIANTS["SepReformer_Base_WSJ0"], include_aux=False) == 14_147_840
+    assert count_parameters(VARIANTS["SepReformer_Large_DM_WHAMR"]) == 56_816_384
+    assert count_parameters(VARIANTS["SepReformer_Large_DM_WHAM"]) == 61_022_976
+
+
+@pytest.mark.parametrize("variant", [v for v in VARIANTS if v != "tiny"])
+def test_yaml_surface(variant):
+    kw = load_model_kwargs(variant_yaml(variant))
+    cfg = SepConfig.from_model_kwargs(**kw, per_level_split=VARIANTS[variant].per_level_split)
+    assert cfg == VARIANTS[variant]
+    assert cfg.model_kwargs() == kw
+    import importlib
+    mod = importlib.import_module(f"models.{variant}.model")
+    m = mod.Model(**kw)
+    assert isinstance(m, torch.nn.Module) and m.cfg == cfg
+
+
+def test_config_rejects_unsupported():
+    kw = VARIANTS["SepReformer_Base_WSJ0"].model_kwargs()
+    kw["module_audio_enc"]["bias"] = True
+    with pytest.raises(ValueError):
+        SepConfig.from_model_kwargs(**kw)
+
+
+def test_frames_and_padding():
+    c = VARIANTS["SepReformer_Base_WSJ0"]
+    assert c.frames(32000) == 7997 and c.padded_frames(7997) == 8000
+    assert c.padded_frames(8000) == 8000          # no pad when already a multiple (module.py:229-230)
+    assert c.frames(73596) == 18396 and c.padded_frames(18396) == 18400
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """reference utils/util_engine.py:98-106 checkpoint layout loads with strict=False / True."""
+    cfg = VARIANTS["tiny"]
+    m = Model.from_config(cfg, init_seed=1).load_synthetic_(3)
+    path = tmp_path / "epoch.0007.pth"
+    torch.save({"epoch": 7, "model_state_dict": m.state_dict(), "optimizer_state_dict": {},
+                "train_loss": 0.0, "valid_loss": 0.0}, path)
+    m2 = Model.from_config(cfg, init_seed=2)
+    ck = torch.load(path, map_location="cpu")
+    missing, unexpected = m2.load_state_dict(ck["model_state_dict"], strict=False)
+    assert not missing and not unexpected
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_default_init_matches_reference_families():
+    m = Model.from_config(VARIANTS["tiny"], init_seed=0)
+    sd = m.state_dict()
+    ls = sd["separator.enc_stages.0.g_block_1.block.gcfn.Layer_scale.layer_scale"]
+    assert torch.allclose(ls, torch.full_like(ls, 1e-5))          # network.py:8
+    w = sd["separator.enc_stages.0.g_block_1.block.gcfn.net1.1.weight"]
+    assert float(w.abs().max()) <= 1 / np.sqrt(w.shape[1]) + 1e-6
+    assert torch.equal(sd["separator.enc_stages.0.downconv.BN.running_var"], torch.ones(64))
+    assert sd["separator.enc_stages.0.downconv.BN.num_batches_tracked"].dtype == torch.long
+
+
+def test_synthetic_weights_are_deterministic_and_o1():
+    cfg = VARIANTS["tiny"]
+    a, b = synth_state_dict(cfg, 0), synth_state_dict(cfg, 0)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = synth_state_dict(cfg, 1)
+    assert not torch.equal(a["out_layer.end_conv1x1.0.weight"], c["out_layer.end_conv1x1.0.weight"])
+    ls = a["separator.enc_stages.0.g_block_1.block.gcfn.Layer_scale.layer_scale"]
+    assert float(ls.min()) >= 0.5 and float(ls.max()) <= 1.5
+    x = synth_mixture(2, 800, seed=5)
+    assert torch.equal(x, synth_mixture(2, 800, seed=5)) and x.dtype == torch.float32
+
+
+def test_nearest_index_matches_torch_tables(golden):
+    g = golden("blocks_tiny")
+    for key in g:
+        if key.startswith("nearest."):
+            _, src, dst = key.split(".")
+            assert np.array_equal(nearest_index(int(src), int(dst)), g[key]), key
+    assert np.array_equal(nearest_index(8, 16), np.arange(16) >> 1)
+    assert np.array_equal(nearest_index(8, 8), np.arange(8))
+
+
+def test_batchnorm_folding_equals_oracle():
+    """pack.py folds eval BatchNorm into linear2 (CLA) and into scale/shift (DownConv)."""
+    from sepreformer_amd import pack
+    cfg = VARIANTS["tiny"]
+    sd = synth_state_dict(cfg, 0)
+    p = "separator.enc_stages.0.l_block_1.block.cla"
+    pk = pack.Packed()
+    pack.pack_cla(pk, sd, p)
+    w2, b2 = pk.keep[6], pk.keep[7]
+    x = torch.randn(3, 50, cfg.feat)
+    want = torch.nn.functional.batch_norm(
+        torch.nn.functional.linear(x, sd[p + ".linear2.weight"], sd[p + ".linear2.bias"]).permute(0, 2, 1),
+        sd[p + ".BN.running_mean"], sd[p + ".BN.running_var"], sd[p + ".BN.weight"], sd[p + ".BN.bias"],
+        False, 0.1, 1e-5).permute(0, 2, 1)
+    got = torch.nn.functional.linear(x, w2, b2)
+    assert orc.agreement_db(got, want) > 120
+    q = "separator.enc_stages.0.downconv"
+    pk = pack.Packed()
+    pack.pack_down(pk, sd, q)
+    w, scale, shift = pk.keep
+    x = torch.randn(2, 40, cfg.feat)
+    conv = torch.nn.functional.conv1d(x.permute(0, 2, 1), sd[q + ".down_conv.weight"], None, stride=2, padding=2, groups=cfg.feat)
+    got = torch.nn.functional.gelu(conv * scale[None, :, None] + shift[None, :, None]).permute(0, 2, 1)
+    assert orc.agreement_db(got, orc.down_conv(sd, q, x)) > 120
+    assert tuple(w.shape) == (cfg.down_kernel, cfg.feat)
+
+
+def test_abi_exports_every_declared_symbol():
+    """The C-ABI library loads and exports exactly what include/sepr.h declares (no compute here)."""
+    hdr = open(os.path.join(ROOT, "include", "sepr.h")).read()
+    declared = set(re.findall(r"\b(sepr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    lib = L.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.sepr_version() == int(re.search(r"#define SEPR_VERSION (\d+)", hdr).group(1))
+    assert b"gfx950" in lib.sepr_build_info()
+    # argument validation happens before any HIP call, so it is checkable without a device
+    assert lib.sepr_workspace_bytes(L.OP_GCFN, 0, 8, 0, 128, 256, 2) == 0
+    n, T, F = 2, 1000, 128
+    want = 2 * n * T * 4 + 6 * F * n * T * 4 + 3 * F * n * T * 4
+    got = lib.sepr_workspace_bytes(L.OP_GCFN, n, T, 0, F, 256, 2)
+    assert want <= got <= want + 8192
+    assert lib.sepr_gcfn_fwd(None, None, 1, 8, 128, None, None, 0, None) == L.SEPR_EINVAL
+    assert lib.sepr_prof_start(0, 10) == L.SEPR_EINVAL
+
+
+def test_struct_layouts_match_header():
+    hdr = open(os.path.join(ROOT, "include", "sepr.h")).read()
+    for cname, cls in (("sepr_gcfn_w", L.GcfnW), ("sepr_cla_w", L.ClaW), ("sepr_mha_w", L.MhaW),
+                       ("sepr_down_w", L.DownW), ("sepr_split_w", L.SplitW), ("sepr_out_w", L.OutW)):
+        body = re.search(r"typedef struct \{([^}]*)\} " + cname + ";", hdr).group(1)
+        fields = re.findall(r"const float\*\s*(\w+);", body)
+        assert fields == [f for f, _ in cls._fields_], cname
+        assert ctypes.sizeof(cls) == 8 * len(fields)
+    assert [f for f, _ in L.EgaW._fields_] == ["attn", "gate_ln_g", "gate_ln_b", "gate_w", "gate_b", "pe_k", "maxlen"]
+
+
+def test_no_cpu_fallback():
+    m = Model.from_config(VARIANTS["tiny"], init_seed=0).eval()
+    with pytest.raises(RuntimeError, match="HIP"):
+        m(torch.zeros(1, 400))
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 400))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "sepreformer_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn

@@ -1,0 +1,86 @@
+"""N>1 path on CPU: two gloo ranks shard a batch by utterance, separate their slice, gather, and reduce a
+metric.  The compute function here is the oracle (allowed in tests); the sharding / gather / reduce
+logic under test is the product's (sepreformer_amd/dist.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from oracle import sepreformer_oracle as orc
+    from sepreformer_amd import dist as sd
+    from sepreformer_amd.config import VARIANTS
+    from sepreformer_amd.synth import synth_mixture, synth_state_dict
+    r, w, _ = sd.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    cfg = VARIANTS["tiny"]
+    weights = synth_state_dict(cfg, 0)
+    x = synth_mixture(total, 600, seed=99) * 4
+
+    def separate(xb):
+        audio, _ = orc.model_forward(weights, cfg, xb)
+        return torch.stack([a.reshape(xb.shape[0], -1) for a in audio], 0)
+
+    full, (a, b) = sd.separate_sharded(separate, x, gather=True, chunk=2)
+    local, (a2, b2) = sd.separate_sharded(separate, x, gather=False, chunk=2) if b > a else (None, (a, b))
+    sums = sd.reduce_metric_sums(torch.tensor([float(b - a), float(full[:, a:b].abs().sum())], dtype=torch.float64))
+    t = sd.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    sd.barrier()
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), full=full.numpy(), rng=np.array([a, b]), sums=sums.numpy(), t=t)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [5, 1])
+def test_two_rank_sharded_inference(tmp_path, total):
+    sys.path.insert(0, ROOT)
+    from oracle import sepreformer_oracle as orc
+    from sepreformer_amd.config import VARIANTS
+    from sepreformer_amd.dist import shard_range
+    from sepreformer_amd.synth import synth_mixture, synth_state_dict
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    cfg = VARIANTS["tiny"]
+    x = synth_mixture(total, 600, seed=99) * 4
+    audio, _ = orc.model_forward(synth_state_dict(cfg, 0), cfg, x)
+    want = torch.stack([a.reshape(total, -1) for a in audio], 0).numpy()
+    got = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    for r in range(world):
+        assert tuple(got[r]["rng"]) == shard_range(total, r, world)
+        # every rank holds the full gathered result and it equals the unsharded run (utterances are
+        # independent in eval mode: SURVEY.md section 8e)
+        assert orc.agreement_db(torch.from_numpy(got[r]["full"]), torch.from_numpy(want)) > 100
+        assert got[r]["sums"][0] == total
+        assert abs(got[r]["sums"][1] - np.abs(want).sum()) < 1e-3 * np.abs(want).sum()
+        assert got[r]["t"] == 2.0
+
+
+def test_shard_range_properties():
+    from sepreformer_amd.dist import shard_range
+    for total in (0, 1, 7, 32, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
