@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Throughput of the SepReformer-Base separator forward on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full ``Model.forward`` (main + the 4 auxiliary heads, exactly what the reference's
+forward evaluates, model.py:38-54) over one batch of 32 synthetic 4 s / 8 kHz two-speaker mixtures
+already resident in HBM (BASELINE.json configs[1]).  With N ranks every rank runs its own batch of 32
+(weak scaling, configs[2]); there is no collective on the data path - only the timing max-reduce.
+Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      dominant kernel = the GCFN F->6F projection (gemm_kernel<PRO_NORM,EPI_STORE,1>, 39 % of
+                the model's FLOPs): algorithmic FLOPs (2*M*N*K per launch) / launch time measured with
+                hipEvents on the launch stream inside the timed region, vs the 157.3 TFLOP/s f32-MFMA peak.
+  cpu_baseline  the oracle (CPU restatement of the reference, same aten op sequence; kind "port")
+                timed on this host's cores on a bounded sample (B=1, one warm-up + best of 3).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+METRIC = "utterances/sec (4 s, 8 kHz, 2-spk) SepReformer-Base at 1/2/4/8 MI355X"
+VARIANT = "SepReformer_Base_WSJ0"
+SAMPLES = 32000
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table
+GFLOP_PER_UTT_MAIN, GFLOP_PER_UTT_FULL = 164.87, 182.16   # SURVEY.md section 8d (4 s, Base)
+
+
+def physical_cores() -> int:
+    """Distinct (socket, core) pairs from /proc/cpuinfo; falls back to the logical count."""
+    try:
+        seen, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        return len(seen) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(cfg, threads: int):
+    """Oracle forward on the host: B=1, 4 s, one warm-up + best of 3 (bounded: ~10-20 s of CPU work)."""
+    from oracle import sepreformer_oracle as orc
+    from sepreformer_amd.synth import synth_mixture, synth_state_dict
+    torch.set_num_threads(threads)
+    sd = synth_state_dict(cfg, 0)
+    x = synth_mixture(1, SAMPLES, seed=1234)
+    best = float("inf")
+    with torch.inference_mode():
+        orc.model_forward(sd, cfg, x)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            orc.model_forward(sd, cfg, x)
+            best = min(best, time.perf_counter() - t0)
+    return {"value": round(1.0 / best, 4), "unit": "utt/s", "cores": threads, "kind": "port",
+            "sample": f"oracle.model_forward (main + aux heads), B=1 x {SAMPLES} samples, fp32, 1 warm-up + best of 3, "
+                      f"{os.cpu_count()} logical CPUs visible"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary heads (NOT the reference's forward)")
+    args = ap.parse_args()
+
+    from sepreformer_amd import dist as sdist
+    from sepreformer_amd import lib as L
+    from sepreformer_amd.config import VARIANTS
+    from sepreformer_amd.model import Model
+    from sepreformer_amd.synth import synth_mixture
+
+    rank, world, local = sdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the separator path)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    lib = L.load()
+
+    cfg = VARIANTS[VARIANT]
+    model = Model.from_config(cfg, init_seed=0).load_synthetic_(0).eval().to(dev)
+    model.compute_aux = not args.no_aux
+    B = args.batch
+    # each rank separates its own utterances: seeds 1234 + global utterance index
+    x = synth_mixture(B, SAMPLES, seed=1234 + rank * B).to(dev)
+
+    def step():
+        return model(x)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize(dev)
+
+    # parity gate in the same run (rank 0's utterance 0 is the committed golden)
+    parity_db = None
+    if rank == 0:
+        import numpy as np
+        from oracle.sepreformer_oracle import agreement_db
+        g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_base_4s.npz"))
+        if args.warmup == 0:
+            out = step()
+        main_out = torch.stack([a[0:1] for a in out[0]], 0).cpu()
+        parity_db = round(agreement_db(main_out, torch.from_numpy(g["main"])), 1)
+
+    launches_per_step = 56                      # GCFN blocks per forward (SURVEY.md section 8g census)
+    L.check(lib.sepr_prof_start(L.SITE_GCFN_UP, launches_per_step * max(args.steps, 1) + 8), "sepr_prof_start")
+    sdist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    sdist.barrier()
+    elapsed = time.perf_counter() - t0
+    n_l, ms, fl = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
+    L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
+    elapsed = sdist.max_over_ranks(elapsed, dev)
+
+    if rank == 0:
+        utt_per_s = world * B * args.steps / elapsed
+        gflop = GFLOP_PER_UTT_MAIN if args.no_aux else GFLOP_PER_UTT_FULL
+        achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_gcfn_up.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        rec = {
+            "metric": METRIC, "value": round(utt_per_s, 3), "unit": "utt/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{VARIANT} inference, batch={B} per GPU, 4 s @ 8 kHz, 2 speakers "
+                                   f"(BASELINE.json configs[{1 if world == 1 else 2}])",
+                       "batch_per_gpu": B, "samples": SAMPLES, "aux_heads": not args.no_aux,
+                       "weights": "synthetic seed 0 (O(1) LayerScale)", "parallelism": f"utterance-sharded x{world}"},
+            "parity_db_vs_golden": parity_db,
+            "model_tflops": round(utt_per_s * gflop / 1e3 / world, 2),
+            "model_mfma_frac": round(utt_per_s * gflop / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+            "roofline": {"kernel": "gemm_kernel<PRO_NORM,EPI_STORE,1> (GCFN F->6F projection, LayerNorm prologue)",
+                         "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "launches": int(n_l.value), "avg_launch_ms": round(ms.value / max(n_l.value, 1), 4),
+                         "algorithmic_gflop_per_launch": round(fl.value / 1e9 / max(n_l.value, 1), 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = int(os.environ.get("SEPR_CPU_THREADS", str(physical_cores())))
+            rec["cpu_baseline"] = cpu_baseline(cfg, threads)
+            rec["speedup_vs_cpu"] = round(utt_per_s / rec["cpu_baseline"]["value"], 1)
+        print(json.dumps(rec), flush=True)
+    sdist.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,7 +59,10 @@ struct GemmArgs {
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_LDS_STRIDE = GEMM_BK + 4;
 constexpr int GEMM_THREADS = 256;
 
-template <int PRO, int EPI>
+// TAG does not change the code: it gives the two GCFN projections (60 % of the model's FLOPs) their own
+// kernel symbols, so a rocprofv3 kernel trace separates them from the other users of the same
+// prologue/epilogue pair (TAG 1 = GCFN F->6F, TAG 2 = GCFN 3F->F, 0 = everything else).
+template <int PRO, int EPI, int TAG = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
   constexpr bool GLU = (EPI == EPI_GLU);
   constexpr int LS = GEMM_LDS_STRIDE;

@@ -33,10 +33,10 @@ static void prof_end(long long slot, double flops, hipStream_t stream) {
   g_prof.flops += flops;
 }
 
-template <int PRO, int EPI>
+template <int PRO, int EPI, int TAG = 0>
 static void launch_inst(const GemmArgs& a, hipStream_t stream) {
   const int grid = gemm_grid(a, EPI == EPI_GLU);
-  hipLaunchKernelGGL((gemm_kernel<PRO, EPI>), dim3(grid), dim3(GEMM_THREADS), 0, stream, a);
+  hipLaunchKernelGGL((gemm_kernel<PRO, EPI, TAG>), dim3(grid), dim3(GEMM_THREADS), 0, stream, a);
 }
 
 int launch_gemm(int pro, int epi, const GemmArgs& a, int site, hipStream_t stream) {
@@ -53,6 +53,11 @@ int launch_gemm(int pro, int epi, const GemmArgs& a, int site, hipStream_t strea
   const bool timed = prof_begin(site, stream, &slot);
 
   const int key = pro * 16 + epi;
+  if (site == SEPR_SITE_GCFN_UP && key == PRO_NORM * 16 + EPI_STORE) {
+    launch_inst<PRO_NORM, EPI_STORE, 1>(a, stream);
+  } else if (site == SEPR_SITE_GCFN_DOWN && key == PRO_PLAIN * 16 + EPI_RES) {
+    launch_inst<PRO_PLAIN, EPI_RES, 2>(a, stream);
+  } else
   switch (key) {
     case PRO_PLAIN * 16 + EPI_STORE: launch_inst<PRO_PLAIN, EPI_STORE>(a, stream); break;
     case PRO_PLAIN * 16 + EPI_GLU:   launch_inst<PRO_PLAIN, EPI_GLU>(a, stream); break;

@@ -13,7 +13,7 @@ import threading
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsepr_hip.so")
+LIB_PATH = os.path.join(_HERE, "_native", "libsepr_hip.so")
 
 SEPR_OK, SEPR_EINVAL, SEPR_EWORKSPACE, SEPR_EHIP = 0, -1, -2, -3
 _ERR = {SEPR_EINVAL: "SEPR_EINVAL (bad shape / unsupported size / null pointer)",
