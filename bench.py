@@ -59,23 +59,33 @@ def physical_cores() -> int:
         return os.cpu_count() or 1
 
 
-def cpu_baseline(cfg, threads: int):
-    """Oracle forward on the host: B=1, 4 s, one warm-up + best of 3 (bounded: ~10-20 s of CPU work)."""
+def cpu_baseline(cfg, max_threads: int):
+    """Oracle forward on the host cores, bounded sample: B=1, 4 s.  aten's intra-op threading stops
+    scaling (and then regresses) long before a 2-socket host is full for these small ops, so the thread
+    count is swept and the FASTEST setting is reported (1 warm-up + best of 2 per setting, ~20-30 s)."""
     from oracle import sepreformer_oracle as orc
     from sepreformer_amd.synth import synth_mixture, synth_state_dict
-    torch.set_num_threads(threads)
     sd = synth_state_dict(cfg, 0)
     x = synth_mixture(1, SAMPLES, seed=1234)
-    best = float("inf")
+    sweep, results = sorted({t for t in (8, 16, 32, 64, max_threads) if t <= max_threads}), {}
+    t_budget = time.perf_counter() + 45.0
     with torch.inference_mode():
-        orc.model_forward(sd, cfg, x)
-        for _ in range(3):
-            t0 = time.perf_counter()
+        for th in sweep:
+            if time.perf_counter() > t_budget and results:
+                break
+            torch.set_num_threads(th)
             orc.model_forward(sd, cfg, x)
-            best = min(best, time.perf_counter() - t0)
-    return {"value": round(1.0 / best, 4), "unit": "utt/s", "cores": threads, "kind": "port",
-            "sample": f"oracle.model_forward (main + aux heads), B=1 x {SAMPLES} samples, fp32, 1 warm-up + best of 3, "
-                      f"{os.cpu_count()} logical CPUs visible"}
+            best = float("inf")
+            for _ in range(2):
+                t0 = time.perf_counter()
+                orc.model_forward(sd, cfg, x)
+                best = min(best, time.perf_counter() - t0)
+            results[th] = best
+    th = min(results, key=results.get)
+    return {"value": round(1.0 / results[th], 4), "unit": "utt/s", "cores": th, "kind": "port",
+            "sample": f"oracle.model_forward (main + aux heads), B=1 x {SAMPLES} samples, fp32, 1 warm-up + best of 2 "
+                      f"per thread count; seconds by threads: " + ", ".join(f"{k}:{v:.2f}" for k, v in results.items())
+                      + f"; host has {physical_cores()} physical / {os.cpu_count()} logical cores"}
 
 
 def main():

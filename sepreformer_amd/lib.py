@@ -90,6 +90,11 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} is missing: the HIP extension is not built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C sepreformer_amd/csrc`). "
                 "There is no CPU fallback for the separator path.")
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be the one already in
+        # the process when libsepr_hip.so is dlopen'ed, otherwise the loader binds this library to
+        # /opt/rocm's copy and the two runtimes do not share devices or streams
+        # ("no ROCm-capable device is detected" at the first launch).
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError -> a declared symbol is not exported

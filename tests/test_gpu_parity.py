@@ -29,8 +29,17 @@ def record(name, db):
     REPORT[name] = round(float(db), 2)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "parity_report.json"), "w") as f:
-        json.dump(REPORT, f, indent=1, sort_keys=True)
+    path = os.path.join(out, "parity_report.json")
+    merged = {}
+    if os.path.exists(path):        # test groups may run as separate processes (tools/gpu_check.sh)
+        try:
+            with open(path) as f:
+                merged = json.load(f)
+        except ValueError:
+            merged = {}
+    merged.update(REPORT)
+    with open(path, "w") as f:
+        json.dump(merged, f, indent=1, sort_keys=True)
 
 
 def agree(name, got, want, min_db=MIN_DB):
