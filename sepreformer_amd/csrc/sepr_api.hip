@@ -16,7 +16,7 @@ static const float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default (network.py:50
 
 // ---- workspace plans (floats unless noted) --------------------------------------------------------
 static size_t ws_gcfn(long long M, int F) {
-  return align_up(2 * M * 4) + align_up(6LL * F * M * 4) + align_up(3LL * F * M * 4) + 1024;
+  return align_up(2 * M * 4) + align_up(3LL * F * M * 4) + 1024;
 }
 static size_t ws_cla(long long M, int F) {
   return align_up(2 * M * 4) + 2 * align_up((long long)F * M * 4) + align_up(2LL * F * M * 4) + 1024;
@@ -96,18 +96,18 @@ extern "C" int sepr_gcfn_fwd(const float* x, float* y, int n, int T, int F, cons
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
   Arena ar(ws, ws_bytes);
   float* stats = ar.f32(2 * M);
-  float* h = ar.f32(6LL * F * M);
   float* g = ar.f32(3LL * F * M);
   if (!ar.ok()) return SEPR_EWORKSPACE;
   SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
-  {  // net1: LayerNorm -> Linear F->6F                                   (network.py:61)
+  {  // net1: LayerNorm -> Linear F->6F, then depthwise k=3 + GLU on the tile while it is still in LDS:
+     // the [rows, 6F] hidden tensor (3 KB per row) never goes to HBM      (network.py:61-65)
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = 6 * F; a.K = F;
     a.A = x; a.lda = F; a.stats = stats; a.gamma = w->ln_g; a.beta = w->ln_b;
-    a.W = w->w1; a.bias = w->b1; a.Y = h; a.ldc = 6 * F;
-    SEPR_TRY(launch_gemm(PRO_NORM, EPI_STORE, a, SEPR_SITE_GCFN_UP, st));
+    a.W = w->w1; a.bias = w->b1; a.Y = g; a.ldc = 3 * F;
+    a.dw_w = w->dw_w; a.dw_b = w->dw_b; a.T = T;
+    SEPR_TRY(launch_gemm(PRO_NORM, EPI_DWGLU, a, SEPR_SITE_GCFN_UP, st));
   }
-  SEPR_TRY(launch_dwglu(h, g, n, T, F, w->dw_w, w->dw_b, st));            // (network.py:62-65)
   {  // net2 Linear 3F->F, LayerScale, residual                            (network.py:65-66)
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = F; a.K = 3 * F;

@@ -22,7 +22,7 @@
 namespace sepr {
 
 enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_CAT2 = 2 };
-enum { EPI_STORE = 0, EPI_GLU = 1, EPI_GELU = 2, EPI_RES = 3, EPI_GATE = 4, EPI_SPLIT = 5, EPI_MASK = 6 };
+enum { EPI_STORE = 0, EPI_GLU = 1, EPI_GELU = 2, EPI_RES = 3, EPI_GATE = 4, EPI_SPLIT = 5, EPI_MASK = 6, EPI_DWGLU = 7 };
 
 struct GemmArgs {
   int M, N, K;
@@ -54,17 +54,25 @@ struct GemmArgs {
   const float* aux;  // EPI_GATE: att [M/fac][N]; EPI_MASK: enc [(M/rows_out/S)*rows_out ...][N]
   int T, Tp, fac;    // EPI_GATE: frames per sequence, pooled frames, T/Tp.  EPI_SPLIT: T
   int S, Fs;         // EPI_SPLIT / EPI_MASK: speakers; EPI_SPLIT: F
+  // EPI_DWGLU (GCFN): depthwise k=3 conv along frames + GLU applied to the projected tile before it
+  // leaves the CU.  dw_w [3][N] tap-major, dw_b [N]; frames per sequence in T.  Output Y is [M][N/2].
+  const float* dw_w;
+  const float* dw_b;
 };
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_LDS_STRIDE = GEMM_BK + 4;
 constexpr int GEMM_THREADS = 256;
+// EPI_DWGLU tiles overlap by one frame on each side (the conv halo is recomputed): 126 new rows per tile
+constexpr int GEMM_DW_ROWS = GEMM_BM - 2;
 
 // TAG does not change the code: it gives the two GCFN projections (60 % of the model's FLOPs) their own
 // kernel symbols, so a rocprofv3 kernel trace separates them from the other users of the same
 // prologue/epilogue pair (TAG 1 = GCFN F->6F, TAG 2 = GCFN 3F->F, 0 = everything else).
 template <int PRO, int EPI, int TAG = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
-  constexpr bool GLU = (EPI == EPI_GLU);
+  constexpr bool DWGLU = (EPI == EPI_DWGLU);
+  constexpr bool GLU = (EPI == EPI_GLU) || DWGLU;   // value / gate column pairing of the weight tile
+  constexpr int ROWS_OUT = DWGLU ? GEMM_DW_ROWS : GEMM_BM;
   constexpr int LS = GEMM_LDS_STRIDE;
   __shared__ __attribute__((aligned(16))) float smem[2 * (GEMM_BM + GEMM_BN) * LS];
   float* const As0 = smem;
@@ -79,13 +87,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
   // XCD-aware tile order: workgroup b runs on XCD b % 8; the NB column tiles of one row tile are made
   // consecutive *on the same XCD* so the A rows they share are served by one L2.
   const int NB = GLU ? (a.N / 2 + 63) / 64 : (a.N + GEMM_BN - 1) / GEMM_BN;
-  const int MB = (a.M + GEMM_BM - 1) / GEMM_BM;
+  const int MB = (a.M + ROWS_OUT - 1) / ROWS_OUT;
   const int xcd = blockIdx.x & 7;
   const int q = blockIdx.x >> 3;
   const int mb = (q / NB) * 8 + xcd;
   const int nb = q % NB;
   if (mb >= MB) return;
-  const int m0 = mb * GEMM_BM;
+  const int m0 = mb * ROWS_OUT - (DWGLU ? 1 : 0);   // DWGLU: tile row 0 is the frame before the first output
 
   // ---- per-thread staging assignment: rows r0 + 32 i, float4 column c4 of the 32-wide K tile ----
   const int c4 = tid & 7;
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
     va[i] = false;
     mean[i] = 0.f;
     rstd[i] = 0.f;
-    if (m < a.M) {
+    if (m >= 0 && m < a.M) {
       long long src = m;
       int seq = 0;
       bool valid = true;
@@ -141,9 +149,24 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
     pw[i] = a.W + (vw[i] ? (long long)wrow * a.K : 0);
   }
 
+  // Row validity as a 0/1 multiplier: keeps the staging code branch-free.  (A select here makes hipcc
+  // predicate the LayerNorm math under exec masks; the loads it then "may not have waited for" force
+  // an s_waitcnt vmcnt(0) in front of the MFMA block and serialise HBM latency with compute.)
+  float mka[4], mkw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mka[i] = va[i] ? 1.f : 0.f;
+    mkw[i] = vw[i] ? 1.f : 0.f;
+  }
+
   float4 ra[4], rb[4];
+  float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = zero4();
   auto load_tile = [&](int kt) {
     const int k = kt * GEMM_BK + 4 * c4;
+    if (PRO == PRO_NORM) {
+      g4 = ld4(a.gamma + k);
+      b4 = ld4(a.beta + k);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (PRO == PRO_CAT2) {
@@ -154,27 +177,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
       rb[i] = ld4(pw[i] + k);
     }
   };
-  auto store_tile = [&](int kt, int buf) {
+  auto store_tile = [&](int buf) {
     float* As = As0 + buf * GEMM_BM * LS;
     float* Bs = Bs0 + buf * GEMM_BN * LS;
-    float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = zero4();
-    if (PRO == PRO_NORM) {
-      const int k = kt * GEMM_BK + 4 * c4;
-      g4 = ld4(a.gamma + k);
-      b4 = ld4(a.beta + k);
-    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = ra[i];
       if (PRO == PRO_NORM) {
-        v.x = (v.x - mean[i]) * rstd[i] * g4.x + b4.x;
-        v.y = (v.y - mean[i]) * rstd[i] * g4.y + b4.y;
-        v.z = (v.z - mean[i]) * rstd[i] * g4.z + b4.z;
-        v.w = (v.w - mean[i]) * rstd[i] * g4.w + b4.w;
+        // invalid rows carry mean = rstd = 0 and mask 0: exactly zero (pad_signal semantics)
+        const float sc = rstd[i] * mka[i];
+        v.x = ((v.x - mean[i]) * sc) * g4.x + b4.x * mka[i];
+        v.y = ((v.y - mean[i]) * sc) * g4.y + b4.y * mka[i];
+        v.z = ((v.z - mean[i]) * sc) * g4.z + b4.z * mka[i];
+        v.w = ((v.w - mean[i]) * sc) * g4.w + b4.w * mka[i];
+      } else {
+        v.x *= mka[i]; v.y *= mka[i]; v.z *= mka[i]; v.w *= mka[i];
       }
-      // rows outside the map are exactly zero (pad_signal semantics), also under PRO_NORM
-      st4(As + (r0 + 32 * i) * LS + 4 * c4, va[i] ? v : zero4());
-      st4(Bs + (r0 + 32 * i) * LS + 4 * c4, vw[i] ? rb[i] : zero4());
+      float4 w = rb[i];
+      w.x *= mkw[i]; w.y *= mkw[i]; w.z *= mkw[i]; w.w *= mkw[i];
+      st4(As + (r0 + 32 * i) * LS + 4 * c4, v);
+      st4(Bs + (r0 + 32 * i) * LS + 4 * c4, w);
     }
   };
 
@@ -192,7 +214,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
 
   const int nk = a.K / GEMM_BK;
   load_tile(0);
-  store_tile(0, 0);
+  store_tile(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -217,8 +239,64 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].w, xf[mt].w, acc[nt][mt], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) store_tile(kt + 1, cur ^ 1);
+    if (kt + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
+  }
+
+  if (DWGLU) {
+    // ---- GCFN epilogue: h tile (+bias) -> LDS, depthwise k=3 along frames, GLU, store g ----------
+    // (the K loop's closing barrier guarantees every wave is done with the staging buffers)
+    constexpr int HS = GEMM_BN + 4;
+    float* const Hs = smem;   // [128 rows][64 value | 64 gate] fp32, 67.6 KB of the 72 KB staging area
+    const int half = a.N / 2;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int cl = wn * 32 + (nt & 1) * 16 + 4 * fg;        // column inside the 64-wide half
+      const int gc = nb * 64 + cl;
+      float4 b = zero4();
+      if (gc < half) b = ld4(a.bias + (nt < 2 ? 0 : half) + gc);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 c = acc[nt][mt];
+        st4(Hs + (wm * 64 + mt * 16 + fi) * HS + (nt >> 1) * 64 + cl,
+            make_float4(c[0] + b.x, c[1] + b.y, c[2] + b.z, c[3] + b.w));
+      }
+    }
+    __syncthreads();
+    const int q4 = tid & 15, rg = tid >> 4;                     // 16 float4 columns x 16 strips of 8 rows
+    const int gc = nb * 64 + 4 * q4;
+    if (gc < half) {
+      const float4 wv0 = ld4(a.dw_w + gc), wv1 = ld4(a.dw_w + a.N + gc), wv2 = ld4(a.dw_w + 2 * a.N + gc);
+      const float4 wg0 = ld4(a.dw_w + half + gc), wg1 = ld4(a.dw_w + a.N + half + gc), wg2 = ld4(a.dw_w + 2 * a.N + half + gc);
+      const float4 bv = ld4(a.dw_b + gc), bg = ld4(a.dw_b + half + gc);
+      const int rs = 1 + 8 * rg;
+      float4 pv = ld4(Hs + (rs - 1) * HS + 4 * q4), pg = ld4(Hs + (rs - 1) * HS + 64 + 4 * q4);
+      float4 cv = ld4(Hs + rs * HS + 4 * q4), cg = ld4(Hs + rs * HS + 64 + 4 * q4);
+      int t = (m0 + rs) % a.T;                                  // m0 + rs >= 0 always
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = rs + q;
+        const int m = m0 + r;
+        if (r > GEMM_DW_ROWS || m >= a.M) break;
+        const float4 nv = ld4(Hs + (r + 1) * HS + 4 * q4), ng = ld4(Hs + (r + 1) * HS + 64 + 4 * q4);
+        const float f0 = (t == 0) ? 0.f : 1.f;                  // zero padding at sequence starts / ends
+        const float f2 = (t == a.T - 1) ? 0.f : 1.f;
+        float4 v, g;
+        v.x = fmaf(wv2.x * f2, nv.x, fmaf(wv1.x, cv.x, fmaf(wv0.x * f0, pv.x, bv.x)));
+        v.y = fmaf(wv2.y * f2, nv.y, fmaf(wv1.y, cv.y, fmaf(wv0.y * f0, pv.y, bv.y)));
+        v.z = fmaf(wv2.z * f2, nv.z, fmaf(wv1.z, cv.z, fmaf(wv0.z * f0, pv.z, bv.z)));
+        v.w = fmaf(wv2.w * f2, nv.w, fmaf(wv1.w, cv.w, fmaf(wv0.w * f0, pv.w, bv.w)));
+        g.x = fmaf(wg2.x * f2, ng.x, fmaf(wg1.x, cg.x, fmaf(wg0.x * f0, pg.x, bg.x)));
+        g.y = fmaf(wg2.y * f2, ng.y, fmaf(wg1.y, cg.y, fmaf(wg0.y * f0, pg.y, bg.y)));
+        g.z = fmaf(wg2.z * f2, ng.z, fmaf(wg1.z, cg.z, fmaf(wg0.z * f0, pg.z, bg.z)));
+        g.w = fmaf(wg2.w * f2, ng.w, fmaf(wg1.w, cg.w, fmaf(wg0.w * f0, pg.w, bg.w)));
+        st4(a.Y + (long long)m * a.ldc + gc,
+            make_float4(v.x * sigmoid_f(g.x), v.y * sigmoid_f(g.y), v.z * sigmoid_f(g.z), v.w * sigmoid_f(g.w)));
+        pv = cv; pg = cg; cv = nv; cg = ng;
+        t = (t + 1 == a.T) ? 0 : t + 1;
+      }
+    }
+    return;
   }
 
   // ---- epilogue: lane holds Y[m][ncol .. ncol+3] per (nt, mt) -----------------------------------
@@ -241,7 +319,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
       const int l = m - seq * a.rows_out;
       aux_row = (long long)(seq / a.S) * a.rows_out + l;
     }
-    if (GLU) {
+    if (EPI == EPI_GLU) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const int ncol = nb * 64 + wn * 32 + nt * 16 + 4 * fg;
@@ -305,9 +383,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
   }
 }
 
-inline int gemm_grid(const GemmArgs& a, bool glu) {
+inline int gemm_grid(const GemmArgs& a, int epi) {
+  const bool glu = (epi == EPI_GLU) || (epi == EPI_DWGLU);
+  const int rows = (epi == EPI_DWGLU) ? GEMM_DW_ROWS : GEMM_BM;
   const int NB = glu ? (a.N / 2 + 63) / 64 : (a.N + GEMM_BN - 1) / GEMM_BN;
-  const int MB = (a.M + GEMM_BM - 1) / GEMM_BM;
+  const int MB = (a.M + rows - 1) / rows;
   return ((MB + 7) / 8) * 8 * NB;
 }
 

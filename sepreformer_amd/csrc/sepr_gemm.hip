@@ -35,7 +35,7 @@ static void prof_end(long long slot, double flops, hipStream_t stream) {
 
 template <int PRO, int EPI, int TAG = 0>
 static void launch_inst(const GemmArgs& a, hipStream_t stream) {
-  const int grid = gemm_grid(a, EPI == EPI_GLU);
+  const int grid = gemm_grid(a, EPI);
   hipLaunchKernelGGL((gemm_kernel<PRO, EPI, TAG>), dim3(grid), dim3(GEMM_THREADS), 0, stream, a);
 }
 
@@ -47,14 +47,15 @@ int launch_gemm(int pro, int epi, const GemmArgs& a, int site, hipStream_t strea
   if ((a.lda % 4) != 0 || (a.ldc % 4) != 0) return SEPR_EINVAL;
   if (pro == PRO_CAT2 && (!a.A2 || (a.ksplit % GEMM_BK) != 0 || (a.lda2 % 4) != 0)) return SEPR_EINVAL;
   if (pro == PRO_NORM && (!a.stats || !a.gamma || !a.beta)) return SEPR_EINVAL;
-  if (epi == EPI_GLU && !a.bias) return SEPR_EINVAL;
+  if ((epi == EPI_GLU || epi == EPI_DWGLU) && !a.bias) return SEPR_EINVAL;
+  if (epi == EPI_DWGLU && (!a.dw_w || !a.dw_b || a.T <= 0 || ((a.N / 2) % 4) != 0)) return SEPR_EINVAL;
 
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
 
   const int key = pro * 16 + epi;
-  if (site == SEPR_SITE_GCFN_UP && key == PRO_NORM * 16 + EPI_STORE) {
-    launch_inst<PRO_NORM, EPI_STORE, 1>(a, stream);
+  if (site == SEPR_SITE_GCFN_UP && key == PRO_NORM * 16 + EPI_DWGLU) {
+    launch_inst<PRO_NORM, EPI_DWGLU, 1>(a, stream);
   } else if (site == SEPR_SITE_GCFN_DOWN && key == PRO_PLAIN * 16 + EPI_RES) {
     launch_inst<PRO_PLAIN, EPI_RES, 2>(a, stream);
   } else
