@@ -172,7 +172,7 @@ def main():
             "parity_db_vs_golden": parity_db,
             "model_tflops": round(utt_per_s * gflop / 1e3 / world, 2),
             "model_mfma_frac": round(utt_per_s * gflop / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
-            "roofline": {"kernel": "gemm_kernel<PRO_NORM,EPI_STORE,1> (GCFN F->6F projection, LayerNorm prologue)",
+            "roofline": {"kernel": "gemm_kernel<PRO_NORM,EPI_DWGLU,1> (GCFN F->6F projection: LayerNorm prologue, depthwise-conv+GLU epilogue)",
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launches": int(n_l.value), "avg_launch_ms": round(ms.value / max(n_l.value, 1), 4),

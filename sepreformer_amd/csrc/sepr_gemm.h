@@ -60,7 +60,22 @@ struct GemmArgs {
   const float* dw_b;
 };
 
-constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_LDS_STRIDE = GEMM_BK + 4;
+#ifndef SEPR_GEMM_PERSIST
+#define SEPR_GEMM_PERSIST 1   // 1: <= 2 workgroups per CU walking tiles, 0: one tile per workgroup (A/B builds)
+#endif
+#ifndef SEPR_GEMM_STAGGER
+#define SEPR_GEMM_STAGGER 1   // 1: de-phase the two co-resident workgroups of a CU at kernel start
+#endif
+#ifndef SEPR_ABL_NOLOAD
+#define SEPR_ABL_NOLOAD 0
+#endif
+#ifndef SEPR_ABL_NOSTORE
+#define SEPR_ABL_NOSTORE 0
+#endif
+#ifndef SEPR_GEMM_LDS_PAD
+#define SEPR_GEMM_LDS_PAD 8   // floats of padding per 32-float LDS row: 8 -> stride 40, conflict-free b128 reads
+#endif
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_LDS_STRIDE = GEMM_BK + SEPR_GEMM_LDS_PAD;
 constexpr int GEMM_THREADS = 256;
 // EPI_DWGLU tiles overlap by one frame on each side (the conv halo is recomputed): 126 new rows per tile
 constexpr int GEMM_DW_ROWS = GEMM_BM - 2;
@@ -68,8 +83,15 @@ constexpr int GEMM_DW_ROWS = GEMM_BM - 2;
 // TAG does not change the code: it gives the two GCFN projections (60 % of the model's FLOPs) their own
 // kernel symbols, so a rocprofv3 kernel trace separates them from the other users of the same
 // prologue/epilogue pair (TAG 1 = GCFN F->6F, TAG 2 = GCFN 3F->F, 0 = everything else).
+//
+// The kernel is PERSISTENT: the grid is at most 2 workgroups per CU and each workgroup walks a strided
+// list of output tiles.  K is only 128-512 here (4-16 K tiles), so a one-tile-per-workgroup kernel spends
+// a third of every wave's life parked on the first HBM round trip and on the store tail (measured: 28 %
+// SQ_WAIT_ANY, 60 % MFMA utilisation at K = 128 against 80 % at K = 4096).  Walking tiles lets the first
+// K tile of the NEXT output tile be fetched before the epilogue of the current one, so the only exposed
+// memory latency is the very first tile's.
 template <int PRO, int EPI, int TAG = 0>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a) {
   constexpr bool DWGLU = (EPI == EPI_DWGLU);
   constexpr bool GLU = (EPI == EPI_GLU) || DWGLU;   // value / gate column pairing of the weight tile
   constexpr int ROWS_OUT = DWGLU ? GEMM_DW_ROWS : GEMM_BM;
@@ -83,85 +105,76 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
   const int wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int fi = lane & 15, fg = lane >> 4;
+  const int c4 = tid & 7;    // staging: float4 column of the 32-wide K tile
+  const int r0 = tid >> 3;   // staging: rows r0 + 32 i
 
-  // XCD-aware tile order: workgroup b runs on XCD b % 8; the NB column tiles of one row tile are made
-  // consecutive *on the same XCD* so the A rows they share are served by one L2.
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 and the grid is a multiple of 8, so a workgroup
+  // stays on "its" XCD for every tile it walks; the NB column tiles of one row tile are consecutive on
+  // the same XCD, so the A rows they share are served by one L2.
   const int NB = GLU ? (a.N / 2 + 63) / 64 : (a.N + GEMM_BN - 1) / GEMM_BN;
   const int MB = (a.M + ROWS_OUT - 1) / ROWS_OUT;
-  const int xcd = blockIdx.x & 7;
-  const int q = blockIdx.x >> 3;
-  const int mb = (q / NB) * 8 + xcd;
-  const int nb = q % NB;
-  if (mb >= MB) return;
-  const int m0 = mb * ROWS_OUT - (DWGLU ? 1 : 0);   // DWGLU: tile row 0 is the frame before the first output
+  const int ntiles = ((MB + 7) / 8) * 8 * NB;
+  const int nk = a.K / GEMM_BK;
 
-  // ---- per-thread staging assignment: rows r0 + 32 i, float4 column c4 of the 32-wide K tile ----
-  const int c4 = tid & 7;
-  const int r0 = tid >> 3;
-  // Loads are unconditional (rows outside the problem point at row 0 and are zeroed by a select), so
-  // the K loop carries no divergent branches.
-  const float* pa[4];
-  const float* pa2[4];
-  bool va[4], vw[4];
-  float mean[4], rstd[4];
-  const float* pw[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + r0 + 32 * i;
-    pa[i] = a.A;
-    pa2[i] = (PRO == PRO_CAT2) ? a.A2 : a.A;
-    va[i] = false;
-    mean[i] = 0.f;
-    rstd[i] = 0.f;
-    if (m >= 0 && m < a.M) {
-      long long src = m;
-      int seq = 0;
-      bool valid = true;
-      if (a.rows_out > 0) {
-        seq = m / a.rows_out;
-        const int r = m - seq * a.rows_out;
-        valid = r < a.rows_valid;
-        const int rr = valid ? (a.idx ? a.idx[r] : r) : 0;
-        src = (long long)seq * a.rows_src + (rr >> a.a_shift);
-      }
-      if (valid) {
-        va[i] = true;
-        pa[i] = a.A + src * a.lda;
-        if (PRO == PRO_CAT2) pa2[i] = a.A2 + (long long)m * a.lda2;
-        if (PRO == PRO_NORM) {
-          const long long si = a.stat_seq ? seq : m;
-          mean[i] = a.stats[2 * si];
-          rstd[i] = a.stats[2 * si + 1];
-        }
-      }
-    }
-    // weight rows of this tile: plain = 128 consecutive rows; GLU = 64 value rows then their 64 gate rows
-    const int rr = r0 + 32 * i;
-    int wrow;
-    if (GLU) {
-      const int c = nb * 64 + (rr & 63);
-      vw[i] = c < a.N / 2;
-      wrow = (rr < 64) ? c : a.N / 2 + c;
-    } else {
-      wrow = nb * GEMM_BN + rr;
-      vw[i] = wrow < a.N;
-    }
-    pw[i] = a.W + (vw[i] ? (long long)wrow * a.K : 0);
-  }
-
-  // Row validity as a 0/1 multiplier: keeps the staging code branch-free.  (A select here makes hipcc
-  // predicate the LayerNorm math under exec masks; the loads it then "may not have waited for" force
-  // an s_waitcnt vmcnt(0) in front of the MFMA block and serialise HBM latency with compute.)
-  float mka[4], mkw[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    mka[i] = va[i] ? 1.f : 0.f;
-    mkw[i] = vw[i] ? 1.f : 0.f;
-  }
-
+  // ---- staging state of the tile being loaded ------------------------------------------------------
+  // 32-bit element offsets from the kernel-argument bases (SGPR base + VGPR offset addressing; the
+  // kernel has to stay within 256 registers for two waves per SIMD).  Row validity is a 0/1 multiplier:
+  // loads are unconditional (invalid rows read row 0) and the staging code is branch-free.
+  unsigned pa[4], pa2[4], pw[4];
+  float mka[4], mean[4], rstd[4];
   float4 ra[4], rb[4];
   float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = zero4();
+
+  auto setup = [&](int m0, int nb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + r0 + 32 * i;
+      pa[i] = 0u;
+      pa2[i] = 0u;
+      mka[i] = 0.f;
+      mean[i] = 0.f;
+      rstd[i] = 0.f;
+      if (m >= 0 && m < a.M) {
+        long long src = m;
+        int seq = 0;
+        bool valid = true;
+        if (a.rows_out > 0) {
+          seq = m / a.rows_out;
+          const int r = m - seq * a.rows_out;
+          valid = r < a.rows_valid;
+          const int rr = valid ? (a.idx ? a.idx[r] : r) : 0;
+          src = (long long)seq * a.rows_src + (rr >> a.a_shift);
+        }
+        if (valid) {
+          mka[i] = 1.f;
+          pa[i] = (unsigned)(src * a.lda);
+          if (PRO == PRO_CAT2) pa2[i] = (unsigned)((long long)m * a.lda2);
+          if (PRO == PRO_NORM) {
+            const long long si = a.stat_seq ? seq : m;
+            mean[i] = a.stats[2 * si];
+            rstd[i] = a.stats[2 * si + 1];
+          }
+        }
+      }
+      // weight rows of the tile: plain = 128 consecutive rows; GLU = 64 value rows then their 64 gate rows
+      const int rr = r0 + 32 * i;
+      int wrow;
+      bool wvalid;
+      if (GLU) {
+        const int c = nb * 64 + (rr & 63);
+        wvalid = c < a.N / 2;
+        wrow = (rr < 64) ? c : a.N / 2 + c;
+      } else {
+        wrow = nb * GEMM_BN + rr;
+        wvalid = wrow < a.N;
+      }
+      pw[i] = wvalid ? (unsigned)wrow * (unsigned)a.K : 0u;
+    }
+  };
   auto load_tile = [&](int kt) {
+#if SEPR_ABL_NOLOAD
+    if (kt > 0 || blockIdx.x != (unsigned)a.M) return;   // timing ablation: no global loads after setup
+#endif
     const int k = kt * GEMM_BK + 4 * c4;
     if (PRO == PRO_NORM) {
       g4 = ld4(a.gamma + k);
@@ -170,11 +183,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (PRO == PRO_CAT2) {
-        ra[i] = (k < a.ksplit) ? ld4(pa[i] + k) : ld4(pa2[i] + (k - a.ksplit));
+        ra[i] = (k < a.ksplit) ? ld4(a.A + (pa[i] + k)) : ld4(a.A2 + (pa2[i] + (k - a.ksplit)));
       } else {
-        ra[i] = ld4(pa[i] + k);
+        ra[i] = ld4(a.A + (pa[i] + k));
       }
-      rb[i] = ld4(pw[i] + k);
+      rb[i] = ld4(a.W + (pw[i] + k));
     }
   };
   auto store_tile = [&](int buf) {
@@ -193,18 +206,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
       } else {
         v.x *= mka[i]; v.y *= mka[i]; v.z *= mka[i]; v.w *= mka[i];
       }
-      float4 w = rb[i];
-      w.x *= mkw[i]; w.y *= mkw[i]; w.z *= mkw[i]; w.w *= mkw[i];
       st4(As + (r0 + 32 * i) * LS + 4 * c4, v);
-      st4(Bs + (r0 + 32 * i) * LS + 4 * c4, w);
+      // weight rows past N read row 0: they only feed output columns that are never stored
+      st4(Bs + (r0 + 32 * i) * LS + 4 * c4, rb[i]);
     }
   };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // LDS row of the weight fragment nt of this wave
   int brow[4];
@@ -212,37 +218,43 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
   for (int nt = 0; nt < 4; ++nt)
     brow[nt] = GLU ? ((nt >> 1) * 64 + wn * 32 + (nt & 1) * 16) : (wn * 64 + nt * 16);
 
-  const int nk = a.K / GEMM_BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const float* As = As0 + cur * GEMM_BM * LS;
-    const float* Bs = Bs0 + cur * GEMM_BN * LS;
+  f32x4 acc[4][4];
+  auto read_frags = [&](const float* As, const float* Bs, int kk, float4 (&wf)[4], float4 (&xf)[4]) {
 #pragma unroll
-    for (int kk = 0; kk < GEMM_BK / 16; ++kk) {
-      float4 wf[4], xf[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        wf[t] = ld4(Bs + (brow[t] + fi) * LS + kk * 16 + 4 * fg);
-        xf[t] = ld4(As + (wm * 64 + t * 16 + fi) * LS + kk * 16 + 4 * fg);
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].x, xf[mt].x, acc[nt][mt], 0, 0, 0);
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].y, xf[mt].y, acc[nt][mt], 0, 0, 0);
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].z, xf[mt].z, acc[nt][mt], 0, 0, 0);
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].w, xf[mt].w, acc[nt][mt], 0, 0, 0);
-        }
+    for (int t = 0; t < 4; ++t) {
+      wf[t] = ld4(Bs + (brow[t] + fi) * LS + kk * 16 + 4 * fg);
+      xf[t] = ld4(As + (wm * 64 + t * 16 + fi) * LS + kk * 16 + 4 * fg);
     }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
-    __syncthreads();
-  }
+  };
+  auto mma16 = [&](const float4 (&wf)[4], const float4 (&xf)[4]) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].x, xf[mt].x, acc[nt][mt], 0, 0, 0);
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].y, xf[mt].y, acc[nt][mt], 0, 0, 0);
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].z, xf[mt].z, acc[nt][mt], 0, 0, 0);
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].w, xf[mt].w, acc[nt][mt], 0, 0, 0);
+      }
+  };
+  auto decode = [&](int tile, int& m0, int& nb) -> bool {
+    const int q = tile >> 3;
+    const int mb = (q / NB) * 8 + (tile & 7);
+    nb = q % NB;
+    m0 = mb * ROWS_OUT - (DWGLU ? 1 : 0);   // DWGLU: tile row 0 is the frame before the first output
+    return mb < MB;
+  };
 
+  auto epilogue = [&](const int m0, const int nb) {
+#if SEPR_ABL_NOSTORE
+    {   // timing ablation: keep the accumulators live, store nothing
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+      return;
+    }
+#endif
   if (DWGLU) {
     // ---- GCFN epilogue: h tile (+bias) -> LDS, depthwise k=3 along frames, GLU, store g ----------
     // (the K loop's closing barrier guarantees every wave is done with the staging buffers)
@@ -299,96 +311,157 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
     return;
   }
 
-  // ---- epilogue: lane holds Y[m][ncol .. ncol+3] per (nt, mt) -----------------------------------
+  // ---- generic epilogue, staged through LDS -------------------------------------------------------------
+  // In the MFMA C layout a store instruction of the accumulators would touch 16 rows x 64 B (partial
+  // cache lines; measured: the direct store tail cost 20 % of the kernel).  The tile goes to LDS first
+  // (the staging buffers are free after the K loop) and is written out row-contiguously: a wave covers two
+  // full 512-byte rows per instruction, and the residual / gate / mask operands are read the same way.
+  {
+    constexpr int HS = GEMM_BN + 4;
+    float* const Hs = smem;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + fi;
-    if (m >= a.M) continue;
-    long long out_row = m;   // row of Y (and of R)
-    long long aux_row = 0;
-    int split_b = 0, split_t = 0;
-    if (EPI == EPI_GATE) {
-      const int seq = m / a.T;
-      const int t = m - seq * a.T;
-      aux_row = (long long)seq * a.Tp + t / a.fac;
-    } else if (EPI == EPI_SPLIT) {
-      split_b = m / a.T;
-      split_t = m - split_b * a.T;
-    } else if (EPI == EPI_MASK) {
-      const int seq = m / a.rows_out;             // b*S + s
-      const int l = m - seq * a.rows_out;
-      aux_row = (long long)(seq / a.S) * a.rows_out + l;
+    for (int nt = 0; nt < 4; ++nt) {
+      const int cl = (EPI == EPI_GLU) ? ((nt >> 1) * 64 + wn * 32 + (nt & 1) * 16 + 4 * fg) : (wn * 64 + nt * 16 + 4 * fg);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 c = acc[nt][mt];
+        st4(Hs + (wm * 64 + mt * 16 + fi) * HS + cl, make_float4(c[0], c[1], c[2], c[3]));
+      }
     }
+    __syncthreads();
     if (EPI == EPI_GLU) {
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int ncol = nb * 64 + wn * 32 + nt * 16 + 4 * fg;
-        if (ncol >= a.N / 2) continue;
+      const int q4 = tid & 15, rg = tid >> 4;       // 16 float4 columns (64 outputs) x 16 strips of 8 rows
+      const int ncol = nb * 64 + 4 * q4;
+      if (ncol < a.N / 2) {
         const float4 bv = ld4(a.bias + ncol), bg = ld4(a.bias + a.N / 2 + ncol);
-        const f32x4 v = acc[nt][mt], g = acc[nt + 2][mt];
-        float4 o;
-        o.x = (v[0] + bv.x) * sigmoid_f(g[0] + bg.x);
-        o.y = (v[1] + bv.y) * sigmoid_f(g[1] + bg.y);
-        o.z = (v[2] + bv.z) * sigmoid_f(g[2] + bg.z);
-        o.w = (v[3] + bv.w) * sigmoid_f(g[3] + bg.w);
-        st4(a.Y + out_row * a.ldc + ncol, o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = rg * 8 + i;
+          const int m = m0 + r;
+          if (m >= a.M) break;
+          const float4 v = ld4(Hs + r * HS + 4 * q4), g = ld4(Hs + r * HS + 64 + 4 * q4);
+          st4(a.Y + (long long)m * a.ldc + ncol,
+              make_float4((v.x + bv.x) * sigmoid_f(g.x + bg.x), (v.y + bv.y) * sigmoid_f(g.y + bg.y),
+                          (v.z + bv.z) * sigmoid_f(g.z + bg.z), (v.w + bv.w) * sigmoid_f(g.w + bg.w)));
+        }
       }
     } else {
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int ncol = nb * GEMM_BN + wn * 64 + nt * 16 + 4 * fg;
-        if (ncol >= a.N) continue;
-        const f32x4 c = acc[nt][mt];
-        float4 v = make_float4(c[0], c[1], c[2], c[3]);
-        if (a.bias) {
-          const float4 b = ld4(a.bias + ncol);
-          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-        }
-        if (EPI == EPI_STORE) {
-          st4(a.Y + out_row * a.ldc + ncol, v);
-        } else if (EPI == EPI_GELU) {
-          v.x = gelu_exact(v.x); v.y = gelu_exact(v.y); v.z = gelu_exact(v.z); v.w = gelu_exact(v.w);
-          st4(a.Y + out_row * a.ldc + ncol, v);
-        } else if (EPI == EPI_RES) {
-          if (a.ls) {
-            const float4 s = ld4(a.ls + ncol);
-            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+      const int q4 = tid & 31, rg = tid >> 5;       // 32 float4 columns (128 outputs) x 8 strips of 16 rows
+      const int ncol = nb * GEMM_BN + 4 * q4;
+      if (ncol < a.N) {
+        const float4 bias = a.bias ? ld4(a.bias + ncol) : zero4();
+        float4 lsv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (EPI == EPI_RES && a.ls) lsv = ld4(a.ls + ncol);
+        const int split_s = (EPI == EPI_SPLIT) ? ncol / a.Fs : 0;
+        const int split_f = (EPI == EPI_SPLIT) ? ncol - split_s * a.Fs : 0;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+          const int r = rg * 16 + i;
+          const int m = m0 + r;
+          if (m >= a.M) break;
+          float4 v = ld4(Hs + r * HS + 4 * q4);
+          v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+          float* const out = a.Y + (long long)m * a.ldc + ncol;
+          if (EPI == EPI_STORE) {
+            st4(out, v);
+          } else if (EPI == EPI_GELU) {
+            st4(out, make_float4(gelu_exact(v.x), gelu_exact(v.y), gelu_exact(v.z), gelu_exact(v.w)));
+          } else if (EPI == EPI_RES) {
+            v.x *= lsv.x; v.y *= lsv.y; v.z *= lsv.z; v.w *= lsv.w;
+            if (a.R) {
+              const float4 rr = ld4(a.R + (long long)m * a.ldc + ncol);
+              v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            st4(out, v);
+          } else if (EPI == EPI_GATE) {
+            const int seq = m / a.T;
+            const int t = m - seq * a.T;
+            const float4 x = ld4(a.R + (long long)m * a.ldc + ncol);
+            const float4 u = ld4(a.aux + ((long long)seq * a.Tp + t / a.fac) * a.N + ncol);
+            st4(out, make_float4(x.x + sigmoid_f(v.x) * u.x, x.y + sigmoid_f(v.y) * u.y,
+                                 x.z + sigmoid_f(v.z) * u.z, x.w + sigmoid_f(v.w) * u.w));
+          } else if (EPI == EPI_SPLIT) {
+            // column n = s*F + f  ->  Y[((b*S + s)*T + t)*F + f]   (reference module.py:123)
+            const int b = m / a.T;
+            const int t = m - b * a.T;
+            st4(a.Y + (((long long)b * a.S + split_s) * a.T + t) * a.Fs + split_f, v);
+          } else if (EPI == EPI_MASK) {
+            const int seq = m / a.rows_out;             // b*S + s
+            const int l = m - seq * a.rows_out;
+            const float4 e = ld4(a.aux + ((long long)(seq / a.S) * a.rows_out + l) * a.N + ncol);
+            st4(out, make_float4(fmaxf(v.x, 0.f) * e.x, fmaxf(v.y, 0.f) * e.y, fmaxf(v.z, 0.f) * e.z, fmaxf(v.w, 0.f) * e.w));
           }
-          if (a.R) {
-            const float4 r = ld4(a.R + out_row * a.ldc + ncol);
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-          }
-          st4(a.Y + out_row * a.ldc + ncol, v);
-        } else if (EPI == EPI_GATE) {
-          const float4 x = ld4(a.R + out_row * a.ldc + ncol);
-          const float4 u = ld4(a.aux + aux_row * a.N + ncol);
-          v.x = x.x + sigmoid_f(v.x) * u.x;
-          v.y = x.y + sigmoid_f(v.y) * u.y;
-          v.z = x.z + sigmoid_f(v.z) * u.z;
-          v.w = x.w + sigmoid_f(v.w) * u.w;
-          st4(a.Y + out_row * a.ldc + ncol, v);
-        } else if (EPI == EPI_SPLIT) {
-          // column n = s*F + f  ->  Y[((b*S + s)*T + t)*F + f]   (reference module.py:123)
-          const int s = ncol / a.Fs;
-          const int f = ncol - s * a.Fs;
-          st4(a.Y + (((long long)split_b * a.S + s) * a.T + split_t) * a.Fs + f, v);
-        } else if (EPI == EPI_MASK) {
-          const float4 e = ld4(a.aux + aux_row * a.N + ncol);
-          v.x = fmaxf(v.x, 0.f) * e.x; v.y = fmaxf(v.y, 0.f) * e.y;
-          v.z = fmaxf(v.z, 0.f) * e.z; v.w = fmaxf(v.w, 0.f) * e.w;
-          st4(a.Y + out_row * a.ldc + ncol, v);
         }
       }
     }
   }
+  };
+
+#if SEPR_GEMM_STAGGER
+  // De-phase the two workgroups that share a CU.  They are dispatched together and run identical tile
+  // sequences, so without this they stay in lockstep: both parked on memory at the same time, then both
+  // contending for the matrix pipe (measured: 28 % SQ_WAIT_ANY yet only 60 % MFMA utilisation with two
+  // resident waves per SIMD).  Half of the workgroups - one of every co-resident pair under either
+  // plausible placement (round-robin over the XCD's 32 CUs, or CU-by-CU) - start half a tile period late.
+  {
+    const int ql = blockIdx.x >> 3;
+    if (((ql & 1) ^ ((ql >> 5) & 1)) != 0) {
+      const int naps = (nk * 2048 + 6144) / (64 * 100);
+      for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(100);
+    }
+  }
+#endif
+  // ---- walk the tiles ---------------------------------------------------------------------------------
+  int tile = blockIdx.x;
+  int m0 = 0, nb = 0;
+  while (tile < ntiles && !decode(tile, m0, nb)) tile += gridDim.x;
+  if (tile >= ntiles) return;
+  setup(m0, nb);
+  load_tile(0);
+  while (true) {
+    // (entering: registers hold K tile 0 of (m0, nb); every wave is past its reads of the staging LDS)
+    store_tile(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) load_tile(kt + 1);
+      const float* As = As0 + cur * GEMM_BM * LS;
+      const float* Bs = Bs0 + cur * GEMM_BN * LS;
+#pragma unroll
+      for (int kk = 0; kk < GEMM_BK / 16; ++kk) {
+        float4 wf[4], xf[4];
+        read_frags(As, Bs, kk, wf, xf);
+        mma16(wf, xf);
+      }
+      if (kt + 1 < nk) store_tile(cur ^ 1);
+      __syncthreads();
+    }
+    // next tile of this workgroup: start its first K tile now, under the epilogue below
+    const int m0c = m0, nbc = nb;
+    int nxt = tile + gridDim.x;
+    while (nxt < ntiles && !decode(nxt, m0, nb)) nxt += gridDim.x;
+    const bool more = nxt < ntiles;
+    if (more) {
+      setup(m0, nb);
+      load_tile(0);
+    }
+    epilogue(m0c, nbc);
+    if (!more) break;
+    tile = nxt;
+    __syncthreads();              // the epilogue staged the tile through the staging LDS
+  }
 }
 
-inline int gemm_grid(const GemmArgs& a, int epi) {
+inline int gemm_tiles(const GemmArgs& a, int epi) {
   const bool glu = (epi == EPI_GLU) || (epi == EPI_DWGLU);
   const int rows = (epi == EPI_DWGLU) ? GEMM_DW_ROWS : GEMM_BM;
   const int NB = glu ? (a.N / 2 + 63) / 64 : (a.N + GEMM_BN - 1) / GEMM_BN;
   const int MB = (a.M + rows - 1) / rows;
-  return ((MB + 7) / 8) * 8 * NB;
+  return ((MB + 7) / 8) * 8 * NB;   // always a multiple of 8 (XCD-aware decode)
 }
 
 // host launcher (defined in sepr_gemm.hip): validates shapes, attributes the launch to a profiling site

@@ -33,9 +33,28 @@ static void prof_end(long long slot, double flops, hipStream_t stream) {
   g_prof.flops += flops;
 }
 
+// co-resident workgroups: 2 per CU (LDS-limited), as a multiple of 8 so a workgroup keeps its XCD
+static int persistent_grid() {
+  static int cached = 0;
+  if (cached == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    cached = ((2 * cus + 7) / 8) * 8;
+  }
+  return cached;
+}
+
 template <int PRO, int EPI, int TAG = 0>
 static void launch_inst(const GemmArgs& a, hipStream_t stream) {
-  const int grid = gemm_grid(a, EPI);
+  const int tiles = gemm_tiles(a, EPI);
+#if SEPR_GEMM_PERSIST
+  const int cap = persistent_grid();
+  const int grid = tiles < cap ? tiles : cap;
+#else
+  const int grid = tiles;
+#endif
   hipLaunchKernelGGL((gemm_kernel<PRO, EPI, TAG>), dim3(grid), dim3(GEMM_THREADS), 0, stream, a);
 }
 
@@ -47,6 +66,12 @@ int launch_gemm(int pro, int epi, const GemmArgs& a, int site, hipStream_t strea
   if ((a.lda % 4) != 0 || (a.ldc % 4) != 0) return SEPR_EINVAL;
   if (pro == PRO_CAT2 && (!a.A2 || (a.ksplit % GEMM_BK) != 0 || (a.lda2 % 4) != 0)) return SEPR_EINVAL;
   if (pro == PRO_NORM && (!a.stats || !a.gamma || !a.beta)) return SEPR_EINVAL;
+  // staging addresses are 32-bit element offsets from the bases
+  {
+    const long long src_rows = a.rows_out > 0 ? ((long long)(a.M + a.rows_out - 1) / a.rows_out) * a.rows_src : a.M;
+    if (src_rows * a.lda >= (1LL << 32) || (long long)a.N * a.K >= (1LL << 32)) return SEPR_EINVAL;
+    if (pro == PRO_CAT2 && (long long)a.M * a.lda2 >= (1LL << 32)) return SEPR_EINVAL;
+  }
   if ((epi == EPI_GLU || epi == EPI_DWGLU) && !a.bias) return SEPR_EINVAL;
   if (epi == EPI_DWGLU && (!a.dw_w || !a.dw_b || a.T <= 0 || ((a.N / 2) % 4) != 0)) return SEPR_EINVAL;
 

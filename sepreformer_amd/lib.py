@@ -13,7 +13,9 @@ import threading
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_native", "libsepr_hip.so")
+# SEPR_LIB_VARIANT=<tag> selects an A/B build (make -C csrc variants); unset = the product library
+_VARIANT = os.environ.get("SEPR_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, "_native", f"libsepr_hip_{_VARIANT}.so" if _VARIANT else "libsepr_hip.so")
 
 SEPR_OK, SEPR_EINVAL, SEPR_EWORKSPACE, SEPR_EHIP = 0, -1, -2, -3
 _ERR = {SEPR_EINVAL: "SEPR_EINVAL (bad shape / unsupported size / null pointer)",
