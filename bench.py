@@ -37,6 +37,7 @@ METRIC = "utterances/sec (4 s, 8 kHz, 2-spk) SepReformer-Base at 1/2/4/8 MI355X"
 VARIANT = "SepReformer_Base_WSJ0"
 SAMPLES = 32000
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0                  # HBM3E spec (6.29 TB/s measured copy), same table
 GFLOP_PER_UTT_MAIN, GFLOP_PER_UTT_FULL = 164.87, 182.16   # SURVEY.md section 8d (4 s, Base)
 
 
@@ -96,6 +97,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary heads (NOT the reference's forward)")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=None,
+                    help="projection arithmetic (default: the package default / SEPR_PRECISION)")
     args = ap.parse_args()
 
     from sepreformer_amd import dist as sdist
@@ -114,7 +117,8 @@ def main():
     lib = L.load()
 
     cfg = VARIANTS[VARIANT]
-    model = Model.from_config(cfg, init_seed=0).load_synthetic_(0).eval().to(dev)
+    model = Model.from_config(cfg, init_seed=0, precision=args.precision).load_synthetic_(0).eval().to(dev)
+    precision = model.precision
     model.compute_aux = not args.no_aux
     B = args.batch
     # each rank separates its own utterances: seeds 1234 + global utterance index
@@ -161,22 +165,41 @@ def main():
         if os.path.exists(pmc):
             with open(pmc) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
+        n_launch = max(n_l.value, 1)
+        if precision == "fp32":
+            dtype = "f32"
+            roof = {"kernel": "gemm_kernel<PRO_NORM,EPI_DWGLU,1> (GCFN F->6F projection: LayerNorm prologue, f32 MFMA, "
+                              "depthwise-conv+GLU epilogue)",
+                    "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic}
+        else:
+            # split-fp32 on the bf16 MFMA: the matrix pipe is no longer the bound, HBM is.  Algorithmic bytes of
+            # the fused GCFN up-projection per row: read F fp32 (x) + write 3F fp32 (g) = 16 F bytes; rows per
+            # launch follow from the algorithmic FLOPs (2 * F * 6F per row).
+            F = cfg.feat
+            rows = fl.value / (2.0 * F * 6 * F)
+            gbs = rows * 16.0 * F / 1e9 / (ms.value / 1e3) if ms.value > 0 else 0.0
+            dtype = "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)"
+            roof = {"kernel": "gemm_x3_kernel<PRO_NORM,EPI_DWGLU,1> (GCFN F->6F projection: LayerNorm prologue, bf16x3 "
+                              "MFMA, depthwise-conv+GLU epilogue)",
+                    "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(rows / n_launch * 16.0 * F),
+                    "mfma_equiv_tflops": round(achieved, 2)}
+        roof.update({"launches": int(n_l.value), "avg_launch_ms": round(ms.value / n_launch, 4),
+                     "algorithmic_gflop_per_launch": round(fl.value / 1e9 / n_launch, 3)})
         rec = {
             "metric": METRIC, "value": round(utt_per_s, 3), "unit": "utt/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{VARIANT} inference, batch={B} per GPU, 4 s @ 8 kHz, 2 speakers "
                                    f"(BASELINE.json configs[{1 if world == 1 else 2}])",
-                       "batch_per_gpu": B, "samples": SAMPLES, "aux_heads": not args.no_aux,
+                       "batch_per_gpu": B, "samples": SAMPLES, "aux_heads": not args.no_aux, "precision": precision,
                        "weights": "synthetic seed 0 (O(1) LayerScale)", "parallelism": f"utterance-sharded x{world}"},
             "parity_db_vs_golden": parity_db,
             "model_tflops": round(utt_per_s * gflop / 1e3 / world, 2),
             "model_mfma_frac": round(utt_per_s * gflop / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
-            "roofline": {"kernel": "gemm_kernel<PRO_NORM,EPI_DWGLU,1> (GCFN F->6F projection: LayerNorm prologue, depthwise-conv+GLU epilogue)",
-                         "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "launches": int(n_l.value), "avg_launch_ms": round(ms.value / max(n_l.value, 1), 4),
-                         "algorithmic_gflop_per_launch": round(fl.value / 1e9 / max(n_l.value, 1), 3)},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = int(os.environ.get("SEPR_CPU_THREADS", str(physical_cores())))

@@ -40,6 +40,15 @@ typedef void* sepr_stream_t; /* hipStream_t */
 
 /* ---- weight bundles (device pointers) --------------------------------------------------------- */
 
+/* Optional second-precision ("bf16x3") form of one projection: the weight matrix pre-split into bf16
+ * hi/lo planes in MFMA fragment order [N/16][K/32][plane][lane][8] with any LayerNorm gamma folded in,
+ * and the bias with LayerNorm beta folded in (sepreformer_amd/pack.py::pack_x3).  wp == NULL selects the
+ * exact f32-MFMA core for that projection; both cores share prologues and epilogues. */
+typedef struct {
+  const void* wp;
+  const float* bias;
+} sepr_x3_w;
+
 /* GCFN, modules/network.py:46-66.  F -> 6F -> (dwconv3, GLU) 3F -> F */
 typedef struct {
   const float* ln_g; /* [F]     net1.0.weight */
@@ -51,6 +60,8 @@ typedef struct {
   const float* w2;   /* [F,3F]  net2.2.weight */
   const float* b2;   /* [F]     net2.2.bias */
   const float* ls;   /* [F]     Layer_scale.layer_scale */
+  sepr_x3_w x3_up;   /* net1 (LayerNorm folded) */
+  sepr_x3_w x3_down; /* net2.2 */
 } sepr_gcfn_w;
 
 /* CLA, modules/network.py:159-187 (eval-mode BatchNorm folded into w2/b2 by the packer) */
@@ -66,6 +77,9 @@ typedef struct {
   const float* w3;   /* [F,2F]  linear3.1.weight */
   const float* b3;   /* [F] */
   const float* ls;   /* [F] */
+  sepr_x3_w x3_1;    /* linear1 (LayerNorm folded) */
+  sepr_x3_w x3_2;    /* linear2 (BatchNorm folded) */
+  sepr_x3_w x3_3;    /* linear3.1 */
 } sepr_cla_w;
 
 /* MultiHeadAttention, modules/network.py:69-124 */
@@ -77,6 +91,8 @@ typedef struct {
   const float* wo;   /* [F,F]   linear_out.weight */
   const float* bo;   /* [F] */
   const float* ls;   /* [F] */
+  sepr_x3_w x3_qkv;  /* stacked q/k/v (LayerNorm folded) */
+  sepr_x3_w x3_out;  /* linear_out */
 } sepr_mha_w;
 
 /* EGA, modules/network.py:126-155 + the shared relative-position table, modules/module.py:42-57 */
@@ -88,6 +104,7 @@ typedef struct {
   const float* gate_b;    /* [F] */
   const float* pe_k;      /* [2*maxlen, F/H]  separator.pos_emb.pe_k.weight */
   int maxlen;
+  sepr_x3_w x3_gate;      /* block.linear.1 (LayerNorm folded) */
 } sepr_ega_w;
 
 /* DownConvLayer, modules/module.py:63-78 (eval BN folded: y = gelu(conv_nobias * scale + shift)) */
@@ -105,7 +122,16 @@ typedef struct {
   const float* b2;   /* [FS] */
   const float* gn_g; /* [F]       norm.weight */
   const float* gn_b; /* [F] */
+  sepr_x3_w x3_1;
+  sepr_x3_w x3_2;
 } sepr_split_w;
+
+/* Decoder-side fusion conv, modules/module.py:187,214 */
+typedef struct {
+  const float* w;    /* [F,2F]  simple_fusion.i.weight */
+  const float* b;    /* [F] */
+  sepr_x3_w x3;
+} sepr_fuse_w;
 
 /* OutputLayer + AudioDecoder, modules/module.py:237-283 */
 typedef struct {
@@ -114,6 +140,8 @@ typedef struct {
   const float* w2;   /* [N,2F]  end_conv1x1.2.weight */
   const float* b2;   /* [N] */
   const float* wdec; /* [K,N]   ConvTranspose1d weight [N,1,K] packed tap-major */
+  sepr_x3_w x3_1;
+  sepr_x3_w x3_2;
 } sepr_out_w;
 
 /* ---- library ---------------------------------------------------------------------------------- */
@@ -176,9 +204,9 @@ int sepr_spksplit_fwd(const float* x, float* y, int B, int S, int T, int F, floa
                       const sepr_split_w* w, void* ws, size_t ws_bytes, sepr_stream_t stream);
 
 /* Decoder-side fusion, modules/module.py:212-214: nearest x2 upsample of lo [n,T/2,F], concat with
- * skip [n,T,F] along channels, Conv1d(2F->F,k=1).  wf [F,2F], bf [F] -> y [n,T,F]. */
-int sepr_fuse_fwd(const float* lo, const float* skip, float* y, int n, int T, int F, const float* wf,
-                  const float* bf, sepr_stream_t stream);
+ * skip [n,T,F] along channels, Conv1d(2F->F,k=1) -> y [n,T,F]. */
+int sepr_fuse_fwd(const float* lo, const float* skip, float* y, int n, int T, int F, const sepr_fuse_w* w,
+                  sepr_stream_t stream);
 
 /* OutputLayer.forward (+Masking when enc != NULL) and AudioDecoder.forward, modules/module.py:249-283,
  * modules/network.py:34-43, model.py:42-52.  x [nS,Tsrc,F]; frame l < L of the head reads source
@@ -195,6 +223,9 @@ int sepr_groupnorm_stats(const float* x, int n, long long count, float eps, floa
 /* y[M,N] = x[M,K] . w[N,K]^T + bias : the f32-MFMA projection core on its own (tests, roofline bench) */
 int sepr_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
                     sepr_stream_t stream);
+/* the same product on the bf16x3 core; wp = pack_x3(w) */
+int sepr_linear_x3_fwd(const float* x, const void* wp, const float* bias, float* y, int M, int N, int K,
+                       sepr_stream_t stream);
 
 /* ---- opt-in kernel timer (bench.py roofline) ------------------------------------------------- */
 /* Sites a projection launch can be attributed to. */

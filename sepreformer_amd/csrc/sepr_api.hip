@@ -2,7 +2,7 @@
 // separator is a short, fixed sequence of launches on the caller's stream.
 #include <string.h>
 
-#include "sepr_gemm.h"
+#include "sepr_gemm_epi.h"
 #include "sepr_pointwise.h"
 
 namespace sepr {
@@ -13,6 +13,16 @@ void set_hip_error(hipError_t e, const char* where) {
 }
 
 static const float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default (network.py:50,81,133,162)
+
+// one projection on whichever core its weights were packed for
+static int project(int pro, int epi, GemmArgs& a, const sepr_x3_w& x3, int site, hipStream_t st) {
+  if (x3.wp) {
+    a.Wp = x3.wp;
+    a.bias = x3.bias;
+    return launch_gemm_x3(pro, epi, a, site, st);
+  }
+  return launch_gemm(pro, epi, a, site, st);
+}
 
 // ---- workspace plans (floats unless noted) --------------------------------------------------------
 static size_t ws_gcfn(long long M, int F) {
@@ -106,14 +116,14 @@ extern "C" int sepr_gcfn_fwd(const float* x, float* y, int n, int T, int F, cons
     a.A = x; a.lda = F; a.stats = stats; a.gamma = w->ln_g; a.beta = w->ln_b;
     a.W = w->w1; a.bias = w->b1; a.Y = g; a.ldc = 3 * F;
     a.dw_w = w->dw_w; a.dw_b = w->dw_b; a.T = T;
-    SEPR_TRY(launch_gemm(PRO_NORM, EPI_DWGLU, a, SEPR_SITE_GCFN_UP, st));
+    SEPR_TRY(project(PRO_NORM, EPI_DWGLU, a, w->x3_up, SEPR_SITE_GCFN_UP, st));
   }
   {  // net2 Linear 3F->F, LayerScale, residual                            (network.py:65-66)
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = F; a.K = 3 * F;
     a.A = g; a.lda = 3 * F; a.W = w->w2; a.bias = w->b2;
     a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
-    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_RES, a, SEPR_SITE_GCFN_DOWN, st));
+    SEPR_TRY(project(PRO_PLAIN, EPI_RES, a, w->x3_down, SEPR_SITE_GCFN_DOWN, st));
   }
   return SEPR_OK;
 }
@@ -136,21 +146,21 @@ extern "C" int sepr_cla_fwd(const float* x, float* y, int n, int T, int F, int K
     a.M = (int)M; a.N = 2 * F; a.K = F;
     a.A = x; a.lda = F; a.stats = stats; a.gamma = w->ln_g; a.beta = w->ln_b;
     a.W = w->w1; a.bias = w->b1; a.Y = u; a.ldc = F;
-    SEPR_TRY(launch_gemm(PRO_NORM, EPI_GLU, a, SEPR_SITE_CLA, st));
+    SEPR_TRY(project(PRO_NORM, EPI_GLU, a, w->x3_1, SEPR_SITE_CLA, st));
   }
   SEPR_TRY(launch_dwconv_same(u, c, n, T, F, K, w->dw_w, w->dw_b, st));   // (network.py:178-180)
   {  // linear2 F->2F, eval BatchNorm (folded), GELU                       (network.py:181-185)
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = 2 * F; a.K = F;
     a.A = c; a.lda = F; a.W = w->w2; a.bias = w->b2; a.Y = d; a.ldc = 2 * F;
-    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_GELU, a, SEPR_SITE_CLA, st));
+    SEPR_TRY(project(PRO_PLAIN, EPI_GELU, a, w->x3_2, SEPR_SITE_CLA, st));
   }
   {  // linear3 2F->F, LayerScale, residual                                (network.py:185-187)
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = F; a.K = 2 * F;
     a.A = d; a.lda = 2 * F; a.W = w->w3; a.bias = w->b3;
     a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
-    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_RES, a, SEPR_SITE_CLA, st));
+    SEPR_TRY(project(PRO_PLAIN, EPI_RES, a, w->x3_3, SEPR_SITE_CLA, st));
   }
   return SEPR_OK;
 }
@@ -181,7 +191,7 @@ extern "C" int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int 
     a.M = (int)Mp; a.N = 3 * F; a.K = F;
     a.A = xpool; a.lda = F; a.stats = stats_p; a.gamma = w->attn.ln_g; a.beta = w->attn.ln_b;
     a.W = w->attn.wqkv; a.bias = w->attn.bqkv; a.Y = qkv; a.ldc = 3 * F;
-    SEPR_TRY(launch_gemm(PRO_NORM, EPI_STORE, a, SEPR_SITE_ATTN_PROJ, st));
+    SEPR_TRY(project(PRO_NORM, EPI_STORE, a, w->attn.x3_qkv, SEPR_SITE_ATTN_PROJ, st));
   }
   SEPR_TRY(launch_relattn(qkv, o, n, Tp, F, H, w->pe_k, w->maxlen, st));   // (network.py:106-122)
   {  // linear_out * LayerScale (no residual inside MHA)                    (network.py:124)
@@ -189,7 +199,7 @@ extern "C" int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int 
     a.M = (int)Mp; a.N = F; a.K = F;
     a.A = o; a.lda = F; a.W = w->attn.wo; a.bias = w->attn.bo;
     a.Y = att; a.ldc = F; a.R = nullptr; a.ls = w->attn.ls;
-    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_RES, a, SEPR_SITE_ATTN_PROJ, st));
+    SEPR_TRY(project(PRO_PLAIN, EPI_RES, a, w->attn.x3_out, SEPR_SITE_ATTN_PROJ, st));
   }
   SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
   {  // x + sigmoid(Linear(LayerNorm(x))) * upsample(att)                   (network.py:132-135,151-153)
@@ -198,7 +208,7 @@ extern "C" int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int 
     a.A = x; a.lda = F; a.stats = stats; a.gamma = w->gate_ln_g; a.beta = w->gate_ln_b;
     a.W = w->gate_w; a.bias = w->gate_b;
     a.Y = y; a.ldc = F; a.R = x; a.aux = att; a.T = T; a.Tp = Tp; a.fac = fac;
-    SEPR_TRY(launch_gemm(PRO_NORM, EPI_GATE, a, SEPR_SITE_EGA_GATE, st));
+    SEPR_TRY(project(PRO_NORM, EPI_GATE, a, w->x3_gate, SEPR_SITE_EGA_GATE, st));
   }
   return SEPR_OK;
 }
@@ -220,7 +230,7 @@ extern "C" int sepr_spkattn_fwd(const float* x, float* y, int nS, int S, int T, 
     a.M = (int)M; a.N = 3 * F; a.K = F;
     a.A = x; a.lda = F; a.stats = stats; a.gamma = w->ln_g; a.beta = w->ln_b;
     a.W = w->wqkv; a.bias = w->bqkv; a.Y = qkv; a.ldc = 3 * F;
-    SEPR_TRY(launch_gemm(PRO_NORM, EPI_STORE, a, SEPR_SITE_ATTN_PROJ, st));
+    SEPR_TRY(project(PRO_NORM, EPI_STORE, a, w->x3_qkv, SEPR_SITE_ATTN_PROJ, st));
   }
   SEPR_TRY(launch_spkmix(qkv, o, nS / S, S, T, F, H, st));
   {  // x + LayerScale(linear_out(.))                                       (network.py:124,244)
@@ -228,7 +238,7 @@ extern "C" int sepr_spkattn_fwd(const float* x, float* y, int nS, int S, int T, 
     a.M = (int)M; a.N = F; a.K = F;
     a.A = o; a.lda = F; a.W = w->wo; a.bias = w->bo;
     a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
-    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_RES, a, SEPR_SITE_ATTN_PROJ, st));
+    SEPR_TRY(project(PRO_PLAIN, EPI_RES, a, w->x3_out, SEPR_SITE_ATTN_PROJ, st));
   }
   return SEPR_OK;
 }
@@ -259,14 +269,14 @@ extern "C" int sepr_spksplit_fwd(const float* x, float* y, int B, int S, int T, 
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = 4 * F * S; a.K = F;
     a.A = x; a.lda = F; a.W = w->w1; a.bias = w->b1; a.Y = z; a.ldc = 2 * F * S;
-    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_GLU, a, SEPR_SITE_SPLIT, st));
+    SEPR_TRY(project(PRO_PLAIN, EPI_GLU, a, w->x3_1, SEPR_SITE_SPLIT, st));
   }
   {  // Conv1d 2FS->FS (k=1), then view(B*S, F, T): channel s*F+f -> sequence b*S+s  (module.py:116,123)
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = F * S; a.K = 2 * F * S;
     a.A = z; a.lda = 2 * F * S; a.W = w->w2; a.bias = w->b2; a.Y = y; a.ldc = F;
     a.T = T; a.S = S; a.Fs = F;
-    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_SPLIT, a, SEPR_SITE_SPLIT, st));
+    SEPR_TRY(project(PRO_PLAIN, EPI_SPLIT, a, w->x3_2, SEPR_SITE_SPLIT, st));
   }
   // GroupNorm(1, F) over (F, T) of every (b, s)                            (module.py:124)
   SEPR_TRY(launch_gn_partial(y, part, n_out, count, nchunk, st));
@@ -275,17 +285,17 @@ extern "C" int sepr_spksplit_fwd(const float* x, float* y, int B, int S, int T, 
   return SEPR_OK;
 }
 
-extern "C" int sepr_fuse_fwd(const float* lo, const float* skip, float* y, int n, int T, int F, const float* wf,
-                             const float* bf, sepr_stream_t stream) {
-  if (!lo || !skip || !y || !wf || !bf || n <= 0 || T <= 0 || (T & 1) || F <= 0 || F % 32 != 0) return SEPR_EINVAL;
+extern "C" int sepr_fuse_fwd(const float* lo, const float* skip, float* y, int n, int T, int F, const sepr_fuse_w* w,
+                             sepr_stream_t stream) {
+  if (!lo || !skip || !y || !w || !w->w || !w->b || n <= 0 || T <= 0 || (T & 1) || F <= 0 || F % 32 != 0) return SEPR_EINVAL;
   const long long M = (long long)n * T;
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
   GemmArgs a = gemm_args_zero();
   a.M = (int)M; a.N = F; a.K = 2 * F;
   a.A = lo; a.lda = F; a.A2 = skip; a.lda2 = F; a.ksplit = F;
   a.rows_out = T; a.rows_src = T / 2; a.rows_valid = T; a.a_shift = 1;   // nearest x2: source frame t>>1
-  a.W = wf; a.bias = bf; a.Y = y; a.ldc = F;
-  return launch_gemm(PRO_CAT2, EPI_STORE, a, SEPR_SITE_FUSE, static_cast<hipStream_t>(stream));
+  a.W = w->w; a.bias = w->b; a.Y = y; a.ldc = F;
+  return project(PRO_CAT2, EPI_STORE, a, w->x3, SEPR_SITE_FUSE, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int sepr_outlayer_decoder_fwd(const float* x, int nS, int S, int Tsrc, int L, const int* idx, const float* enc,
@@ -305,7 +315,7 @@ extern "C" int sepr_outlayer_decoder_fwd(const float* x, int nS, int S, int Tsrc
     a.M = (int)M; a.N = 4 * F; a.K = F;
     a.A = x; a.lda = F; a.rows_out = L; a.rows_src = Tsrc; a.rows_valid = L; a.idx = idx;
     a.W = w->w1; a.bias = w->b1; a.Y = o1; a.ldc = 2 * F;
-    SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_GLU, a, SEPR_SITE_OUT, st));
+    SEPR_TRY(project(PRO_PLAIN, EPI_GLU, a, w->x3_1, SEPR_SITE_OUT, st));
   }
   {  // Linear 2F->N (+ ReLU(.) * encoder_output for the auxiliary heads)   (module.py:252-260, network.py:41)
     GemmArgs a = gemm_args_zero();
@@ -317,9 +327,9 @@ extern "C" int sepr_outlayer_decoder_fwd(const float* x, int nS, int S, int Tsrc
       // EPI_MASK reads rows_out as the per-sequence frame count; keep the A-side map an identity
       GemmArgs m = a;
       m.rows_out = L; m.rows_src = L; m.rows_valid = L;
-      SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_MASK, m, SEPR_SITE_OUT, st));
+      SEPR_TRY(project(PRO_PLAIN, EPI_MASK, m, w->x3_2, SEPR_SITE_OUT, st));
     } else {
-      SEPR_TRY(launch_gemm(PRO_PLAIN, EPI_STORE, a, SEPR_SITE_OUT, st));
+      SEPR_TRY(project(PRO_PLAIN, EPI_STORE, a, w->x3_2, SEPR_SITE_OUT, st));
     }
   }
   const int Tout = (L - 1) * stride + K;
@@ -347,4 +357,13 @@ extern "C" int sepr_linear_fwd(const float* x, const float* w, const float* bias
   a.M = M; a.N = N; a.K = K;
   a.A = x; a.lda = K; a.W = w; a.bias = bias; a.Y = y; a.ldc = N;
   return launch_gemm(PRO_PLAIN, EPI_STORE, a, SEPR_SITE_LINEAR, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int sepr_linear_x3_fwd(const float* x, const void* wp, const float* bias, float* y, int M, int N, int K,
+                                  sepr_stream_t stream) {
+  if (!x || !wp || !y || M <= 0) return SEPR_EINVAL;
+  GemmArgs a = gemm_args_zero();
+  a.M = M; a.N = N; a.K = K;
+  a.A = x; a.lda = K; a.Wp = wp; a.bias = bias; a.Y = y; a.ldc = N;
+  return launch_gemm_x3(PRO_PLAIN, EPI_STORE, a, SEPR_SITE_LINEAR, static_cast<hipStream_t>(stream));
 }

@@ -19,7 +19,7 @@ struct Prof {
 Prof g_prof;
 }  // namespace
 
-static bool prof_begin(int site, hipStream_t stream, long long* slot) {
+bool prof_begin(int site, hipStream_t stream, long long* slot) {
   if (g_prof.site == SEPR_SITE_NONE || site != g_prof.site) return false;
   std::lock_guard<std::mutex> lk(g_prof.mu);
   if (site != g_prof.site || g_prof.launches >= g_prof.cap) return false;
@@ -27,14 +27,14 @@ static bool prof_begin(int site, hipStream_t stream, long long* slot) {
   (void)hipEventRecord(g_prof.ev[2 * *slot], stream);
   return true;
 }
-static void prof_end(long long slot, double flops, hipStream_t stream) {
+void prof_end(long long slot, double flops, hipStream_t stream) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   (void)hipEventRecord(g_prof.ev[2 * slot + 1], stream);
   g_prof.flops += flops;
 }
 
 // co-resident workgroups: 2 per CU (LDS-limited), as a multiple of 8 so a workgroup keeps its XCD
-static int persistent_grid() {
+int persistent_grid() {
   static int cached = 0;
   if (cached == 0) {
     int dev = 0, cus = 0;

@@ -1,0 +1,195 @@
+// Shared pieces of the two projection cores (f32 MFMA: sepr_gemm.h, bf16x3 split MFMA: sepr_gemm_x3.h):
+// the argument block and the row-contiguous epilogue that runs from an LDS-staged accumulator tile.
+#pragma once
+#include "sepr_common.h"
+
+namespace sepr {
+
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_CAT2 = 2 };
+enum { EPI_STORE = 0, EPI_GLU = 1, EPI_GELU = 2, EPI_RES = 3, EPI_GATE = 4, EPI_SPLIT = 5, EPI_MASK = 6, EPI_DWGLU = 7 };
+
+struct GemmArgs {
+  int M, N, K;
+  // ---- A side ----
+  const float* A;   // source rows, leading dimension lda
+  int lda;
+  const float* A2;  // PRO_CAT2: second source for k >= ksplit, leading dimension lda2
+  int lda2;
+  int ksplit;
+  // Row map.  rows_out == 0: source row = m.  Otherwise m -> (seq = m / rows_out, r = m % rows_out);
+  // the row is all-zero unless r < rows_valid; source row = seq*rows_src + (idx ? idx[r] : r) >> a_shift.
+  // (a_shift applies to A only, never to A2: the fusion conv reads lo at t>>1 and skip at t.)
+  int rows_out, rows_src, rows_valid, a_shift;
+  const int* idx;
+  // PRO_NORM: v = (a - mean) * rstd * gamma[k] + beta[k]; (mean, rstd) = stats[2*i], i = m (stat_seq == 0)
+  // or m / rows_out (stat_seq == 1)
+  const float* stats;
+  int stat_seq;
+  const float* gamma;
+  const float* beta;
+  // ---- W side ----
+  const float* W;     // [N][K] row-major (torch Linear / 1x1 Conv weight)
+  const float* bias;  // [N] or null
+  // ---- output ----
+  float* Y;
+  int ldc;
+  const float* R;    // EPI_RES: residual [M][ldc] or null.  EPI_GATE: x [M][ldc]
+  const float* ls;   // EPI_RES: per-column scale [N] or null
+  const float* aux;  // EPI_GATE: att [M/fac][N]; EPI_MASK: enc [(M/rows_out/S)*rows_out ...][N]
+  int T, Tp, fac;    // EPI_GATE: frames per sequence, pooled frames, T/Tp.  EPI_SPLIT: T
+  int S, Fs;         // EPI_SPLIT / EPI_MASK: speakers; EPI_SPLIT: F
+  // EPI_DWGLU (GCFN): depthwise k=3 conv along frames + GLU applied to the projected tile before it
+  // leaves the CU.  dw_w [3][N] tap-major, dw_b [N]; frames per sequence in T.  Output Y is [M][N/2].
+  const float* dw_w;
+  const float* dw_b;
+  // bf16x3 core only: weights pre-split into bf16 (hi, lo) planes in MFMA-fragment order
+  // ([N/16][K/32][plane][lane][8], see pack.py::pack_x3); LayerNorm gamma/beta are folded into Wp / bias.
+  const void* Wp;
+};
+
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128;
+constexpr int GEMM_THREADS = 256;
+// EPI_DWGLU tiles overlap by one frame on each side (the conv halo is recomputed): 126 new rows per tile
+constexpr int GEMM_DW_ROWS = GEMM_BM - 2;
+constexpr int GEMM_HS = GEMM_BN + 4;   // row stride (floats) of the LDS-staged accumulator tile
+
+inline int gemm_tiles(const GemmArgs& a, int epi) {
+  const bool glu = (epi == EPI_GLU) || (epi == EPI_DWGLU);
+  const int rows = (epi == EPI_DWGLU) ? GEMM_DW_ROWS : GEMM_BM;
+  const int NB = glu ? (a.N / 2 + 63) / 64 : (a.N + GEMM_BN - 1) / GEMM_BN;
+  const int MB = (a.M + rows - 1) / rows;
+  return ((MB + 7) / 8) * 8 * NB;   // always a multiple of 8 (XCD-aware decode)
+}
+
+inline GemmArgs gemm_args_zero() {
+  GemmArgs a;
+  __builtin_memset(&a, 0, sizeof(a));
+  return a;
+}
+
+// host launchers: validate shapes, attribute the launch to a profiling site
+int launch_gemm(int pro, int epi, const GemmArgs& a, int site, hipStream_t stream);      // f32 MFMA core
+int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t stream);   // bf16x3 core
+// profiling hooks shared by both launchers (sepr_gemm.hip)
+bool prof_begin(int site, hipStream_t stream, long long* slot);
+void prof_end(long long slot, double flops, hipStream_t stream);
+int persistent_grid();
+
+// ---------------------------------------------------------------------------------------------------------
+// Epilogue from LDS.  Hs holds the raw accumulators of one 128-row tile, [128][GEMM_HS] fp32: plain tiles
+// keep their 128 columns in order, value/gate tiles (GLU, DWGLU) keep the 64 value columns in 0..63 and
+// their gates in 64..127.  In the MFMA C layout a direct store would touch 16 rows x 64 B per instruction
+// (partial cache lines; measured: the direct store tail cost 20 % of the kernel); from LDS a wave writes
+// whole 256/512-byte row segments, and the residual / gate / mask operands are read the same way.
+// The caller has issued __syncthreads() after writing Hs.
+// ---------------------------------------------------------------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void epilogue_from_lds(const GemmArgs& a, const float* Hs, const int m0, const int nb,
+                                                  const int tid) {
+  constexpr int HS = GEMM_HS;
+  if (EPI == EPI_DWGLU) {
+    // GCFN: h = acc + b1, depthwise k=3 conv along frames (zero padding at sequence ends), GLU
+    // (reference modules/network.py:61-65).  Tile row 0 / 127 are halo frames.
+    const int half = a.N / 2;
+    const int q4 = tid & 15, rg = tid >> 4;                     // 16 float4 columns x 16 strips of 8 rows
+    const int gc = nb * 64 + 4 * q4;
+    if (gc >= half) return;
+    const float4 wv0 = ld4(a.dw_w + gc), wv1 = ld4(a.dw_w + a.N + gc), wv2 = ld4(a.dw_w + 2 * a.N + gc);
+    const float4 wg0 = ld4(a.dw_w + half + gc), wg1 = ld4(a.dw_w + a.N + half + gc), wg2 = ld4(a.dw_w + 2 * a.N + half + gc);
+    const float4 bv = ld4(a.dw_b + gc), bg = ld4(a.dw_b + half + gc);
+    const float4 hv = ld4(a.bias + gc), hg = ld4(a.bias + half + gc);     // Linear bias b1 (value / gate)
+    auto ldv = [&](int r) { float4 v = ld4(Hs + r * HS + 4 * q4); v.x += hv.x; v.y += hv.y; v.z += hv.z; v.w += hv.w; return v; };
+    auto ldg = [&](int r) { float4 v = ld4(Hs + r * HS + 64 + 4 * q4); v.x += hg.x; v.y += hg.y; v.z += hg.z; v.w += hg.w; return v; };
+    const int rs = 1 + 8 * rg;
+    float4 pv = ldv(rs - 1), pg = ldg(rs - 1);
+    float4 cv = ldv(rs), cg = ldg(rs);
+    int t = (m0 + rs) % a.T;                                    // m0 + rs >= 0 always
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = rs + q;
+      const int m = m0 + r;
+      if (r > GEMM_DW_ROWS || m >= a.M) break;
+      const float4 nv = ldv(r + 1), ng = ldg(r + 1);
+      const float f0 = (t == 0) ? 0.f : 1.f;                    // zero padding at sequence starts / ends
+      const float f2 = (t == a.T - 1) ? 0.f : 1.f;
+      float4 v, g;
+      v.x = fmaf(wv2.x * f2, nv.x, fmaf(wv1.x, cv.x, fmaf(wv0.x * f0, pv.x, bv.x)));
+      v.y = fmaf(wv2.y * f2, nv.y, fmaf(wv1.y, cv.y, fmaf(wv0.y * f0, pv.y, bv.y)));
+      v.z = fmaf(wv2.z * f2, nv.z, fmaf(wv1.z, cv.z, fmaf(wv0.z * f0, pv.z, bv.z)));
+      v.w = fmaf(wv2.w * f2, nv.w, fmaf(wv1.w, cv.w, fmaf(wv0.w * f0, pv.w, bv.w)));
+      g.x = fmaf(wg2.x * f2, ng.x, fmaf(wg1.x, cg.x, fmaf(wg0.x * f0, pg.x, bg.x)));
+      g.y = fmaf(wg2.y * f2, ng.y, fmaf(wg1.y, cg.y, fmaf(wg0.y * f0, pg.y, bg.y)));
+      g.z = fmaf(wg2.z * f2, ng.z, fmaf(wg1.z, cg.z, fmaf(wg0.z * f0, pg.z, bg.z)));
+      g.w = fmaf(wg2.w * f2, ng.w, fmaf(wg1.w, cg.w, fmaf(wg0.w * f0, pg.w, bg.w)));
+      st4(a.Y + (long long)m * a.ldc + gc,
+          make_float4(v.x * sigmoid_f(g.x), v.y * sigmoid_f(g.y), v.z * sigmoid_f(g.z), v.w * sigmoid_f(g.w)));
+      pv = cv; pg = cg; cv = nv; cg = ng;
+      t = (t + 1 == a.T) ? 0 : t + 1;
+    }
+  } else if (EPI == EPI_GLU) {
+    const int q4 = tid & 15, rg = tid >> 4;       // 16 float4 columns (64 outputs) x 16 strips of 8 rows
+    const int ncol = nb * 64 + 4 * q4;
+    if (ncol >= a.N / 2) return;
+    const float4 bv = ld4(a.bias + ncol), bg = ld4(a.bias + a.N / 2 + ncol);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = rg * 8 + i;
+      const int m = m0 + r;
+      if (m >= a.M) break;
+      const float4 v = ld4(Hs + r * HS + 4 * q4), g = ld4(Hs + r * HS + 64 + 4 * q4);
+      st4(a.Y + (long long)m * a.ldc + ncol,
+          make_float4((v.x + bv.x) * sigmoid_f(g.x + bg.x), (v.y + bv.y) * sigmoid_f(g.y + bg.y),
+                      (v.z + bv.z) * sigmoid_f(g.z + bg.z), (v.w + bv.w) * sigmoid_f(g.w + bg.w)));
+    }
+  } else {
+    const int q4 = tid & 31, rg = tid >> 5;       // 32 float4 columns (128 outputs) x 8 strips of 16 rows
+    const int ncol = nb * GEMM_BN + 4 * q4;
+    if (ncol >= a.N) return;
+    const float4 bias = a.bias ? ld4(a.bias + ncol) : zero4();
+    float4 lsv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (EPI == EPI_RES && a.ls) lsv = ld4(a.ls + ncol);
+    const int split_s = (EPI == EPI_SPLIT) ? ncol / a.Fs : 0;
+    const int split_f = (EPI == EPI_SPLIT) ? ncol - split_s * a.Fs : 0;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int r = rg * 16 + i;
+      const int m = m0 + r;
+      if (m >= a.M) break;
+      float4 v = ld4(Hs + r * HS + 4 * q4);
+      v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+      float* const out = a.Y + (long long)m * a.ldc + ncol;
+      if (EPI == EPI_STORE) {
+        st4(out, v);
+      } else if (EPI == EPI_GELU) {
+        st4(out, make_float4(gelu_exact(v.x), gelu_exact(v.y), gelu_exact(v.z), gelu_exact(v.w)));
+      } else if (EPI == EPI_RES) {
+        v.x *= lsv.x; v.y *= lsv.y; v.z *= lsv.z; v.w *= lsv.w;
+        if (a.R) {
+          const float4 rr = ld4(a.R + (long long)m * a.ldc + ncol);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        st4(out, v);
+      } else if (EPI == EPI_GATE) {
+        const int seq = m / a.T;
+        const int t = m - seq * a.T;
+        const float4 x = ld4(a.R + (long long)m * a.ldc + ncol);
+        const float4 u = ld4(a.aux + ((long long)seq * a.Tp + t / a.fac) * a.N + ncol);
+        st4(out, make_float4(x.x + sigmoid_f(v.x) * u.x, x.y + sigmoid_f(v.y) * u.y,
+                             x.z + sigmoid_f(v.z) * u.z, x.w + sigmoid_f(v.w) * u.w));
+      } else if (EPI == EPI_SPLIT) {
+        // column n = s*F + f  ->  Y[((b*S + s)*T + t)*F + f]   (reference module.py:123)
+        const int b = m / a.T;
+        const int t = m - b * a.T;
+        st4(a.Y + (((long long)b * a.S + split_s) * a.T + t) * a.Fs + split_f, v);
+      } else if (EPI == EPI_MASK) {
+        const int seq = m / a.rows_out;             // b*S + s
+        const int l = m - seq * a.rows_out;
+        const float4 e = ld4(a.aux + ((long long)(seq / a.S) * a.rows_out + l) * a.N + ncol);
+        st4(out, make_float4(fmaxf(v.x, 0.f) * e.x, fmaxf(v.y, 0.f) * e.y, fmaxf(v.z, 0.f) * e.z, fmaxf(v.w, 0.f) * e.w));
+      }
+    }
+  }
+}
+
+}  // namespace sepr

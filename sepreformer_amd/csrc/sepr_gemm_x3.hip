@@ -1,0 +1,55 @@
+// Instantiations + host launcher of the bf16x3 projection core.
+#include "sepr_gemm_x3.h"
+
+namespace sepr {
+
+template <int PRO, int EPI, int TAG = 0>
+static void launch_x3_inst(const GemmArgs& a, hipStream_t stream) {
+  const int tiles = gemm_tiles(a, EPI);
+  const int cap = persistent_grid();
+  const int grid = tiles < cap ? tiles : cap;
+  hipLaunchKernelGGL((gemm_x3_kernel<PRO, EPI, TAG>), dim3(grid), dim3(GEMM_THREADS), 0, stream, a);
+}
+
+int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t stream) {
+  if (a.M <= 0) return SEPR_OK;
+  if (a.N <= 0 || a.K <= 0 || (a.K % X3_BKS) != 0 || (a.N % 16) != 0) return SEPR_EINVAL;
+  const bool glu = (epi == EPI_GLU || epi == EPI_DWGLU);
+  if (glu && (((a.N / 2) % 16) != 0 || !a.bias)) return SEPR_EINVAL;
+  if (!a.A || !a.Wp || !a.Y) return SEPR_EINVAL;
+  if ((a.lda % 4) != 0 || (a.ldc % 4) != 0) return SEPR_EINVAL;
+  if (pro == PRO_CAT2 && (!a.A2 || (a.ksplit % 32) != 0 || (a.lda2 % 4) != 0)) return SEPR_EINVAL;
+  if (pro == PRO_NORM && !a.stats) return SEPR_EINVAL;
+  if (epi == EPI_DWGLU && (!a.dw_w || !a.dw_b || a.T <= 0)) return SEPR_EINVAL;
+  {
+    const long long src_rows = a.rows_out > 0 ? ((long long)(a.M + a.rows_out - 1) / a.rows_out) * a.rows_src : a.M;
+    if (src_rows * a.lda >= (1LL << 32)) return SEPR_EINVAL;
+    if (pro == PRO_CAT2 && (long long)a.M * a.lda2 >= (1LL << 32)) return SEPR_EINVAL;
+  }
+  long long slot = -1;
+  const bool timed = prof_begin(site, stream, &slot);
+  const int key = pro * 16 + epi;
+  if (site == SEPR_SITE_GCFN_UP && key == PRO_NORM * 16 + EPI_DWGLU) {
+    launch_x3_inst<PRO_NORM, EPI_DWGLU, 1>(a, stream);
+  } else if (site == SEPR_SITE_GCFN_DOWN && key == PRO_PLAIN * 16 + EPI_RES) {
+    launch_x3_inst<PRO_PLAIN, EPI_RES, 2>(a, stream);
+  } else
+  switch (key) {
+    case PRO_PLAIN * 16 + EPI_STORE: launch_x3_inst<PRO_PLAIN, EPI_STORE>(a, stream); break;
+    case PRO_PLAIN * 16 + EPI_GLU:   launch_x3_inst<PRO_PLAIN, EPI_GLU>(a, stream); break;
+    case PRO_PLAIN * 16 + EPI_GELU:  launch_x3_inst<PRO_PLAIN, EPI_GELU>(a, stream); break;
+    case PRO_PLAIN * 16 + EPI_RES:   launch_x3_inst<PRO_PLAIN, EPI_RES>(a, stream); break;
+    case PRO_PLAIN * 16 + EPI_SPLIT: launch_x3_inst<PRO_PLAIN, EPI_SPLIT>(a, stream); break;
+    case PRO_PLAIN * 16 + EPI_MASK:  launch_x3_inst<PRO_PLAIN, EPI_MASK>(a, stream); break;
+    case PRO_NORM * 16 + EPI_STORE:  launch_x3_inst<PRO_NORM, EPI_STORE>(a, stream); break;
+    case PRO_NORM * 16 + EPI_GLU:    launch_x3_inst<PRO_NORM, EPI_GLU>(a, stream); break;
+    case PRO_NORM * 16 + EPI_GATE:   launch_x3_inst<PRO_NORM, EPI_GATE>(a, stream); break;
+    case PRO_CAT2 * 16 + EPI_STORE:  launch_x3_inst<PRO_CAT2, EPI_STORE>(a, stream); break;
+    default: return SEPR_EINVAL;
+  }
+  if (timed) prof_end(slot, 2.0 * (double)a.M * (double)a.N * (double)a.K, stream);
+  SEPR_CHECK_LAUNCH("gemm_x3_kernel");
+  return SEPR_OK;
+}
+
+}  // namespace sepr

@@ -126,7 +126,7 @@ class SeparatorEngine:
 
     def fuse(self, lo, skip, wb, n, T):
         y = torch.empty_like(skip)
-        L.check(self.lib.sepr_fuse_fwd(lo.data_ptr(), skip.data_ptr(), y.data_ptr(), n, T, self.cfg.feat, wb[0], wb[1], self._st), "sepr_fuse_fwd")
+        L.check(self.lib.sepr_fuse_fwd(lo.data_ptr(), skip.data_ptr(), y.data_ptr(), n, T, self.cfg.feat, C.byref(wb), self._st), "sepr_fuse_fwd")
         return y
 
     def head(self, x, w, nS, Tsrc, L_, idx, enc, B):

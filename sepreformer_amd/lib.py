@@ -29,23 +29,29 @@ _ERR = {SEPR_EINVAL: "SEPR_EINVAL (bad shape / unsupported size / null pointer)"
 _fp = C.c_void_p  # device pointers travel as plain addresses
 
 
-def _struct(name, fields):
-    return type(name, (C.Structure,), {"_fields_": [(f, _fp) for f in fields]})
+class X3W(C.Structure):
+    """sepr_x3_w: optional bf16x3 form of one projection (wp NULL = exact f32 core)."""
+    _fields_ = [("wp", _fp), ("bias", _fp)]
 
 
-GcfnW = _struct("GcfnW", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "ls"])
-ClaW = _struct("ClaW", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "w3", "b3", "ls"])
-MhaW = _struct("MhaW", ["ln_g", "ln_b", "wqkv", "bqkv", "wo", "bo", "ls"])
+def _struct(name, fields, x3=()):
+    return type(name, (C.Structure,), {"_fields_": [(f, _fp) for f in fields] + [(f, X3W) for f in x3]})
+
+
+GcfnW = _struct("GcfnW", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "ls"], ["x3_up", "x3_down"])
+ClaW = _struct("ClaW", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "w3", "b3", "ls"], ["x3_1", "x3_2", "x3_3"])
+MhaW = _struct("MhaW", ["ln_g", "ln_b", "wqkv", "bqkv", "wo", "bo", "ls"], ["x3_qkv", "x3_out"])
 
 
 class EgaW(C.Structure):
     _fields_ = [("attn", MhaW), ("gate_ln_g", _fp), ("gate_ln_b", _fp), ("gate_w", _fp), ("gate_b", _fp),
-                ("pe_k", _fp), ("maxlen", C.c_int)]
+                ("pe_k", _fp), ("maxlen", C.c_int), ("x3_gate", X3W)]
 
 
 DownW = _struct("DownW", ["w", "scale", "shift"])
-SplitW = _struct("SplitW", ["w1", "b1", "w2", "b2", "gn_g", "gn_b"])
-OutW = _struct("OutW", ["w1", "b1", "w2", "b2", "wdec"])
+SplitW = _struct("SplitW", ["w1", "b1", "w2", "b2", "gn_g", "gn_b"], ["x3_1", "x3_2"])
+FuseW = _struct("FuseW", ["w", "b"], ["x3"])
+OutW = _struct("OutW", ["w1", "b1", "w2", "b2", "wdec"], ["x3_1", "x3_2"])
 
 _i, _f, _sz, _ll = C.c_int, C.c_float, C.c_size_t, C.c_longlong
 
@@ -63,10 +69,11 @@ SIGNATURES = {
     "sepr_spkattn_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _i, C.POINTER(MhaW), _fp, _sz, _fp]),
     "sepr_downconv_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, C.POINTER(DownW), _fp]),
     "sepr_spksplit_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _f, C.POINTER(SplitW), _fp, _sz, _fp]),
-    "sepr_fuse_fwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp]),
+    "sepr_fuse_fwd": (_i, [_fp, _fp, _fp, _i, _i, _i, C.POINTER(FuseW), _fp]),
     "sepr_outlayer_decoder_fwd": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, C.POINTER(OutW), _fp, _fp, _sz, _fp]),
     "sepr_groupnorm_stats": (_i, [_fp, _i, _ll, _f, _fp, _fp, _sz, _fp]),
     "sepr_linear_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
+    "sepr_linear_x3_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
     "sepr_prof_start": (_i, [_i, _i]),
     "sepr_prof_stop": (_i, [C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

@@ -18,20 +18,24 @@ batch-statistics BatchNorm, autograd through the kernels) is a later row of SURV
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
 
 from .config import SepConfig
 from .engine import SeparatorEngine
-from .pack import PackedModel
+from .pack import PRECISIONS, PackedModel
 from .params import build_param_tree
+
+
+DEFAULT_PRECISION = "fp32"
 
 
 class Model(torch.nn.Module):
     def __init__(self, num_stages: int, num_spks: int, module_audio_enc: dict, module_feature_projector: dict,
                  module_separator: dict, module_output_layer: dict, module_audio_dec: dict,
-                 per_level_split: bool = False, init_seed: Optional[int] = None):
+                 per_level_split: bool = False, init_seed: Optional[int] = None, precision: Optional[str] = None):
         super().__init__()
         self.cfg = SepConfig.from_model_kwargs(num_stages, num_spks, module_audio_enc, module_feature_projector,
                                                module_separator, module_output_layer, module_audio_dec,
@@ -42,6 +46,11 @@ class Model(torch.nn.Module):
         self._engine: Optional[SeparatorEngine] = None
         self._engine_key = None
         self.compute_aux = True    # the reference evaluates the aux heads in every forward (model.py:47-52)
+        # projection arithmetic: "fp32" = exact f32 MFMA; "bf16x3" = split-fp32 on the bf16 MFMA (3 MFMAs per
+        # product, ~100 dB agreement with fp32, 5x less matrix time).  Default from SEPR_PRECISION.
+        self.precision = precision or os.environ.get("SEPR_PRECISION", DEFAULT_PRECISION)
+        if self.precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}")
 
     # ---- weights -----------------------------------------------------------------------------------
     @classmethod
@@ -66,11 +75,11 @@ class Model(torch.nn.Module):
                 "sepreformer_amd.Model computes on an MI355X (HIP) device only; move the module with "
                 ".to('cuda'). There is deliberately no CPU fallback (the CPU restatement lives in oracle/ "
                 "and is test infrastructure).")
-        key = (dev, self._weights_key())
+        key = (dev, self.precision, self._weights_key())
         if self._engine is None or self._engine_key != key:
             sd = {k: v.detach() for k, v in self.state_dict(keep_vars=True).items()}
             with torch.cuda.device(dev):
-                self._engine = SeparatorEngine(self.cfg, PackedModel(self.cfg, sd), dev)
+                self._engine = SeparatorEngine(self.cfg, PackedModel(self.cfg, sd, self.precision), dev)
             self._engine_key = key
         return self._engine
 

@@ -24,16 +24,55 @@ BN_EPS = 1e-5      # torch.nn.BatchNorm1d default
 GN_EPS = 1e-8      # reference modules/module.py:28,117
 
 
+PRECISIONS = ("fp32", "bf16x3")
+
+
+def pack_x3(w: torch.Tensor) -> torch.Tensor:
+    """fp32 ``[N,K]`` -> bf16 hi/lo planes in MFMA fragment order ``[N/16][K/32][plane][lane][8]``.
+
+    ``hi = bf16(w)`` (round to nearest even), ``lo = bf16(w - hi)``.  A wave of the bf16x3 core reads the
+    64 x 16-byte fragment of one (16-column tile, 32-deep K step, plane) as one contiguous 1 KiB block:
+    lane ``g*16 + i`` holds ``w[16*tile + i][32*step + 8*g : 32*step + 8*g + 8]``
+    (sepreformer_amd/csrc/sepr_gemm_x3.h)."""
+    N, K = w.shape
+    if N % 16 or K % 32:
+        raise ValueError(f"bf16x3 packing needs N % 16 == 0 and K % 32 == 0, got {N}x{K}")
+    w = w.detach().to(torch.float32)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+
+    def frag(p):
+        return p.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4)      # [tile, step, g, i, 8]
+
+    return torch.stack([frag(hi), frag(lo)], dim=2).contiguous()             # [tile, step, plane, g, i, 8]
+
+
 class Packed:
     """Packed device tensors + the ctypes structs pointing at them (tensors are kept alive here)."""
 
-    def __init__(self):
+    def __init__(self, precision: str = "fp32"):
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}")
+        self.precision = precision
         self.keep: List[torch.Tensor] = []
 
     def t(self, x: torch.Tensor) -> int:
         x = x.detach().to(torch.float32).contiguous()
         self.keep.append(x)
         return x.data_ptr()
+
+    def x3(self, w: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor = None, beta: torch.Tensor = None) -> L.X3W:
+        """bf16x3 form of ``y = LN_affine(x) . w^T + bias`` (NULL struct in fp32 mode).  LayerNorm's affine
+        is folded in fp64:  (x*g + b) . w^T = x . (w*g)^T + w . b."""
+        if self.precision != "bf16x3":
+            return L.X3W()
+        w64, b64 = w.detach().double(), bias.detach().double()
+        if gamma is not None:
+            b64 = b64 + w64 @ beta.detach().double()
+            w64 = w64 * gamma.detach().double()[None, :]
+        wp = pack_x3(w64.float())
+        self.keep.append(wp)
+        return L.X3W(wp=wp.data_ptr(), bias=self.t(b64.float()))
 
 
 def _tapmajor(w: torch.Tensor) -> torch.Tensor:
@@ -46,7 +85,9 @@ def pack_gcfn(pk: Packed, sd: Dict[str, torch.Tensor], p: str) -> L.GcfnW:
         w1=pk.t(sd[p + ".net1.1.weight"]), b1=pk.t(sd[p + ".net1.1.bias"]),
         dw_w=pk.t(_tapmajor(sd[p + ".depthwise.weight"])), dw_b=pk.t(sd[p + ".depthwise.bias"]),
         w2=pk.t(sd[p + ".net2.2.weight"]), b2=pk.t(sd[p + ".net2.2.bias"]),
-        ls=pk.t(sd[p + ".Layer_scale.layer_scale"].reshape(-1)))
+        ls=pk.t(sd[p + ".Layer_scale.layer_scale"].reshape(-1)),
+        x3_up=pk.x3(sd[p + ".net1.1.weight"], sd[p + ".net1.1.bias"], sd[p + ".net1.0.weight"], sd[p + ".net1.0.bias"]),
+        x3_down=pk.x3(sd[p + ".net2.2.weight"], sd[p + ".net2.2.bias"]))
 
 
 def pack_cla(pk: Packed, sd, p: str) -> L.ClaW:
@@ -59,7 +100,10 @@ def pack_cla(pk: Packed, sd, p: str) -> L.ClaW:
         dw_w=pk.t(_tapmajor(sd[p + ".dw_conv_1d.weight"])), dw_b=pk.t(sd[p + ".dw_conv_1d.bias"]),
         w2=pk.t(w2), b2=pk.t(b2),
         w3=pk.t(sd[p + ".linear3.1.weight"]), b3=pk.t(sd[p + ".linear3.1.bias"]),
-        ls=pk.t(sd[p + ".Layer_scale.layer_scale"].reshape(-1)))
+        ls=pk.t(sd[p + ".Layer_scale.layer_scale"].reshape(-1)),
+        x3_1=pk.x3(sd[p + ".linear1.weight"], sd[p + ".linear1.bias"], sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"]),
+        x3_2=pk.x3(w2, b2),
+        x3_3=pk.x3(sd[p + ".linear3.1.weight"], sd[p + ".linear3.1.bias"]))
 
 
 def pack_mha(pk: Packed, sd, p: str) -> L.MhaW:
@@ -69,7 +113,9 @@ def pack_mha(pk: Packed, sd, p: str) -> L.MhaW:
         ln_g=pk.t(sd[p + ".layer_norm.weight"]), ln_b=pk.t(sd[p + ".layer_norm.bias"]),
         wqkv=pk.t(wqkv), bqkv=pk.t(bqkv),
         wo=pk.t(sd[p + ".linear_out.weight"]), bo=pk.t(sd[p + ".linear_out.bias"]),
-        ls=pk.t(sd[p + ".Layer_scale.layer_scale"].reshape(-1)))
+        ls=pk.t(sd[p + ".Layer_scale.layer_scale"].reshape(-1)),
+        x3_qkv=pk.x3(wqkv, bqkv, sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"]),
+        x3_out=pk.x3(sd[p + ".linear_out.weight"], sd[p + ".linear_out.bias"]))
 
 
 def pack_ega(pk: Packed, sd, p: str, pe_ptr: int, maxlen: int) -> L.EgaW:
@@ -77,7 +123,9 @@ def pack_ega(pk: Packed, sd, p: str, pe_ptr: int, maxlen: int) -> L.EgaW:
         attn=pack_mha(pk, sd, p + ".block.self_attn"),
         gate_ln_g=pk.t(sd[p + ".block.linear.0.weight"]), gate_ln_b=pk.t(sd[p + ".block.linear.0.bias"]),
         gate_w=pk.t(sd[p + ".block.linear.1.weight"]), gate_b=pk.t(sd[p + ".block.linear.1.bias"]),
-        pe_k=pe_ptr, maxlen=maxlen)
+        pe_k=pe_ptr, maxlen=maxlen,
+        x3_gate=pk.x3(sd[p + ".block.linear.1.weight"], sd[p + ".block.linear.1.bias"],
+                      sd[p + ".block.linear.0.weight"], sd[p + ".block.linear.0.bias"]))
 
 
 def pack_down(pk: Packed, sd, p: str) -> L.DownW:
@@ -90,21 +138,30 @@ def pack_split(pk: Packed, sd, p: str) -> L.SplitW:
     return L.SplitW(
         w1=pk.t(sd[p + ".linear.0.weight"][:, :, 0]), b1=pk.t(sd[p + ".linear.0.bias"]),
         w2=pk.t(sd[p + ".linear.2.weight"][:, :, 0]), b2=pk.t(sd[p + ".linear.2.bias"]),
-        gn_g=pk.t(sd[p + ".norm.weight"]), gn_b=pk.t(sd[p + ".norm.bias"]))
+        gn_g=pk.t(sd[p + ".norm.weight"]), gn_b=pk.t(sd[p + ".norm.bias"]),
+        x3_1=pk.x3(sd[p + ".linear.0.weight"][:, :, 0], sd[p + ".linear.0.bias"]),
+        x3_2=pk.x3(sd[p + ".linear.2.weight"][:, :, 0], sd[p + ".linear.2.bias"]))
+
+
+def pack_fuse(pk: Packed, sd, p: str) -> L.FuseW:
+    w, b = sd[p + ".weight"][:, :, 0], sd[p + ".bias"]
+    return L.FuseW(w=pk.t(w), b=pk.t(b), x3=pk.x3(w, b))
 
 
 def pack_out(pk: Packed, sd, p: str, dec_weight: torch.Tensor) -> L.OutW:
     return L.OutW(
         w1=pk.t(sd[p + ".end_conv1x1.0.weight"]), b1=pk.t(sd[p + ".end_conv1x1.0.bias"]),
         w2=pk.t(sd[p + ".end_conv1x1.2.weight"]), b2=pk.t(sd[p + ".end_conv1x1.2.bias"]),
-        wdec=pk.t(_tapmajor(dec_weight)))
+        wdec=pk.t(_tapmajor(dec_weight)),
+        x3_1=pk.x3(sd[p + ".end_conv1x1.0.weight"], sd[p + ".end_conv1x1.0.bias"]),
+        x3_2=pk.x3(sd[p + ".end_conv1x1.2.weight"], sd[p + ".end_conv1x1.2.bias"]))
 
 
 class PackedModel(Packed):
     """All blocks of one model, addressed the way the forward driver walks them."""
 
-    def __init__(self, cfg: SepConfig, sd: Dict[str, torch.Tensor]):
-        super().__init__()
+    def __init__(self, cfg: SepConfig, sd: Dict[str, torch.Tensor], precision: str = "fp32"):
+        super().__init__(precision)
         R = cfg.num_stages
         self.cfg = cfg
         self.enc_w = self.t(_tapmajor(sd["audio_encoder.conv1d.weight"]))
@@ -131,8 +188,7 @@ class PackedModel(Packed):
         else:
             one = pack_split(self, sd, "separator.spk_split_block")
             self.splits = [one] * (R + 1)
-        self.fuse = [(self.t(sd[f"separator.simple_fusion.{i}.weight"][:, :, 0]),
-                      self.t(sd[f"separator.simple_fusion.{i}.bias"])) for i in range(R)]
+        self.fuse = [pack_fuse(self, sd, f"separator.simple_fusion.{i}") for i in range(R)]
         self.dec_stages = []
         for i in range(R):
             p = f"separator.dec_stages.{i}"

@@ -164,12 +164,50 @@ def test_abi_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     hdr = open(os.path.join(ROOT, "include", "sepr.h")).read()
     for cname, cls in (("sepr_gcfn_w", L.GcfnW), ("sepr_cla_w", L.ClaW), ("sepr_mha_w", L.MhaW),
-                       ("sepr_down_w", L.DownW), ("sepr_split_w", L.SplitW), ("sepr_out_w", L.OutW)):
+                       ("sepr_down_w", L.DownW), ("sepr_split_w", L.SplitW), ("sepr_fuse_w", L.FuseW),
+                       ("sepr_out_w", L.OutW), ("sepr_x3_w", L.X3W)):
         body = re.search(r"typedef struct \{([^}]*)\} " + cname + ";", hdr).group(1)
-        fields = re.findall(r"const float\*\s*(\w+);", body)
+        fields = re.findall(r"(?:const float\*|const void\*|sepr_x3_w)\s*(\w+);", body)
         assert fields == [f for f, _ in cls._fields_], cname
-        assert ctypes.sizeof(cls) == 8 * len(fields)
-    assert [f for f, _ in L.EgaW._fields_] == ["attn", "gate_ln_g", "gate_ln_b", "gate_w", "gate_b", "pe_k", "maxlen"]
+        n_x3 = len(re.findall(r"sepr_x3_w\s+\w+;", body))
+        assert ctypes.sizeof(cls) == 8 * (len(fields) - n_x3) + 16 * n_x3
+    assert [f for f, _ in L.EgaW._fields_] == ["attn", "gate_ln_g", "gate_ln_b", "gate_w", "gate_b", "pe_k", "maxlen", "x3_gate"]
+
+
+def test_pack_x3_layout_and_split():
+    """bf16x3 packing: fragment order and hi+lo reconstruction (error <= 2^-16 relative)."""
+    from sepreformer_amd.pack import pack_x3
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(48, 96, generator=g)
+    p = pack_x3(w)                                   # [tile, step, plane, g, i, 8]
+    assert tuple(p.shape) == (3, 3, 2, 4, 16, 8) and p.dtype == torch.bfloat16 and p.is_contiguous()
+    rec = (p[:, :, 0].float() + p[:, :, 1].float())  # [tile, step, g, i, 8]
+    rec = rec.permute(0, 3, 1, 2, 4).reshape(48, 96) # tile,i | step,g,8
+    assert float((rec - w).abs().max() / w.abs().max()) < 2.0 ** -16
+    # lane g*16+i of (tile t, step s) holds w[16t+i][32s+8g : 32s+8g+8]
+    t, s_, gg, i = 2, 1, 3, 5
+    hi = p[t, s_, 0, gg, i].float()
+    assert torch.allclose(hi, w[16 * t + i, 32 * s_ + 8 * gg: 32 * s_ + 8 * gg + 8].to(torch.bfloat16).float())
+    with pytest.raises(ValueError):
+        pack_x3(torch.zeros(20, 64))
+
+
+def test_x3_layernorm_folding():
+    """pack.Packed.x3 folds LayerNorm's affine: (xhat*g + b) . W^T + c == xhat . (W*g)^T + (c + W.b)."""
+    from sepreformer_amd import pack
+    g = torch.Generator().manual_seed(1)
+    W, c = torch.randn(32, 64, generator=g), torch.randn(32, generator=g)
+    gam, bet = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    pk = pack.Packed("bf16x3")
+    x3 = pk.x3(W, c, gam, bet)
+    assert x3.wp and x3.bias
+    wp, bias = pk.keep[-2], pk.keep[-1]
+    Wf = (wp[:, :, 0].float() + wp[:, :, 1].float()).permute(0, 3, 1, 2, 4).reshape(32, 64)
+    xhat = torch.randn(10, 64, generator=g)
+    want = (xhat * gam + bet) @ W.t() + c
+    got = xhat @ Wf.t() + bias
+    assert orc.agreement_db(got, want) > 85
+    assert not pack.Packed("fp32").x3(W, c).wp
 
 
 def test_no_cpu_fallback():

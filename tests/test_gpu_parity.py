@@ -53,13 +53,15 @@ def agree(name, got, want, min_db=MIN_DB):
 
 
 _models = {}
+PRECISIONS = ["fp32", "bf16x3"]
 
 
-def gpu_model(variant):
-    if variant not in _models:
-        m = Model.from_config(VARIANTS[variant], init_seed=0).load_synthetic_(0).eval().to("cuda")
-        _models[variant] = (m, synth_state_dict(VARIANTS[variant], 0))
-    return _models[variant]
+def gpu_model(variant, precision="fp32"):
+    key = (variant, precision)
+    if key not in _models:
+        m = Model.from_config(VARIANTS[variant], init_seed=0, precision=precision).load_synthetic_(0).eval().to("cuda")
+        _models[key] = (m, synth_state_dict(VARIANTS[variant], 0))
+    return _models[key]
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -94,22 +96,39 @@ def test_linear_core(M, N, K):
     agree(f"linear_nobias.{M}x{N}x{K}", y2, (x.double() @ w.double().t()).float(), 120.0)
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (130, 192, 64), (4099, 768, 128), (257, 64, 512), (128, 1024, 128), (5, 128, 384)])
+def test_linear_core_bf16x3(M, N, K):
+    """Second precision: split-fp32 on the bf16 MFMA.  Operand split error 2^-17, dropped lo.lo term 2^-16:
+    >= 85 dB against fp64 is required (measured ~100 dB), i.e. far better than plain bf16 (~47 dB)."""
+    from sepreformer_amd.pack import pack_x3
+    lib = L.load()
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2) / K ** 0.5, rnd(N, seed=3)
+    xd, bd = x.cuda(), b.cuda()
+    wp = pack_x3(w.cuda())
+    y = torch.empty(M, N, device="cuda")
+    L.check(lib.sepr_linear_x3_fwd(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), M, N, K,
+                                   torch.cuda.current_stream().cuda_stream), "sepr_linear_x3_fwd")
+    want = (x.double() @ w.double().t() + b.double()).float()
+    agree(f"linear_x3.{M}x{N}x{K}", y, want, 85.0)
+
+
 # ---------------------------------------------------------------------------------------------------
 # every fused block against the oracle's restatement of the same reference module
 # ---------------------------------------------------------------------------------------------------
 BLOCK_VARIANTS = ["tiny", "SepReformer_Base_WSJ0", "SepReformer_Large_DM_WHAMR"]
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("variant", BLOCK_VARIANTS)
-def test_blocks(variant):
-    m, sd = gpu_model(variant)
+def test_blocks(variant, precision):
+    m, sd = gpu_model(variant, precision)
     cfg = m.cfg
     eng = m.engine()
     pk = eng.pk
     F, H, S, N = cfg.feat, cfg.heads, cfg.num_spks, cfg.enc_channels
     eng.prepare(8, 2400, 2400)
     e0 = "separator.enc_stages.0"
-    tag = variant.split("_")[1] if "_" in variant else variant
+    tag = (variant.split("_")[1] if "_" in variant else variant) + ("" if precision == "fp32" else ".x3")
 
     # GCFN (network.py:46-66): T not a multiple of anything, several sequences
     for n, T in ((2, 37), (3, 300)):
@@ -217,10 +236,12 @@ E2E = [("tiny", "tiny"), ("tiny", "tiny_b1"), ("SepReformer_Base_WSJ0", "base_0p
        ("SepReformer_Large_DM_WHAMR", "large_whamr_0p5s"), ("SepReformer_Large_DM_WHAM", "large_wham_0p5s")]
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("variant,tag", E2E)
-def test_e2e_golden(golden, variant, tag):
+def test_e2e_golden(golden, variant, tag, precision):
     g = golden("e2e_" + tag)
-    m, _ = gpu_model(variant)
+    m, _ = gpu_model(variant, precision)
+    tag = tag + ("" if precision == "fp32" else ".x3")
     x = torch.from_numpy(g["x"]).cuda()
     audio, aux = m(x)
     assert len(audio) == m.num_spks and len(aux) == m.num_stages and len(aux[0]) == m.num_spks
@@ -234,10 +255,11 @@ def test_e2e_golden(golden, variant, tag):
             agree(f"e2e.{tag}.aux{i}", auxt[i], torch.from_numpy(g["aux"][i]))
 
 
-def test_e2e_pit_si_snr_gate(golden):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_e2e_pit_si_snr_gate(golden, precision):
     """north_star tolerance: PIT SI-SNR of the separated waveforms within 1e-3 dB of the reference's."""
     g = golden("e2e_base_4s")
-    m, _ = gpu_model("SepReformer_Base_WSJ0")
+    m, _ = gpu_model("SepReformer_Base_WSJ0", precision)
     src = torch.from_numpy(synth_sources(1, 32000, seed=1234))          # [1, 2, T] the mixture's sources
     assert np.allclose(src.sum(1).numpy(), g["x"], atol=1e-7)
     audio, _ = m(torch.from_numpy(g["x"]).cuda())
@@ -245,9 +267,10 @@ def test_e2e_pit_si_snr_gate(golden):
     srcs = [src[:, 0, :T], src[:, 1, :T]]
     got = orc.pit_si_snr_db([a.cpu() for a in audio], srcs)
     ref = orc.pit_si_snr_db([torch.from_numpy(g["main"][0]), torch.from_numpy(g["main"][1])], srcs)
-    record("pit_si_snr.hip_db", got[0])
+    sfx = "" if precision == "fp32" else ".x3"
+    record("pit_si_snr.hip_db" + sfx, got[0])
     record("pit_si_snr.ref_db", ref[0])
-    record("pit_si_snr.abs_delta_db", (got - ref).abs().max())
+    record("pit_si_snr.abs_delta_db" + sfx, (got - ref).abs().max())
     assert float((got - ref).abs().max()) <= 1e-3
 
 
@@ -266,8 +289,9 @@ def test_intermediate_taps_vs_oracle():
 # ---------------------------------------------------------------------------------------------------
 # BASELINE config 2 size (B=32, 4 s): size-independent properties + spot checks against the oracle
 # ---------------------------------------------------------------------------------------------------
-def test_full_size_batch_properties():
-    m, sd = gpu_model("SepReformer_Base_WSJ0")
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_batch_properties(precision):
+    m, sd = gpu_model("SepReformer_Base_WSJ0", precision)
     B = 32
     x = synth_mixture(B, 32000, seed=1234)
     xd = x.cuda()
@@ -279,31 +303,32 @@ def test_full_size_batch_properties():
     # batch equals the same utterance run alone, and a permuted batch permutes the outputs
     for b in (0, 17, 31):
         alone = m.separate(xd[b:b + 1])
-        agree(f"full.batch_vs_alone.b{b}", wav[:, b:b + 1], alone.cpu(), 120.0)
+        agree(f"full.{precision}.batch_vs_alone.b{b}", wav[:, b:b + 1], alone.cpu(), 120.0)
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
-    agree("full.permutation", m.separate(xd[perm.cuda()]), wav[:, perm.cuda()].cpu(), 120.0)
+    agree(f"full.{precision}.permutation", m.separate(xd[perm.cuda()]), wav[:, perm.cuda()].cpu(), 120.0)
     # spot check two utterances of the full batch against the oracle on the host
     for b in (3, 29):
         audio, _ = orc.model_forward(sd, m.cfg, x[b:b + 1])
-        agree(f"full.vs_oracle.b{b}", wav[:, b:b + 1], torch.stack(list(audio), 0))
+        agree(f"full.{precision}.vs_oracle.b{b}", wav[:, b:b + 1], torch.stack(list(audio), 0))
     # utterance 0 of this batch is the committed golden (seed 1234)
     g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_base_4s.npz"))
-    agree("full.vs_golden.b0", wav[:, 0:1], torch.from_numpy(g["main"]))
+    agree(f"full.{precision}.vs_golden.b0", wav[:, 0:1], torch.from_numpy(g["main"]))
 
 
 # ---------------------------------------------------------------------------------------------------
 # edge cases and error behaviour
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("T", [28, 76, 652, 1040, 1036])
-def test_ragged_lengths_tiny(T):
+def test_ragged_lengths_tiny(T, precision):
     """Shortest inputs (a single pooled frame), frame counts that are / are not multiples of 2**R."""
-    m, sd = gpu_model("tiny")
+    m, sd = gpu_model("tiny", precision)
     x = synth_mixture(2, T, seed=T) * 4
     audio, aux = m(x.cuda())
     o_audio, o_aux = orc.model_forward(sd, m.cfg, x)
     for s in range(2):
-        agree(f"ragged.T{T}.main{s}", audio[s], o_audio[s].reshape(2, -1))
-        agree(f"ragged.T{T}.aux0.{s}", aux[0][s], o_aux[0][s].reshape(2, -1))
+        agree(f"ragged.{precision}.T{T}.main{s}", audio[s], o_audio[s].reshape(2, -1))
+        agree(f"ragged.{precision}.T{T}.aux0.{s}", aux[0][s], o_aux[0][s].reshape(2, -1))
 
 
 def test_no_padding_case_base():

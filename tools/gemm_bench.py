@@ -35,7 +35,21 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         tf = 2.0 * M * N * K / ms / 1e9
         gbs = (M * K + M * N) * 4 / ms / 1e6
-        print(f"  M={M:7d} N={N:5d} K={K:5d}  {ms:8.3f} ms  {tf:7.1f} TFLOP/s  {gbs:7.0f} GB/s(min traffic)")
+        line = f"  M={M:7d} N={N:5d} K={K:5d}  f32 {ms:8.3f} ms {tf:7.1f} TF {gbs:6.0f} GB/s"
+        if K % 64 == 0:
+            from sepreformer_amd.pack import pack_x3
+            wp = pack_x3(w)
+            for _ in range(3):
+                L.check(lib.sepr_linear_x3_fwd(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, st), "x3")
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                lib.sepr_linear_x3_fwd(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, st)
+            e1.record()
+            torch.cuda.synchronize()
+            ms3 = e0.elapsed_time(e1) / reps
+            line += f" | bf16x3 {ms3:8.3f} ms {2.0 * M * N * K / ms3 / 1e9:7.1f} TF-eq {(M * K + M * N) * 4 / ms3 / 1e6:6.0f} GB/s"
+        print(line)
         del x, w, b, y
 
 
