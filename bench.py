@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary heads (NOT the reference's forward)")
+    ap.add_argument("--no-alt-precision", action="store_true", help="skip the second-precision side measurement")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=None,
                     help="projection arithmetic (default: the package default / SEPR_PRECISION)")
     args = ap.parse_args()
@@ -201,6 +202,21 @@ def main():
             "model_mfma_frac": round(utt_per_s * gflop / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
             "roofline": roof,
         }
+        if world == 1 and not args.no_alt_precision:
+            # the other projection arithmetic on the same workload (2 timed steps): exact f32 MFMA vs bf16x3
+            alt = "fp32" if precision == "bf16x3" else "bf16x3"
+            model.precision = alt
+            step(); torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(2):
+                out_alt = step()
+            torch.cuda.synchronize(dev)
+            alt_s = (time.perf_counter() - t1) / 2
+            rec["alt_precision"] = {"precision": alt, "value": round(B / alt_s, 3), "unit": "utt/s",
+                                    "ms_per_step": round(1e3 * alt_s, 3),
+                                    "parity_db_vs_golden": round(agreement_db(torch.stack([a[0:1] for a in out_alt[0]], 0).cpu(),
+                                                                              torch.from_numpy(g["main"])), 1)}
+            model.precision = precision
         if world == 1 and not args.no_cpu_baseline:
             threads = int(os.environ.get("SEPR_CPU_THREADS", str(physical_cores())))
             rec["cpu_baseline"] = cpu_baseline(cfg, threads)

@@ -12,8 +12,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- math -----------------------------------------------------------------------------------------
 // exact-erf GELU (torch.nn.GELU() default, reference modules/module.py:17,70, modules/network.py:169)
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// (explicit fmaf / no implicit contraction: the result of an element must not depend on how the compiler
+//  happened to vectorise the loop iteration it sits in)
+__device__ __forceinline__ float gelu_exact(float x) {
+#pragma clang fp contract(off)
+  const float h = 0.5f * x;
+  return fmaf(h, erff(x * 0.70710678118654752440f), h);
+}
+__device__ __forceinline__ float sigmoid_f(float x) {
+#pragma clang fp contract(off)
+  return 1.0f / (1.0f + __expf(-x));
+}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
     }
   };
   auto store_tile = [&](int buf) {
+#pragma clang fp contract(off)
     float* As = As0 + buf * GEMM_BM * LS;
     float* Bs = Bs0 + buf * GEMM_BN * LS;
 #pragma unroll
@@ -157,10 +158,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
       if (PRO == PRO_NORM) {
         // invalid rows carry mean = rstd = 0 and mask 0: exactly zero (pad_signal semantics)
         const float sc = rstd[i] * mka[i];
-        v.x = ((v.x - mean[i]) * sc) * g4.x + b4.x * mka[i];
-        v.y = ((v.y - mean[i]) * sc) * g4.y + b4.y * mka[i];
-        v.z = ((v.z - mean[i]) * sc) * g4.z + b4.z * mka[i];
-        v.w = ((v.w - mean[i]) * sc) * g4.w + b4.w * mka[i];
+        v.x = fmaf((v.x - mean[i]) * sc, g4.x, b4.x * mka[i]);
+        v.y = fmaf((v.y - mean[i]) * sc, g4.y, b4.y * mka[i]);
+        v.z = fmaf((v.z - mean[i]) * sc, g4.z, b4.z * mka[i]);
+        v.w = fmaf((v.w - mean[i]) * sc, g4.w, b4.w * mka[i]);
       } else {
         v.x *= mka[i]; v.y *= mka[i]; v.z *= mka[i]; v.w *= mka[i];
       }

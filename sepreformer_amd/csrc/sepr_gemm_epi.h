@@ -87,6 +87,10 @@ int persistent_grid();
 template <int EPI>
 __device__ __forceinline__ void epilogue_from_lds(const GemmArgs& a, const float* Hs, const int m0, const int nb,
                                                   const int tid) {
+  // Every fused multiply-add below is written as fmaf(); implicit contraction is off so that the compiler
+  // cannot fuse some unrolled row iterations and not others (that made results depend on a row's position
+  // inside its tile at the 1-ulp level, i.e. a batch of 32 was not bit-identical to 32 single runs).
+#pragma clang fp contract(off)
   constexpr int HS = GEMM_HS;
   if (EPI == EPI_DWGLU) {
     // GCFN: h = acc + b1, depthwise k=3 conv along frames (zero padding at sequence ends), GLU
@@ -164,10 +168,12 @@ __device__ __forceinline__ void epilogue_from_lds(const GemmArgs& a, const float
       } else if (EPI == EPI_GELU) {
         st4(out, make_float4(gelu_exact(v.x), gelu_exact(v.y), gelu_exact(v.z), gelu_exact(v.w)));
       } else if (EPI == EPI_RES) {
-        v.x *= lsv.x; v.y *= lsv.y; v.z *= lsv.z; v.w *= lsv.w;
         if (a.R) {
           const float4 rr = ld4(a.R + (long long)m * a.ldc + ncol);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          v.x = fmaf(v.x, lsv.x, rr.x); v.y = fmaf(v.y, lsv.y, rr.y);
+          v.z = fmaf(v.z, lsv.z, rr.z); v.w = fmaf(v.w, lsv.w, rr.w);
+        } else {
+          v.x *= lsv.x; v.y *= lsv.y; v.z *= lsv.z; v.w *= lsv.w;
         }
         st4(out, v);
       } else if (EPI == EPI_GATE) {
@@ -175,8 +181,8 @@ __device__ __forceinline__ void epilogue_from_lds(const GemmArgs& a, const float
         const int t = m - seq * a.T;
         const float4 x = ld4(a.R + (long long)m * a.ldc + ncol);
         const float4 u = ld4(a.aux + ((long long)seq * a.Tp + t / a.fac) * a.N + ncol);
-        st4(out, make_float4(x.x + sigmoid_f(v.x) * u.x, x.y + sigmoid_f(v.y) * u.y,
-                             x.z + sigmoid_f(v.z) * u.z, x.w + sigmoid_f(v.w) * u.w));
+        st4(out, make_float4(fmaf(sigmoid_f(v.x), u.x, x.x), fmaf(sigmoid_f(v.y), u.y, x.y),
+                             fmaf(sigmoid_f(v.z), u.z, x.z), fmaf(sigmoid_f(v.w), u.w, x.w)));
       } else if (EPI == EPI_SPLIT) {
         // column n = s*F + f  ->  Y[((b*S + s)*T + t)*F + f]   (reference module.py:123)
         const int b = m / a.T;

@@ -109,6 +109,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
     for (int j = 0; j < 8; ++j) ra[j] = ld4(src + 4 * j);
   };
   auto store_slab = [&](int buf) {
+#pragma clang fp contract(off)
     unsigned short* hi = smem + (buf * 2 + 0) * X3_PLANE + srow * X3_LDK + kh;
     unsigned short* lo = smem + (buf * 2 + 1) * X3_PLANE + srow * X3_LDK + kh;
     const float sc = (PRO == PRO_NORM) ? rstd * mka : mka;   // invalid rows: exactly zero (pad_signal)

@@ -29,7 +29,7 @@ from .pack import PRECISIONS, PackedModel
 from .params import build_param_tree
 
 
-DEFAULT_PRECISION = "fp32"
+DEFAULT_PRECISION = "bf16x3"
 
 
 class Model(torch.nn.Module):

@@ -303,9 +303,12 @@ def test_full_size_batch_properties(precision):
     # batch equals the same utterance run alone, and a permuted batch permutes the outputs
     for b in (0, 17, 31):
         alone = m.separate(xd[b:b + 1])
-        agree(f"full.{precision}.batch_vs_alone.b{b}", wav[:, b:b + 1], alone.cpu(), 120.0)
+        # fp32: position-independent arithmetic (bit-identical in practice); bf16x3 amplifies any 1-ulp
+        # upstream difference to its own 2^-17 split noise, so only the noise floor is required there
+        agree(f"full.{precision}.batch_vs_alone.b{b}", wav[:, b:b + 1], alone.cpu(), 120.0 if precision == "fp32" else 95.0)
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
-    agree(f"full.{precision}.permutation", m.separate(xd[perm.cuda()]), wav[:, perm.cuda()].cpu(), 120.0)
+    agree(f"full.{precision}.permutation", m.separate(xd[perm.cuda()]), wav[:, perm.cuda()].cpu(),
+          120.0 if precision == "fp32" else 95.0)
     # spot check two utterances of the full batch against the oracle on the host
     for b in (3, 29):
         audio, _ = orc.model_forward(sd, m.cfg, x[b:b + 1])
