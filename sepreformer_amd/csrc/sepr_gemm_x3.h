@@ -26,6 +26,18 @@ namespace sepr {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef SEPR_ABL_NOLOAD
+#define SEPR_ABL_NOLOAD 0
+#endif
+#ifndef SEPR_ABL_NOSTORE
+#define SEPR_ABL_NOSTORE 0
+#endif
+#ifndef SEPR_ABL_NOW
+#define SEPR_ABL_NOW 0
+#endif
+#ifndef SEPR_ABL_NOMMA
+#define SEPR_ABL_NOMMA 0
+#endif
 constexpr int X3_BKS = 64;                  // K extent of one LDS slab
 constexpr int X3_LDK = X3_BKS + 16;         // bf16 elements per LDS row (160 B)
 constexpr int X3_PLANE = GEMM_BM * X3_LDK;  // elements of one plane of one buffer
@@ -102,6 +114,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
     }
   };
   auto load_slab = [&](int s) {
+#if SEPR_ABL_NOLOAD
+    if (s > 0 || blockIdx.x != (unsigned)a.M) return;   // timing ablation
+#endif
     const int k = s * X3_BKS + kh;
     const float* src = a.A + pa + k;
     if (PRO == PRO_CAT2 && k >= a.ksplit) src = a.A2 + pa2 + (k - a.ksplit);
@@ -130,6 +145,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
   };
   // weight fragments of K step ks (global, fragment order: one coalesced 1 KiB load per tile and plane)
   auto load_w = [&](int ks, uint4 (&wh)[2], uint4 (&wl)[2]) {
+#if SEPR_ABL_NOW
+    if (ks > 0 || blockIdx.x != (unsigned)a.M) return;  // timing ablation
+#endif
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const uint4* p = Wp + wbase[nt] + (unsigned)ks * 128u + lane;
@@ -141,6 +159,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
   f32x4 acc[2][8];
   auto mma_half = [&](const unsigned short* ph, const unsigned short* pl, int kk, int half, const uint4 (&wh)[2],
                       const uint4 (&wl)[2]) {
+#if SEPR_ABL_NOMMA
+    if (blockIdx.x != (unsigned)a.M) return;            // timing ablation
+#endif
     bf16x8 xh[4], xl[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -178,6 +199,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
     return mb < MB;
   };
   auto epilogue = [&](const int m0, const int nb) {
+#if SEPR_ABL_NOSTORE
+    {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+      return;
+    }
+#endif
     float* const Hs = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -198,9 +228,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
   while (tile < ntiles && !decode(tile, m0, nb)) tile += gridDim.x;
   if (tile >= ntiles) return;
   setup(m0, nb);
-  load_slab(0);
   uint4 wh[2], wl[2], wh2[2], wl2[2];
   load_w(0, wh, wl);
+  load_slab(0);
   while (true) {
     store_slab(0);
 #pragma unroll
@@ -210,11 +240,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
       const int cur = s & 1;
-      if (s + 1 < nslab) load_slab(s + 1);
       const unsigned short* ph = smem + (cur * 2 + 0) * X3_PLANE;
       const unsigned short* pl = smem + (cur * 2 + 1) * X3_PLANE;
-      // two K steps per slab; the next step's weight fragments are in flight under the current MFMAs
+      // two K steps per slab; the next step's weight fragments are in flight under the current MFMAs.
+      // vmcnt retires in order: the (L2-resident) weight fragments are requested BEFORE the next slab's HBM
+      // loads, so waiting for them does not also wait for the slab.
       load_w(2 * s + 1, wh2, wl2);
+      if (s + 1 < nslab) load_slab(s + 1);
       mma_half(ph, pl, 0, 0, wh, wl);
       mma_half(ph, pl, 0, 1, wh, wl);
       if (s + 1 < nslab) load_w(2 * s + 2, wh, wl);
@@ -230,8 +262,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
     const bool more = nxt < ntiles;
     if (more) {
       setup(m0, nb);
-      load_slab(0);
       load_w(0, wh, wl);
+      load_slab(0);
     }
     epilogue(m0c, nbc);
     if (!more) break;

@@ -525,54 +525,46 @@ int launch_encoder(const float* wav, int B, int T, int L, const float* w, int N,
 // ---------------------------------------------------------------------------------------------------
 // AudioDecoder: ConvTranspose1d(N -> 1, K taps, stride, no bias) (module.py:268-283) as
 //   D[l][k] = sum_c O2[l][c] * wdec[k][c]   then   wav[tau] = sum_{l*stride + k = tau} D[l][k]
-// A workgroup = 64 frames (+ (K-1)/stride halo frames recomputed) of one (utterance, speaker); the
-// overlap-add happens in LDS, so each output sample is written exactly once (no atomics).
-// Output layout [S,B,Tout]: speaker-major, matching model.py:43-44's list of per-speaker [B,T] tensors.
+// A workgroup = 64 frame rows of one (utterance, speaker): 61 new frames + (K-1)/stride = 3 halo frames that
+// are recomputed, one 16-frame sub-tile per wave.  D^T[tap][frame] runs on the f32 MFMA with both operands
+// read straight from global memory as 16-byte fragments (the [16, N] tap matrix stays in L1/L2; every
+// activation row is read once), then the overlap-add happens in LDS so each output sample is written exactly
+// once (no atomics).  Output layout [S,B,Tout]: speaker-major, matching model.py:43-44's list of per-speaker
+// [B,T] tensors.
 // ---------------------------------------------------------------------------------------------------
-constexpr int DEC_FT = 64, DEC_HB = 3, DEC_NMAX = 256;
+constexpr int DEC_ROWS = 64, DEC_HB = 3, DEC_FT = DEC_ROWS - DEC_HB;
 
 template <int K>
 __global__ __launch_bounds__(TPB) void decoder_kernel(const float* __restrict__ O2, int S, int B, int L, int N, int stride,
                                                      const float* __restrict__ wdec, float* __restrict__ wav, int Tout) {
-  constexpr int XS = DEC_NMAX + 4;
-  __shared__ __attribute__((aligned(16))) float xs[(DEC_FT + DEC_HB) * XS];
-  __shared__ __attribute__((aligned(16))) float wsm[K * XS];
-  __shared__ float Ds[(DEC_FT + DEC_HB) * K];
-  const int hb = (K - 1) / stride;
-  const int rows = DEC_FT + hb;
+  static_assert(K == 16, "one 16-tap MFMA tile");
+  __shared__ __attribute__((aligned(16))) float Ds[DEC_ROWS * K];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int hb = (K - 1) / stride;                 // == DEC_HB (checked by the launcher)
   const int seq = blockIdx.y, l0 = blockIdx.x * DEC_FT;
-  const int N4 = N / 4;
-  for (int i = threadIdx.x; i < rows * N4; i += TPB) {
-    const int r = i / N4, q = i % N4;
-    const int l = l0 - hb + r;
-    st4(xs + r * XS + 4 * q, (l >= 0 && l < L) ? ld4(O2 + ((long long)seq * L + l) * N + 4 * q) : zero4());
+  // tile row r <-> frame l0 - hb + r; this lane's frame
+  const int l = l0 - hb + 16 * w + fi;
+  const bool valid = (l >= 0 && l < L);
+  const float* xrow = O2 + ((long long)seq * L + (valid ? l : 0)) * N + 4 * fg;
+  const float* wrow = wdec + (long long)fi * N + 4 * fg;     // tap fi
+  f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int steps = N / 16;
+  for (int cc = 0; cc < steps; ++cc) {
+    float4 x = ld4(xrow + 16 * cc);
+    const float4 wv = ld4(wrow + 16 * cc);
+    if (!valid) x = zero4();
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, x.x, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, x.y, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, x.z, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, x.w, d, 0, 0, 0);
   }
-  for (int i = threadIdx.x; i < K * N4; i += TPB) {
-    const int k = i / N4, q = i % N4;
-    st4(wsm + k * XS + 4 * q, ld4(wdec + (long long)k * N + 4 * q));
-  }
-  __syncthreads();
-  for (int it = threadIdx.x; it < rows * (K / 4); it += TPB) {
-    const int r = it / (K / 4), kq = it % (K / 4);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float* xr = xs + r * XS;
-    const float* w0 = wsm + (4 * kq) * XS;
-    for (int q = 0; q < N4; ++q) {
-      const float4 x = ld4(xr + 4 * q);
-      a0 += dot4(x, ld4(w0 + 4 * q));
-      a1 += dot4(x, ld4(w0 + XS + 4 * q));
-      a2 += dot4(x, ld4(w0 + 2 * XS + 4 * q));
-      a3 += dot4(x, ld4(w0 + 3 * XS + 4 * q));
-    }
-    Ds[r * K + 4 * kq] = a0;
-    Ds[r * K + 4 * kq + 1] = a1;
-    Ds[r * K + 4 * kq + 2] = a2;
-    Ds[r * K + 4 * kq + 3] = a3;
-  }
+  // lane holds D[frame = 16w + fi][tap = 4fg + r]
+  st4(Ds + (16 * w + fi) * K + 4 * fg, make_float4(d[0], d[1], d[2], d[3]));
   __syncthreads();
   const int s = seq % S, b = seq / S;
   float* dst = wav + ((long long)s * B + b) * Tout;
-  for (int tl = threadIdx.x; tl < DEC_FT * stride; tl += TPB) {
+  for (int tl = tid; tl < DEC_FT * stride; tl += TPB) {
     const long long tau = (long long)l0 * stride + tl;
     if (tau >= Tout) continue;
     const int lr = tl / stride, ph = tl - lr * stride;
@@ -588,7 +580,7 @@ __global__ __launch_bounds__(TPB) void decoder_kernel(const float* __restrict__ 
 int launch_decoder(const float* O2, int nS, int S, int L, int N, int K, int stride, const float* wdec, float* wav,
                    int Tout, hipStream_t s) {
   if (nS <= 0 || L <= 0) return SEPR_EINVAL;
-  if (K != 16 || stride < 4 || stride > 16 || N > DEC_NMAX || N % 4 != 0 || S <= 0 || nS % S != 0) return SEPR_EINVAL;
+  if (K != 16 || stride < 4 || stride > 16 || N > 4096 || N % 16 != 0 || S <= 0 || nS % S != 0) return SEPR_EINVAL;
   if ((K - 1) / stride > DEC_HB) return SEPR_EINVAL;
   const int hb = (K - 1) / stride;
   const int tiles = (L + hb + DEC_FT - 1) / DEC_FT;

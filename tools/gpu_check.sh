@@ -23,7 +23,7 @@ timeout 600 python bench.py --steps $STEPS --warmup 2 > $OUT/bench.log 2> $OUT/b
 cat $OUT/bench.log | tee -a $OUT/summary.txt
 tail -5 $OUT/bench.err
 echo "== rocprofv3 kernel trace" | tee -a $OUT/summary.txt
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/prof.log 2>&1; echo "rocprof rc=$?" | tee -a $OLDPWD/$OUT/summary.txt
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-precision > $OLDPWD/$OUT/prof.log 2>&1; echo "rocprof rc=$?" | tee -a $OLDPWD/$OUT/summary.txt
 cd $OLDPWD
 find $OUT/prof -name "*stats*" | head; 
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f" | cut -c1-200 | tee -a $OUT/summary.txt
