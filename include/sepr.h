@@ -62,6 +62,10 @@ typedef struct {
   const float* ls;   /* [F]     Layer_scale.layer_scale */
   sepr_x3_w x3_up;   /* net1 (LayerNorm folded) */
   sepr_x3_w x3_down; /* net2.2 */
+  /* optional fully fused form (bf16x3, F = 64 or 128; pack.py::pack_gcfn_fused); both or none */
+  const void* fused_w1p;   /* per 32-channel hidden chunk: [v0 v1 g0 g1][F/32][plane][64][8] bf16 (gamma folded)
+                              + 4 KB fp32 constants [2][b1v b1g wv0 wv1 wv2 wg0 wg1 wg2 cbv cbg][16] */
+  const void* fused_w2p;   /* [3F/32][F/16][plane][64][8] bf16, permuted k-slot order */
 } sepr_gcfn_w;
 
 /* CLA, modules/network.py:159-187 (eval-mode BatchNorm folded into w2/b2 by the packer) */
@@ -175,7 +179,8 @@ int sepr_projector_fwd(const float* enc, int B, int L, int Lp, int N, int F, con
                        const float* gn_g, const float* gn_b, const float* w, float* out,
                        sepr_stream_t stream);
 
-/* GCFN.forward, modules/network.py:60-66.  x,y [n,T,F]; y may alias x. */
+/* GCFN.forward, modules/network.py:60-66.  x,y [n,T,F]; y may alias x (the fully fused form needs x != y and
+ * is skipped when they alias). */
 int sepr_gcfn_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_w* w, void* ws,
                   size_t ws_bytes, sepr_stream_t stream);
 

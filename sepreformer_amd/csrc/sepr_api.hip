@@ -14,6 +14,13 @@ void set_hip_error(hipError_t e, const char* where) {
 
 static const float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default (network.py:50,81,133,162)
 
+struct GcfnFusedArgs {
+  const float* x; float* y; int M, T;
+  const void* w1p; const void* w2p;
+  const float* b2; const float* ls; float eps;
+};
+int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream);   // sepr_gcfn_fused.hip
+
 // one projection on whichever core its weights were packed for
 static int project(int pro, int epi, GemmArgs& a, const sepr_x3_w& x3, int site, hipStream_t st) {
   if (x3.wp) {
@@ -104,6 +111,14 @@ extern "C" int sepr_gcfn_fwd(const float* x, float* y, int n, int T, int F, cons
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long M = (long long)n * T;
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
+  if (w->fused_w1p && w->fused_w2p && x != y && (F == 64 || F == 128)) {
+    // one kernel: LayerNorm + both projections + depthwise conv + GLU + LayerScale + residual
+    GcfnFusedArgs f;
+    f.x = x; f.y = y; f.M = (int)M; f.T = T;
+    f.w1p = w->fused_w1p; f.w2p = w->fused_w2p;
+    f.b2 = w->b2; f.ls = w->ls; f.eps = LN_EPS;
+    return launch_gcfn_fused(f, F, SEPR_SITE_GCFN_UP, st);
+  }
   Arena ar(ws, ws_bytes);
   float* stats = ar.f32(2 * M);
   float* g = ar.f32(3LL * F * M);

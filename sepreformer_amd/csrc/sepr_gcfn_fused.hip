@@ -1,0 +1,350 @@
+// Fully fused GCFN block on the bf16x3 core (reference modules/network.py:46-66):
+//     y = x + layer_scale * Linear_3F->F( GLU( dwconv_k3( Linear_F->6F( LayerNorm(x) ) ) ) )
+// in ONE kernel.  Neither the [rows, 6F] hidden tensor nor the [rows, 3F] gated tensor nor the LayerNorm
+// statistics ever reach HBM: algorithmic traffic is "read x once, write y once" (1 KB per frame at F=128
+// against ~4 KB for the two-projection form).
+//
+// Row-stationary design.  A wave owns 32 consecutive frames (30 outputs + one halo frame on each side, the
+// halo is recomputed so waves never exchange activations):
+//   * its frames are loaded once, straight from global memory into the MFMA B-fragment layout (lane = frame,
+//     4 lane groups x 8 consecutive channels per K step); LayerNorm statistics are two shuffles across the 4
+//     lane groups; the normalised frames are split into bf16 hi/lo and stay in registers for the whole tile;
+//   * the hidden dimension is walked in chunks of 32 value + 32 gate channels.  Per chunk the packed weight
+//     fragments (48 KB for F=128: up-projection tiles + the matching K slice of the down-projection) are
+//     copied global -> LDS once per workgroup in fragment order (conflict-free 16-byte reads);
+//   * up-projection: A = weight fragment (rows = hidden channel), B = frame fragment, so a lane holds 4
+//     consecutive hidden channels of ONE frame.  The depthwise k=3 convolution runs along frames = along the
+//     16 lanes of a DPP row (row_ror:1 / row_ror:15 + a select at the two tile seams), GLU in registers;
+//   * the 8 gated values a lane then holds (4 from each 16-channel tile of the chunk) ARE the B fragment of
+//     the down-projection's K step: the down-projection weights are packed with the matching k-slot order,
+//     so the gated tensor is never transposed, staged or stored;
+//   * down-projection accumulates [F channels] x [32 frames] in 64 accumulator registers across the chunks;
+//   * epilogue: bias, LayerScale, residual; staged through LDS two waves at a time for row-contiguous stores.
+// Two 4-wave workgroups share a CU (48 KB LDS each): one copies its next weight chunk while the other
+// multiplies.
+#include "sepr_gemm_epi.h"
+
+namespace sepr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// frames written per wave = 16*MT - 2 (one recomputed halo frame on each side), per workgroup = NW times that
+
+struct GcfnFusedArgs {
+  const float* x;     // [M, F]
+  float* y;           // [M, F]
+  int M, T;           // rows, frames per sequence
+  const void* w1p;    // per chunk: [4 tiles: v0 v1 g0 g1][KS][plane][64][8] bf16 (LayerNorm gamma folded), then 4 KB of
+                      // constants [2 tile pairs][10: b1v b1g wv0 wv1 wv2 wg0 wg1 wg2 cbv cbg][16 channels] fp32
+  const void* w2p;    // [NCH][F/16][plane][64][8] bf16, k-slot order (g,e) -> e<4 ? 4g+e : 16+4g+e-4
+  const float* b2;    // [F]
+  const float* ls;    // [F]
+  float eps;
+};
+
+__device__ __forceinline__ float dpp_ror1(float v) {   // lane i <- lane (i-1) mod 16 of its 16-lane row
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_rol1(float v) {   // lane i <- lane (i+1) mod 16
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x12f, 0xf, 0xf, false));
+}
+
+template <int F, int MT, int NW>
+__global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused_kernel(const GcfnFusedArgs a) {
+  constexpr int NT = 64 * NW;            // threads
+  constexpr int GF_ROWS_OUT = 16 * MT - 2;
+  constexpr int GF_TILE = NW * GF_ROWS_OUT;
+  constexpr int EH = (16 * MT * NW) / 64; // epilogue passes of 64 frames through LDS
+  constexpr int KS = F / 32;             // K steps of the up-projection
+  constexpr int NCH = 3 * F / 32;        // hidden chunks (32 value + 32 gate channels each)
+  constexpr int FT = F / 16;             // 16-channel output tiles of the down-projection
+  constexpr int W1F_U4 = 4 * KS * 2 * 64; // uint4 of up-projection fragments per chunk
+  constexpr int CS_U4 = 256;              // + 4 KB of per-channel constants (bias, conv taps) of the chunk
+  constexpr int W1_U4 = W1F_U4 + CS_U4;   // uint4 per chunk of w1p
+  constexpr int W2_U4 = FT * 2 * 64;      // uint4 per chunk of w2p
+  constexpr int OS = F + 4;              // epilogue staging row stride (floats)
+  // LDS: up-projection fragments | down-projection fragments | two constants blocks (chunk parity: the block
+  // of chunk c+1 is copied while the conv of chunk c still reads its own)
+  __shared__ __attribute__((aligned(16))) uint4 wl[W1F_U4 + W2_U4 + 2 * CS_U4];
+  static_assert(sizeof(uint4) * (W1F_U4 + W2_U4) >= sizeof(float) * 64 * OS, "epilogue staging must fit");
+  static_assert(W1F_U4 % NT == 0 && CS_U4 % NT == 0 && W2_U4 % NT == 0 && W1F_U4 / NT <= 16 && (16 * MT * NW) % 64 == 0, "copy / epilogue partition");
+  const uint4* const w1s = wl;
+  const uint4* const w2s = wl + W1F_U4;
+  uint4* const csl = wl + W1F_U4 + W2_U4;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int ntiles = (a.M + GF_TILE - 1) / GF_TILE;
+  const uint4* const W1g = static_cast<const uint4*>(a.w1p);
+  const uint4* const W2g = static_cast<const uint4*>(a.w2p);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- this wave's 32 frames: load, LayerNorm statistics, split -------------------------------------
+    const int mw0 = tile * GF_TILE + w * GF_ROWS_OUT - 1;       // wave row 0 (halo)
+    bf16x8 xh[MT][KS], xl[MT][KS];
+    int trow[MT];                                                // frame index inside its sequence
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mw0 + 16 * mt + fi;
+      const bool valid = (m >= 0 && m < a.M);
+      trow[mt] = valid ? m % a.T : -2;
+      const float* xp = a.x + (long long)(valid ? m : 0) * F + 8 * fg;
+      float v[KS][8];
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 p = ld4(xp + 32 * ks), q = ld4(xp + 32 * ks + 4);
+        v[ks][0] = p.x; v[ks][1] = p.y; v[ks][2] = p.z; v[ks][3] = p.w;
+        v[ks][4] = q.x; v[ks][5] = q.y; v[ks][6] = q.z; v[ks][7] = q.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[ks][e];
+      }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s * (1.0f / F);
+      float d = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float c = v[ks][e] - mean;
+          d = fmaf(c, c, d);
+        }
+      d += __shfl_xor(d, 16, 64);
+      d += __shfl_xor(d, 32, 64);
+      const float rstd = valid ? 1.0f / sqrtf(d * (1.0f / F) + a.eps) : 0.f;   // invalid frames: exactly zero
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xn = (v[ks][e] - mean) * rstd;
+          const __bf16 hh = (__bf16)xn;
+          h[e] = hh;
+          l[e] = (__bf16)(xn - (float)hh);
+        }
+        xh[mt][ks] = h;
+        xl[mt][ks] = l;
+      }
+    }
+    f32x4 acc[FT][MT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // zero-padding flags of the depthwise conv at sequence starts / ends
+    float f0[MT], f2[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f0[mt] = (trow[mt] == 0) ? 0.f : 1.f;
+      f2[mt] = (trow[mt] == a.T - 1) ? 0.f : 1.f;
+    }
+
+    // ---- weight chunks: global (fragment order) -> LDS by LDS-DMA (global_load_lds, 1 KiB per wave
+    // instruction, no VGPRs).  The copies are asynchronous: the up-projection fragments of chunk c+1 land under
+    // the conv + down-projection of chunk c, the down-projection fragments of chunk c+1 under the
+    // up-projection of chunk c+1; __syncthreads() (which drains vmcnt) is the only wait.
+    // (address = wave-uniform 64-bit base in SGPRs + one 32-bit per-lane byte offset; the offset is laundered
+    //  through an empty asm so the compiler cannot hoist a dozen 64-bit per-lane addresses out of the chunk
+    //  loop and spill them)
+    auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {
+      unsigned loff = (unsigned)lane * 16u;
+      asm volatile("" : "+v"(loff));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i >= nblk) break;
+        const int blk = i * NW + w;
+        const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+      }
+    };
+    auto dma_w1 = [&](int c) {
+      dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / NT);
+      dma(W1g + (long long)c * W1_U4 + W1F_U4, csl + (c & 1) * CS_U4, CS_U4 / NT);
+    };
+    auto dma_w2 = [&](int c) { dma(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / NT); };
+    // hipcc only drains vmcnt at a barrier when it can SEE an LDS-DMA in flight on that path; the copies here
+    // are loop-carried, so every barrier that publishes DMA data carries its own explicit wait.
+    auto dma_barrier = [&]() {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    };
+    __syncthreads();   // the previous tile's epilogue staging is fully consumed
+    dma_w1(0);
+    dma_w2(0);
+    dma_barrier();     // chunk 0 landed
+    for (int c = 0; c < NCH; ++c) {
+      bf16x8 gh[MT], gw[MT];          // gated values (bf16 hi / lo) in down-projection k-slot order, per frame tile
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {   // the chunk's two 16-channel (value, gate) tile pairs
+        // ---- up-projection: h[channel 4fg+r of tile][frame fi] ---------------------------------------
+        f32x4 hv[MT], hg[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          hv[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          hg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          {
+            const uint4 uh = w1s[((j * KS + ks) * 2 + 0) * 64 + lane], ul = w1s[((j * KS + ks) * 2 + 1) * 64 + lane];
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&uh), wlo = *reinterpret_cast<const bf16x8*>(&ul);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hv[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hv[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hv[mt], 0, 0, 0);
+          }
+          {
+            const uint4 uh = w1s[(((2 + j) * KS + ks) * 2 + 0) * 64 + lane], ul = w1s[(((2 + j) * KS + ks) * 2 + 1) * 64 + lane];
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&uh), wlo = *reinterpret_cast<const bf16x8*>(&ul);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hg[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hg[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hg[mt], 0, 0, 0);
+          }
+        }
+        if (j == 1) {
+          dma_barrier();                         // every wave has read its up-projection fragments of chunk c;
+                                                 // this chunk's down-projection fragments have landed
+          if (c + 1 < NCH) dma_w1(c + 1);        // lands under the conv + down-projection below
+        }
+        // ---- + bias, depthwise k=3 conv along frames (DPP row), GLU ------------------------------------
+        // per-channel constants of the chunk ride along with the weight fragments (LDS, scalar reads per
+        // channel: keeping all eleven float4s live cost 44 registers)
+        const float* cs = reinterpret_cast<const float*>(csl + (c & 1) * CS_U4) + j * 160 + 4 * fg;
+        float gl[MT][4];                                  // gated values [frame tile][channel r]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float hval[MT], hgat[MT];
+          const float b1v = cs[0 * 16 + r], b1g = cs[1 * 16 + r];
+          const float wv0 = cs[2 * 16 + r], wv1 = cs[3 * 16 + r], wv2 = cs[4 * 16 + r];
+          const float wg0 = cs[5 * 16 + r], wg1 = cs[6 * 16 + r], wg2 = cs[7 * 16 + r];
+          const float cbv = cs[8 * 16 + r], cbg = cs[9 * 16 + r];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            hval[mt] = hv[mt][r] + b1v;
+            hgat[mt] = hg[mt][r] + b1g;
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            // previous / next frame: the neighbouring lane of the DPP row, the adjacent tile at the seams
+            float pv = dpp_ror1(hval[mt]), pg = dpp_ror1(hgat[mt]);
+            float nx = dpp_rol1(hval[mt]), ng = dpp_rol1(hgat[mt]);
+            if (mt > 0) {
+              const float sv = dpp_ror1(hval[mt - 1]), sg = dpp_ror1(hgat[mt - 1]);   // lane 0 <- previous tile, frame 15
+              pv = (fi == 0) ? sv : pv;
+              pg = (fi == 0) ? sg : pg;
+            }
+            if (mt + 1 < MT) {
+              const float sv = dpp_rol1(hval[mt + 1]), sg = dpp_rol1(hgat[mt + 1]);   // lane 15 <- next tile, frame 0
+              nx = (fi == 15) ? sv : nx;
+              ng = (fi == 15) ? sg : ng;
+            }
+            const float val = fmaf(wv2 * f2[mt], nx, fmaf(wv1, hval[mt], fmaf(wv0 * f0[mt], pv, cbv)));
+            const float gat = fmaf(wg2 * f2[mt], ng, fmaf(wg1, hgat[mt], fmaf(wg0 * f0[mt], pg, cbg)));
+            gl[mt][r] = val * sigmoid_f(gat);
+          }
+        }
+        // ---- the 4 gated channels of tile j are k-slots 4j..4j+3 of this chunk's down-projection step ---
+        // (kept per j in gsl; after both j the 8 slots form the B fragment)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const __bf16 hh = (__bf16)gl[mt][r];
+            gh[mt][4 * j + r] = hh;
+            gw[mt][4 * j + r] = (__bf16)(gl[mt][r] - (float)hh);
+          }
+      }
+      // ---- down-projection K step of this chunk ---------------------------------------------------------
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        const uint4 uh = w2s[(ft * 2 + 0) * 64 + lane], ul = w2s[(ft * 2 + 1) * 64 + lane];
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&uh), wlo = *reinterpret_cast<const bf16x8*>(&ul);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[mt], acc[ft][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gw[mt], acc[ft][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[mt], acc[ft][mt], 0, 0, 0);
+      }
+      dma_barrier();                             // down-projection fragments consumed; chunk c+1's up-projection
+      if (c + 1 < NCH) dma_w2(c + 1);            // fragments have landed
+    }
+
+    // ---- epilogue: y = x + ls * (acc + b2), two waves at a time through LDS ---------------------------------
+    float* const Os = reinterpret_cast<float*>(wl);
+    constexpr int WPP = 64 / (16 * MT);   // waves per 64-frame epilogue pass
+#pragma unroll 1
+    for (int half = 0; half < EH; ++half) {
+      if (half > 0) __syncthreads();   // previous pass fully stored (the chunk loop ended on a barrier)
+      if (w / WPP == half) {
+        float* base = Os + (w % WPP) * (16 * MT) * OS;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = acc[ft][mt];
+            st4(base + (16 * mt + fi) * OS + 16 * ft + 4 * fg, make_float4(v[0], v[1], v[2], v[3]));
+          }
+      }
+      __syncthreads();
+      {
+#pragma clang fp contract(off)
+        constexpr int Q = F / 4;                 // float4 per row
+        constexpr int RPP = NT / Q;              // rows per pass
+        const int q4 = tid % Q, rr = tid / Q;
+        const float4 b2 = ld4(a.b2 + 4 * q4), lsv = ld4(a.ls + 4 * q4);
+#pragma unroll
+        for (int p = 0; p < (64 + RPP - 1) / RPP; ++p) {
+          const int row = rr + p * RPP;          // 0..63: WPP waves x 16*MT frames
+          if (row >= 64) break;
+          const int ww = WPP * half + row / (16 * MT), lr = row % (16 * MT);
+          const int m = tile * GF_TILE + ww * GF_ROWS_OUT - 1 + lr;
+          if (lr >= 1 && lr <= GF_ROWS_OUT && m < a.M) {
+            const float4 o = ld4(Os + row * OS + 4 * q4);
+            const float4 xr = ld4(a.x + (long long)m * F + 4 * q4);
+            st4(a.y + (long long)m * F + 4 * q4,
+                make_float4(fmaf(o.x + b2.x, lsv.x, xr.x), fmaf(o.y + b2.y, lsv.y, xr.y),
+                            fmaf(o.z + b2.z, lsv.z, xr.z), fmaf(o.w + b2.w, lsv.w, xr.w)));
+          }
+        }
+      }
+    }
+  }
+}
+
+#ifndef SEPR_GF_MT
+#define SEPR_GF_MT 2    // frame tiles per wave (1 -> 14 frames out of 16, 8 waves; 2 -> 30 of 32, 4 waves)
+#endif
+constexpr int GF_MT = SEPR_GF_MT, GF_NW = (SEPR_GF_MT == 1) ? 8 : 4;
+
+int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream) {
+  if (a.M <= 0) return SEPR_OK;
+  if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || !a.ls || a.T <= 0) return SEPR_EINVAL;
+  if (a.x == a.y) return SEPR_EINVAL;   // halo frames of a tile are outputs of its neighbours
+  constexpr int tile_rows = GF_NW * (16 * GF_MT - 2);
+  const int ntiles = (a.M + tile_rows - 1) / tile_rows;
+  const int cap = persistent_grid();
+  const int grid = ntiles < cap ? ntiles : cap;
+  long long slot = -1;
+  const bool timed = prof_begin(site, stream, &slot);
+  if (F == 128) {
+    hipLaunchKernelGGL((gcfn_fused_kernel<128, GF_MT, GF_NW>), dim3(grid), dim3(64 * GF_NW), 0, stream, a);
+  } else if (F == 64) {
+    hipLaunchKernelGGL((gcfn_fused_kernel<64, GF_MT, GF_NW>), dim3(grid), dim3(64 * GF_NW), 0, stream, a);
+  } else {
+    return SEPR_EINVAL;
+  }
+  // algorithmic FLOPs of the block: both projections + the depthwise conv
+  if (timed) prof_end(slot, (double)a.M * (2.0 * F * 6 * F + 2.0 * 3 * 6 * F + 2.0 * 3 * F * F), stream);
+  SEPR_CHECK_LAUNCH("gcfn_fused_kernel");
+  return SEPR_OK;
+}
+
+}  // namespace sepr

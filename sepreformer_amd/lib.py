@@ -34,11 +34,12 @@ class X3W(C.Structure):
     _fields_ = [("wp", _fp), ("bias", _fp)]
 
 
-def _struct(name, fields, x3=()):
-    return type(name, (C.Structure,), {"_fields_": [(f, _fp) for f in fields] + [(f, X3W) for f in x3]})
+def _struct(name, fields, x3=(), tail=()):
+    return type(name, (C.Structure,), {"_fields_": [(f, _fp) for f in fields] + [(f, X3W) for f in x3] + [(f, _fp) for f in tail]})
 
 
-GcfnW = _struct("GcfnW", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "ls"], ["x3_up", "x3_down"])
+GcfnW = _struct("GcfnW", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "ls"], ["x3_up", "x3_down"],
+                ["fused_w1p", "fused_w2p"])
 ClaW = _struct("ClaW", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "w3", "b3", "ls"], ["x3_1", "x3_2", "x3_3"])
 MhaW = _struct("MhaW", ["ln_g", "ln_b", "wqkv", "bqkv", "wo", "bo", "ls"], ["x3_qkv", "x3_out"])
 

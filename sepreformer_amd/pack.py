@@ -13,6 +13,7 @@ Done once per weight version on the device that owns the parameters (plain torch
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List
 
 import torch
@@ -54,6 +55,7 @@ class Packed:
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {PRECISIONS}")
         self.precision = precision
+        self.fuse_gcfn = os.environ.get("SEPR_FUSE_GCFN", "1") != "0"     # A/B switch for the fused GCFN kernel
         self.keep: List[torch.Tensor] = []
 
     def t(self, x: torch.Tensor) -> int:
@@ -74,6 +76,74 @@ class Packed:
         self.keep.append(wp)
         return L.X3W(wp=wp.data_ptr(), bias=self.t(b64.float()))
 
+    def gcfn_fused(self, sd, p: str) -> dict:
+        """Fused-GCFN weight forms (bf16x3 mode, F in {64, 128}); empty dict otherwise."""
+        F = sd[p + ".net1.0.weight"].shape[0]
+        if self.precision != "bf16x3" or F not in (64, 128) or not self.fuse_gcfn:
+            return {}
+        w1p, w2p = pack_gcfn_fused(sd[p + ".net1.1.weight"], sd[p + ".net1.1.bias"], sd[p + ".net1.0.weight"],
+                                   sd[p + ".net1.0.bias"], sd[p + ".net2.2.weight"], sd[p + ".depthwise.weight"],
+                                   sd[p + ".depthwise.bias"])
+        self.keep += [w1p, w2p]
+        return {"fused_w1p": w1p.data_ptr(), "fused_w2p": w2p.data_ptr()}
+
+
+def _split_frag(w: torch.Tensor) -> torch.Tensor:
+    """fp32 ``[R*16, K]`` (K % 32 == 0) -> ``[R][K/32][plane][64][8]`` bf16 fragments (see ``pack_x3``)."""
+    R16, K = w.shape
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+
+    def frag(p):
+        return p.view(R16 // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(R16 // 16, K // 32, 64, 8)
+
+    return torch.stack([frag(hi), frag(lo)], dim=2)                          # [R, K/32, plane, 64, 8]
+
+
+def pack_gcfn_fused(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w2: torch.Tensor,
+                    dw_w: torch.Tensor, dw_b: torch.Tensor):
+    """Weights of the fully fused GCFN kernel (sepreformer_amd/csrc/sepr_gcfn_fused.hip).
+
+    ``w1`` ``[6F,F]`` (value rows then gate rows), ``w2`` ``[F,3F]``, ``dw_w`` ``[6F,1,3]``, ``dw_b`` ``[6F]``.
+    Returns two byte tensors:
+
+    * ``w1p``: per 32-channel hidden chunk, the up-projection fragments ``[4][F/32][2][64][8]`` bf16 (value tiles 0,1
+      then their gate tiles; LayerNorm gamma folded) followed by a 4 KB fp32 constants block
+      ``[2 tile pairs][b1v b1g wv0 wv1 wv2 wg0 wg1 wg2 cbv cbg][16 channels]`` (bias with beta folded, conv taps,
+      conv bias), zero padded;
+    * ``w2p`` ``[3F/32][F/16][2][64][8]`` bf16: the chunk's K slice of the down-projection with the k-slot order the
+      kernel's registers provide (lane group g, slot e -> hidden channel ``e<4 ? 4g+e : 16+4g+e-4`` of the chunk)."""
+    F = w1.shape[1]
+    H3 = 3 * F
+    nch = H3 // 32
+    dev = w1.device
+    w1f = (w1.detach().double() * gamma.detach().double()[None, :]).float()
+    b1f = (b1.detach().double() + w1.detach().double() @ beta.detach().double()).float()
+    taps = dw_w.detach().float()[:, 0, :]                                        # [6F, 3]
+    cb = dw_b.detach().float()
+    chunks = []
+    for c in range(nch):
+        rows = []
+        for t in range(4):
+            base = (0 if t < 2 else H3) + 32 * c + 16 * (t & 1)
+            rows.append(w1f[base:base + 16])
+        frag = _split_frag(torch.cat(rows, 0)).contiguous().view(torch.uint8).reshape(-1)   # [4][KS][2][64][8] bf16
+        cst = torch.zeros(1024, dtype=torch.float32, device=dev)
+        for j in range(2):
+            v = 32 * c + 16 * j
+            g_ = H3 + v
+            vals = [b1f[v:v + 16], b1f[g_:g_ + 16], taps[v:v + 16, 0], taps[v:v + 16, 1], taps[v:v + 16, 2],
+                    taps[g_:g_ + 16, 0], taps[g_:g_ + 16, 1], taps[g_:g_ + 16, 2], cb[v:v + 16], cb[g_:g_ + 16]]
+            cst[j * 160:(j + 1) * 160] = torch.cat(vals)
+        chunks.append(torch.cat([frag, cst.view(torch.uint8)]))
+    w1p = torch.stack(chunks, 0).contiguous()
+    g = torch.arange(4, device=dev)[:, None]
+    e = torch.arange(8, device=dev)[None, :]
+    perm = torch.where(e < 4, 4 * g + e, 16 + 4 * g + (e - 4)).reshape(-1)       # [32] slot (g,e) -> channel
+    w2c = [_split_frag(w2.detach().float()[:, 32 * c + perm])[:, 0] for c in range(nch)]   # [F/16, plane, 64, 8]
+    w2p = torch.stack(w2c, 0).contiguous()
+    return w1p, w2p
+
 
 def _tapmajor(w: torch.Tensor) -> torch.Tensor:
     return w[:, 0, :].t().contiguous()          # [C,1,K] -> [K,C]
@@ -87,7 +157,8 @@ def pack_gcfn(pk: Packed, sd: Dict[str, torch.Tensor], p: str) -> L.GcfnW:
         w2=pk.t(sd[p + ".net2.2.weight"]), b2=pk.t(sd[p + ".net2.2.bias"]),
         ls=pk.t(sd[p + ".Layer_scale.layer_scale"].reshape(-1)),
         x3_up=pk.x3(sd[p + ".net1.1.weight"], sd[p + ".net1.1.bias"], sd[p + ".net1.0.weight"], sd[p + ".net1.0.bias"]),
-        x3_down=pk.x3(sd[p + ".net2.2.weight"], sd[p + ".net2.2.bias"]))
+        x3_down=pk.x3(sd[p + ".net2.2.weight"], sd[p + ".net2.2.bias"]),
+        **pk.gcfn_fused(sd, p))
 
 
 def pack_cla(pk: Packed, sd, p: str) -> L.ClaW:

@@ -210,6 +210,62 @@ def test_x3_layernorm_folding():
     assert not pack.Packed("fp32").x3(W, c).wp
 
 
+def test_pack_gcfn_fused_layout():
+    """Fused-GCFN packing: un-permute the fragment / k-slot order and run the block in fp64 with the
+    reconstructed (gamma-folded) matrices; must equal the oracle's GCFN up to the bf16 hi+lo split (2^-17)."""
+    from sepreformer_amd.pack import pack_gcfn_fused
+    cfg = VARIANTS["tiny"]
+    sd = synth_state_dict(cfg, 0)
+    p = "separator.enc_stages.0.g_block_1.block.gcfn"
+    F = cfg.feat
+    w1pb, w2p = pack_gcfn_fused(sd[p + ".net1.1.weight"], sd[p + ".net1.1.bias"], sd[p + ".net1.0.weight"],
+                                sd[p + ".net1.0.bias"], sd[p + ".net2.2.weight"], sd[p + ".depthwise.weight"],
+                                sd[p + ".depthwise.bias"])
+    nch, KS = 3 * F // 32, F // 32
+    nfrag = 4 * KS * 2 * 64 * 8 * 2                                   # fragment bytes per chunk
+    assert tuple(w1pb.shape) == (nch, nfrag + 4096) and w1pb.dtype == torch.uint8
+    assert tuple(w2p.shape) == (nch, F // 16, 2, 64, 8)
+    w1p = w1pb[:, :nfrag].contiguous().view(torch.bfloat16).view(nch, 4, KS, 2, 64, 8)
+    cst = w1pb[:, nfrag:].contiguous().view(torch.float32).view(nch, 1024)
+    b1f = torch.zeros(6 * F)
+    dwt = torch.zeros(6 * F, 3)
+    dwb = torch.zeros(6 * F)
+    for c in range(nch):
+        for j in range(2):
+            blk = cst[c, j * 160:(j + 1) * 160].view(10, 16)
+            v, g_ = 32 * c + 16 * j, 3 * F + 32 * c + 16 * j
+            b1f[v:v + 16], b1f[g_:g_ + 16] = blk[0], blk[1]
+            dwt[v:v + 16] = blk[2:5].t()
+            dwt[g_:g_ + 16] = blk[5:8].t()
+            dwb[v:v + 16], dwb[g_:g_ + 16] = blk[8], blk[9]
+    assert torch.equal(dwt, sd[p + ".depthwise.weight"][:, 0, :]) and torch.equal(dwb, sd[p + ".depthwise.bias"])
+    W1 = torch.zeros(6 * F, F, dtype=torch.float64)
+    W2 = torch.zeros(F, 3 * F, dtype=torch.float64)
+    w1s = (w1p[:, :, :, 0].double() + w1p[:, :, :, 1].double())      # [c, t, ks, lane, 8]
+    w2s = (w2p[:, :, 0].double() + w2p[:, :, 1].double())            # [c, ft, lane, 8]
+    for c in range(nch):
+        for t in range(4):
+            base = (0 if t < 2 else 3 * F) + 32 * c + 16 * (t & 1)
+            for ks in range(KS):
+                for g in range(4):
+                    for i in range(16):
+                        W1[base + i, 32 * ks + 8 * g: 32 * ks + 8 * g + 8] = w1s[c, t, ks, g * 16 + i]
+        for ft in range(F // 16):
+            for g in range(4):
+                for i in range(16):
+                    for e in range(8):
+                        n = 4 * g + e if e < 4 else 16 + 4 * g + e - 4
+                        W2[16 * ft + i, 32 * c + n] = w2s[c, ft, g * 16 + i, e]
+    x = torch.randn(2, 21, F, dtype=torch.float64)
+    xn = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    h = xn @ W1.t() + b1f.double()
+    h = torch.nn.functional.conv1d(h.permute(0, 2, 1), sd[p + ".depthwise.weight"].double(), sd[p + ".depthwise.bias"].double(),
+                                   padding=1, groups=6 * F).permute(0, 2, 1)
+    g_ = h[..., : 3 * F] * torch.sigmoid(h[..., 3 * F:])
+    y = x + (g_ @ W2.t() + sd[p + ".net2.2.bias"].double()) * sd[p + ".Layer_scale.layer_scale"].double()
+    assert orc.agreement_db(y.float(), orc.gcfn(sd, p, x.float())) > 95
+
+
 def test_no_cpu_fallback():
     m = Model.from_config(VARIANTS["tiny"], init_seed=0).eval()
     with pytest.raises(RuntimeError, match="HIP"):
