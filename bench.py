@@ -12,9 +12,12 @@ already resident in HBM (BASELINE.json configs[1]).  With N ranks every rank run
 Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      dominant kernel = the GCFN F->6F projection (gemm_kernel<PRO_NORM,EPI_STORE,1>, 39 % of
-                the model's FLOPs): algorithmic FLOPs (2*M*N*K per launch) / launch time measured with
-                hipEvents on the launch stream inside the timed region, vs the 157.3 TFLOP/s f32-MFMA peak.
+  roofline      dominant kernel = the fused GCFN block (gcfn_fused_kernel, ~1/3 of the step; 56 launches per
+                forward with the aux heads): default precision bf16x3 -> bound "mfma" against the dense bf16 MFMA
+                peak, achieved = 3 x algorithmic projection FLOPs (the split-fp32 products) / launch time
+                measured with hipEvents on the launch stream inside the timed region; the fp32-equivalent rate
+                and the HBM-side rate ride along.  With --precision fp32 the dominant kernel is the f32-MFMA
+                GCFN up-projection (gemm_kernel<PRO_NORM,EPI_DWGLU,1>) against the 157.3 TFLOP/s f32 peak.
   cpu_baseline  the oracle (CPU restatement of the reference, same aten op sequence; kind "port")
                 timed on this host's cores on a bounded sample (B=1, one warm-up + best of 3).
 """
@@ -37,6 +40,7 @@ METRIC = "utterances/sec (4 s, 8 kHz, 2-spk) SepReformer-Base at 1/2/4/8 MI355X"
 VARIANT = "SepReformer_Base_WSJ0"
 SAMPLES = 32000
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA, same table (2495 TF measured)
 HBM_PEAK_GBS = 8000.0                  # HBM3E spec (6.29 TB/s measured copy), same table
 GFLOP_PER_UTT_MAIN, GFLOP_PER_UTT_FULL = 164.87, 182.16   # SURVEY.md section 8d (4 s, Base)
 
@@ -143,7 +147,7 @@ def main():
         main_out = torch.stack([a[0:1] for a in out[0]], 0).cpu()
         parity_db = round(agreement_db(main_out, torch.from_numpy(g["main"])), 1)
 
-    launches_per_step = 56                      # GCFN blocks per forward (SURVEY.md section 8g census)
+    launches_per_step = 56                      # GCFN launches per forward incl. aux heads (upper bound; sizes the event pool)
     L.check(lib.sepr_prof_start(L.SITE_GCFN_UP, launches_per_step * max(args.steps, 1) + 8), "sepr_prof_start")
     sdist.barrier()
     torch.cuda.synchronize(dev)
@@ -174,19 +178,27 @@ def main():
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic}
         else:
-            # split-fp32 on the bf16 MFMA: the matrix pipe is no longer the bound, HBM is.  Algorithmic bytes of
-            # the fused GCFN up-projection per row: read F fp32 (x) + write 3F fp32 (g) = 16 F bytes; rows per
-            # launch follow from the algorithmic FLOPs (2 * F * 6F per row).
+            # the fused GCFN kernel (one launch per GCFN block: LayerNorm, F->6F, depthwise conv + GLU, 3F->F,
+            # LayerScale, residual).  Per frame row it moves 8F bytes of HBM (read x, write y, fp32) and issues
+            # 3 bf16 MFMA products per algorithmic multiply-add (split-fp32): 3 * 18F^2 * 2 / 8F = 864 bf16 FLOP
+            # per HBM byte at F=128, far above the machine balance (2500 TF / 8 TB/s = 312), so the bf16 matrix
+            # pipe is the roof.  achieved = bf16 MFMA FLOP/s actually required by the arithmetic (3 x the
+            # algorithmic projection FLOPs) over the HIP-event launch time; the fp32-equivalent algorithmic rate
+            # and the HBM-side rate are reported next to it.
             F = cfg.feat
-            rows = fl.value / (2.0 * F * 6 * F)
-            gbs = rows * 16.0 * F / 1e9 / (ms.value / 1e3) if ms.value > 0 else 0.0
+            flop_row = 18.0 * F * F + 36.0 * F            # what launch_gcfn_fused reports per row
+            rows = fl.value / flop_row
+            sec = ms.value / 1e3
+            mfma_tf = 3.0 * rows * 18.0 * F * F / 1e12 / sec if sec > 0 else 0.0
+            gbs = rows * 8.0 * F / 1e9 / sec if sec > 0 else 0.0
             dtype = "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)"
-            roof = {"kernel": "gemm_x3_kernel<PRO_NORM,EPI_DWGLU,1> (GCFN F->6F projection: LayerNorm prologue, bf16x3 "
-                              "MFMA, depthwise-conv+GLU epilogue)",
-                    "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": round(rows / n_launch * 16.0 * F),
-                    "mfma_equiv_tflops": round(achieved, 2)}
+            roof = {"kernel": "gcfn_fused_kernel<128,2,4> (whole GCFN block in one launch: LayerNorm, F->6F bf16x3 MFMA, "
+                              "depthwise conv k=3 + GLU, 3F->F bf16x3 MFMA, LayerScale, residual)",
+                    "bound": "mfma", "achieved": round(mfma_tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(mfma_tf / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(rows / n_launch * 8.0 * F),
+                    "algorithmic_fp32_tflops": round(achieved, 2),
+                    "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
         roof.update({"launches": int(n_l.value), "avg_launch_ms": round(ms.value / n_launch, 4),
                      "algorithmic_gflop_per_launch": round(fl.value / 1e9 / n_launch, 3)})
         rec = {

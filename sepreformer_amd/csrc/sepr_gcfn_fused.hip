@@ -319,21 +319,300 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused_kernel(const
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+#ifndef SEPR_GF2_INTERLEAVE
+#define SEPR_GF2_INTERLEAVE 0   // 1: issue the second tile pair's up-projection before the first pair's conv
+#endif
+// Version 2 of the fused kernel: ONE 8-wave workgroup per CU (240 frames per tile: the packed weights are
+// streamed once per 240 frames instead of once per 120), every weight buffer double-buffered in LDS
+// (2 x (32 + 16 + 4) KB), so the LDS-DMA of chunk c+1 is issued at the top of chunk c and has a whole chunk to
+// land: one barrier per chunk and no exposed copy latency (v1: three barriers per chunk, 48 % SQ_WAIT_ANY).
+// Inside a wave the up-projection of tile pair 1 is issued before the depthwise conv of tile pair 0, so the conv's
+// VALU work has independent MFMAs to hide under.
+// ---------------------------------------------------------------------------------------------------------
+template <int F, int MT, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void gcfn_fused2_kernel(const GcfnFusedArgs a) {
+  constexpr int NT = 64 * NW;
+  constexpr int KS = F / 32, NCH = 3 * F / 32, FT = F / 16;
+  constexpr int W1F_U4 = 4 * KS * 2 * 64, CS_U4 = 256, W1_U4 = W1F_U4 + CS_U4, W2_U4 = FT * 2 * 64;
+  constexpr int BUF_U4 = W1F_U4 + W2_U4 + CS_U4;       // one chunk's LDS image
+  constexpr int OS = F + 4;
+  constexpr int ROWS_OUT = 16 * MT - 2, TILE = NW * ROWS_OUT;
+  __shared__ __attribute__((aligned(16))) uint4 wl[2 * BUF_U4];
+  static_assert(sizeof(uint4) * 2 * BUF_U4 >= sizeof(float) * 128 * OS, "epilogue staging (128 frames) must fit");
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int ntiles = (a.M + TILE - 1) / TILE;
+  const uint4* const W1g = static_cast<const uint4*>(a.w1p);
+  const uint4* const W2g = static_cast<const uint4*>(a.w2p);
+
+  auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {
+    unsigned loff = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(loff));
+    for (int blk = w; blk < nblk; blk += NW) {
+      const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+    }
+  };
+  auto dma_chunk = [&](int c) {   // chunk c -> buffer c & 1: [up-projection fragments | down-projection | constants]
+    uint4* buf = wl + (c & 1) * BUF_U4;
+    dma(W1g + (long long)c * W1_U4, buf, W1F_U4 / 64);
+    dma(W2g + (long long)c * W2_U4, buf + W1F_U4, W2_U4 / 64);
+    dma(W1g + (long long)c * W1_U4 + W1F_U4, buf + W1F_U4 + W2_U4, CS_U4 / 64);
+  };
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();               // the previous tile's epilogue staging is fully consumed
+    dma_chunk(0);                  // lands under the frame loads / LayerNorm below
+
+    // ---- this wave's 32 frames: load, LayerNorm statistics, split -------------------------------------
+    const int mw0 = tile * TILE + w * ROWS_OUT - 1;
+    bf16x8 xh[MT][KS], xl[MT][KS];
+    float f0[MT], f2[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mw0 + 16 * mt + fi;
+      const bool valid = (m >= 0 && m < a.M);
+      const int trow = valid ? m % a.T : -2;
+      f0[mt] = (trow == 0) ? 0.f : 1.f;           // zero padding of the depthwise conv at sequence ends
+      f2[mt] = (trow == a.T - 1) ? 0.f : 1.f;
+      const float* xp = a.x + (long long)(valid ? m : 0) * F + 8 * fg;
+      float v[KS][8];
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 p = ld4(xp + 32 * ks), q = ld4(xp + 32 * ks + 4);
+        v[ks][0] = p.x; v[ks][1] = p.y; v[ks][2] = p.z; v[ks][3] = p.w;
+        v[ks][4] = q.x; v[ks][5] = q.y; v[ks][6] = q.z; v[ks][7] = q.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[ks][e];
+      }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s * (1.0f / F);
+      float d = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float cc = v[ks][e] - mean;
+          d = fmaf(cc, cc, d);
+        }
+      d += __shfl_xor(d, 16, 64);
+      d += __shfl_xor(d, 32, 64);
+      const float rstd = valid ? 1.0f / sqrtf(d * (1.0f / F) + a.eps) : 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xn = (v[ks][e] - mean) * rstd;
+          const __bf16 hh = (__bf16)xn;
+          h[e] = hh;
+          l[e] = (__bf16)(xn - (float)hh);
+        }
+        xh[mt][ks] = h;
+        xl[mt][ks] = l;
+      }
+    }
+    f32x4 acc[FT][MT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < NCH; ++c) {
+      // chunk c has landed (its copy was issued one chunk ago); every wave is done with chunk c-1's buffer
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (c + 1 < NCH) dma_chunk(c + 1);
+      const uint4* const w1s = wl + (c & 1) * BUF_U4;
+      const uint4* const w2s = w1s + W1F_U4;
+      const float* const csb = reinterpret_cast<const float*>(w1s + W1F_U4 + W2_U4) + 4 * fg;
+
+      // up-projection of one (value, gate) tile pair: h[channel 4fg+r][frame fi]
+      auto up = [&](int j, f32x4 (&hv)[MT], f32x4 (&hg)[MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          hv[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          hg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          {
+            const uint4 uh = w1s[((j * KS + ks) * 2 + 0) * 64 + lane], ul = w1s[((j * KS + ks) * 2 + 1) * 64 + lane];
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&uh), wlo = *reinterpret_cast<const bf16x8*>(&ul);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hv[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hv[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hv[mt], 0, 0, 0);
+          }
+          {
+            const uint4 uh = w1s[(((2 + j) * KS + ks) * 2 + 0) * 64 + lane], ul = w1s[(((2 + j) * KS + ks) * 2 + 1) * 64 + lane];
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&uh), wlo = *reinterpret_cast<const bf16x8*>(&ul);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hg[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hg[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hg[mt], 0, 0, 0);
+          }
+        }
+      };
+      bf16x8 gh[MT], gw[MT];          // gated values (bf16 hi / lo) in down-projection k-slot order
+      // + bias, depthwise k=3 conv along frames (DPP row), GLU, split -> k-slots 4j..4j+3
+      auto conv = [&](int j, const f32x4 (&hv)[MT], const f32x4 (&hg)[MT]) {
+        const float* cs = csb + j * 160;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float hval[MT], hgat[MT];
+          const float b1v = cs[0 * 16 + r], b1g = cs[1 * 16 + r];
+          const float wv0 = cs[2 * 16 + r], wv1 = cs[3 * 16 + r], wv2 = cs[4 * 16 + r];
+          const float wg0 = cs[5 * 16 + r], wg1 = cs[6 * 16 + r], wg2 = cs[7 * 16 + r];
+          const float cbv = cs[8 * 16 + r], cbg = cs[9 * 16 + r];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            hval[mt] = hv[mt][r] + b1v;
+            hgat[mt] = hg[mt][r] + b1g;
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            float pv = dpp_ror1(hval[mt]), pg = dpp_ror1(hgat[mt]);
+            float nx = dpp_rol1(hval[mt]), ng = dpp_rol1(hgat[mt]);
+            if (mt > 0) {
+              const float sv = dpp_ror1(hval[mt - 1]), sg = dpp_ror1(hgat[mt - 1]);
+              pv = (fi == 0) ? sv : pv;
+              pg = (fi == 0) ? sg : pg;
+            }
+            if (mt + 1 < MT) {
+              const float sv = dpp_rol1(hval[mt + 1]), sg = dpp_rol1(hgat[mt + 1]);
+              nx = (fi == 15) ? sv : nx;
+              ng = (fi == 15) ? sg : ng;
+            }
+            const float val = fmaf(wv2 * f2[mt], nx, fmaf(wv1, hval[mt], fmaf(wv0 * f0[mt], pv, cbv)));
+            const float gat = fmaf(wg2 * f2[mt], ng, fmaf(wg1, hgat[mt], fmaf(wg0 * f0[mt], pg, cbg)));
+            const float gv = val * sigmoid_f(gat);
+            const __bf16 hh = (__bf16)gv;
+            gh[mt][4 * j + r] = hh;
+            gw[mt][4 * j + r] = (__bf16)(gv - (float)hh);
+          }
+        }
+      };
+#if SEPR_GF2_INTERLEAVE
+      f32x4 hv0[MT], hg0[MT], hv1[MT], hg1[MT];
+      up(0, hv0, hg0);
+      up(1, hv1, hg1);      // independent of conv(0): its MFMAs cover the conv's VALU work
+      conv(0, hv0, hg0);
+      conv(1, hv1, hg1);
+#else
+      {
+        f32x4 hv[MT], hg[MT];
+        up(0, hv, hg);
+        conv(0, hv, hg);
+        up(1, hv, hg);
+        conv(1, hv, hg);
+      }
+#endif
+      // ---- down-projection K step of this chunk ---------------------------------------------------------
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        const uint4 uh = w2s[(ft * 2 + 0) * 64 + lane], ul = w2s[(ft * 2 + 1) * 64 + lane];
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&uh), wlo = *reinterpret_cast<const bf16x8*>(&ul);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[mt], acc[ft][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gw[mt], acc[ft][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[mt], acc[ft][mt], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue: y = x + ls * (acc + b2), 128 frames at a time through LDS -----------------------------
+    float* const Os = reinterpret_cast<float*>(wl);
+    constexpr int WPP = 128 / (16 * MT);          // waves per 128-frame pass
+#pragma unroll 1
+    for (int half = 0; half < NW / WPP; ++half) {
+      __syncthreads();   // weight fragments / the previous pass fully consumed
+      if (w / WPP == half) {
+        float* base = Os + (w % WPP) * (16 * MT) * OS;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = acc[ft][mt];
+            st4(base + (16 * mt + fi) * OS + 16 * ft + 4 * fg, make_float4(v[0], v[1], v[2], v[3]));
+          }
+      }
+      __syncthreads();
+      {
+#pragma clang fp contract(off)
+        constexpr int Q = F / 4, RPP = NT / Q;
+        const int q4 = tid % Q, rr = tid / Q;
+        const float4 b2 = ld4(a.b2 + 4 * q4), lsv = ld4(a.ls + 4 * q4);
+#pragma unroll
+        for (int p = 0; p < (128 + RPP - 1) / RPP; ++p) {
+          const int row = rr + p * RPP;          // 0..127: WPP waves x 16*MT frames
+          if (row >= 128) break;
+          const int ww = WPP * half + row / (16 * MT), lr = row % (16 * MT);
+          const int m = tile * TILE + ww * ROWS_OUT - 1 + lr;
+          if (lr >= 1 && lr <= ROWS_OUT && m < a.M) {
+            const float4 o = ld4(Os + row * OS + 4 * q4);
+            const float4 xr = ld4(a.x + (long long)m * F + 4 * q4);
+            st4(a.y + (long long)m * F + 4 * q4,
+                make_float4(fmaf(o.x + b2.x, lsv.x, xr.x), fmaf(o.y + b2.y, lsv.y, xr.y),
+                            fmaf(o.z + b2.z, lsv.z, xr.z), fmaf(o.w + b2.w, lsv.w, xr.w)));
+          }
+        }
+      }
+    }
+  }
+}
+
+#ifndef SEPR_GF_VERSION
+#define SEPR_GF_VERSION 1
+#endif
+#ifndef SEPR_GF2_INTERLEAVE
+#define SEPR_GF2_INTERLEAVE 0
+#endif
+#ifndef SEPR_GF2_MT
+#define SEPR_GF2_MT 2      // v2 geometry: 1 -> 16 waves x 14 frames (4 waves per SIMD hide the LDS fragment-read
+#endif                     // latency), 2 -> 8 waves x 30 frames
+constexpr int GF2_MT = SEPR_GF2_MT, GF2_NW = (SEPR_GF2_MT == 1) ? 16 : 8;
 #ifndef SEPR_GF_MT
 #define SEPR_GF_MT 2    // frame tiles per wave (1 -> 14 frames out of 16, 8 waves; 2 -> 30 of 32, 4 waves)
 #endif
-constexpr int GF_MT = SEPR_GF_MT, GF_NW = (SEPR_GF_MT == 1) ? 8 : 4;
+[[maybe_unused]] constexpr int GF_MT = SEPR_GF_MT, GF_NW = (SEPR_GF_MT == 1) ? 8 : 4;
 
 int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream) {
   if (a.M <= 0) return SEPR_OK;
   if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || !a.ls || a.T <= 0) return SEPR_EINVAL;
   if (a.x == a.y) return SEPR_EINVAL;   // halo frames of a tile are outputs of its neighbours
+  long long slot = -1;
+  const bool timed = prof_begin(site, stream, &slot);
+#if SEPR_GF_VERSION == 2
+  {
+    constexpr int tile_rows = GF2_NW * (16 * GF2_MT - 2);
+    const int ntiles = (a.M + tile_rows - 1) / tile_rows;
+    const int cap = persistent_grid() / 2;       // one workgroup per CU
+    const int grid = ntiles < cap ? ntiles : cap;
+    if (F == 128) {
+      hipLaunchKernelGGL((gcfn_fused2_kernel<128, GF2_MT, GF2_NW>), dim3(grid), dim3(64 * GF2_NW), 0, stream, a);
+    } else if (F == 64) {
+      hipLaunchKernelGGL((gcfn_fused2_kernel<64, GF2_MT, GF2_NW>), dim3(grid), dim3(64 * GF2_NW), 0, stream, a);
+    } else {
+      return SEPR_EINVAL;
+    }
+  }
+#else
   constexpr int tile_rows = GF_NW * (16 * GF_MT - 2);
   const int ntiles = (a.M + tile_rows - 1) / tile_rows;
   const int cap = persistent_grid();
   const int grid = ntiles < cap ? ntiles : cap;
-  long long slot = -1;
-  const bool timed = prof_begin(site, stream, &slot);
   if (F == 128) {
     hipLaunchKernelGGL((gcfn_fused_kernel<128, GF_MT, GF_NW>), dim3(grid), dim3(64 * GF_NW), 0, stream, a);
   } else if (F == 64) {
@@ -341,6 +620,7 @@ int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t strea
   } else {
     return SEPR_EINVAL;
   }
+#endif
   // algorithmic FLOPs of the block: both projections + the depthwise conv
   if (timed) prof_end(slot, (double)a.M * (2.0 * F * 6 * F + 2.0 * 3 * 6 * F + 2.0 * 3 * F * F), stream);
   SEPR_CHECK_LAUNCH("gcfn_fused_kernel");

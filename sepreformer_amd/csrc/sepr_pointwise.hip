@@ -2,11 +2,22 @@
 // speaker mixing, waveform encoder / decoder.  All activations are channel-last fp32 rows, so a wave's
 // 64 lanes always sweep contiguous channels of one frame (16-byte loads where the op allows it).
 #include "sepr_pointwise.h"
+#include <stdlib.h>
 
 namespace sepr {
 
 namespace {
 constexpr int TPB = 256;
+
+// SEPR_LEGACY_POINTWISE=1 routes the 65-tap depthwise conv and the speaker mix through their first-generation
+// kernels (A/B measurements and bisecting a parity failure; read once)
+static bool legacy_pointwise() {
+  static const bool v = [] {
+    const char* e = getenv("SEPR_LEGACY_POINTWISE");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
 
 __device__ __forceinline__ float reduce16(float v) {
   v += __shfl_xor(v, 8, 16);
@@ -324,11 +335,121 @@ __global__ __launch_bounds__(TPB) void dwconv_same_kernel(const float* __restric
   }
 }
 
+// Same op for 128-channel slabs, built around what bounds it: 65 FMAs per element is VALU work (2.1 GFMA for
+// 32 x 8000 frames, ~31 us of packed FMAs on 256 CUs; the HBM pass is ~35 us), so
+//  * a lane owns TWO adjacent channels and every multiply-add is a v_pk_fma_f32 (2 FMAs per lane-instruction);
+//  * 8 waves per workgroup (2 per SIMD) instead of 4, each wave = 16 output frames x 128 channels: a tile row is
+//    read from LDS once per wave (80 + 65 ds_read_b64 per 1040 packed FMAs);
+//  * the input tile goes global -> LDS by LDS-DMA (no VGPR round trip, two 512 B rows per wave instruction);
+//  * persistent workgroups (one per CU: tile 96 KB + taps 33 KB of LDS); the taps are staged once per workgroup.
+// Accumulation order per output is bias, tap 0, ..., tap 64 with fused multiply-adds: the same chain as
+// dwconv_same_kernel, so the two kernels agree bit for bit.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int KW>
+__global__ __launch_bounds__(512) void dwconv_same_pk_kernel(const float* __restrict__ U, float* __restrict__ C, int T, int F,
+                                                            int tiles_per_seq, int ntiles, const float* __restrict__ w,
+                                                            const float* __restrict__ b) {
+  constexpr int HALO = KW / 2, TT = 128, ROWS = TT + KW - 1, CH = 128, OPT = 16, NT = 512;
+  static_assert(ROWS % 16 == 0, "DMA loop: 8 waves x 2 rows per instruction");
+  __shared__ __attribute__((aligned(16))) float tile[ROWS * CH];
+  __shared__ __attribute__((aligned(16))) float ws[KW * CH];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int per_chunk = ntiles / (F / CH);
+  int cur_chunk = -1;
+#pragma unroll 1
+  for (int tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    // chunk-major tile order: a workgroup's consecutive tiles share the channel slab and its taps
+    const int chunk = tix / per_chunk, rem = tix % per_chunk;
+    const int seq = rem / tiles_per_seq, t0 = (rem % tiles_per_seq) * TT;
+    const int c0 = chunk * CH;
+    if (chunk != cur_chunk) {   // workgroup-uniform
+      cur_chunk = chunk;
+      for (int i = threadIdx.x; i < KW * (CH / 4); i += NT) {
+        const int j = i / (CH / 4), q = i % (CH / 4);
+        st4(ws + j * CH + 4 * q, ld4(w + (long long)j * F + c0 + 4 * q));
+      }
+    }
+    const float* src = U + (long long)seq * T * F + c0;
+    {  // rows t0-HALO .. t0+TT+HALO-1 -> LDS; out-of-range rows are fetched from a clamped address, zeroed below
+      const int half = lane >> 5, q = lane & 31;
+#pragma unroll
+      for (int i = 0; i < ROWS / 16; ++i) {
+        const int r0 = 2 * (i * 8 + wv);
+        int t = t0 - HALO + r0 + half;
+        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+        const float* g = src + (long long)t * F + 4 * q;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(tile + r0 * CH), 16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t0 < HALO || t0 + TT + HALO > T) {   // workgroup-uniform: the zero-padding rows of Conv1d(padding=32)
+      for (int i = threadIdx.x; i < ROWS * (CH / 4); i += NT) {
+        const int t = t0 - HALO + i / (CH / 4);
+        if (t < 0 || t >= T) st4(tile + 4 * i, zero4());
+      }
+      __syncthreads();
+    }
+    const int rb = wv * OPT;
+    if (t0 + rb < T) {   // wave-uniform
+      f32x2 acc[OPT];
+      const f32x2 bias = *reinterpret_cast<const f32x2*>(b + c0 + 2 * lane);
+#pragma unroll
+      for (int o = 0; o < OPT; ++o) acc[o] = bias;
+      const float* trow = tile + rb * CH + 2 * lane;
+      const float* wrow = ws + 2 * lane;
+      // 16 taps per trip of a real (not unrolled) loop: 256 packed FMAs against 16 new window rows + 16 taps, the
+      // 15 rows the next trip re-uses carried in registers.  (One 1040-FMA basic block lets the scheduler hoist
+      // all 145 LDS reads to the top and spill; a loop bounds what it can hoist.)
+      static_assert(KW % 16 == 1 && OPT == 16, "tap loop: 16 taps per trip + the last tap");
+      f32x2 xc[31];
+#pragma unroll
+      for (int i = 0; i < 15; ++i) xc[i] = *reinterpret_cast<const f32x2*>(trow + i * CH);
+#pragma unroll 1
+      for (int jb = 0; jb < KW - 1; jb += 16) {
+        const float* tr = trow + jb * CH;
+        const float* wr = wrow + jb * CH;
+        f32x2 wq[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          xc[15 + i] = *reinterpret_cast<const f32x2*>(tr + (15 + i) * CH);
+          wq[i] = *reinterpret_cast<const f32x2*>(wr + i * CH);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj)
+#pragma unroll
+          for (int o = 0; o < OPT; ++o) acc[o] = __builtin_elementwise_fma(wq[jj], xc[o + jj], acc[o]);
+#pragma unroll
+        for (int i = 0; i < 15; ++i) xc[i] = xc[i + 16];
+      }
+      {  // tap KW-1: window rows KW-1 .. KW+14 (xc[0..14] + one more row)
+        const f32x2 wl = *reinterpret_cast<const f32x2*>(wrow + (KW - 1) * CH);
+        const f32x2 xl = *reinterpret_cast<const f32x2*>(trow + (KW - 1 + 15) * CH);
+#pragma unroll
+        for (int o = 0; o < 15; ++o) acc[o] = __builtin_elementwise_fma(wl, xc[o], acc[o]);
+        acc[15] = __builtin_elementwise_fma(wl, xl, acc[15]);
+      }
+      float* dst = C + ((long long)seq * T + t0 + rb) * F + c0 + 2 * lane;
+#pragma unroll
+      for (int o = 0; o < OPT; ++o)
+        if (t0 + rb + o < T) *reinterpret_cast<f32x2*>(dst + (long long)o * F) = acc[o];
+    }
+    __syncthreads();   // tile fully consumed before the next DMA overwrites it
+  }
+}
+
 int launch_dwconv_same(const float* U, float* C, int n, int T, int F, int K, const float* w, const float* b, hipStream_t s) {
   if (n <= 0 || T <= 0) return SEPR_OK;
   if (K != 65 || F % 64 != 0) return SEPR_EINVAL;
   const int tiles = (T + 127) / 128;
-  if (F % 128 == 0) {
+  if (F % 128 == 0 && !legacy_pointwise()) {
+    const long long nt = (long long)tiles * n * (F / 128);
+    if (nt > 0x7fffffffLL) return SEPR_EINVAL;
+    const int grid = (int)(nt < 256 ? nt : 256);   // one 129 KB workgroup per CU
+    hipLaunchKernelGGL((dwconv_same_pk_kernel<65>), dim3(grid), dim3(512), 0, s, U, C, T, F, tiles, (int)nt, w, b);
+  } else if (F % 128 == 0) {
     hipLaunchKernelGGL((dwconv_same_kernel<65, 128>), dim3(tiles * (F / 128), n), dim3(TPB), 0, s, U, C, T, F, w, b);
   } else {
     hipLaunchKernelGGL((dwconv_same_kernel<65, 64>), dim3(tiles * (F / 64), n), dim3(TPB), 0, s, U, C, T, F, w, b);
@@ -444,6 +565,80 @@ __global__ __launch_bounds__(TPB) void spkmix_kernel(const float* __restrict__ Q
   }
 }
 
+// Coalesced form: a lane owns one float4 of one frame row (F/4 lanes per row, consecutive lanes = consecutive
+// addresses, so every q/k/v load and every store is a full 512 B row segment), the dk/4 lanes of a head combine
+// their partial q.k sums with an xor butterfly.  spkmix_kernel above (one lane = one whole head, 64 B lane
+// stride) remains for head sizes whose lane group is not a power of two.
+template <int S, int LPH>
+__global__ __launch_bounds__(TPB) void spkmix_rows_kernel(const float* __restrict__ QKV, float* __restrict__ O,
+                                                         long long total4, int T, int F4, float inv_sqrt_dk) {
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total4) return;   // total4 is a multiple of LPH and groups are LPH-aligned: a head is all in or out
+  const int f4 = (int)(gid % F4);
+  const long long bt = gid / F4;
+  const int t = (int)(bt % T);
+  const long long b = bt / T;
+  const long long ld = 12LL * F4;
+  float4 q[S], k[S], v[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const float* row = QKV + ((b * S + s) * T + t) * ld + 4 * f4;
+    q[s] = ld4(row);
+    k[s] = ld4(row + 4 * F4);
+    v[s] = ld4(row + 8 * F4);
+  }
+  float sc[S][S];
+#pragma unroll
+  for (int a = 0; a < S; ++a)
+#pragma unroll
+    for (int c = 0; c < S; ++c) {
+      float p = dot4(q[a], k[c]);
+#pragma unroll
+      for (int m = 1; m < LPH; m <<= 1) p += __shfl_xor(p, m, 64);
+      sc[a][c] = p * inv_sqrt_dk;
+    }
+#pragma unroll
+  for (int a = 0; a < S; ++a) {
+    float mx = sc[a][0];
+#pragma unroll
+    for (int c = 1; c < S; ++c) mx = fmaxf(mx, sc[a][c]);
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < S; ++c) {
+      sc[a][c] = __expf(sc[a][c] - mx);
+      den += sc[a][c];
+    }
+    const float inv = 1.0f / den;
+    float4 o = zero4();
+#pragma unroll
+    for (int c = 0; c < S; ++c) {
+      const float p = sc[a][c] * inv;
+      o.x = fmaf(p, v[c].x, o.x);
+      o.y = fmaf(p, v[c].y, o.y);
+      o.z = fmaf(p, v[c].z, o.z);
+      o.w = fmaf(p, v[c].w, o.w);
+    }
+    st4(O + (((b * S + a) * T + t) * F4 + f4) * 4, o);
+  }
+}
+
+template <int S>
+static bool launch_spkmix_rows(const float* QKV, float* O, int B, int T, int F, int H, float isd, hipStream_t s) {
+  const int lph = F / H / 4;
+  const long long total4 = (long long)B * T * (F / 4);
+  const long long blocks = (total4 + TPB - 1) / TPB;
+  if (blocks > 0x7fffffffLL) return false;
+  const dim3 g((unsigned)blocks), t(TPB);
+  switch (lph) {
+    case 1: hipLaunchKernelGGL((spkmix_rows_kernel<S, 1>), g, t, 0, s, QKV, O, total4, T, F / 4, isd); return true;
+    case 2: hipLaunchKernelGGL((spkmix_rows_kernel<S, 2>), g, t, 0, s, QKV, O, total4, T, F / 4, isd); return true;
+    case 4: hipLaunchKernelGGL((spkmix_rows_kernel<S, 4>), g, t, 0, s, QKV, O, total4, T, F / 4, isd); return true;
+    case 8: hipLaunchKernelGGL((spkmix_rows_kernel<S, 8>), g, t, 0, s, QKV, O, total4, T, F / 4, isd); return true;
+    case 16: hipLaunchKernelGGL((spkmix_rows_kernel<S, 16>), g, t, 0, s, QKV, O, total4, T, F / 4, isd); return true;
+    default: return false;
+  }
+}
+
 int launch_spkmix(const float* QKV, float* O, int B, int S, int T, int F, int H, hipStream_t s) {
   if (B <= 0 || T <= 0) return SEPR_OK;
   if (H <= 0 || F % H != 0 || (F / H) % 4 != 0) return SEPR_EINVAL;
@@ -451,7 +646,10 @@ int launch_spkmix(const float* QKV, float* O, int B, int S, int T, int F, int H,
   const long long blocks = (total + TPB - 1) / TPB;
   if (blocks > 0x7fffffffLL) return SEPR_EINVAL;
   const float isd = 1.0f / sqrtf((float)(F / H));
-  if (S == 2) {
+  const bool rows_form = !legacy_pointwise();
+  if (rows_form && S == 2 && launch_spkmix_rows<2>(QKV, O, B, T, F, H, isd, s)) {
+  } else if (rows_form && S == 3 && launch_spkmix_rows<3>(QKV, O, B, T, F, H, isd, s)) {
+  } else if (S == 2) {
     hipLaunchKernelGGL((spkmix_kernel<2>), dim3((unsigned)blocks), dim3(TPB), 0, s, QKV, O, total, T, F, H, isd);
   } else if (S == 3) {
     hipLaunchKernelGGL((spkmix_kernel<3>), dim3((unsigned)blocks), dim3(TPB), 0, s, QKV, O, total, T, F, H, isd);

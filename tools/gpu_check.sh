@@ -22,6 +22,10 @@ echo "== bench" | tee -a $OUT/summary.txt
 timeout 600 python bench.py --steps $STEPS --warmup 2 > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
 cat $OUT/bench.log | tee -a $OUT/summary.txt
 tail -5 $OUT/bench.err
+if [ -n "${AB_ENV:-}" ]; then   # optional A/B leg: AB_ENV="SEPR_LEGACY_POINTWISE=1" etc.
+  echo "== bench with $AB_ENV" | tee -a $OUT/summary.txt
+  env $AB_ENV timeout 300 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-alt-precision 2>> $OUT/bench.err | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['value'], 'utt/s', r['ms_per_step'], 'ms/step parity', r['parity_db_vs_golden'])" | tee -a $OUT/summary.txt
+fi
 echo "== rocprofv3 kernel trace" | tee -a $OUT/summary.txt
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-precision > $OLDPWD/$OUT/prof.log 2>&1; echo "rocprof rc=$?" | tee -a $OLDPWD/$OUT/summary.txt
 cd $OLDPWD
