@@ -23,6 +23,7 @@
 // Two 4-wave workgroups share a CU (48 KB LDS each): one copies its next weight chunk while the other
 // multiplies.
 #include "sepr_gemm_epi.h"
+#include <stdlib.h>
 
 namespace sepr {
 
@@ -321,64 +322,64 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused_kernel(const
 
 
 // ---------------------------------------------------------------------------------------------------------
-#ifndef SEPR_GF2_INTERLEAVE
-#define SEPR_GF2_INTERLEAVE 0   // 1: issue the second tile pair's up-projection before the first pair's conv
-#endif
-// Version 2 of the fused kernel: ONE 8-wave workgroup per CU (240 frames per tile: the packed weights are
-// streamed once per 240 frames instead of once per 120), every weight buffer double-buffered in LDS
-// (2 x (32 + 16 + 4) KB), so the LDS-DMA of chunk c+1 is issued at the top of chunk c and has a whole chunk to
-// land: one barrier per chunk and no exposed copy latency (v1: three barriers per chunk, 48 % SQ_WAIT_ANY).
-// Inside a wave the up-projection of tile pair 1 is issued before the depthwise conv of tile pair 0, so the conv's
-// VALU work has independent MFMAs to hide under.
+// Version 3 of the fused kernel: same tiling, LDS layout and barrier structure as gcfn_fused_kernel above, with
+// the per-wave instruction stream reworked (v1 profile: 4.7 VALU instructions per MFMA, every MFMA group waiting
+// on the LDS read issued right in front of it):
+//  * frames are INTERLEAVED over the two frame tiles (frame = 2*fi + mt instead of 16*mt + fi): the previous /
+//    next frame of a lane's tile-0 / tile-1 value is the lane's own other register, the remaining neighbour is one
+//    DPP row rotation, and the two rotation wrap-arounds land exactly on the two halo frames whose outputs are
+//    discarded - no seam selects (12 DPP + 4 selects per channel before, 4 DPP now);
+//  * the up-projection bias is the MFMA accumulator's initial value instead of an add per element;
+//  * the zero-padding flags of the depthwise conv (4 multiplies per element) only exist in the instantiation run
+//    by waves whose 32 frames touch a sequence boundary (1 wave in ~260 at T=8000);
+//  * weight fragments are read from LDS two MFMA groups ahead (explicit ring + scheduling barriers), the first
+//    groups of the next phase are requested before the conv's VALU work.
 // ---------------------------------------------------------------------------------------------------------
-template <int F, int MT, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 4) void gcfn_fused2_kernel(const GcfnFusedArgs a) {
+template <bool V>
+struct bool_c { static constexpr bool value = V; };
+
+template <int F, int NW>
+__global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
+  constexpr int MT = 2;
   constexpr int NT = 64 * NW;
-  constexpr int KS = F / 32, NCH = 3 * F / 32, FT = F / 16;
-  constexpr int W1F_U4 = 4 * KS * 2 * 64, CS_U4 = 256, W1_U4 = W1F_U4 + CS_U4, W2_U4 = FT * 2 * 64;
-  constexpr int BUF_U4 = W1F_U4 + W2_U4 + CS_U4;       // one chunk's LDS image
+  constexpr int GF_ROWS_OUT = 16 * MT - 2;
+  constexpr int GF_TILE = NW * GF_ROWS_OUT;
+  constexpr int EH = (16 * MT * NW) / 64;
+  constexpr int KS = F / 32;
+  constexpr int NCH = 3 * F / 32;
+  constexpr int FT = F / 16;
+  constexpr int W1F_U4 = 4 * KS * 2 * 64;
+  constexpr int CS_U4 = 256;
+  constexpr int W1_U4 = W1F_U4 + CS_U4;
+  constexpr int W2_U4 = FT * 2 * 64;
   constexpr int OS = F + 4;
-  constexpr int ROWS_OUT = 16 * MT - 2, TILE = NW * ROWS_OUT;
-  __shared__ __attribute__((aligned(16))) uint4 wl[2 * BUF_U4];
-  static_assert(sizeof(uint4) * 2 * BUF_U4 >= sizeof(float) * 128 * OS, "epilogue staging (128 frames) must fit");
+  __shared__ __attribute__((aligned(16))) uint4 wl[W1F_U4 + W2_U4 + 2 * CS_U4];
+  static_assert(sizeof(uint4) * (W1F_U4 + W2_U4) >= sizeof(float) * 64 * OS, "epilogue staging must fit");
+  static_assert(W1F_U4 % NT == 0 && CS_U4 % NT == 0 && W2_U4 % NT == 0 && W1F_U4 / NT <= 16 && (16 * MT * NW) % 64 == 0, "copy / epilogue partition");
+  const uint4* const w1s = wl;
+  const uint4* const w2s = wl + W1F_U4;
+  uint4* const csl = wl + W1F_U4 + W2_U4;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fi = lane & 15, fg = lane >> 4;
-  const int ntiles = (a.M + TILE - 1) / TILE;
+  const int ntiles = (a.M + GF_TILE - 1) / GF_TILE;
   const uint4* const W1g = static_cast<const uint4*>(a.w1p);
   const uint4* const W2g = static_cast<const uint4*>(a.w2p);
 
-  auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {
-    unsigned loff = (unsigned)lane * 16u;
-    asm volatile("" : "+v"(loff));
-    for (int blk = w; blk < nblk; blk += NW) {
-      const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
-    }
-  };
-  auto dma_chunk = [&](int c) {   // chunk c -> buffer c & 1: [up-projection fragments | down-projection | constants]
-    uint4* buf = wl + (c & 1) * BUF_U4;
-    dma(W1g + (long long)c * W1_U4, buf, W1F_U4 / 64);
-    dma(W2g + (long long)c * W2_U4, buf + W1F_U4, W2_U4 / 64);
-    dma(W1g + (long long)c * W1_U4 + W1F_U4, buf + W1F_U4 + W2_U4, CS_U4 / 64);
-  };
-
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();               // the previous tile's epilogue staging is fully consumed
-    dma_chunk(0);                  // lands under the frame loads / LayerNorm below
-
-    // ---- this wave's 32 frames: load, LayerNorm statistics, split -------------------------------------
-    const int mw0 = tile * TILE + w * ROWS_OUT - 1;
+    // ---- this wave's 32 frames (lane fi holds frames 2*fi and 2*fi+1): load, LayerNorm, split --------------
+    const int mw0 = tile * GF_TILE + w * GF_ROWS_OUT - 1;       // wave frame 0 (halo)
     bf16x8 xh[MT][KS], xl[MT][KS];
-    float f0[MT], f2[MT];
+    float f0[MT], f2[MT];                                        // conv zero-padding flags (sequence start / end)
+    bool edge_lane = false;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int m = mw0 + 16 * mt + fi;
+      const int m = mw0 + MT * fi + mt;
       const bool valid = (m >= 0 && m < a.M);
       const int trow = valid ? m % a.T : -2;
-      f0[mt] = (trow == 0) ? 0.f : 1.f;           // zero padding of the depthwise conv at sequence ends
+      f0[mt] = (trow == 0) ? 0.f : 1.f;
       f2[mt] = (trow == a.T - 1) ? 0.f : 1.f;
+      edge_lane = edge_lane || trow == 0 || trow == a.T - 1;
       const float* xp = a.x + (long long)(valid ? m : 0) * F + 8 * fg;
       float v[KS][8];
       float s = 0.f;
@@ -398,12 +399,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gcfn_fused2_kernel(const Gcfn
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float cc = v[ks][e] - mean;
-          d = fmaf(cc, cc, d);
+          const float c = v[ks][e] - mean;
+          d = fmaf(c, c, d);
         }
       d += __shfl_xor(d, 16, 64);
       d += __shfl_xor(d, 32, 64);
-      const float rstd = valid ? 1.0f / sqrtf(d * (1.0f / F) + a.eps) : 0.f;
+      const float rstd = valid ? 1.0f / sqrtf(d * (1.0f / F) + a.eps) : 0.f;   // invalid frames: exactly zero
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         bf16x8 h, l;
@@ -418,126 +419,182 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gcfn_fused2_kernel(const Gcfn
         xl[mt][ks] = l;
       }
     }
+    const bool edge = __builtin_amdgcn_ballot_w64(edge_lane) != 0ull;   // wave-uniform
     f32x4 acc[FT][MT];
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int c = 0; c < NCH; ++c) {
-      // chunk c has landed (its copy was issued one chunk ago); every wave is done with chunk c-1's buffer
+    // ---- weight chunks: global -> LDS by LDS-DMA, same protocol as gcfn_fused_kernel ---------------------------
+    auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {
+      unsigned loff = (unsigned)lane * 16u;
+      asm volatile("" : "+v"(loff));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i >= nblk) break;
+        const int blk = i * NW + w;
+        const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+      }
+    };
+    auto dma_w1 = [&](int c) {
+      dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / NT);
+      dma(W1g + (long long)c * W1_U4 + W1F_U4, csl + (c & 1) * CS_U4, CS_U4 / NT);
+    };
+    auto dma_w2 = [&](int c) { dma(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / NT); };
+    auto dma_barrier = [&]() {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (c + 1 < NCH) dma_chunk(c + 1);
-      const uint4* const w1s = wl + (c & 1) * BUF_U4;
-      const uint4* const w2s = w1s + W1F_U4;
-      const float* const csb = reinterpret_cast<const float*>(w1s + W1F_U4 + W2_U4) + 4 * fg;
+    };
+    // fragment pair (bf16 hi plane, lo plane) of one 16-channel tile at one K step
+    auto ld_up = [&](int j, int g, uint4 (&d)[2]) {   // g = 2*ks + (0 value tile | 1 gate tile)
+      const uint4* p = w1s + ((((g & 1) * 2 + j) * KS + (g >> 1)) * 2) * 64 + lane;
+      d[0] = p[0];
+      d[1] = p[64];
+    };
+    auto ld_dn = [&](int ft, uint4 (&d)[2]) {
+      const uint4* p = w2s + (ft * 2) * 64 + lane;
+      d[0] = p[0];
+      d[1] = p[64];
+    };
 
-      // up-projection of one (value, gate) tile pair: h[channel 4fg+r][frame fi]
-      auto up = [&](int j, f32x4 (&hv)[MT], f32x4 (&hg)[MT]) {
+    auto chunks = [&](auto edge_c) {
+      constexpr bool EDGE = decltype(edge_c)::value;
+      for (int c = 0; c < NCH; ++c) {
+        bf16x8 gh[MT], gw[MT];          // gated values (bf16 hi / lo) in down-projection k-slot order
+        uint4 fb[3][2];                 // fragment ring: two MFMA groups in flight ahead of the one being multiplied
+        ld_up(0, 0, fb[0]);
+        ld_up(0, 1, fb[1]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          hv[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          hg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int j = 0; j < 2; ++j) {
+          const float* cs = reinterpret_cast<const float*>(csl + (c & 1) * CS_U4) + j * 160 + 4 * fg;
+          // ---- up-projection, accumulators start at the bias ------------------------------------------------
+          f32x4 hv[MT], hg[MT];
           {
-            const uint4 uh = w1s[((j * KS + ks) * 2 + 0) * 64 + lane], ul = w1s[((j * KS + ks) * 2 + 1) * 64 + lane];
-            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&uh), wlo = *reinterpret_cast<const bf16x8*>(&ul);
+            const float4 bv = ld4(cs), bg = ld4(cs + 16);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hv[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hv[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hv[mt], 0, 0, 0);
-          }
-          {
-            const uint4 uh = w1s[(((2 + j) * KS + ks) * 2 + 0) * 64 + lane], ul = w1s[(((2 + j) * KS + ks) * 2 + 1) * 64 + lane];
-            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&uh), wlo = *reinterpret_cast<const bf16x8*>(&ul);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hg[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hg[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hg[mt], 0, 0, 0);
-          }
-        }
-      };
-      bf16x8 gh[MT], gw[MT];          // gated values (bf16 hi / lo) in down-projection k-slot order
-      // + bias, depthwise k=3 conv along frames (DPP row), GLU, split -> k-slots 4j..4j+3
-      auto conv = [&](int j, const f32x4 (&hv)[MT], const f32x4 (&hg)[MT]) {
-        const float* cs = csb + j * 160;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float hval[MT], hgat[MT];
-          const float b1v = cs[0 * 16 + r], b1g = cs[1 * 16 + r];
-          const float wv0 = cs[2 * 16 + r], wv1 = cs[3 * 16 + r], wv2 = cs[4 * 16 + r];
-          const float wg0 = cs[5 * 16 + r], wg1 = cs[6 * 16 + r], wg2 = cs[7 * 16 + r];
-          const float cbv = cs[8 * 16 + r], cbg = cs[9 * 16 + r];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            hval[mt] = hv[mt][r] + b1v;
-            hgat[mt] = hg[mt][r] + b1g;
-          }
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            float pv = dpp_ror1(hval[mt]), pg = dpp_ror1(hgat[mt]);
-            float nx = dpp_rol1(hval[mt]), ng = dpp_rol1(hgat[mt]);
-            if (mt > 0) {
-              const float sv = dpp_ror1(hval[mt - 1]), sg = dpp_ror1(hgat[mt - 1]);
-              pv = (fi == 0) ? sv : pv;
-              pg = (fi == 0) ? sg : pg;
+            for (int mt = 0; mt < MT; ++mt) {
+              hv[mt] = (f32x4){bv.x, bv.y, bv.z, bv.w};
+              hg[mt] = (f32x4){bg.x, bg.y, bg.z, bg.w};
             }
-            if (mt + 1 < MT) {
-              const float sv = dpp_rol1(hval[mt + 1]), sg = dpp_rol1(hgat[mt + 1]);
-              nx = (fi == 15) ? sv : nx;
-              ng = (fi == 15) ? sg : ng;
-            }
-            const float val = fmaf(wv2 * f2[mt], nx, fmaf(wv1, hval[mt], fmaf(wv0 * f0[mt], pv, cbv)));
-            const float gat = fmaf(wg2 * f2[mt], ng, fmaf(wg1, hgat[mt], fmaf(wg0 * f0[mt], pg, cbg)));
-            const float gv = val * sigmoid_f(gat);
-            const __bf16 hh = (__bf16)gv;
-            gh[mt][4 * j + r] = hh;
-            gw[mt][4 * j + r] = (__bf16)(gv - (float)hh);
           }
+#pragma unroll
+          for (int g = 0; g < 2 * KS; ++g) {
+            if (g + 2 < 2 * KS) ld_up(j, g + 2, fb[(g + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[g % 3][0]);
+            const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[g % 3][1]);
+            const int ks = g >> 1;
+            if ((g & 1) == 0) {
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hv[mt], 0, 0, 0);
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hv[mt], 0, 0, 0);
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hv[mt], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hg[mt], 0, 0, 0);
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hg[mt], 0, 0, 0);
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hg[mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (j == 0) {                            // the second tile pair's first fragments arrive under the conv
+            ld_up(1, 0, fb[0]);
+            ld_up(1, 1, fb[1]);
+          } else {
+            dma_barrier();                         // every wave has read its up-projection fragments of chunk c;
+                                                   // this chunk's down-projection fragments have landed
+            if (c + 1 < NCH) dma_w1(c + 1);        // lands under the conv + down-projection below
+            ld_dn(0, fb[0]);
+            ld_dn(1, fb[1]);
+          }
+          // ---- depthwise k=3 conv along frames, GLU ---------------------------------------------------------
+          // frame 2*fi+mt: tile 0's previous frame is the left lane's tile-1 value, its next frame the lane's own
+          // tile-1 value (and mirrored for tile 1); the rotations wrap onto the two halo frames only.
+          float gl[MT][4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float wv0 = cs[2 * 16 + r], wv1 = cs[3 * 16 + r], wv2 = cs[4 * 16 + r];
+            const float wg0 = cs[5 * 16 + r], wg1 = cs[6 * 16 + r], wg2 = cs[7 * 16 + r];
+            const float cbv = cs[8 * 16 + r], cbg = cs[9 * 16 + r];
+            const float v0 = hv[0][r], v1 = hv[1][r], g0 = hg[0][r], g1 = hg[1][r];
+            const float pv[MT] = {dpp_ror1(v1), v0}, nv[MT] = {v1, dpp_rol1(v0)};
+            const float pg[MT] = {dpp_ror1(g1), g0}, ng[MT] = {g1, dpp_rol1(g0)};
+            const float cv[MT] = {v0, v1}, cg[MT] = {g0, g1};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const float a0v = EDGE ? wv0 * f0[mt] : wv0, a2v = EDGE ? wv2 * f2[mt] : wv2;
+              const float a0g = EDGE ? wg0 * f0[mt] : wg0, a2g = EDGE ? wg2 * f2[mt] : wg2;
+              const float val = fmaf(a2v, nv[mt], fmaf(wv1, cv[mt], fmaf(a0v, pv[mt], cbv)));
+              const float gat = fmaf(a2g, ng[mt], fmaf(wg1, cg[mt], fmaf(a0g, pg[mt], cbg)));
+              gl[mt][r] = val * sigmoid_f(gat);
+            }
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const __bf16 hh = (__bf16)gl[mt][r];
+              gh[mt][4 * j + r] = hh;
+              gw[mt][4 * j + r] = (__bf16)(gl[mt][r] - (float)hh);
+            }
         }
-      };
-#if SEPR_GF2_INTERLEAVE
-      f32x4 hv0[MT], hg0[MT], hv1[MT], hg1[MT];
-      up(0, hv0, hg0);
-      up(1, hv1, hg1);      // independent of conv(0): its MFMAs cover the conv's VALU work
-      conv(0, hv0, hg0);
-      conv(1, hv1, hg1);
-#else
-      {
-        f32x4 hv[MT], hg[MT];
-        up(0, hv, hg);
-        conv(0, hv, hg);
-        up(1, hv, hg);
-        conv(1, hv, hg);
+        // ---- down-projection K step of this chunk -----------------------------------------------------------
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+          if (ft + 2 < FT) ld_dn(ft + 2, fb[(ft + 2) % 3]);
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[ft % 3][0]);
+          const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[ft % 3][1]);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[mt], acc[ft][mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gw[mt], acc[ft][mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[mt], acc[ft][mt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        dma_barrier();                             // down-projection fragments consumed; chunk c+1's up-projection
+        if (c + 1 < NCH) dma_w2(c + 1);            // fragments have landed
       }
-#endif
-      // ---- down-projection K step of this chunk ---------------------------------------------------------
-#pragma unroll
-      for (int ft = 0; ft < FT; ++ft) {
-        const uint4 uh = w2s[(ft * 2 + 0) * 64 + lane], ul = w2s[(ft * 2 + 1) * 64 + lane];
-        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&uh), wlo = *reinterpret_cast<const bf16x8*>(&ul);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[mt], acc[ft][mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gw[mt], acc[ft][mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[mt], acc[ft][mt], 0, 0, 0);
-      }
-    }
+    };
+    __syncthreads();   // the previous tile's epilogue staging is fully consumed
+    dma_w1(0);
+    dma_w2(0);
+    dma_barrier();     // chunk 0 landed
+    if (edge) chunks(bool_c<true>{}); else chunks(bool_c<false>{});
 
-    // ---- epilogue: y = x + ls * (acc + b2), 128 frames at a time through LDS -----------------------------
+    // ---- epilogue: y = x + ls * (acc + b2), two waves at a time through LDS ---------------------------------
     float* const Os = reinterpret_cast<float*>(wl);
-    constexpr int WPP = 128 / (16 * MT);          // waves per 128-frame pass
+    constexpr int WPP = 64 / (16 * MT);   // waves per 64-frame epilogue pass
+    constexpr int Q = F / 4;                 // float4 per row
+    constexpr int RPP = NT / Q;              // rows per pass
+    constexpr int NP = 64 / RPP;
+    static_assert(64 % RPP == 0, "epilogue pass partition");
+    const int q4 = tid % Q, rr = tid / Q;
+    const float4 b2 = ld4(a.b2 + 4 * q4), lsv = ld4(a.ls + 4 * q4);
 #pragma unroll 1
-    for (int half = 0; half < NW / WPP; ++half) {
-      __syncthreads();   // weight fragments / the previous pass fully consumed
+    for (int half = 0; half < EH; ++half) {
+      if (half > 0) __syncthreads();   // previous pass fully stored (the chunk loop ended on a barrier)
+      // the residual rows of this pass are requested first, from clamped branch-free addresses: they fly under
+      // the staging writes and the barrier, and the pass pays one global-load latency instead of one per row
+      float4 xr[NP];
+      int mrow[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int row = rr + p * RPP;          // 0..63: WPP waves x 16*MT frames
+        const int ww = WPP * half + row / (16 * MT), lr = row % (16 * MT);
+        const int m = tile * GF_TILE + ww * GF_ROWS_OUT - 1 + lr;
+        const bool ok = lr >= 1 && lr <= GF_ROWS_OUT && m < a.M;
+        mrow[p] = ok ? m : -1;
+        xr[p] = ld4(a.x + (long long)(ok ? m : 0) * F + 4 * q4);
+      }
       if (w / WPP == half) {
         float* base = Os + (w % WPP) * (16 * MT) * OS;
 #pragma unroll
@@ -545,27 +602,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gcfn_fused2_kernel(const Gcfn
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const f32x4 v = acc[ft][mt];
-            st4(base + (16 * mt + fi) * OS + 16 * ft + 4 * fg, make_float4(v[0], v[1], v[2], v[3]));
+            st4(base + (MT * fi + mt) * OS + 16 * ft + 4 * fg, make_float4(v[0], v[1], v[2], v[3]));
           }
       }
       __syncthreads();
       {
 #pragma clang fp contract(off)
-        constexpr int Q = F / 4, RPP = NT / Q;
-        const int q4 = tid % Q, rr = tid / Q;
-        const float4 b2 = ld4(a.b2 + 4 * q4), lsv = ld4(a.ls + 4 * q4);
 #pragma unroll
-        for (int p = 0; p < (128 + RPP - 1) / RPP; ++p) {
-          const int row = rr + p * RPP;          // 0..127: WPP waves x 16*MT frames
-          if (row >= 128) break;
-          const int ww = WPP * half + row / (16 * MT), lr = row % (16 * MT);
-          const int m = tile * TILE + ww * ROWS_OUT - 1 + lr;
-          if (lr >= 1 && lr <= ROWS_OUT && m < a.M) {
-            const float4 o = ld4(Os + row * OS + 4 * q4);
-            const float4 xr = ld4(a.x + (long long)m * F + 4 * q4);
-            st4(a.y + (long long)m * F + 4 * q4,
-                make_float4(fmaf(o.x + b2.x, lsv.x, xr.x), fmaf(o.y + b2.y, lsv.y, xr.y),
-                            fmaf(o.z + b2.z, lsv.z, xr.z), fmaf(o.w + b2.w, lsv.w, xr.w)));
+        for (int p = 0; p < NP; ++p) {
+          if (mrow[p] >= 0) {
+            const float4 o = ld4(Os + (rr + p * RPP) * OS + 4 * q4);
+            st4(a.y + (long long)mrow[p] * F + 4 * q4,
+                make_float4(fmaf(o.x + b2.x, lsv.x, xr[p].x), fmaf(o.y + b2.y, lsv.y, xr[p].y),
+                            fmaf(o.z + b2.z, lsv.z, xr[p].z), fmaf(o.w + b2.w, lsv.w, xr[p].w)));
           }
         }
       }
@@ -574,17 +623,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gcfn_fused2_kernel(const Gcfn
 }
 
 #ifndef SEPR_GF_VERSION
-#define SEPR_GF_VERSION 1
+#define SEPR_GF_VERSION 3   // 1: gcfn_fused_kernel, 3: gcfn_fused3_kernel
 #endif
-#ifndef SEPR_GF2_INTERLEAVE
-#define SEPR_GF2_INTERLEAVE 0
-#endif
-#ifndef SEPR_GF2_MT
-#define SEPR_GF2_MT 2      // v2 geometry: 1 -> 16 waves x 14 frames (4 waves per SIMD hide the LDS fragment-read
-#endif                     // latency), 2 -> 8 waves x 30 frames
-constexpr int GF2_MT = SEPR_GF2_MT, GF2_NW = (SEPR_GF2_MT == 1) ? 16 : 8;
 #ifndef SEPR_GF_MT
-#define SEPR_GF_MT 2    // frame tiles per wave (1 -> 14 frames out of 16, 8 waves; 2 -> 30 of 32, 4 waves)
+#define SEPR_GF_MT 2    // v1 frame tiles per wave (1 -> 14 frames out of 16, 8 waves; 2 -> 30 of 32, 4 waves)
 #endif
 [[maybe_unused]] constexpr int GF_MT = SEPR_GF_MT, GF_NW = (SEPR_GF_MT == 1) ? 8 : 4;
 
@@ -594,25 +636,29 @@ int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t strea
   if (a.x == a.y) return SEPR_EINVAL;   // halo frames of a tile are outputs of its neighbours
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
-#if SEPR_GF_VERSION == 2
-  {
-    constexpr int tile_rows = GF2_NW * (16 * GF2_MT - 2);
-    const int ntiles = (a.M + tile_rows - 1) / tile_rows;
-    const int cap = persistent_grid() / 2;       // one workgroup per CU
-    const int grid = ntiles < cap ? ntiles : cap;
-    if (F == 128) {
-      hipLaunchKernelGGL((gcfn_fused2_kernel<128, GF2_MT, GF2_NW>), dim3(grid), dim3(64 * GF2_NW), 0, stream, a);
-    } else if (F == 64) {
-      hipLaunchKernelGGL((gcfn_fused2_kernel<64, GF2_MT, GF2_NW>), dim3(grid), dim3(64 * GF2_NW), 0, stream, a);
-    } else {
-      return SEPR_EINVAL;
-    }
+#if SEPR_GF_VERSION == 3
+  constexpr int tile_rows = 4 * 30;
+  const int ntiles = (a.M + tile_rows - 1) / tile_rows;
+  const int cap = persistent_grid();
+  const int grid = ntiles < cap ? ntiles : cap;
+  if (F == 128) {
+    hipLaunchKernelGGL((gcfn_fused3_kernel<128, 4>), dim3(grid), dim3(256), 0, stream, a);
+  } else if (F == 64) {
+    hipLaunchKernelGGL((gcfn_fused3_kernel<64, 4>), dim3(grid), dim3(256), 0, stream, a);
+  } else {
+    return SEPR_EINVAL;
   }
 #else
   constexpr int tile_rows = GF_NW * (16 * GF_MT - 2);
   const int ntiles = (a.M + tile_rows - 1) / tile_rows;
-  const int cap = persistent_grid();
-  const int grid = ntiles < cap ? ntiles : cap;
+  static const int cap = [] {   // SEPR_GF_GRID: "tiles" -> one tile per workgroup, k -> k workgroups per CU
+    const char* e = getenv("SEPR_GF_GRID");
+    if (!e || !e[0]) return persistent_grid();
+    if (e[0] == 't') return 0;
+    const int k = atoi(e);
+    return k > 0 ? persistent_grid() / 2 * k : persistent_grid();
+  }();
+  const int grid = (cap <= 0 || ntiles < cap) ? ntiles : cap;
   if (F == 128) {
     hipLaunchKernelGGL((gcfn_fused_kernel<128, GF_MT, GF_NW>), dim3(grid), dim3(64 * GF_NW), 0, stream, a);
   } else if (F == 64) {

@@ -155,44 +155,69 @@ __device__ __forceinline__ void epilogue_from_lds(const GemmArgs& a, const float
     if (EPI == EPI_RES && a.ls) lsv = ld4(a.ls + ncol);
     const int split_s = (EPI == EPI_SPLIT) ? ncol / a.Fs : 0;
     const int split_f = (EPI == EPI_SPLIT) ? ncol - split_s * a.Fs : 0;
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-      const int r = rg * 16 + i;
-      const int m = m0 + r;
-      if (m >= a.M) break;
-      float4 v = ld4(Hs + r * HS + 4 * q4);
-      v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-      float* const out = a.Y + (long long)m * a.ldc + ncol;
-      if (EPI == EPI_STORE) {
-        st4(out, v);
-      } else if (EPI == EPI_GELU) {
-        st4(out, make_float4(gelu_exact(v.x), gelu_exact(v.y), gelu_exact(v.z), gelu_exact(v.w)));
-      } else if (EPI == EPI_RES) {
-        if (a.R) {
-          const float4 rr = ld4(a.R + (long long)m * a.ldc + ncol);
-          v.x = fmaf(v.x, lsv.x, rr.x); v.y = fmaf(v.y, lsv.y, rr.y);
-          v.z = fmaf(v.z, lsv.z, rr.z); v.w = fmaf(v.w, lsv.w, rr.w);
-        } else {
-          v.x *= lsv.x; v.y *= lsv.y; v.z *= lsv.z; v.w *= lsv.w;
+    // Rows go in batches of 8: the side operands of a batch (residual, gate inputs, encoder frames) are
+    // requested together from clamped, branch-free addresses BEFORE any of them is consumed, so a tile pays two
+    // global-load latencies instead of sixteen (a load guarded by "row < M" cannot be hoisted above the guard of
+    // the previous row; that serialisation was ~40 % of these kernels).  Only the stores are predicated.
+    const bool has_r = (EPI != EPI_RES) || a.R != nullptr;
+#pragma unroll
+    for (int ib = 0; ib < 16; ib += 8) {
+      if (m0 + rg * 16 + ib >= a.M) break;          // whole batch past the last row
+      float4 s1[8], s2[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int mr = m0 + rg * 16 + ib + i;
+        const int m = mr < a.M ? mr : a.M - 1;
+        s1[i] = zero4();
+        s2[i] = zero4();
+        if (EPI == EPI_RES) {
+          if (has_r) s1[i] = ld4(a.R + (long long)m * a.ldc + ncol);
+        } else if (EPI == EPI_GATE) {
+          const int seq = m / a.T;
+          const int t = m - seq * a.T;
+          s1[i] = ld4(a.R + (long long)m * a.ldc + ncol);
+          s2[i] = ld4(a.aux + ((long long)seq * a.Tp + t / a.fac) * a.N + ncol);
+        } else if (EPI == EPI_MASK) {
+          const int seq = m / a.rows_out;             // b*S + s
+          const int l = m - seq * a.rows_out;
+          s1[i] = ld4(a.aux + ((long long)(seq / a.S) * a.rows_out + l) * a.N + ncol);
         }
-        st4(out, v);
-      } else if (EPI == EPI_GATE) {
-        const int seq = m / a.T;
-        const int t = m - seq * a.T;
-        const float4 x = ld4(a.R + (long long)m * a.ldc + ncol);
-        const float4 u = ld4(a.aux + ((long long)seq * a.Tp + t / a.fac) * a.N + ncol);
-        st4(out, make_float4(fmaf(sigmoid_f(v.x), u.x, x.x), fmaf(sigmoid_f(v.y), u.y, x.y),
-                             fmaf(sigmoid_f(v.z), u.z, x.z), fmaf(sigmoid_f(v.w), u.w, x.w)));
-      } else if (EPI == EPI_SPLIT) {
-        // column n = s*F + f  ->  Y[((b*S + s)*T + t)*F + f]   (reference module.py:123)
-        const int b = m / a.T;
-        const int t = m - b * a.T;
-        st4(a.Y + (((long long)b * a.S + split_s) * a.T + t) * a.Fs + split_f, v);
-      } else if (EPI == EPI_MASK) {
-        const int seq = m / a.rows_out;             // b*S + s
-        const int l = m - seq * a.rows_out;
-        const float4 e = ld4(a.aux + ((long long)(seq / a.S) * a.rows_out + l) * a.N + ncol);
-        st4(out, make_float4(fmaxf(v.x, 0.f) * e.x, fmaxf(v.y, 0.f) * e.y, fmaxf(v.z, 0.f) * e.z, fmaxf(v.w, 0.f) * e.w));
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = rg * 16 + ib + i;
+        const int m = m0 + r;
+        if (m < a.M) {
+          float4 v = ld4(Hs + r * HS + 4 * q4);
+          v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+          float* const out = a.Y + (long long)m * a.ldc + ncol;
+          if (EPI == EPI_STORE) {
+            st4(out, v);
+          } else if (EPI == EPI_GELU) {
+            st4(out, make_float4(gelu_exact(v.x), gelu_exact(v.y), gelu_exact(v.z), gelu_exact(v.w)));
+          } else if (EPI == EPI_RES) {
+            if (has_r) {
+              const float4 rr = s1[i];
+              v.x = fmaf(v.x, lsv.x, rr.x); v.y = fmaf(v.y, lsv.y, rr.y);
+              v.z = fmaf(v.z, lsv.z, rr.z); v.w = fmaf(v.w, lsv.w, rr.w);
+            } else {
+              v.x *= lsv.x; v.y *= lsv.y; v.z *= lsv.z; v.w *= lsv.w;
+            }
+            st4(out, v);
+          } else if (EPI == EPI_GATE) {
+            const float4 x = s1[i], u = s2[i];
+            st4(out, make_float4(fmaf(sigmoid_f(v.x), u.x, x.x), fmaf(sigmoid_f(v.y), u.y, x.y),
+                                 fmaf(sigmoid_f(v.z), u.z, x.z), fmaf(sigmoid_f(v.w), u.w, x.w)));
+          } else if (EPI == EPI_SPLIT) {
+            // column n = s*F + f  ->  Y[((b*S + s)*T + t)*F + f]   (reference module.py:123)
+            const int b = m / a.T;
+            const int t = m - b * a.T;
+            st4(a.Y + (((long long)b * a.S + split_s) * a.T + t) * a.Fs + split_f, v);
+          } else if (EPI == EPI_MASK) {
+            const float4 e = s1[i];
+            st4(out, make_float4(fmaxf(v.x, 0.f) * e.x, fmaxf(v.y, 0.f) * e.y, fmaxf(v.z, 0.f) * e.z, fmaxf(v.w, 0.f) * e.w));
+          }
+        }
       }
     }
   }

@@ -1,13 +1,27 @@
 // Instantiations + host launcher of the bf16x3 projection core.
 #include "sepr_gemm_x3.h"
+#include <stdlib.h>
 
 namespace sepr {
+
+// workgroups per launch: SEPR_X3_GRID = "tiles" -> one tile per workgroup (no persistent walk), an integer k ->
+// k workgroups per CU; default 2 per CU (what fits: 80 KB of LDS each)
+static int x3_grid_cap() {
+  static const int v = [] {
+    const char* e = getenv("SEPR_X3_GRID");
+    if (!e || !e[0]) return persistent_grid();
+    if (e[0] == 't') return 0;
+    const int k = atoi(e);
+    return k > 0 ? persistent_grid() / 2 * k : persistent_grid();
+  }();
+  return v;
+}
 
 template <int PRO, int EPI, int TAG = 0>
 static void launch_x3_inst(const GemmArgs& a, hipStream_t stream) {
   const int tiles = gemm_tiles(a, EPI);
-  const int cap = persistent_grid();
-  const int grid = tiles < cap ? tiles : cap;
+  const int cap = x3_grid_cap();
+  const int grid = (cap <= 0 || tiles < cap) ? tiles : cap;
   hipLaunchKernelGGL((gemm_x3_kernel<PRO, EPI, TAG>), dim3(grid), dim3(GEMM_THREADS), 0, stream, a);
 }
 
