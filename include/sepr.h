@@ -97,6 +97,11 @@ typedef struct {
   const float* ls;   /* [F] */
   sepr_x3_w x3_qkv;  /* stacked q/k/v (LayerNorm folded) */
   sepr_x3_w x3_out;  /* linear_out */
+  /* optional fully fused speaker-attention form (bf16x3, F = 128, 16-channel heads, S = 2;
+     pack.py::pack_spk_fused); both or none; only read by sepr_spkattn_fwd */
+  const void* fused_qkv_p; /* per head pair: [q0 q1 k0 k1 v0 v1][F/32][plane][64][8] bf16 (gamma folded)
+                              + 4 KB fp32 constants [6 tiles][16] biases */
+  const void* fused_out_p; /* [F/32][F/16][plane][64][8] bf16, permuted k-slot order */
 } sepr_mha_w;
 
 /* EGA, modules/network.py:126-155 + the shared relative-position table, modules/module.py:42-57 */

@@ -20,6 +20,17 @@ struct GcfnFusedArgs {
   const float* b2; const float* ls; float eps;
 };
 int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream);   // sepr_gcfn_fused.hip
+struct SpkFusedArgs {
+  const float* x;
+  float* y;
+  int NF, T;
+  const void* w1p;
+  const void* w2p;
+  const float* bo;
+  const float* ls;
+  float eps, inv_sqrt_dk;
+};
+int launch_spk_fused(const SpkFusedArgs& a, int F, int site, hipStream_t stream);     // sepr_spk_fused.hip
 
 // one projection on whichever core its weights were packed for
 static int project(int pro, int epi, GemmArgs& a, const sepr_x3_w& x3, int site, hipStream_t st) {
@@ -234,6 +245,14 @@ extern "C" int sepr_spkattn_fwd(const float* x, float* y, int nS, int S, int T, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long M = (long long)nS * T;
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
+  if (w->fused_qkv_p && w->fused_out_p && S == 2 && F == 128 && H == 8 && x != y) {
+    // one kernel: LayerNorm + q/k/v + attention across the two speakers + output projection + LayerScale + residual
+    SpkFusedArgs f;
+    f.x = x; f.y = y; f.NF = (int)(M / 2); f.T = T;
+    f.w1p = w->fused_qkv_p; f.w2p = w->fused_out_p;
+    f.bo = w->bo; f.ls = w->ls; f.eps = LN_EPS; f.inv_sqrt_dk = 1.0f / sqrtf((float)(F / H));
+    return launch_spk_fused(f, F, SEPR_SITE_ATTN_PROJ, st);
+  }
   Arena ar(ws, ws_bytes);
   float* stats = ar.f32(2 * M);
   float* qkv = ar.f32(3LL * F * M);

@@ -1,0 +1,316 @@
+// Fully fused speaker-attention block on the bf16x3 core (reference modules/network.py:229-247 around the
+// MultiHeadAttention of :69-124, two speakers):
+//     y = x + layer_scale * Linear_out( softmax_over_speakers( q k^T / sqrt(dk) ) v ),   q,k,v = Linear(LayerNorm(x))
+// in ONE kernel.  The [rows, 3F] q/k/v tensor, the mixed [rows, F] tensor and the LayerNorm statistics never reach
+// HBM: traffic is "read x once, write y once" (1 KB per row at F = 128) instead of 6 KB for
+// rowstats + q/k/v projection + speaker mix + output projection.
+//
+// Same row-stationary skeleton as sepr_gcfn_fused.hip (gcfn_fused3_kernel); what differs:
+//   * a wave owns 16 frames of BOTH speakers of one mixture: frame tile 0 = speaker 0, frame tile 1 = speaker 1
+//     (speaker s of frame (b,t) is row (b*2+s)*T + t), so the attention across speakers is lane-local: a lane's
+//     two accumulator sets are the two speakers of the same frame.  No halo frames;
+//   * the hidden walk is over head pairs (32 output channels of q, k and v each): per head 3 tiles x F/32 K steps
+//     of MFMAs give q, k, v (bias = accumulator init) with a lane holding 4 of the head's 16 channels for both
+//     speakers; the 2x2 scores are 4-channel partial dot products summed over the 4 lane groups (two xor
+//     shuffles); softmax over two speakers is a logistic of the score difference; the mixed values are split to
+//     bf16 hi/lo and ARE the B fragment of the output projection's K step for that head pair (weights packed in the
+//     matching k-slot order, exactly the down-projection trick of the GCFN kernel);
+//   * per head pair 48 KB of q/k/v fragments + 16 KB of output-projection fragments + 4 KB constants go
+//     global -> LDS by LDS-DMA under the arithmetic of the previous pair; two 4-wave workgroups share a CU.
+#include "sepr_gemm_epi.h"
+#include <stdlib.h>
+
+namespace sepr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct SpkFusedArgs {
+  const float* x;     // [nS*T, F], sequences ordered b*2 + s
+  float* y;           // [nS*T, F]
+  int NF, T;          // frames over all mixtures (= B*T), frames per sequence
+  const void* w1p;    // per head pair: [6 tiles: q0 q1 k0 k1 v0 v1][F/32][plane][64][8] bf16 (LayerNorm gamma folded),
+                      // then 4 KB of constants: [6 tiles][16 channels] fp32 biases (beta folded), zero padded
+  const void* w2p;    // [F/32][F/16][plane][64][8] bf16, k-slot order (g,e) -> e<4 ? 4g+e : 16+4g+e-4
+  const float* bo;    // [F]
+  const float* ls;    // [F]
+  float eps, inv_sqrt_dk;
+};
+
+template <int F, int NW>
+__global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const SpkFusedArgs a) {
+  constexpr int MT = 2;                  // = speakers
+  constexpr int NT = 64 * NW;
+  constexpr int TILE = 16 * NW;          // frames per workgroup tile
+  constexpr int EH = (16 * MT * NW) / 64;
+  constexpr int KS = F / 32;
+  constexpr int NCH = F / 32;            // head pairs
+  constexpr int FT = F / 16;
+  constexpr int W1F_U4 = 6 * KS * 2 * 64;
+  constexpr int CS_U4 = 256;
+  constexpr int W1_U4 = W1F_U4 + CS_U4;
+  constexpr int W2_U4 = FT * 2 * 64;
+  constexpr int OS = F + 4;
+  __shared__ __attribute__((aligned(16))) uint4 wl[W1F_U4 + W2_U4 + 2 * CS_U4];
+  static_assert(sizeof(uint4) * (W1F_U4 + W2_U4) >= sizeof(float) * 64 * OS, "epilogue staging must fit");
+  static_assert(W1F_U4 % NT == 0 && CS_U4 % NT == 0 && W2_U4 % NT == 0 && W1F_U4 / NT <= 16 && (16 * MT * NW) % 64 == 0, "copy / epilogue partition");
+  const uint4* const w1s = wl;
+  const uint4* const w2s = wl + W1F_U4;
+  uint4* const csl = wl + W1F_U4 + W2_U4;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int ntiles = (a.NF + TILE - 1) / TILE;
+  const uint4* const W1g = static_cast<const uint4*>(a.w1p);
+  const uint4* const W2g = static_cast<const uint4*>(a.w2p);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- this wave's 16 frames x 2 speakers: load, LayerNorm, split ------------------------------------------
+    bf16x8 xh[MT][KS], xl[MT][KS];
+    {
+      const int f = tile * TILE + w * 16 + fi;
+      const bool valid = f < a.NF;
+      const int b = valid ? f / a.T : 0, t = valid ? f - b * a.T : 0;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float* xp = a.x + ((long long)(b * MT + mt) * a.T + t) * F + 8 * fg;
+        float v[KS][8];
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 p = ld4(xp + 32 * ks), q = ld4(xp + 32 * ks + 4);
+          v[ks][0] = p.x; v[ks][1] = p.y; v[ks][2] = p.z; v[ks][3] = p.w;
+          v[ks][4] = q.x; v[ks][5] = q.y; v[ks][6] = q.z; v[ks][7] = q.w;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s += v[ks][e];
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.0f / F);
+        float d = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float c = v[ks][e] - mean;
+            d = fmaf(c, c, d);
+          }
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+        const float rstd = 1.0f / sqrtf(d * (1.0f / F) + a.eps);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 h, l;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xn = (v[ks][e] - mean) * rstd;
+            const __bf16 hh = (__bf16)xn;
+            h[e] = hh;
+            l[e] = (__bf16)(xn - (float)hh);
+          }
+          xh[mt][ks] = h;
+          xl[mt][ks] = l;
+        }
+      }
+    }
+    f32x4 acc[FT][MT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- weight chunks: global -> LDS by LDS-DMA (protocol of gcfn_fused3_kernel) ------------------------------
+    auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {
+      unsigned loff = (unsigned)lane * 16u;
+      asm volatile("" : "+v"(loff));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i >= nblk) break;
+        const int blk = i * NW + w;
+        const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+      }
+    };
+    auto dma_w1 = [&](int c) {
+      dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / NT);
+      dma(W1g + (long long)c * W1_U4 + W1F_U4, csl + (c & 1) * CS_U4, CS_U4 / NT);
+    };
+    auto dma_w2 = [&](int c) { dma(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / NT); };
+    auto dma_barrier = [&]() {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    };
+    // fragment pair (bf16 hi plane, lo plane): head hh of the pair, group g = 3*ks + (0 q | 1 k | 2 v)
+    auto ld_up = [&](int hh, int g, uint4 (&d)[2]) {
+      const uint4* p = w1s + ((((g % 3) * 2 + hh) * KS + (g / 3)) * 2) * 64 + lane;
+      d[0] = p[0];
+      d[1] = p[64];
+    };
+    auto ld_dn = [&](int ft, uint4 (&d)[2]) {
+      const uint4* p = w2s + (ft * 2) * 64 + lane;
+      d[0] = p[0];
+      d[1] = p[64];
+    };
+
+    __syncthreads();   // the previous tile's epilogue staging is fully consumed
+    dma_w1(0);
+    dma_w2(0);
+    dma_barrier();     // head pair 0 landed
+    for (int c = 0; c < NCH; ++c) {
+      bf16x8 gh[MT], gw[MT];          // mixed values (bf16 hi / lo) in output-projection k-slot order, per speaker
+      uint4 fb[3][2];                 // fragment ring: two MFMA groups in flight ahead of the one being multiplied
+      ld_up(0, 0, fb[0]);
+      ld_up(0, 1, fb[1]);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const float* cs = reinterpret_cast<const float*>(csl + (c & 1) * CS_U4) + 4 * fg;
+        // ---- q, k, v of this head for both speakers; accumulators start at the bias -----------------------------
+        f32x4 pq[3][MT];
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+          const float4 bv = ld4(cs + (tt * 2 + hh) * 16);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) pq[tt][mt] = (f32x4){bv.x, bv.y, bv.z, bv.w};
+        }
+#pragma unroll
+        for (int g = 0; g < 3 * KS; ++g) {
+          if (g + 2 < 3 * KS) ld_up(hh, g + 2, fb[(g + 2) % 3]);
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[g % 3][0]);
+          const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[g % 3][1]);
+          const int ks = g / 3, tt = g % 3;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) pq[tt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], pq[tt][mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) pq[tt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], pq[tt][mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) pq[tt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], pq[tt][mt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (hh == 0) {                           // the second head's first fragments arrive under the mix below
+          ld_up(1, 0, fb[0]);
+          ld_up(1, 1, fb[1]);
+        } else {
+          dma_barrier();                         // every wave has read its q/k/v fragments of pair c; the pair's
+                                                 // output-projection fragments have landed
+          if (c + 1 < NCH) dma_w1(c + 1);        // lands under the mix + output projection below
+          ld_dn(0, fb[0]);
+          ld_dn(1, fb[1]);
+        }
+        // ---- 2x2 attention across the speakers of each frame (network.py:106-122 with T = S) --------------------
+        float sc[MT][MT];
+#pragma unroll
+        for (int qa = 0; qa < MT; ++qa)
+#pragma unroll
+          for (int kc = 0; kc < MT; ++kc) {
+            float p = pq[0][qa][0] * pq[1][kc][0];
+            p = fmaf(pq[0][qa][1], pq[1][kc][1], p);
+            p = fmaf(pq[0][qa][2], pq[1][kc][2], p);
+            p = fmaf(pq[0][qa][3], pq[1][kc][3], p);
+            p += __shfl_xor(p, 16, 64);          // the head's 16 channels live in the 4 lane groups
+            p += __shfl_xor(p, 32, 64);
+            sc[qa][kc] = p;
+          }
+#pragma unroll
+        for (int qa = 0; qa < MT; ++qa) {
+          // softmax over two keys: p0 = 1 / (1 + exp(s1 - s0)), p1 = 1 - p0
+          const float p0 = sigmoid_f((sc[qa][0] - sc[qa][1]) * a.inv_sqrt_dk);
+          const float p1 = 1.0f - p0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float o = fmaf(p0, pq[2][0][r], p1 * pq[2][1][r]);
+            const __bf16 hb = (__bf16)o;
+            gh[qa][4 * hh + r] = hb;
+            gw[qa][4 * hh + r] = (__bf16)(o - (float)hb);
+          }
+        }
+      }
+      // ---- output-projection K step of this head pair -------------------------------------------------------------
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        if (ft + 2 < FT) ld_dn(ft + 2, fb[(ft + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[ft % 3][0]);
+        const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[ft % 3][1]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[mt], acc[ft][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gw[mt], acc[ft][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[mt], acc[ft][mt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      dma_barrier();                             // output-projection fragments consumed; pair c+1's q/k/v
+      if (c + 1 < NCH) dma_w2(c + 1);            // fragments have landed
+    }
+
+    // ---- epilogue: y = x + ls * (acc + bo), two waves at a time through LDS -------------------------------------
+    float* const Os = reinterpret_cast<float*>(wl);
+    constexpr int WPP = 64 / (16 * MT);      // waves per 64-row epilogue pass
+    constexpr int Q = F / 4;                 // float4 per row
+    constexpr int RPP = NT / Q;              // rows per pass
+    constexpr int NP = 64 / RPP;
+    static_assert(64 % RPP == 0, "epilogue pass partition");
+    const int q4 = tid % Q, rr = tid / Q;
+    const float4 bo = ld4(a.bo + 4 * q4), lsv = ld4(a.ls + 4 * q4);
+#pragma unroll 1
+    for (int half = 0; half < EH; ++half) {
+      if (half > 0) __syncthreads();   // previous pass fully stored (the chunk loop ended on a barrier)
+      float4 xr[NP];
+      long long mrow[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int row = rr + p * RPP;          // 0..63: WPP waves x (speaker, frame)
+        const int ww = WPP * half + row / (16 * MT), lr = row % (16 * MT);
+        const int f = tile * TILE + ww * 16 + (lr & 15);
+        const bool ok = f < a.NF;
+        const int b = ok ? f / a.T : 0, t = ok ? f - b * a.T : 0;
+        const long long m = (long long)(b * MT + (lr >> 4)) * a.T + t;
+        mrow[p] = ok ? m : -1;
+        xr[p] = ld4(a.x + m * F + 4 * q4);
+      }
+      if (w / WPP == half) {
+        float* base = Os + (w % WPP) * (16 * MT) * OS;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = acc[ft][mt];
+            st4(base + (16 * mt + fi) * OS + 16 * ft + 4 * fg, make_float4(v[0], v[1], v[2], v[3]));
+          }
+      }
+      __syncthreads();
+      {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          if (mrow[p] >= 0) {
+            const float4 o = ld4(Os + (rr + p * RPP) * OS + 4 * q4);
+            st4(a.y + mrow[p] * F + 4 * q4,
+                make_float4(fmaf(o.x + bo.x, lsv.x, xr[p].x), fmaf(o.y + bo.y, lsv.y, xr[p].y),
+                            fmaf(o.z + bo.z, lsv.z, xr[p].z), fmaf(o.w + bo.w, lsv.w, xr[p].w)));
+          }
+        }
+      }
+    }
+  }
+}
+
+int launch_spk_fused(const SpkFusedArgs& a, int F, int site, hipStream_t stream) {
+  if (a.NF <= 0) return SEPR_OK;
+  if (!a.x || !a.y || !a.w1p || !a.w2p || !a.bo || !a.ls || a.T <= 0 || a.NF % a.T != 0) return SEPR_EINVAL;
+  if (a.x == a.y) return SEPR_EINVAL;
+  if (F != 128) return SEPR_EINVAL;
+  long long slot = -1;
+  const bool timed = prof_begin(site, stream, &slot);
+  const int ntiles = (a.NF + 63) / 64;
+  const int cap = persistent_grid();
+  const int grid = ntiles < cap ? ntiles : cap;
+  hipLaunchKernelGGL((spk_fused_kernel<128, 4>), dim3(grid), dim3(256), 0, stream, a);
+  // algorithmic FLOPs: q/k/v and output projections of both speakers' rows
+  if (timed) prof_end(slot, 2.0 * a.NF * (2.0 * F * 3 * F + 2.0 * F * F), stream);
+  SEPR_CHECK_LAUNCH("spk_fused_kernel");
+  return SEPR_OK;
+}
+
+}  // namespace sepr

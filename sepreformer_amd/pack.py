@@ -56,6 +56,7 @@ class Packed:
             raise ValueError(f"precision must be one of {PRECISIONS}")
         self.precision = precision
         self.fuse_gcfn = os.environ.get("SEPR_FUSE_GCFN", "1") != "0"     # A/B switch for the fused GCFN kernel
+        self.fuse_spk = os.environ.get("SEPR_FUSE_SPK", "1") != "0"       # A/B switch for the fused speaker attention
         self.keep: List[torch.Tensor] = []
 
     def t(self, x: torch.Tensor) -> int:
@@ -86,6 +87,19 @@ class Packed:
                                    sd[p + ".depthwise.bias"])
         self.keep += [w1p, w2p]
         return {"fused_w1p": w1p.data_ptr(), "fused_w2p": w2p.data_ptr()}
+
+
+    def spk_fused(self, sd, p: str, heads: int, num_spks: int) -> dict:
+        """Fused speaker-attention weight forms (bf16x3, F = 128, 16-channel heads, two speakers); else empty."""
+        F = sd[p + ".layer_norm.weight"].shape[0]
+        if self.precision != "bf16x3" or F != 128 or F // heads != 16 or num_spks != 2 or not self.fuse_spk:
+            return {}
+        wqkv = torch.cat([sd[f"{p}.linear_{n}.weight"] for n in "qkv"], dim=0)
+        bqkv = torch.cat([sd[f"{p}.linear_{n}.bias"] for n in "qkv"], dim=0)
+        w1p, w2p = pack_spk_fused(wqkv, bqkv, sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"],
+                                  sd[p + ".linear_out.weight"])
+        self.keep += [w1p, w2p]
+        return {"fused_qkv_p": w1p.data_ptr(), "fused_out_p": w2p.data_ptr()}
 
 
 def _split_frag(w: torch.Tensor) -> torch.Tensor:
@@ -137,12 +151,41 @@ def pack_gcfn_fused(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.Tensor, bet
             cst[j * 160:(j + 1) * 160] = torch.cat(vals)
         chunks.append(torch.cat([frag, cst.view(torch.uint8)]))
     w1p = torch.stack(chunks, 0).contiguous()
+    w2p = _kslot_frags(w2, nch)
+    return w1p, w2p
+
+
+def _kslot_frags(w2: torch.Tensor, nch: int) -> torch.Tensor:
+    """``w2`` ``[F, 32*nch]`` -> ``[nch][F/16][2][64][8]`` bf16: per 32-wide K chunk, the fragments with the k-slot
+    order the fused kernels' registers provide (lane group g, slot e -> channel ``e<4 ? 4g+e : 16+4g+e-4``)."""
+    dev = w2.device
     g = torch.arange(4, device=dev)[:, None]
     e = torch.arange(8, device=dev)[None, :]
     perm = torch.where(e < 4, 4 * g + e, 16 + 4 * g + (e - 4)).reshape(-1)       # [32] slot (g,e) -> channel
-    w2c = [_split_frag(w2.detach().float()[:, 32 * c + perm])[:, 0] for c in range(nch)]   # [F/16, plane, 64, 8]
-    w2p = torch.stack(w2c, 0).contiguous()
-    return w1p, w2p
+    return torch.stack([_split_frag(w2.detach().float()[:, 32 * c + perm])[:, 0] for c in range(nch)], 0).contiguous()
+
+
+def pack_spk_fused(wqkv: torch.Tensor, bqkv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, wo: torch.Tensor):
+    """Weights of the fused speaker-attention kernel (sepreformer_amd/csrc/sepr_spk_fused.hip), 16-channel heads.
+
+    ``wqkv`` ``[3F,F]`` (q rows, k rows, v rows), ``wo`` ``[F,F]``.  Returns two byte tensors:
+
+    * ``w1p``: per head pair ``c`` the fragments ``[6][F/32][2][64][8]`` bf16 of the tiles
+      ``q(2c) q(2c+1) k(2c) k(2c+1) v(2c) v(2c+1)`` (LayerNorm gamma folded) followed by a 4 KB fp32 constants block
+      ``[6 tiles][16 channels]`` of biases (beta folded), zero padded;
+    * ``w2p`` ``[F/32][F/16][2][64][8]`` bf16: the pair's K slice of the output projection in k-slot order."""
+    F = wqkv.shape[1]
+    dev = wqkv.device
+    wf = (wqkv.detach().double() * gamma.detach().double()[None, :]).float()
+    bf = (bqkv.detach().double() + wqkv.detach().double() @ beta.detach().double()).float()
+    chunks = []
+    for c in range(F // 32):
+        bases = [tt * F + 16 * (2 * c + hh) for tt in range(3) for hh in range(2)]
+        frag = _split_frag(torch.cat([wf[b:b + 16] for b in bases], 0)).contiguous().view(torch.uint8).reshape(-1)
+        cst = torch.zeros(1024, dtype=torch.float32, device=dev)
+        cst[:96] = torch.cat([bf[b:b + 16] for b in bases])
+        chunks.append(torch.cat([frag, cst.view(torch.uint8)]))
+    return torch.stack(chunks, 0).contiguous(), _kslot_frags(wo, F // 32)
 
 
 def _tapmajor(w: torch.Tensor) -> torch.Tensor:
@@ -177,7 +220,7 @@ def pack_cla(pk: Packed, sd, p: str) -> L.ClaW:
         x3_3=pk.x3(sd[p + ".linear3.1.weight"], sd[p + ".linear3.1.bias"]))
 
 
-def pack_mha(pk: Packed, sd, p: str) -> L.MhaW:
+def pack_mha(pk: Packed, sd, p: str, spk_fused: dict = None) -> L.MhaW:
     wqkv = torch.cat([sd[f"{p}.linear_{n}.weight"] for n in "qkv"], dim=0)
     bqkv = torch.cat([sd[f"{p}.linear_{n}.bias"] for n in "qkv"], dim=0)
     return L.MhaW(
@@ -186,7 +229,8 @@ def pack_mha(pk: Packed, sd, p: str) -> L.MhaW:
         wo=pk.t(sd[p + ".linear_out.weight"]), bo=pk.t(sd[p + ".linear_out.bias"]),
         ls=pk.t(sd[p + ".Layer_scale.layer_scale"].reshape(-1)),
         x3_qkv=pk.x3(wqkv, bqkv, sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"]),
-        x3_out=pk.x3(sd[p + ".linear_out.weight"], sd[p + ".linear_out.bias"]))
+        x3_out=pk.x3(sd[p + ".linear_out.weight"], sd[p + ".linear_out.bias"]),
+        **(spk_fused or {}))
 
 
 def pack_ega(pk: Packed, sd, p: str, pe_ptr: int, maxlen: int) -> L.EgaW:
@@ -266,7 +310,8 @@ class PackedModel(Packed):
             self.dec_stages.append({
                 "g": [glob(f"{p}.g_block_{j}") for j in (1, 2, 3)],
                 "l": [loc(f"{p}.l_block_{j}") for j in (1, 2, 3)],
-                "spk": [(pack_mha(self, sd, f"{p}.spk_attn_{j}.self_attn"),
+                "spk": [(pack_mha(self, sd, f"{p}.spk_attn_{j}.self_attn",
+                                  self.spk_fused(sd, f"{p}.spk_attn_{j}.self_attn", cfg.heads, cfg.num_spks)),
                          pack_gcfn(self, sd, f"{p}.spk_attn_{j}.feed_forward")) for j in (1, 2, 3)],
             })
         self.out_main = pack_out(self, sd, "out_layer", sd["audio_decoder.weight"])
