@@ -84,6 +84,11 @@ typedef struct {
   sepr_x3_w x3_1;    /* linear1 (LayerNorm folded) */
   sepr_x3_w x3_2;    /* linear2 (BatchNorm folded) */
   sepr_x3_w x3_3;    /* linear3.1 */
+  /* optional fused head / tail forms (bf16x3, F = 128; pack.py::pack_cla_fused); all three or none */
+  const void* fused_w1p;   /* per 32 output channels: [v0 v1 g0 g1][F/32][plane][64][8] bf16 (gamma folded)
+                              + 4 KB fp32 constants [4 tiles][16] biases */
+  const void* fused_w2p;   /* per 64 hidden channels: [4 tiles][F/32][plane][64][8] bf16 + 4 KB [4][16] biases */
+  const void* fused_w3p;   /* [2F/32][F/16][plane][64][8] bf16, permuted k-slot order */
 } sepr_cla_w;
 
 /* MultiHeadAttention, modules/network.py:69-124 */

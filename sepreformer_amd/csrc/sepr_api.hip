@@ -31,6 +31,19 @@ struct SpkFusedArgs {
   float eps, inv_sqrt_dk;
 };
 int launch_spk_fused(const SpkFusedArgs& a, int F, int site, hipStream_t stream);     // sepr_spk_fused.hip
+struct ClaFusedArgs {
+  const float* x;
+  const float* res;
+  float* y;
+  int M;
+  const void* w1p;
+  const void* w2p;
+  const float* b3;
+  const float* ls;
+  float eps;
+};
+int launch_cla_head(const ClaFusedArgs& a, int F, int site, hipStream_t stream);      // sepr_cla_fused.hip
+int launch_cla_tail(const ClaFusedArgs& a, int F, int site, hipStream_t stream);
 
 // one projection on whichever core its weights were packed for
 static int project(int pro, int epi, GemmArgs& a, const sepr_x3_w& x3, int site, hipStream_t st) {
@@ -166,6 +179,18 @@ extern "C" int sepr_cla_fwd(const float* x, float* y, int n, int T, int F, int K
   float* c = ar.f32((long long)F * M);
   float* d = ar.f32(2LL * F * M);
   if (!ar.ok()) return SEPR_EWORKSPACE;
+  if (w->fused_w1p && w->fused_w2p && w->fused_w3p && F == 128 && x != y) {
+    // three launches: LayerNorm+linear1+GLU | depthwise conv | linear2+BN+GELU+linear3+LayerScale+residual
+    ClaFusedArgs h;
+    h.x = x; h.res = nullptr; h.y = u; h.M = (int)M;
+    h.w1p = w->fused_w1p; h.w2p = nullptr; h.b3 = nullptr; h.ls = nullptr; h.eps = LN_EPS;
+    SEPR_TRY(launch_cla_head(h, F, SEPR_SITE_CLA, st));
+    SEPR_TRY(launch_dwconv_same(u, c, n, T, F, K, w->dw_w, w->dw_b, st));
+    ClaFusedArgs t;
+    t.x = c; t.res = x; t.y = y; t.M = (int)M;
+    t.w1p = w->fused_w2p; t.w2p = w->fused_w3p; t.b3 = w->b3; t.ls = w->ls; t.eps = 0.f;
+    return launch_cla_tail(t, F, SEPR_SITE_CLA, st);
+  }
   SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
   {  // LayerNorm -> linear1 F->2F -> GLU                                  (network.py:175-177)
     GemmArgs a = gemm_args_zero();

@@ -1,0 +1,423 @@
+// The two projection stages of the CLA block on the bf16x3 core, row-stationary like sepr_gcfn_fused.hip
+// (reference modules/network.py:159-187):
+//
+//   cla_head_kernel   u = GLU( Linear_F->2F( LayerNorm(x) ) )                               (:175-177)
+//   [dwconv_same_pk_kernel: c = depthwise k=65 conv of u along frames, sepr_pointwise.hip]   (:178-180)
+//   cla_tail_kernel   y = x + layer_scale * Linear_2F->F( GELU( BN( Linear_F->2F(c) ) ) )    (:181-187)
+//
+// Neither the LayerNorm statistics nor the [rows, 2F] hidden tensor between linear2 and linear3 reach HBM; a CLA
+// block moves 7 F floats per frame (x, u, u, c, c, x, y) instead of 11.5 F and takes 3 launches instead of 5.
+//
+// Both kernels: a wave owns 32 consecutive frames (frame = 2*fi + mt, no halo), loads them once straight into the
+// MFMA B-fragment layout, keeps them as bf16 hi/lo in registers; weights arrive per hidden chunk by LDS-DMA in
+// fragment order and are read two MFMA groups ahead; bias = accumulator init; outputs leave through an LDS
+// staging tile as row-contiguous 512 B stores.
+//   head: chunk = 32 output channels (value tiles v0 v1 + gate tiles g0 g1, the GCFN up-projection layout); the
+//         gated values are collected in a [F x 32 frames] register tile.
+//   tail: chunk = 64 hidden channels (4 tiles up, 2 K steps down); exact-erf GELU in registers; the activated
+//         values are the B fragments of the down-projection (k-slot-ordered weights, as in the GCFN kernel).
+#include "sepr_gemm_epi.h"
+#include <stdlib.h>
+
+namespace sepr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ClaFusedArgs {
+  const float* x;     // head: block input [M,F];  tail: conv output c [M,F]
+  const float* res;   // tail: block input (residual) [M,F]
+  float* y;           // head: u [M,F];  tail: block output [M,F]
+  int M;
+  const void* w1p;    // head: per 32-channel chunk [v0 v1 g0 g1][F/32][plane][64][8] bf16 (gamma folded) + 4 KB constants
+                      //       [4 tiles][16] biases;  tail: per 64-channel chunk [4 tiles][F/32][plane][64][8] + 4 KB [4][16]
+  const void* w2p;    // tail: [2F/32][F/16][plane][64][8] bf16, k-slot order
+  const float* b3;    // tail [F]
+  const float* ls;    // tail [F]
+  float eps;
+};
+
+namespace {
+
+constexpr int CF_NW = 4, CF_NT = 256, CF_MT = 2;
+
+// ---- shared pieces -----------------------------------------------------------------------------------------------
+// 32 frames of a wave -> bf16 hi/lo B fragments; NORM: LayerNorm without affine (gamma/beta live in the weights)
+template <int F, bool NORM>
+__device__ __forceinline__ void load_frames(const float* __restrict__ X, int m0, int M, float eps, int fi, int fg,
+                                            bf16x8 (&xh)[CF_MT][F / 32], bf16x8 (&xl)[CF_MT][F / 32]) {
+  constexpr int KS = F / 32;
+#pragma unroll
+  for (int mt = 0; mt < CF_MT; ++mt) {
+    const int m = m0 + CF_MT * fi + mt;
+    const bool valid = m < M;
+    const float* xp = X + (long long)(valid ? m : 0) * F + 8 * fg;
+    float v[KS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 p = ld4(xp + 32 * ks), q = ld4(xp + 32 * ks + 4);
+      v[ks][0] = p.x; v[ks][1] = p.y; v[ks][2] = p.z; v[ks][3] = p.w;
+      v[ks][4] = q.x; v[ks][5] = q.y; v[ks][6] = q.z; v[ks][7] = q.w;
+      if (NORM) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[ks][e];
+      }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (NORM) {
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      mean = s * (1.0f / F);
+      float d = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float c = v[ks][e] - mean;
+          d = fmaf(c, c, d);
+        }
+      d += __shfl_xor(d, 16, 64);
+      d += __shfl_xor(d, 32, 64);
+      rstd = 1.0f / sqrtf(d * (1.0f / F) + eps);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 h, l;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xn = NORM ? (v[ks][e] - mean) * rstd : v[ks][e];
+        const __bf16 hh = (__bf16)xn;
+        h[e] = hh;
+        l[e] = (__bf16)(xn - (float)hh);
+      }
+      xh[mt][ks] = h;
+      xl[mt][ks] = l;
+    }
+  }
+}
+
+__device__ __forceinline__ void dma_blocks(const uint4* gbase, uint4* lbase, int nblk, int lane, int w) {
+  // 1 KiB per wave instruction; per-lane byte offset laundered so the addresses are not hoisted and spilled
+  unsigned loff = (unsigned)lane * 16u;
+  asm volatile("" : "+v"(loff));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i >= nblk) break;
+    const int blk = i * CF_NW + w;
+    const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ void dma_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// [F x 32 frames] register tile -> LDS -> row-contiguous stores; RES: y = res + ls * (tile + b)
+template <int F, bool RES>
+__device__ __forceinline__ void store_tile(const f32x4 (&acc)[F / 16][CF_MT], float* Os, const ClaFusedArgs& a, int tile0,
+                                           int tid, int w, int fi, int fg) {
+  constexpr int FT = F / 16, OS = F + 4, MT = CF_MT;
+  constexpr int EH = (16 * MT * CF_NW) / 64, WPP = 64 / (16 * MT);
+  constexpr int Q = F / 4, RPP = CF_NT / Q, NP = 64 / RPP;
+  static_assert(64 % RPP == 0, "epilogue pass partition");
+  const int q4 = tid % Q, rr = tid / Q;
+  float4 bb = zero4(), lsv = zero4();
+  if (RES) {
+    bb = ld4(a.b3 + 4 * q4);
+    lsv = ld4(a.ls + 4 * q4);
+  }
+#pragma unroll 1
+  for (int half = 0; half < EH; ++half) {
+    if (half > 0) __syncthreads();   // previous pass fully stored
+    float4 xr[NP];
+    int mrow[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int m = tile0 + 64 * half + rr + p * RPP;     // staging row = frame inside the tile
+      mrow[p] = m < a.M ? m : -1;
+      if (RES) xr[p] = ld4(a.res + (long long)(m < a.M ? m : 0) * F + 4 * q4);
+    }
+    if (w / WPP == half) {
+      float* base = Os + (w % WPP) * (16 * MT) * OS;
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 v = acc[ft][mt];
+          st4(base + (MT * fi + mt) * OS + 16 * ft + 4 * fg, make_float4(v[0], v[1], v[2], v[3]));
+        }
+    }
+    __syncthreads();
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if (mrow[p] >= 0) {
+          const float4 o = ld4(Os + (rr + p * RPP) * OS + 4 * q4);
+          float* dst = a.y + (long long)mrow[p] * F + 4 * q4;
+          if (RES) {
+            st4(dst, make_float4(fmaf(o.x + bb.x, lsv.x, xr[p].x), fmaf(o.y + bb.y, lsv.y, xr[p].y),
+                                 fmaf(o.z + bb.z, lsv.z, xr[p].z), fmaf(o.w + bb.w, lsv.w, xr[p].w)));
+          } else {
+            st4(dst, o);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// head: u = GLU(Linear(LayerNorm(x)))
+// ---------------------------------------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(CF_NT, 2) void cla_head_kernel(const ClaFusedArgs a) {
+  constexpr int MT = CF_MT, NW = CF_NW, NT = CF_NT;
+  constexpr int TILE = 32 * NW;
+  constexpr int KS = F / 32;
+  constexpr int NCH = F / 32;            // 32 output channels per chunk
+  constexpr int FT = F / 16;
+  constexpr int W1F_U4 = 4 * KS * 2 * 64;
+  constexpr int CS_U4 = 256;
+  constexpr int W1_U4 = W1F_U4 + CS_U4;
+  constexpr int OS = F + 4;
+  // two (fragments + constants) buffers: chunk c+1 is copied while chunk c is multiplied
+  __shared__ __attribute__((aligned(16))) uint4 wl[2 * W1_U4];
+  static_assert(sizeof(uint4) * 2 * W1_U4 >= sizeof(float) * 64 * OS, "epilogue staging must fit");
+  static_assert(W1_U4 % NT == 0 && W1_U4 / NT <= 16, "copy partition");
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int ntiles = (a.M + TILE - 1) / TILE;
+  const uint4* const W1g = static_cast<const uint4*>(a.w1p);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    bf16x8 xh[MT][KS], xl[MT][KS];
+    load_frames<F, true>(a.x, tile * TILE + w * 32, a.M, a.eps, fi, fg, xh, xl);
+    f32x4 acc[FT][MT];                   // gated values: channel tile ft = 2*c + j
+
+    __syncthreads();   // the previous tile's epilogue staging is fully consumed
+    dma_blocks(W1g, wl, W1_U4 / NT, lane, w);
+    dma_barrier();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const uint4* const w1s = wl + (c & 1) * W1_U4;
+      if (c + 1 < NCH) dma_blocks(W1g + (long long)(c + 1) * W1_U4, wl + ((c + 1) & 1) * W1_U4, W1_U4 / NT, lane, w);
+      auto ld_up = [&](int j, int g, uint4 (&d)[2]) {   // g = 2*ks + (0 value tile | 1 gate tile)
+        const uint4* p = w1s + ((((g & 1) * 2 + j) * KS + (g >> 1)) * 2) * 64 + lane;
+        d[0] = p[0];
+        d[1] = p[64];
+      };
+      const float* cs = reinterpret_cast<const float*>(w1s + W1F_U4) + 4 * fg;   // [v0 v1 g0 g1][16]
+      uint4 fb[3][2];
+      ld_up(0, 0, fb[0]);
+      ld_up(0, 1, fb[1]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4 hv[MT], hg[MT];
+        {
+          const float4 bv = ld4(cs + j * 16), bg = ld4(cs + (2 + j) * 16);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            hv[mt] = (f32x4){bv.x, bv.y, bv.z, bv.w};
+            hg[mt] = (f32x4){bg.x, bg.y, bg.z, bg.w};
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 2 * KS; ++g) {
+          if (g + 2 < 2 * KS) ld_up(j, g + 2, fb[(g + 2) % 3]);
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[g % 3][0]);
+          const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[g % 3][1]);
+          const int ks = g >> 1;
+          if ((g & 1) == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hv[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hv[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hv[mt], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hg[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hg[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hg[mt], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j == 0) {
+          ld_up(1, 0, fb[0]);
+          ld_up(1, 1, fb[1]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = hv[mt][r] * sigmoid_f(hg[mt][r]);
+          acc[2 * c + j][mt] = o;
+        }
+      }
+      dma_barrier();   // chunk c fully read by every wave, chunk c+1 landed
+    }
+    store_tile<F, false>(acc, reinterpret_cast<float*>(wl), a, tile * TILE, tid, w, fi, fg);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tail: y = x + ls * Linear3(GELU(Linear2'(c)))      (eval BatchNorm folded into Linear2')
+// ---------------------------------------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(CF_NT, 2) void cla_tail_kernel(const ClaFusedArgs a) {
+  constexpr int MT = CF_MT, NW = CF_NW, NT = CF_NT;
+  constexpr int TILE = 32 * NW;
+  constexpr int KS = F / 32;
+  constexpr int NCH = 2 * F / 64;        // 64 hidden channels per chunk
+  constexpr int FT = F / 16;
+  constexpr int W1F_U4 = 4 * KS * 2 * 64;
+  constexpr int CS_U4 = 256;
+  constexpr int W1_U4 = W1F_U4 + CS_U4;
+  constexpr int W2_U4 = 2 * FT * 2 * 64;  // two K steps of the down-projection
+  constexpr int OS = F + 4;
+  __shared__ __attribute__((aligned(16))) uint4 wl[W1F_U4 + W2_U4 + 2 * CS_U4];
+  static_assert(sizeof(uint4) * (W1F_U4 + W2_U4) >= sizeof(float) * 64 * OS, "epilogue staging must fit");
+  static_assert(W1F_U4 % NT == 0 && CS_U4 % NT == 0 && W2_U4 % NT == 0 && W1F_U4 / NT <= 16 && W2_U4 / NT <= 16, "copy partition");
+  const uint4* const w1s = wl;
+  const uint4* const w2s = wl + W1F_U4;
+  uint4* const csl = wl + W1F_U4 + W2_U4;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int ntiles = (a.M + TILE - 1) / TILE;
+  const uint4* const W1g = static_cast<const uint4*>(a.w1p);
+  const uint4* const W2g = static_cast<const uint4*>(a.w2p);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    bf16x8 xh[MT][KS], xl[MT][KS];
+    load_frames<F, false>(a.x, tile * TILE + w * 32, a.M, 0.f, fi, fg, xh, xl);
+    f32x4 acc[FT][MT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto dma_w1 = [&](int c) {
+      dma_blocks(W1g + (long long)c * W1_U4, wl, W1F_U4 / NT, lane, w);
+      dma_blocks(W1g + (long long)c * W1_U4 + W1F_U4, csl + (c & 1) * CS_U4, CS_U4 / NT, lane, w);
+    };
+    auto dma_w2 = [&](int c) { dma_blocks(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / NT, lane, w); };
+    auto ld_up = [&](int g, uint4 (&d)[2]) {          // g = tile*KS + ks
+      const uint4* p = w1s + (g * 2) * 64 + lane;
+      d[0] = p[0];
+      d[1] = p[64];
+    };
+    auto ld_dn = [&](int g, uint4 (&d)[2]) {          // g = kstep*FT + ft
+      const uint4* p = w2s + (g * 2) * 64 + lane;
+      d[0] = p[0];
+      d[1] = p[64];
+    };
+
+    __syncthreads();   // the previous tile's epilogue staging is fully consumed
+    dma_w1(0);
+    dma_w2(0);
+    dma_barrier();
+    for (int c = 0; c < NCH; ++c) {
+      bf16x8 gh[2][MT], gw[2][MT];     // activated values (bf16 hi / lo) per down-projection K step, k-slot order
+      const float* cs = reinterpret_cast<const float*>(csl + (c & 1) * CS_U4) + 4 * fg;
+      uint4 fb[3][2];
+      ld_up(0, fb[0]);
+      ld_up(1, fb[1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 h[MT];
+        {
+          const float4 bv = ld4(cs + j * 16);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) h[mt] = (f32x4){bv.x, bv.y, bv.z, bv.w};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int g = j * KS + ks;
+          if (g + 2 < 4 * KS) ld_up(g + 2, fb[(g + 2) % 3]);
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[g % 3][0]);
+          const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[g % 3][1]);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) h[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], h[mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) h[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], h[mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) h[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], h[mt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j == 3) {
+          dma_barrier();                         // every wave has read its up-projection fragments of chunk c;
+                                                 // this chunk's down-projection fragments have landed
+          if (c + 1 < NCH) dma_w1(c + 1);        // lands under the GELU + down-projection below
+          ld_dn(0, fb[0]);
+          ld_dn(1, fb[1]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float o = gelu_exact(h[mt][r]);
+            const __bf16 hb = (__bf16)o;
+            gh[j >> 1][mt][4 * (j & 1) + r] = hb;
+            gw[j >> 1][mt][4 * (j & 1) + r] = (__bf16)(o - (float)hb);
+          }
+      }
+#pragma unroll
+      for (int g = 0; g < 2 * FT; ++g) {
+        if (g + 2 < 2 * FT) ld_dn(g + 2, fb[(g + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[g % 3][0]);
+        const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[g % 3][1]);
+        const int s = g / FT, ft = g % FT;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[s][mt], acc[ft][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gw[s][mt], acc[ft][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[s][mt], acc[ft][mt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      dma_barrier();                             // down-projection fragments consumed; chunk c+1's up-projection
+      if (c + 1 < NCH) dma_w2(c + 1);            // fragments have landed
+    }
+    store_tile<F, true>(acc, reinterpret_cast<float*>(wl), a, tile * TILE, tid, w, fi, fg);
+  }
+}
+
+int launch_cla_head(const ClaFusedArgs& a, int F, int site, hipStream_t stream) {
+  if (a.M <= 0) return SEPR_OK;
+  if (!a.x || !a.y || !a.w1p || a.x == a.y || F != 128) return SEPR_EINVAL;
+  long long slot = -1;
+  const bool timed = prof_begin(site, stream, &slot);
+  const int ntiles = (a.M + 127) / 128;
+  const int cap = persistent_grid();
+  hipLaunchKernelGGL((cla_head_kernel<128>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
+  if (timed) prof_end(slot, (double)a.M * 2.0 * F * 2 * F, stream);
+  SEPR_CHECK_LAUNCH("cla_head_kernel");
+  return SEPR_OK;
+}
+
+int launch_cla_tail(const ClaFusedArgs& a, int F, int site, hipStream_t stream) {
+  if (a.M <= 0) return SEPR_OK;
+  if (!a.x || !a.res || !a.y || !a.w1p || !a.w2p || !a.b3 || !a.ls || a.x == a.y || F != 128) return SEPR_EINVAL;
+  long long slot = -1;
+  const bool timed = prof_begin(site, stream, &slot);
+  const int ntiles = (a.M + 127) / 128;
+  const int cap = persistent_grid();
+  hipLaunchKernelGGL((cla_tail_kernel<128>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
+  if (timed) prof_end(slot, (double)a.M * (2.0 * F * 2 * F + 2.0 * 2 * F * F), stream);
+  SEPR_CHECK_LAUNCH("cla_tail_kernel");
+  return SEPR_OK;
+}
+
+}  // namespace sepr

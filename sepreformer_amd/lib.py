@@ -40,7 +40,8 @@ def _struct(name, fields, x3=(), tail=()):
 
 GcfnW = _struct("GcfnW", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "ls"], ["x3_up", "x3_down"],
                 ["fused_w1p", "fused_w2p"])
-ClaW = _struct("ClaW", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "w3", "b3", "ls"], ["x3_1", "x3_2", "x3_3"])
+ClaW = _struct("ClaW", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "w3", "b3", "ls"], ["x3_1", "x3_2", "x3_3"],
+               ["fused_w1p", "fused_w2p", "fused_w3p"])
 MhaW = _struct("MhaW", ["ln_g", "ln_b", "wqkv", "bqkv", "wo", "bo", "ls"], ["x3_qkv", "x3_out"],
                ["fused_qkv_p", "fused_out_p"])
 

@@ -57,6 +57,7 @@ class Packed:
         self.precision = precision
         self.fuse_gcfn = os.environ.get("SEPR_FUSE_GCFN", "1") != "0"     # A/B switch for the fused GCFN kernel
         self.fuse_spk = os.environ.get("SEPR_FUSE_SPK", "1") != "0"       # A/B switch for the fused speaker attention
+        self.fuse_cla = os.environ.get("SEPR_FUSE_CLA", "1") != "0"       # A/B switch for the fused CLA head / tail
         self.keep: List[torch.Tensor] = []
 
     def t(self, x: torch.Tensor) -> int:
@@ -88,6 +89,16 @@ class Packed:
         self.keep += [w1p, w2p]
         return {"fused_w1p": w1p.data_ptr(), "fused_w2p": w2p.data_ptr()}
 
+
+    def cla_fused(self, sd, p: str, w2: torch.Tensor, b2: torch.Tensor) -> dict:
+        """Fused CLA head / tail weight forms (bf16x3, F = 128); ``w2`` / ``b2`` = linear2 with BatchNorm folded."""
+        F = sd[p + ".layer_norm.weight"].shape[0]
+        if self.precision != "bf16x3" or F != 128 or not self.fuse_cla:
+            return {}
+        w1p, w2p, w3p = pack_cla_fused(sd[p + ".linear1.weight"], sd[p + ".linear1.bias"], sd[p + ".layer_norm.weight"],
+                                       sd[p + ".layer_norm.bias"], w2, b2, sd[p + ".linear3.1.weight"])
+        self.keep += [w1p, w2p, w3p]
+        return {"fused_w1p": w1p.data_ptr(), "fused_w2p": w2p.data_ptr(), "fused_w3p": w3p.data_ptr()}
 
     def spk_fused(self, sd, p: str, heads: int, num_spks: int) -> dict:
         """Fused speaker-attention weight forms (bf16x3, F = 128, 16-channel heads, two speakers); else empty."""
@@ -165,6 +176,34 @@ def _kslot_frags(w2: torch.Tensor, nch: int) -> torch.Tensor:
     return torch.stack([_split_frag(w2.detach().float()[:, 32 * c + perm])[:, 0] for c in range(nch)], 0).contiguous()
 
 
+def pack_cla_fused(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w2: torch.Tensor,
+                   b2: torch.Tensor, w3: torch.Tensor):
+    """Weights of the fused CLA head / tail kernels (sepreformer_amd/csrc/sepr_cla_fused.hip).
+
+    ``w1`` ``[2F,F]`` (value rows then gate rows, LayerNorm in front), ``w2`` ``[2F,F]`` / ``b2`` with the eval
+    BatchNorm already folded, ``w3`` ``[F,2F]``.  Returns three byte tensors:
+
+    * ``w1p``: per 32 output channels the fragments ``[v0 v1 g0 g1][F/32][2][64][8]`` bf16 (gamma folded) + a 4 KB fp32
+      constants block ``[v0 v1 g0 g1][16]`` of biases (beta folded), zero padded;
+    * ``w2p``: per 64 hidden channels the fragments ``[4 tiles][F/32][2][64][8]`` + 4 KB constants ``[4][16]`` biases;
+    * ``w3p`` ``[2F/32][F/16][2][64][8]``: linear3 in k-slot order (``_kslot_frags``)."""
+    F = w1.shape[1]
+    dev = w1.device
+    w1f = (w1.detach().double() * gamma.detach().double()[None, :]).float()
+    b1f = (b1.detach().double() + w1.detach().double() @ beta.detach().double()).float()
+    w2f, b2f = w2.detach().float(), b2.detach().float()
+
+    def chunk(wm, bm, bases):
+        frag = _split_frag(torch.cat([wm[b:b + 16] for b in bases], 0)).contiguous().view(torch.uint8).reshape(-1)
+        cst = torch.zeros(1024, dtype=torch.float32, device=dev)
+        cst[:16 * len(bases)] = torch.cat([bm[b:b + 16] for b in bases])
+        return torch.cat([frag, cst.view(torch.uint8)])
+
+    w1p = torch.stack([chunk(w1f, b1f, [32 * c, 32 * c + 16, F + 32 * c, F + 32 * c + 16]) for c in range(F // 32)], 0)
+    w2p = torch.stack([chunk(w2f, b2f, [64 * c + 16 * j for j in range(4)]) for c in range(2 * F // 64)], 0)
+    return w1p.contiguous(), w2p.contiguous(), _kslot_frags(w3, 2 * F // 32)
+
+
 def pack_spk_fused(wqkv: torch.Tensor, bqkv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, wo: torch.Tensor):
     """Weights of the fused speaker-attention kernel (sepreformer_amd/csrc/sepr_spk_fused.hip), 16-channel heads.
 
@@ -217,7 +256,8 @@ def pack_cla(pk: Packed, sd, p: str) -> L.ClaW:
         ls=pk.t(sd[p + ".Layer_scale.layer_scale"].reshape(-1)),
         x3_1=pk.x3(sd[p + ".linear1.weight"], sd[p + ".linear1.bias"], sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"]),
         x3_2=pk.x3(w2, b2),
-        x3_3=pk.x3(sd[p + ".linear3.1.weight"], sd[p + ".linear3.1.bias"]))
+        x3_3=pk.x3(sd[p + ".linear3.1.weight"], sd[p + ".linear3.1.bias"]),
+        **pk.cla_fused(sd, p, w2, b2))
 
 
 def pack_mha(pk: Packed, sd, p: str, spk_fused: dict = None) -> L.MhaW:
