@@ -14,7 +14,7 @@
 // staging tile as row-contiguous 512 B stores.
 //   head: chunk = 32 output channels (value tiles v0 v1 + gate tiles g0 g1, the GCFN up-projection layout); the
 //         gated values are collected in a [F x 32 frames] register tile.
-//   tail: chunk = 64 hidden channels (4 tiles up, 2 K steps down); exact-erf GELU in registers; the activated
+//   tail: chunk = 64 hidden channels (4 tiles up, 2 K steps down); GELU (gelu_fast, 1.5e-7 erf) in registers; the activated
 //         values are the B fragments of the down-projection (k-slot-ordered weights, as in the GCFN kernel).
 #include "sepr_gemm_epi.h"
 #include <stdlib.h>
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(CF_NT, 2) void cla_tail_kernel(const ClaFusedArgs a
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float o = gelu_exact(h[mt][r]);
+            const float o = gelu_fast(h[mt][r]);
             const __bf16 hb = (__bf16)o;
             gh[j >> 1][mt][4 * (j & 1) + r] = hb;
             gw[j >> 1][mt][4 * (j & 1) + r] = (__bf16)(o - (float)hb);
