@@ -192,7 +192,7 @@ def main():
             mfma_tf = 3.0 * rows * 18.0 * F * F / 1e12 / sec if sec > 0 else 0.0
             gbs = rows * 8.0 * F / 1e9 / sec if sec > 0 else 0.0
             dtype = "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)"
-            roof = {"kernel": "gcfn_fused_kernel<128,2,4> (whole GCFN block in one launch: LayerNorm, F->6F bf16x3 MFMA, "
+            roof = {"kernel": "gcfn_fused3_kernel<128,4> (whole GCFN block in one launch: LayerNorm, F->6F bf16x3 MFMA, "
                               "depthwise conv k=3 + GLU, 3F->F bf16x3 MFMA, LayerScale, residual)",
                     "bound": "mfma", "achieved": round(mfma_tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(mfma_tf / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -210,8 +210,11 @@ def main():
                        "batch_per_gpu": B, "samples": SAMPLES, "aux_heads": not args.no_aux, "precision": precision,
                        "weights": "synthetic seed 0 (O(1) LayerScale)", "parallelism": f"utterance-sharded x{world}"},
             "parity_db_vs_golden": parity_db,
+            # whole-forward algorithmic rate per GPU (fp32-equivalent FLOPs of the reference's op list) and the
+            # fraction of the matrix pipe it needs in this arithmetic (bf16x3 issues 3 bf16 MFMA FLOPs per FLOP)
             "model_tflops": round(utt_per_s * gflop / 1e3 / world, 2),
-            "model_mfma_frac": round(utt_per_s * gflop / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+            "model_mfma_frac": round(utt_per_s * gflop / 1e3 / world * (3.0 / BF16_MFMA_PEAK_TFLOPS if precision == "bf16x3"
+                                                                         else 1.0 / FP32_MFMA_PEAK_TFLOPS), 4),
             "roofline": roof,
         }
         if world == 1 and not args.no_alt_precision:
