@@ -136,9 +136,14 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const 
       dma(W1g + (long long)c * W1_U4 + W1F_U4, csl + (c & 1) * CS_U4, CS_U4 / NT);
     };
     auto dma_w2 = [&](int c) { dma(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / NT); };
+#ifndef SEPR_SPK_ABL
+#define SEPR_SPK_ABL 0      // timing ablations (wrong results): 1 = weight chunks copied once per tile, 2 = no chunk
+#endif                      // barriers, 4 = no chunk loop (prologue + epilogue only), 8 = no score shuffles
     auto dma_barrier = [&]() {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if (SEPR_SPK_ABL & 2) == 0
       __syncthreads();
+#endif
     };
     // fragment pair (bf16 hi plane, lo plane): head hh of the pair, group g = 3*ks + (0 q | 1 k | 2 v)
     auto ld_up = [&](int hh, int g, uint4 (&d)[2]) {
@@ -156,9 +161,9 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const 
     dma_w1(0);
     dma_w2(0);
     dma_barrier();     // head pair 0 landed
-    for (int c = 0; c < NCH; ++c) {
+    for (int c = 0; c < ((SEPR_SPK_ABL & 4) ? 0 : NCH); ++c) {
       bf16x8 gh[MT], gw[MT];          // mixed values (bf16 hi / lo) in output-projection k-slot order, per speaker
-      uint4 fb[3][2];                 // fragment ring: two MFMA groups in flight ahead of the one being multiplied
+      uint4 fb[4][2];                 // fragment ring: the next PAIR of MFMA groups in flight under the current pair
       ld_up(0, 0, fb[0]);
       ld_up(0, 1, fb[1]);
 #pragma unroll
@@ -172,19 +177,33 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const 
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) pq[tt][mt] = (f32x4){bv.x, bv.y, bv.z, bv.w};
         }
+        // MFMA groups go in PAIRS (two weight tiles x two speakers = four independent accumulators, issued
+        // term-major): back-to-back MFMAs on the same accumulator are 4 instructions apart instead of 2, which
+        // is what the 16x16x32 pipeline depth needs; the next pair's fragments are requested first.
 #pragma unroll
-        for (int g = 0; g < 3 * KS; ++g) {
-          if (g + 2 < 3 * KS) ld_up(hh, g + 2, fb[(g + 2) % 3]);
+        for (int gp = 0; gp < 3 * KS; gp += 2) {
+          if (gp + 2 < 3 * KS) {
+            ld_up(hh, gp + 2, fb[(gp + 2) & 3]);
+            ld_up(hh, gp + 3, fb[(gp + 3) & 3]);
+          }
           __builtin_amdgcn_sched_barrier(0);
-          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[g % 3][0]);
-          const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[g % 3][1]);
-          const int ks = g / 3, tt = g % 3;
+          const bf16x8 wh0 = *reinterpret_cast<const bf16x8*>(&fb[gp & 3][0]);
+          const bf16x8 wl0 = *reinterpret_cast<const bf16x8*>(&fb[gp & 3][1]);
+          const bf16x8 wh1 = *reinterpret_cast<const bf16x8*>(&fb[(gp + 1) & 3][0]);
+          const bf16x8 wl1 = *reinterpret_cast<const bf16x8*>(&fb[(gp + 1) & 3][1]);
+          const int ks0 = gp / 3, tt0 = gp % 3, ks1 = (gp + 1) / 3, tt1 = (gp + 1) % 3;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) pq[tt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], pq[tt][mt], 0, 0, 0);
+          for (int mt = 0; mt < MT; ++mt) pq[tt0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0, xh[mt][ks0], pq[tt0][mt], 0, 0, 0);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) pq[tt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], pq[tt][mt], 0, 0, 0);
+          for (int mt = 0; mt < MT; ++mt) pq[tt1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1, xh[mt][ks1], pq[tt1][mt], 0, 0, 0);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) pq[tt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], pq[tt][mt], 0, 0, 0);
+          for (int mt = 0; mt < MT; ++mt) pq[tt0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0, xl[mt][ks0], pq[tt0][mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) pq[tt1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1, xl[mt][ks1], pq[tt1][mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) pq[tt0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl0, xh[mt][ks0], pq[tt0][mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) pq[tt1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl1, xh[mt][ks1], pq[tt1][mt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (hh == 0) {                           // the second head's first fragments arrive under the mix below
@@ -193,7 +212,9 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const 
         } else {
           dma_barrier();                         // every wave has read its q/k/v fragments of pair c; the pair's
                                                  // output-projection fragments have landed
+#if (SEPR_SPK_ABL & 1) == 0
           if (c + 1 < NCH) dma_w1(c + 1);        // lands under the mix + output projection below
+#endif
           ld_dn(0, fb[0]);
           ld_dn(1, fb[1]);
         }
@@ -207,8 +228,10 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const 
             p = fmaf(pq[0][qa][1], pq[1][kc][1], p);
             p = fmaf(pq[0][qa][2], pq[1][kc][2], p);
             p = fmaf(pq[0][qa][3], pq[1][kc][3], p);
+#if (SEPR_SPK_ABL & 8) == 0
             p += __shfl_xor(p, 16, 64);          // the head's 16 channels live in the 4 lane groups
             p += __shfl_xor(p, 32, 64);
+#endif
             sc[qa][kc] = p;
           }
 #pragma unroll
@@ -227,21 +250,34 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const 
       }
       // ---- output-projection K step of this head pair -------------------------------------------------------------
 #pragma unroll
-      for (int ft = 0; ft < FT; ++ft) {
-        if (ft + 2 < FT) ld_dn(ft + 2, fb[(ft + 2) % 3]);
+      for (int ft = 0; ft < FT; ft += 2) {
+        if (ft + 2 < FT) {
+          ld_dn(ft + 2, fb[(ft + 2) & 3]);
+          ld_dn(ft + 3, fb[(ft + 3) & 3]);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[ft % 3][0]);
-        const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[ft % 3][1]);
+        const bf16x8 wh0 = *reinterpret_cast<const bf16x8*>(&fb[ft & 3][0]);
+        const bf16x8 wl0 = *reinterpret_cast<const bf16x8*>(&fb[ft & 3][1]);
+        const bf16x8 wh1 = *reinterpret_cast<const bf16x8*>(&fb[(ft + 1) & 3][0]);
+        const bf16x8 wl1 = *reinterpret_cast<const bf16x8*>(&fb[(ft + 1) & 3][1]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[mt], acc[ft][mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0, gh[mt], acc[ft][mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gw[mt], acc[ft][mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[ft + 1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1, gh[mt], acc[ft + 1][mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[mt], acc[ft][mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0, gw[mt], acc[ft][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft + 1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1, gw[mt], acc[ft + 1][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl0, gh[mt], acc[ft][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ft + 1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl1, gh[mt], acc[ft + 1][mt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       dma_barrier();                             // output-projection fragments consumed; pair c+1's q/k/v
+#if (SEPR_SPK_ABL & 1) == 0
       if (c + 1 < NCH) dma_w2(c + 1);            // fragments have landed
+#endif
     }
 
     // ---- epilogue: y = x + ls * (acc + bo), two waves at a time through LDS -------------------------------------
