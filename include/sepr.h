@@ -168,7 +168,7 @@ const char* sepr_last_hip_error(void);
 /* ops for sepr_workspace_bytes */
 enum {
   SEPR_OP_ENCODER = 0, SEPR_OP_GCFN, SEPR_OP_CLA, SEPR_OP_EGA, SEPR_OP_SPKATTN,
-  SEPR_OP_SPKSPLIT, SEPR_OP_OUTLAYER, SEPR_OP_COUNT
+  SEPR_OP_SPKSPLIT, SEPR_OP_OUTLAYER, SEPR_OP_PIT /* n = utterances, T = samples, S = speakers */, SEPR_OP_COUNT
 };
 /* Scratch bytes op needs for n sequences of T frames (Tp = pooled frames for EGA, source frames for
  * OUTLAYER; otherwise ignored), width F, encoder channels N, S speakers.  0 on bad arguments. */
@@ -241,6 +241,20 @@ int sepr_linear_fwd(const float* x, const float* w, const float* bias, float* y,
 /* the same product on the bf16x3 core; wp = pack_x3(w) */
 int sepr_linear_x3_fwd(const float* x, const void* wp, const float* bias, float* y, int M, int N, int K,
                        sepr_stream_t stream);
+
+/* ---- criteria --------------------------------------------------------- */
+/* Permutation-invariant SI-SNR of S <= 3 separated waveforms, utils/implements/criterions.py:
+ *   PIT_SISNR_time.__call__ :191-217   loss[b]   = min over permutations of sum_s clamp(-SISNR(est_s, tgt_p(s)), clamp_min)
+ *   PIT_SISNRi.__call__     :232-260   sisnri[b] = per-estimate SISNR(est_s, tgt_p(s)) - SISNR(mix, tgt_p(s)) of the
+ *                                                  permutation maximising their sum
+ * est, tgt [S,B,T] (the reference's lists of [B,T] stacked), mix [B,T] or NULL (then sisnri / sisnri_perm must be
+ * NULL).  eps_loss = 1e-8 (:199), eps_i = the caller's eps (1e-15 in engine.py:131), clamp_min = -30 (:212).
+ * loss [B]; loss_perm / sisnri_perm [B,S] = target index per estimate (NULL to skip); sisnri [B,S].  The batch
+ * mean the reference returns (sum / num_utts) is a host-side mean of `loss`.  Scale-invariant form only
+ * (scale_inv: true in every shipped config).  Workspace: sepr_workspace_bytes(SEPR_OP_PIT, B, T, 0, 0, 0, S). */
+int sepr_pit_sisnr_fwd(const float* est, const float* tgt, const float* mix, int S, int B, int T,
+                       double eps_loss, double eps_i, double clamp_min, float* loss, int* loss_perm,
+                       float* sisnri, int* sisnri_perm, void* ws, size_t ws_bytes, sepr_stream_t stream);
 
 /* ---- opt-in kernel timer (bench.py roofline) ------------------------------------------------- */
 /* Sites a projection launch can be attributed to. */

@@ -1,0 +1,97 @@
+"""Device-side permutation-invariant SI-SNR criteria behind the reference's criterion call surface.
+
+Mirrors ``utils/implements/criterions.py`` of the reference:
+
+* ``PIT_SISNR_time(device, num_spks, scale_inv)(estims=..., input_sizes=..., target_attr=...)`` -> scalar loss
+  (reference :180-217, called by ``engine.py:70,103``);
+* ``PIT_SISNRi(device, num_spks, scale_inv)(estims=..., mixture=..., input_sizes=..., target_attr=..., eps=...)``
+  -> ``(mean summed improvement, per-speaker improvements)`` (reference :220-260, called by ``engine.py:131``).
+
+``estims`` / ``target_attr`` are lists of ``[B,T]`` tensors (or one ``[S,B,T]`` tensor) on the HIP device.  The
+arithmetic is one pass over the waveforms in ``csrc/sepr_criterion.hip`` through ``sepr_pit_sisnr_fwd``; there is no
+CPU implementation here (the CPU restatement is ``oracle/criterion_oracle.py``, test infrastructure).  Forward
+only: the returned tensors carry no autograd graph (backward is section 8f-2).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Union
+
+import torch
+
+from . import lib as L
+
+_TensorList = Union[torch.Tensor, Sequence[torch.Tensor]]
+
+
+def _stack(x: _TensorList, what: str) -> torch.Tensor:
+    t = x if isinstance(x, torch.Tensor) else torch.stack(list(x), dim=0)
+    if t.dim() != 3:
+        raise RuntimeError(f"{what}: expected num_spks tensors of shape [batch, samples]")
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} is not on the HIP device (no CPU fallback exists)")
+    return t.detach().to(torch.float32).contiguous()
+
+
+def pit_sisnr(estims: _TensorList, targets: _TensorList, mixture: torch.Tensor = None, eps_loss: float = 1.0e-8,
+              eps_i: float = 1.0e-15, clamp_min: float = -30.0):
+    """One launch pair over ``[S,B,T]`` estimates / targets.  Returns a dict with ``loss`` ``[B]`` (PIT_SISNR_time per
+    utterance), ``loss_perm`` ``[B,S]`` and, when ``mixture`` is given, ``sisnri`` ``[B,S]`` / ``sisnri_perm`` ``[B,S]``."""
+    est, tgt = _stack(estims, "estims"), _stack(targets, "target_attr")
+    if est.shape != tgt.shape:
+        raise RuntimeError(f"estims {tuple(est.shape)} and targets {tuple(tgt.shape)} differ")
+    S, B, T = est.shape
+    dev = est.device
+    mix = None
+    if mixture is not None:
+        mix = mixture.detach().to(torch.float32).contiguous()
+        if tuple(mix.shape) != (B, T) or mix.device != dev:
+            raise RuntimeError("mixture must be [batch, samples] on the same device as the estimates")
+    lib = L.load()
+    with torch.cuda.device(dev):
+        nbytes = lib.sepr_workspace_bytes(L.OP_PIT, B, T, 0, 0, 0, S)
+        if nbytes == 0:
+            raise RuntimeError(f"unsupported PIT problem: num_spks={S}, batch={B}, samples={T}")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        loss_perm = torch.empty(B, S, dtype=torch.int32, device=dev)
+        sisnri = torch.empty(B, S, dtype=torch.float32, device=dev) if mix is not None else None
+        sisnri_perm = torch.empty(B, S, dtype=torch.int32, device=dev) if mix is not None else None
+        L.check(lib.sepr_pit_sisnr_fwd(
+            est.data_ptr(), tgt.data_ptr(), None if mix is None else mix.data_ptr(), S, B, T, eps_loss, eps_i, clamp_min,
+            loss.data_ptr(), loss_perm.data_ptr(), None if sisnri is None else sisnri.data_ptr(),
+            None if sisnri_perm is None else sisnri_perm.data_ptr(), ws.data_ptr(), ws.numel(),
+            torch.cuda.current_stream(dev).cuda_stream), "sepr_pit_sisnr_fwd")
+    return {"loss": loss, "loss_perm": loss_perm, "sisnri": sisnri, "sisnri_perm": sisnri_perm}
+
+
+class _Base:
+    def __init__(self, device, num_spks: int, scale_inv: bool = True):
+        if not scale_inv:
+            raise NotImplementedError("only the scale-invariant form is built (scale_inv: true in every shipped config)")
+        self.device, self.num_spks, self.scale_inv = torch.device(device), num_spks, scale_inv
+
+    def __repr__(self):
+        return f"<{type(self).__name__}(device={self.device!r}, num_spks={self.num_spks!r}, scale_inv={self.scale_inv!r})>"
+
+    def _check(self, estims):
+        n = estims.shape[0] if isinstance(estims, torch.Tensor) else len(estims)
+        if n != self.num_spks:
+            raise RuntimeError(f"expected {self.num_spks} estimates, got {n}")
+
+
+class PIT_SISNR_time(_Base):
+    def __call__(self, **kwargs) -> torch.Tensor:
+        estims, targets = kwargs["estims"], kwargs["target_attr"]
+        self._check(estims)
+        out = pit_sisnr(estims, targets)
+        return torch.sum(out["loss"]) / kwargs["input_sizes"].shape[0]           # reference :216-217
+
+
+class PIT_SISNRi(_Base):
+    def __call__(self, **kwargs):
+        estims, targets = kwargs["estims"], kwargs["target_attr"]
+        self._check(estims)
+        out = pit_sisnr(estims, targets, mixture=kwargs["mixture"], eps_i=kwargs["eps"])
+        per = out["sisnri"]
+        mean = torch.sum(per) / kwargs["input_sizes"].shape[0]                    # reference :255-257
+        return mean, (per[0] if per.shape[0] == 1 else per)

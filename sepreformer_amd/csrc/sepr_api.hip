@@ -42,6 +42,7 @@ struct ClaFusedArgs {
   const float* ls;
   float eps;
 };
+size_t pit_workspace_bytes(int S, int B, int T);                                      // sepr_criterion.hip
 int launch_cla_head(const ClaFusedArgs& a, int F, int site, hipStream_t stream);      // sepr_cla_fused.hip
 int launch_cla_tail(const ClaFusedArgs& a, int F, int site, hipStream_t stream);
 
@@ -87,6 +88,7 @@ extern "C" const char* sepr_build_info(void) {
 extern "C" const char* sepr_last_hip_error(void) { return g_err; }
 
 extern "C" size_t sepr_workspace_bytes(int op, int n, int T, int Tp, int F, int N, int S) {
+  if (op == SEPR_OP_PIT) return pit_workspace_bytes(S, n, T);
   if (n <= 0 || T <= 0 || F <= 0) return 0;
   const long long M = (long long)n * T;
   switch (op) {

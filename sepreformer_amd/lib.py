@@ -22,7 +22,7 @@ _ERR = {SEPR_EINVAL: "SEPR_EINVAL (bad shape / unsupported size / null pointer)"
         SEPR_EWORKSPACE: "SEPR_EWORKSPACE (workspace too small)",
         SEPR_EHIP: "SEPR_EHIP (HIP launch failed)"}
 
-(OP_ENCODER, OP_GCFN, OP_CLA, OP_EGA, OP_SPKATTN, OP_SPKSPLIT, OP_OUTLAYER) = range(7)
+(OP_ENCODER, OP_GCFN, OP_CLA, OP_EGA, OP_SPKATTN, OP_SPKSPLIT, OP_OUTLAYER, OP_PIT) = range(8)
 (SITE_NONE, SITE_GCFN_UP, SITE_GCFN_DOWN, SITE_CLA, SITE_ATTN_PROJ, SITE_EGA_GATE, SITE_SPLIT, SITE_FUSE,
  SITE_OUT, SITE_PROJECTOR, SITE_LINEAR) = range(11)
 
@@ -77,6 +77,8 @@ SIGNATURES = {
     "sepr_groupnorm_stats": (_i, [_fp, _i, _ll, _f, _fp, _fp, _sz, _fp]),
     "sepr_linear_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
     "sepr_linear_x3_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
+    "sepr_pit_sisnr_fwd": (_i, [_fp, _fp, _fp, _i, _i, _i, C.c_double, C.c_double, C.c_double, _fp, _fp, _fp, _fp,
+                                _fp, _sz, _fp]),
     "sepr_prof_start": (_i, [_i, _i]),
     "sepr_prof_stop": (_i, [C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

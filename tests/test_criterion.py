@@ -1,0 +1,125 @@
+"""PIT SI-SNR criteria: oracle vs the reference's golden values (CPU), device kernel vs
+oracle / golden through the C ABI (GPU).
+
+Tolerances, in dB of SI-SNR (floating point):
+  * oracle (fp32, the reference's op sequence) vs committed reference outputs: 1e-4 dB;
+  * device (fp64 moments) vs the fp64 evaluation of the oracle: 2e-4 dB (the outputs are rounded to float32,
+    |value| <= ~90 dB);
+  * device vs the reference's own fp32 evaluation: 2e-3 dB (the reference's fp32 residual norm loses digits at high
+    SI-SNR; cases above 60 dB are compared at 2e-2 dB).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import criterion_oracle as co
+
+CASES = ["s2", "s3", "s2_short"]
+
+
+def _case(golden, tag):
+    g = golden("criterion")
+    src = [torch.from_numpy(a) for a in g[f"{tag}.src"]]
+    est = [torch.from_numpy(a) for a in g[f"{tag}.est"]]
+    mix = torch.from_numpy(g[f"{tag}.mix"])
+    return g, src, est, mix
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_oracle_matches_reference_values(golden, tag):
+    g, src, est, mix = _case(golden, tag)
+    mean, per_utt, perm = co.pit_sisnr_time(est, src)
+    assert abs(float(mean) - float(g[f"{tag}.loss_mean"])) < 1e-4
+    assert np.allclose(per_utt.numpy(), g[f"{tag}.loss_per_utt"], atol=1e-4)
+    assert np.array_equal(perm.numpy(), g[f"{tag}.loss_perm"])
+    i_mean, i_per, _ = co.pit_sisnri(est, src, mix)
+    assert np.allclose(i_per.numpy(), g[f"{tag}.sisnri_per"], atol=1e-4)
+    assert abs(float(i_mean) - float(g[f"{tag}.sisnri_mean"].mean())) < 1e-4
+
+
+def test_oracle_clamp_and_permutation_semantics():
+    torch.manual_seed(3)
+    src = [torch.randn(2, 4000), torch.randn(2, 4000)]
+    est = [src[1] + 1e-4 * torch.randn(2, 4000), src[0] + 0.5 * torch.randn(2, 4000)]      # speaker-swapped; 80 dB / 6 dB
+    mean, per_utt, perm = co.pit_sisnr_time(est, src)
+    assert perm.tolist() == [[1, 0], [1, 0]]
+    one = -20 * torch.log10(torch.norm(src[0] - src[0].mean(-1, keepdim=True), dim=-1) / torch.norm(0.5 * torch.randn(2, 4000), dim=-1))
+    assert (per_utt < -30 + 0.0).all() and (per_utt > -30 - 12).all(), (per_utt, one)     # first term clamped at -30
+
+
+def test_host_class_has_no_cpu_path():
+    from sepreformer_amd.criterion import PIT_SISNR_time
+    crit = PIT_SISNR_time("cpu", 2, True)
+    x = [torch.zeros(1, 16), torch.zeros(1, 16)]
+    with pytest.raises(RuntimeError, match="HIP device"):
+        crit(estims=x, input_sizes=torch.tensor([16]), target_attr=x)
+    with pytest.raises(NotImplementedError):
+        PIT_SISNR_time("cpu", 2, False)
+
+
+# ---- device ----------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", CASES)
+def test_device_matches_oracle_and_reference(golden, tag):
+    from sepreformer_amd.criterion import pit_sisnr, PIT_SISNR_time, PIT_SISNRi
+    g, src, est, mix = _case(golden, tag)
+    dev = torch.device("cuda:0")
+    out = pit_sisnr([e.to(dev) for e in est], [s.to(dev) for s in src], mixture=mix.to(dev))
+    mean64, per64, perm64 = co.pit_sisnr_time(est, src, dtype=torch.float64)
+    i_mean64, i_per64, iperm64 = co.pit_sisnri(est, src, mix, dtype=torch.float64)
+    assert np.allclose(out["loss"].cpu().numpy(), per64.numpy(), atol=2e-4)
+    assert np.array_equal(out["loss_perm"].cpu().numpy(), perm64.numpy())
+    assert np.allclose(out["sisnri"].cpu().numpy(), i_per64.numpy(), atol=2e-4)
+    assert np.array_equal(out["sisnri_perm"].cpu().numpy(), iperm64.numpy())
+    # the reference's own fp32 numbers
+    tol = np.where(np.abs(g[f"{tag}.loss_per_utt"]) > 60, 2e-2, 2e-3)
+    assert (np.abs(out["loss"].cpu().numpy() - g[f"{tag}.loss_per_utt"]) <= tol).all()
+    assert np.allclose(out["sisnri"].cpu().numpy(), g[f"{tag}.sisnri_per"], atol=2e-2)
+    # reference call surface
+    S, B = len(est), est[0].shape[0]
+    sizes = torch.full((B,), est[0].shape[1])
+    loss = PIT_SISNR_time(dev, S, True)(estims=[e.to(dev) for e in est], input_sizes=sizes, target_attr=[s.to(dev) for s in src])
+    assert abs(float(loss) - float(g[f"{tag}.loss_mean"])) < 2e-3
+    m, per = PIT_SISNRi(dev, S, True)(estims=[e[:1].to(dev) for e in est], mixture=mix[:1].to(dev), input_sizes=sizes[:1],
+                                      target_attr=[s[:1].to(dev) for s in src], eps=1.0e-15)
+    assert per.shape == (S,) and abs(float(m) - float(g[f"{tag}.sisnri_mean"][0])) < 2e-2
+
+
+@pytest.mark.gpu
+def test_device_full_batch_determinism_and_model_outputs():
+    """B = 32 x 32000 samples (BASELINE.json configs[1] size): bitwise repeatable, equal to the fp64 oracle, and the
+    [S,B,T] tensor the separator returns is accepted as it is."""
+    from sepreformer_amd.criterion import pit_sisnr
+    from sepreformer_amd.synth import synth_sources
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(synth_sources(32, 32000, seed=77)).permute(1, 0, 2).contiguous()     # [2, 32, 32000]
+    g = torch.Generator().manual_seed(5)
+    est = torch.stack([src[1], src[0]], 0) * 0.8 + 0.003 * torch.randn(src.shape, generator=g)
+    mix = src.sum(0)
+    a = pit_sisnr(est.to(dev), src.to(dev), mixture=mix.to(dev))
+    b = pit_sisnr(est.to(dev), src.to(dev), mixture=mix.to(dev))
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    _, per64, perm64 = co.pit_sisnr_time(list(est), list(src), dtype=torch.float64)
+    assert np.allclose(a["loss"].cpu().numpy(), per64.numpy(), atol=2e-4)
+    assert np.array_equal(a["loss_perm"].cpu().numpy(), perm64.numpy())
+    assert (a["loss_perm"].cpu() == torch.tensor([1, 0])).all()
+
+
+@pytest.mark.gpu
+def test_device_error_codes():
+    from sepreformer_amd import lib as L
+    from sepreformer_amd.criterion import pit_sisnr
+    dev = torch.device("cuda:0")
+    x = torch.zeros(4, 2, 64, device=dev)
+    with pytest.raises(RuntimeError, match="unsupported PIT problem"):
+        pit_sisnr(x, x)                                            # 4 speakers: S! walk is built for S <= 3
+    lib = L.load()
+    y = torch.zeros(2, 2, 64, device=dev)
+    loss = torch.zeros(2, device=dev)
+    rc = lib.sepr_pit_sisnr_fwd(y.data_ptr(), y.data_ptr(), None, 2, 2, 64, 1e-8, 1e-15, -30.0, loss.data_ptr(), None, None, None,
+                                None, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == L.SEPR_EWORKSPACE
+    rc = lib.sepr_pit_sisnr_fwd(y.data_ptr(), y.data_ptr(), None, 2, 2, 64, 1e-8, 1e-15, -30.0, loss.data_ptr(), None, loss.data_ptr(),
+                                None, loss.data_ptr(), 4096, torch.cuda.current_stream().cuda_stream)
+    assert rc == L.SEPR_EINVAL                                     # improvements requested without a mixture
