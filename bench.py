@@ -232,6 +232,27 @@ def main():
                                     "parity_db_vs_golden": round(agreement_db(torch.stack([a[0:1] for a in out_alt[0]], 0).cpu(),
                                                                               torch.from_numpy(g["main"])), 1)}
             model.precision = precision
+        if world == 1 and not args.no_alt_precision:
+            # single-utterance latency: B=1 x 4 s, eager launches vs the captured hipGraph
+            x1 = x[:1].contiguous()
+            eng = model.engine()
+
+            def med_ms(fn, reps=15):
+                ts = []
+                for _ in range(reps):
+                    torch.cuda.synchronize(dev)
+                    t = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize(dev)
+                    ts.append(time.perf_counter() - t)
+                return round(1e3 * sorted(ts)[len(ts) // 2], 3)
+
+            eng.forward(x1, with_aux=True)
+            eager = med_ms(lambda: eng.forward(x1, with_aux=True))
+            eng.forward_graphed(x1, with_aux=True)
+            graphed = med_ms(lambda: eng.forward_graphed(x1, with_aux=True))
+            rec["latency_b1"] = {"unit": "ms per 4 s utterance (batch 1, full forward incl. aux heads)",
+                                 "eager": eager, "hipgraph": graphed}
         if world == 1 and not args.no_cpu_baseline:
             threads = int(os.environ.get("SEPR_CPU_THREADS", str(physical_cores())))
             rec["cpu_baseline"] = cpu_baseline(cfg, threads)

@@ -43,6 +43,7 @@ class SeparatorEngine:
         self.lib = L.load()
         self._ws: Optional[torch.Tensor] = None
         self._idx_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._graphs: Dict[tuple, tuple] = {}
 
     # ---- plumbing ---------------------------------------------------------------------------------
     def _stream(self) -> int:
@@ -138,6 +139,33 @@ class SeparatorEngine:
             None if enc is None else enc.data_ptr(), c.feat, c.enc_channels, c.enc_kernel, c.enc_stride,
             C.byref(w), wav.data_ptr(), *self._wsargs, self._st), "sepr_outlayer_decoder_fwd")
         return wav
+
+    # ---- latency mode: the whole forward as one hipGraph ----------------------------------------------
+    @torch.no_grad()
+    def forward_graphed(self, x: torch.Tensor, with_aux: bool = True):
+        """Same result as ``forward`` but replayed from a captured hipGraph (one per input shape): the ~450 kernel
+        launches of a forward are enqueued by the driver in one call instead of 450 Python -> ctypes -> HIP round
+        trips, which is what bounds a single short utterance.  The returned tensors are the
+        graph's static output buffers: they are overwritten by the next call with the same shape."""
+        key = (tuple(x.shape), bool(with_aux))
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_x = x.detach().clone()
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):              # warm-up off the capture: workspace, index tables, allocator pools
+                for _ in range(2):
+                    self.forward(static_x, with_aux=with_aux)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.forward(static_x, with_aux=with_aux)
+            entry = (graph, static_x, out, self._ws)   # the captured launches point into this workspace: keep it alive
+            self._graphs[key] = entry
+        graph, static_x, out = entry[:3]
+        static_x.copy_(x)
+        graph.replay()
+        return out
 
     # ---- whole forward --------------------------------------------------------------------------------
     @torch.no_grad()
