@@ -119,6 +119,8 @@ typedef struct {
   const float* pe_k;      /* [2*maxlen, F/H]  separator.pos_emb.pe_k.weight */
   int maxlen;
   sepr_x3_w x3_gate;      /* block.linear.1 (LayerNorm folded) */
+  const void* fused_gate_p; /* optional (bf16x3, F = 128; pack.py::pack_gate_fused): per 64 output channels
+                               [4 tiles][F/32][plane][64][8] bf16 (gamma folded) + 4 KB fp32 constants [4][16] biases */
 } sepr_ega_w;
 
 /* DownConvLayer, modules/module.py:63-78 (eval BN folded: y = gelu(conv_nobias * scale + shift)) */

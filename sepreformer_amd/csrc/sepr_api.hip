@@ -41,8 +41,11 @@ struct ClaFusedArgs {
   const float* b3;
   const float* ls;
   float eps;
+  const float* att;
+  int T, Tp, fac;
 };
 size_t pit_workspace_bytes(int S, int B, int T);                                      // sepr_criterion.hip
+int launch_ega_gate(const ClaFusedArgs& a, int F, int site, hipStream_t stream);      // sepr_cla_fused.hip
 int launch_cla_head(const ClaFusedArgs& a, int F, int site, hipStream_t stream);      // sepr_cla_fused.hip
 int launch_cla_tail(const ClaFusedArgs& a, int F, int site, hipStream_t stream);
 
@@ -186,11 +189,13 @@ extern "C" int sepr_cla_fwd(const float* x, float* y, int n, int T, int F, int K
     ClaFusedArgs h;
     h.x = x; h.res = nullptr; h.y = u; h.M = (int)M;
     h.w1p = w->fused_w1p; h.w2p = nullptr; h.b3 = nullptr; h.ls = nullptr; h.eps = LN_EPS;
+    h.att = nullptr; h.T = 0; h.Tp = 0; h.fac = 0;
     SEPR_TRY(launch_cla_head(h, F, SEPR_SITE_CLA, st));
     SEPR_TRY(launch_dwconv_same(u, c, n, T, F, K, w->dw_w, w->dw_b, st));
     ClaFusedArgs t;
     t.x = c; t.res = x; t.y = y; t.M = (int)M;
     t.w1p = w->fused_w2p; t.w2p = w->fused_w3p; t.b3 = w->b3; t.ls = w->ls; t.eps = 0.f;
+    t.att = nullptr; t.T = 0; t.Tp = 0; t.fac = 0;
     return launch_cla_tail(t, F, SEPR_SITE_CLA, st);
   }
   SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
@@ -253,6 +258,13 @@ extern "C" int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int 
     a.A = o; a.lda = F; a.W = w->attn.wo; a.bias = w->attn.bo;
     a.Y = att; a.ldc = F; a.R = nullptr; a.ls = w->attn.ls;
     SEPR_TRY(project(PRO_PLAIN, EPI_RES, a, w->attn.x3_out, SEPR_SITE_ATTN_PROJ, st));
+  }
+  if (w->fused_gate_p && F == 128) {
+    ClaFusedArgs g;
+    g.x = x; g.res = x; g.y = y; g.M = (int)M;
+    g.w1p = w->fused_gate_p; g.w2p = nullptr; g.b3 = nullptr; g.ls = nullptr; g.eps = LN_EPS;
+    g.att = att; g.T = T; g.Tp = Tp; g.fac = fac;
+    return launch_ega_gate(g, F, SEPR_SITE_EGA_GATE, st);
   }
   SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
   {  // x + sigmoid(Linear(LayerNorm(x))) * upsample(att)                   (network.py:132-135,151-153)

@@ -34,6 +34,8 @@ struct ClaFusedArgs {
   const float* b3;    // tail [F]
   const float* ls;    // tail [F]
   float eps;
+  const float* att;   // gate: pooled attention output [n, Tp, F]
+  int T, Tp, fac;     // gate: frames per sequence, pooled frames, T / Tp
 };
 
 namespace {
@@ -114,8 +116,10 @@ __device__ __forceinline__ void dma_barrier() {
   __syncthreads();
 }
 
-// [F x 32 frames] register tile -> LDS -> row-contiguous stores; RES: y = res + ls * (tile + b)
-template <int F, bool RES>
+// [F x 32 frames] register tile -> LDS -> row-contiguous stores
+//   ST_PLAIN: y = tile;  ST_RES: y = res + ls * (tile + b);  ST_GATE: y = res + sigmoid(tile) * att[seq, t / fac]
+constexpr int ST_PLAIN = 0, ST_RES = 1, ST_GATE = 2;
+template <int F, int MODE>
 __device__ __forceinline__ void store_tile(const f32x4 (&acc)[F / 16][CF_MT], float* Os, const ClaFusedArgs& a, int tile0,
                                            int tid, int w, int fi, int fg) {
   constexpr int FT = F / 16, OS = F + 4, MT = CF_MT;
@@ -123,21 +127,27 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[F / 16][CF_MT], fl
   constexpr int Q = F / 4, RPP = CF_NT / Q, NP = 64 / RPP;
   static_assert(64 % RPP == 0, "epilogue pass partition");
   const int q4 = tid % Q, rr = tid / Q;
+  constexpr bool RES = (MODE != ST_PLAIN);
   float4 bb = zero4(), lsv = zero4();
-  if (RES) {
+  if (MODE == ST_RES) {
     bb = ld4(a.b3 + 4 * q4);
     lsv = ld4(a.ls + 4 * q4);
   }
 #pragma unroll 1
   for (int half = 0; half < EH; ++half) {
     if (half > 0) __syncthreads();   // previous pass fully stored
-    float4 xr[NP];
+    float4 xr[NP], ar[NP];
     int mrow[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int m = tile0 + 64 * half + rr + p * RPP;     // staging row = frame inside the tile
       mrow[p] = m < a.M ? m : -1;
-      if (RES) xr[p] = ld4(a.res + (long long)(m < a.M ? m : 0) * F + 4 * q4);
+      const int mc = m < a.M ? m : 0;
+      if (RES) xr[p] = ld4(a.res + (long long)mc * F + 4 * q4);
+      if (MODE == ST_GATE) {
+        const int seq = mc / a.T, t = mc - seq * a.T;
+        ar[p] = ld4(a.att + ((long long)seq * a.Tp + t / a.fac) * F + 4 * q4);
+      }
     }
     if (w / WPP == half) {
       float* base = Os + (w % WPP) * (16 * MT) * OS;
@@ -157,9 +167,12 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[F / 16][CF_MT], fl
         if (mrow[p] >= 0) {
           const float4 o = ld4(Os + (rr + p * RPP) * OS + 4 * q4);
           float* dst = a.y + (long long)mrow[p] * F + 4 * q4;
-          if (RES) {
+          if (MODE == ST_RES) {
             st4(dst, make_float4(fmaf(o.x + bb.x, lsv.x, xr[p].x), fmaf(o.y + bb.y, lsv.y, xr[p].y),
                                  fmaf(o.z + bb.z, lsv.z, xr[p].z), fmaf(o.w + bb.w, lsv.w, xr[p].w)));
+          } else if (MODE == ST_GATE) {
+            st4(dst, make_float4(fmaf(sigmoid_f(o.x), ar[p].x, xr[p].x), fmaf(sigmoid_f(o.y), ar[p].y, xr[p].y),
+                                 fmaf(sigmoid_f(o.z), ar[p].z, xr[p].z), fmaf(sigmoid_f(o.w), ar[p].w, xr[p].w)));
           } else {
             st4(dst, o);
           }
@@ -174,12 +187,15 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[F / 16][CF_MT], fl
 // ---------------------------------------------------------------------------------------------------------------------
 // head: u = GLU(Linear(LayerNorm(x)))
 // ---------------------------------------------------------------------------------------------------------------------
-template <int F>
+// GATE = false: the CLA head.  GATE = true: the EGA gate  y = x + sigmoid(Linear_F->F(LayerNorm(x))) * upsample(att)
+// (network.py:132-135,151-153): the same chunk walk with the four tiles of a chunk as four plain output tiles
+// (64 output channels per chunk) and the gate applied in the store pass.
+template <int F, bool GATE>
 __global__ __launch_bounds__(CF_NT, 2) void cla_head_kernel(const ClaFusedArgs a) {
   constexpr int MT = CF_MT, NW = CF_NW, NT = CF_NT;
   constexpr int TILE = 32 * NW;
   constexpr int KS = F / 32;
-  constexpr int NCH = F / 32;            // 32 output channels per chunk
+  constexpr int NCH = GATE ? F / 64 : F / 32;   // output channels per chunk: 64 plain or 32 gated
   constexpr int FT = F / 16;
   constexpr int W1F_U4 = 4 * KS * 2 * 64;
   constexpr int CS_U4 = 256;
@@ -257,15 +273,20 @@ __global__ __launch_bounds__(CF_NT, 2) void cla_head_kernel(const ClaFusedArgs a
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          f32x4 o;
+          if (GATE) {
+            acc[4 * c + j][mt] = hv[mt];
+            acc[4 * c + 2 + j][mt] = hg[mt];
+          } else {
+            f32x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = hv[mt][r] * sigmoid_f(hg[mt][r]);
-          acc[2 * c + j][mt] = o;
+            for (int r = 0; r < 4; ++r) o[r] = hv[mt][r] * sigmoid_f(hg[mt][r]);
+            acc[2 * c + j][mt] = o;
+          }
         }
       }
       dma_barrier();   // chunk c fully read by every wave, chunk c+1 landed
     }
-    store_tile<F, false>(acc, reinterpret_cast<float*>(wl), a, tile * TILE, tid, w, fi, fg);
+    store_tile<F, GATE ? ST_GATE : ST_PLAIN>(acc, reinterpret_cast<float*>(wl), a, tile * TILE, tid, w, fi, fg);
   }
 }
 
@@ -390,7 +411,7 @@ __global__ __launch_bounds__(CF_NT, 2) void cla_tail_kernel(const ClaFusedArgs a
       dma_barrier();                             // down-projection fragments consumed; chunk c+1's up-projection
       if (c + 1 < NCH) dma_w2(c + 1);            // fragments have landed
     }
-    store_tile<F, true>(acc, reinterpret_cast<float*>(wl), a, tile * TILE, tid, w, fi, fg);
+    store_tile<F, ST_RES>(acc, reinterpret_cast<float*>(wl), a, tile * TILE, tid, w, fi, fg);
   }
 }
 
@@ -401,9 +422,23 @@ int launch_cla_head(const ClaFusedArgs& a, int F, int site, hipStream_t stream) 
   const bool timed = prof_begin(site, stream, &slot);
   const int ntiles = (a.M + 127) / 128;
   const int cap = persistent_grid();
-  hipLaunchKernelGGL((cla_head_kernel<128>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
+  hipLaunchKernelGGL((cla_head_kernel<128, false>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
   if (timed) prof_end(slot, (double)a.M * 2.0 * F * 2 * F, stream);
   SEPR_CHECK_LAUNCH("cla_head_kernel");
+  return SEPR_OK;
+}
+
+int launch_ega_gate(const ClaFusedArgs& a, int F, int site, hipStream_t stream) {
+  if (a.M <= 0) return SEPR_OK;
+  if (!a.x || !a.res || !a.att || !a.y || !a.w1p || a.x == a.y || F != 128 || a.T <= 0 || a.Tp <= 0 || a.fac <= 0)
+    return SEPR_EINVAL;
+  long long slot = -1;
+  const bool timed = prof_begin(site, stream, &slot);
+  const int ntiles = (a.M + 127) / 128;
+  const int cap = persistent_grid();
+  hipLaunchKernelGGL((cla_head_kernel<128, true>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
+  if (timed) prof_end(slot, (double)a.M * 2.0 * F * F, stream);
+  SEPR_CHECK_LAUNCH("ega_gate_kernel");
   return SEPR_OK;
 }
 

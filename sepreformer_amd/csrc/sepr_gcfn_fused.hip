@@ -374,7 +374,47 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
   const uint4* const W1g = static_cast<const uint4*>(a.w1p);
   const uint4* const W2g = static_cast<const uint4*>(a.w2p);
 
+  // ---- weight chunks: global -> LDS by LDS-DMA, same protocol as gcfn_fused_kernel ---------------------------
+  auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {
+    unsigned loff = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(loff));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i >= nblk) break;
+      const int blk = i * NW + w;
+      const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+    }
+  };
+  auto dma_w1 = [&](int c) {
+    dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / NT);
+    dma(W1g + (long long)c * W1_U4 + W1F_U4, csl + (c & 1) * CS_U4, CS_U4 / NT);
+  };
+  auto dma_w2 = [&](int c) { dma(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / NT); };
+  auto dma_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(SEPR_GF_ABL & 4)) __syncthreads();
+  };
+  // fragment pair (bf16 hi plane, lo plane) of one 16-channel tile at one K step
+  auto ld_up = [&](int j, int g, uint4 (&d)[2]) {   // g = 2*ks + (0 value tile | 1 gate tile)
+    const uint4* p = w1s + ((((g & 1) * 2 + j) * KS + (g >> 1)) * 2) * 64 + lane;
+    if ((SEPR_GF_ABL & 8) && (j | g)) return;   // ablation: one fragment read per chunk
+    d[0] = p[0];
+    d[1] = p[64];
+  };
+  auto ld_dn = [&](int ft, uint4 (&d)[2]) {
+    const uint4* p = w2s + (ft * 2) * 64 + lane;
+    if ((SEPR_GF_ABL & 8) && ft) return;
+    d[0] = p[0];
+    d[1] = p[64];
+  };
+
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // chunk 0 of the weights is requested first: it lands under the frame loads and the LayerNorm below
+    __syncthreads();   // the previous tile's epilogue staging is fully consumed
+    dma_w1(0);
+    dma_w2(0);
     // ---- this wave's 32 frames (lane fi holds frames 2*fi and 2*fi+1): load, LayerNorm, split --------------
     const int mw0 = tile * GF_TILE + w * GF_ROWS_OUT - 1;       // wave frame 0 (halo)
     bf16x8 xh[MT][KS], xl[MT][KS];
@@ -433,42 +473,6 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // ---- weight chunks: global -> LDS by LDS-DMA, same protocol as gcfn_fused_kernel ---------------------------
-    auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {
-      unsigned loff = (unsigned)lane * 16u;
-      asm volatile("" : "+v"(loff));
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (i >= nblk) break;
-        const int blk = i * NW + w;
-        const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
-      }
-    };
-    auto dma_w1 = [&](int c) {
-      dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / NT);
-      dma(W1g + (long long)c * W1_U4 + W1F_U4, csl + (c & 1) * CS_U4, CS_U4 / NT);
-    };
-    auto dma_w2 = [&](int c) { dma(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / NT); };
-    auto dma_barrier = [&]() {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (!(SEPR_GF_ABL & 4)) __syncthreads();
-    };
-    // fragment pair (bf16 hi plane, lo plane) of one 16-channel tile at one K step
-    auto ld_up = [&](int j, int g, uint4 (&d)[2]) {   // g = 2*ks + (0 value tile | 1 gate tile)
-      const uint4* p = w1s + ((((g & 1) * 2 + j) * KS + (g >> 1)) * 2) * 64 + lane;
-      if ((SEPR_GF_ABL & 8) && (j | g)) return;   // ablation: one fragment read per chunk
-      d[0] = p[0];
-      d[1] = p[64];
-    };
-    auto ld_dn = [&](int ft, uint4 (&d)[2]) {
-      const uint4* p = w2s + (ft * 2) * 64 + lane;
-      if ((SEPR_GF_ABL & 8) && ft) return;
-      d[0] = p[0];
-      d[1] = p[64];
-    };
 
     auto chunks = [&](auto edge_c) {
       constexpr bool EDGE = decltype(edge_c)::value;
@@ -574,9 +578,6 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
         if (c + 1 < NCH && !(SEPR_GF_ABL & 2)) dma_w2(c + 1);            // fragments have landed
       }
     };
-    __syncthreads();   // the previous tile's epilogue staging is fully consumed
-    dma_w1(0);
-    dma_w2(0);
     dma_barrier();     // chunk 0 landed
     if (edge) chunks(bool_c<true>{}); else chunks(bool_c<false>{});
 

@@ -58,6 +58,7 @@ class Packed:
         self.fuse_gcfn = os.environ.get("SEPR_FUSE_GCFN", "1") != "0"     # A/B switch for the fused GCFN kernel
         self.fuse_spk = os.environ.get("SEPR_FUSE_SPK", "1") != "0"       # A/B switch for the fused speaker attention
         self.fuse_cla = os.environ.get("SEPR_FUSE_CLA", "1") != "0"       # A/B switch for the fused CLA head / tail
+        self.fuse_gate = os.environ.get("SEPR_FUSE_GATE", "1") != "0"     # A/B switch for the fused EGA gate
         self.keep: List[torch.Tensor] = []
 
     def t(self, x: torch.Tensor) -> int:
@@ -99,6 +100,16 @@ class Packed:
                                        sd[p + ".layer_norm.bias"], w2, b2, sd[p + ".linear3.1.weight"])
         self.keep += [w1p, w2p, w3p]
         return {"fused_w1p": w1p.data_ptr(), "fused_w2p": w2p.data_ptr(), "fused_w3p": w3p.data_ptr()}
+
+    def gate_fused(self, sd, p: str) -> dict:
+        """Fused EGA-gate weight form (bf16x3, F = 128)."""
+        F = sd[p + ".block.linear.0.weight"].shape[0]
+        if self.precision != "bf16x3" or F != 128 or not self.fuse_gate:
+            return {}
+        wp = pack_gate_fused(sd[p + ".block.linear.1.weight"], sd[p + ".block.linear.1.bias"],
+                             sd[p + ".block.linear.0.weight"], sd[p + ".block.linear.0.bias"])
+        self.keep.append(wp)
+        return {"fused_gate_p": wp.data_ptr()}
 
     def spk_fused(self, sd, p: str, heads: int, num_spks: int) -> dict:
         """Fused speaker-attention weight forms (bf16x3, F = 128, 16-channel heads, two speakers); else empty."""
@@ -174,6 +185,24 @@ def _kslot_frags(w2: torch.Tensor, nch: int) -> torch.Tensor:
     e = torch.arange(8, device=dev)[None, :]
     perm = torch.where(e < 4, 4 * g + e, 16 + 4 * g + (e - 4)).reshape(-1)       # [32] slot (g,e) -> channel
     return torch.stack([_split_frag(w2.detach().float()[:, 32 * c + perm])[:, 0] for c in range(nch)], 0).contiguous()
+
+
+def _chunk_frags(wm: torch.Tensor, bm: torch.Tensor, bases) -> torch.Tensor:
+    """One LDS-DMA chunk of the row-stationary kernels: the bf16 hi/lo fragments of the 16-row tiles starting at
+    ``bases`` (``[len(bases)][K/32][2][64][8]``) followed by a 4 KB fp32 block holding their biases ``[len(bases)][16]``."""
+    frag = _split_frag(torch.cat([wm[b:b + 16] for b in bases], 0)).contiguous().view(torch.uint8).reshape(-1)
+    cst = torch.zeros(1024, dtype=torch.float32, device=wm.device)
+    cst[:16 * len(bases)] = torch.cat([bm[b:b + 16] for b in bases])
+    return torch.cat([frag, cst.view(torch.uint8)])
+
+
+def pack_gate_fused(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """EGA gate projection ``[F,F]`` behind a LayerNorm for the fused gate kernel: per 64 output channels four
+    16-row tiles (gamma folded into the weights, beta into the bias)."""
+    F = w.shape[1]
+    wf = (w.detach().double() * gamma.detach().double()[None, :]).float()
+    bf = (b.detach().double() + w.detach().double() @ beta.detach().double()).float()
+    return torch.stack([_chunk_frags(wf, bf, [64 * c + 16 * j for j in range(4)]) for c in range(F // 64)], 0).contiguous()
 
 
 def pack_cla_fused(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w2: torch.Tensor,
@@ -280,7 +309,8 @@ def pack_ega(pk: Packed, sd, p: str, pe_ptr: int, maxlen: int) -> L.EgaW:
         gate_w=pk.t(sd[p + ".block.linear.1.weight"]), gate_b=pk.t(sd[p + ".block.linear.1.bias"]),
         pe_k=pe_ptr, maxlen=maxlen,
         x3_gate=pk.x3(sd[p + ".block.linear.1.weight"], sd[p + ".block.linear.1.bias"],
-                      sd[p + ".block.linear.0.weight"], sd[p + ".block.linear.0.bias"]))
+                      sd[p + ".block.linear.0.weight"], sd[p + ".block.linear.0.bias"]),
+        **pk.gate_fused(sd, p))
 
 
 def pack_down(pk: Packed, sd, p: str) -> L.DownW:
