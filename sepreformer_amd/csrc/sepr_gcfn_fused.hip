@@ -345,10 +345,14 @@ struct bool_c { static constexpr bool value = V; };
 #ifndef SEPR_GF3_RING
 #define SEPR_GF3_RING 2
 #endif
+#ifndef SEPR_GF3_UPFIRST
+#define SEPR_GF3_UPFIRST 1   // 1: both up-projections before both convolutions (the next chunk copy gets one more conv to land; ~1 %)
+#endif
 template <int F, int NW>
 __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
   constexpr int MT = 2;
   constexpr int RD = SEPR_GF3_RING;      // LDS fragment read-ahead, in MFMA groups
+  constexpr bool UF = SEPR_GF3_UPFIRST != 0;
   constexpr int NT = 64 * NW;
   constexpr int GF_ROWS_OUT = 16 * MT - 2;
   constexpr int GF_TILE = NW * GF_ROWS_OUT;
@@ -481,11 +485,18 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
         uint4 fb[RD + 1][2];            // fragment ring: RD MFMA groups in flight ahead of the one being multiplied
 #pragma unroll
         for (int g = 0; g < RD; ++g) ld_up(0, g, fb[g]);
+        f32x4 hvA[UF ? 2 : 1][MT], hgA[UF ? 2 : 1][MT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int jj = 0; jj < (UF ? 4 : 2); ++jj) {
+          // UF (up-first): both up-projections, then both convolutions - the copy of the next chunk's up-projection
+          // fragments is then issued one conv earlier and has conv + conv + down-projection to land
+          const int j = UF ? (jj & 1) : jj;
+          const bool do_up = !UF || jj < 2, do_conv = !UF || jj >= 2;
           const float* cs = reinterpret_cast<const float*>(csl + (c & 1) * CS_U4) + j * 160 + 4 * fg;
+          f32x4 (&hv)[MT] = hvA[UF ? j : 0];
+          f32x4 (&hg)[MT] = hgA[UF ? j : 0];
+          if (do_up) {
           // ---- up-projection, accumulators start at the bias ------------------------------------------------
-          f32x4 hv[MT], hg[MT];
           {
             const float4 bv = ld4(cs), bg = ld4(cs + 16);
 #pragma unroll
@@ -528,6 +539,8 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
 #pragma unroll
             for (int g = 0; g < RD; ++g) ld_dn(g, fb[g]);
           }
+          }
+          if (!do_conv) continue;
           // ---- depthwise k=3 conv along frames, GLU ---------------------------------------------------------
           // frame 2*fi+mt: tile 0's previous frame is the left lane's tile-1 value, its next frame the lane's own
           // tile-1 value (and mirrored for tile 1); the rotations wrap onto the two halo frames only.
