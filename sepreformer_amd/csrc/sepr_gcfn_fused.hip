@@ -348,15 +348,15 @@ struct bool_c { static constexpr bool value = V; };
 #ifndef SEPR_GF3_UPFIRST
 #define SEPR_GF3_UPFIRST 1   // 1: both up-projections before both convolutions (the next chunk copy gets one more conv to land; ~1 %)
 #endif
-template <int F, int NW>
+template <int F, int MT, int NW>
 __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
-  constexpr int MT = 2;
+  static_assert(MT == 1 || MT == 2, "frame tiles per wave");
   constexpr int RD = SEPR_GF3_RING;      // LDS fragment read-ahead, in MFMA groups
   constexpr bool UF = SEPR_GF3_UPFIRST != 0;
   constexpr int NT = 64 * NW;
   constexpr int GF_ROWS_OUT = 16 * MT - 2;
   constexpr int GF_TILE = NW * GF_ROWS_OUT;
-  constexpr int EH = (16 * MT * NW) / 64;
+  constexpr int EH = (16 * MT * NW + 63) / 64;   // epilogue passes of up to 64 frames
   constexpr int KS = F / 32;
   constexpr int NCH = 3 * F / 32;
   constexpr int FT = F / 16;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
   constexpr int OS = F + 4;
   __shared__ __attribute__((aligned(16))) uint4 wl[W1F_U4 + W2_U4 + 2 * CS_U4];
   static_assert(sizeof(uint4) * (W1F_U4 + W2_U4) >= sizeof(float) * 64 * OS, "epilogue staging must fit");
-  static_assert(W1F_U4 % NT == 0 && CS_U4 % NT == 0 && W2_U4 % NT == 0 && W1F_U4 / NT <= 16 && (16 * MT * NW) % 64 == 0, "copy / epilogue partition");
+  static_assert(W1F_U4 / 64 <= 16 * NW, "copy partition");
   const uint4* const w1s = wl;
   const uint4* const w2s = wl + W1F_U4;
   uint4* const csl = wl + W1F_U4 + W2_U4;
@@ -379,23 +379,25 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
   const uint4* const W2g = static_cast<const uint4*>(a.w2p);
 
   // ---- weight chunks: global -> LDS by LDS-DMA, same protocol as gcfn_fused_kernel ---------------------------
-  auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {
+  auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {   // nblk 1 KiB blocks, dealt round-robin to the waves
     unsigned loff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(loff));
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      if (i >= nblk) break;
+      if (i * NW >= nblk) break;
       const int blk = i * NW + w;
-      const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+      if (blk < nblk) {
+        const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+      }
     }
   };
   auto dma_w1 = [&](int c) {
-    dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / NT);
-    dma(W1g + (long long)c * W1_U4 + W1F_U4, csl + (c & 1) * CS_U4, CS_U4 / NT);
+    dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / 64);
+    dma(W1g + (long long)c * W1_U4 + W1F_U4, csl + (c & 1) * CS_U4, CS_U4 / 64);
   };
-  auto dma_w2 = [&](int c) { dma(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / NT); };
+  auto dma_w2 = [&](int c) { dma(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / 64); };
   auto dma_barrier = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!(SEPR_GF_ABL & 4)) __syncthreads();
@@ -550,10 +552,19 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
             const float wv0 = cs[2 * 16 + r], wv1 = cs[3 * 16 + r], wv2 = cs[4 * 16 + r];
             const float wg0 = cs[5 * 16 + r], wg1 = cs[6 * 16 + r], wg2 = cs[7 * 16 + r];
             const float cbv = cs[8 * 16 + r], cbg = cs[9 * 16 + r];
-            const float v0 = hv[0][r], v1 = hv[1][r], g0 = hg[0][r], g1 = hg[1][r];
-            const float pv[MT] = {dpp_ror1(v1), v0}, nv[MT] = {v1, dpp_rol1(v0)};
-            const float pg[MT] = {dpp_ror1(g1), g0}, ng[MT] = {g1, dpp_rol1(g0)};
-            const float cv[MT] = {v0, v1}, cg[MT] = {g0, g1};
+            float cv[MT], cg[MT], pv[MT], pg[MT], nv[MT], ng[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              cv[mt] = hv[mt][r];
+              cg[mt] = hg[mt][r];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              pv[mt] = mt > 0 ? cv[mt - 1] : dpp_ror1(cv[MT - 1]);
+              pg[mt] = mt > 0 ? cg[mt - 1] : dpp_ror1(cg[MT - 1]);
+              nv[mt] = mt + 1 < MT ? cv[mt + 1] : dpp_rol1(cv[0]);
+              ng[mt] = mt + 1 < MT ? cg[mt + 1] : dpp_rol1(cg[0]);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const float a0v = EDGE ? wv0 * f0[mt] : wv0, a2v = EDGE ? wv2 * f2[mt] : wv2;
@@ -599,8 +610,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     constexpr int WPP = 64 / (16 * MT);   // waves per 64-frame epilogue pass
     constexpr int Q = F / 4;                 // float4 per row
     constexpr int RPP = NT / Q;              // rows per pass
-    constexpr int NP = 64 / RPP;
-    static_assert(64 % RPP == 0, "epilogue pass partition");
+    constexpr int NP = (64 + RPP - 1) / RPP;
     const int q4 = tid % Q, rr = tid / Q;
     const float4 b2 = ld4(a.b2 + 4 * q4), lsv = ld4(a.ls + 4 * q4);
 #pragma unroll 1
@@ -615,7 +625,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
         const int row = rr + p * RPP;          // 0..63: WPP waves x 16*MT frames
         const int ww = WPP * half + row / (16 * MT), lr = row % (16 * MT);
         const int m = tile * GF_TILE + ww * GF_ROWS_OUT - 1 + lr;
-        const bool ok = lr >= 1 && lr <= GF_ROWS_OUT && m < a.M;
+        const bool ok = row < 64 && ww < NW && lr >= 1 && lr <= GF_ROWS_OUT && m < a.M;
         mrow[p] = ok ? m : -1;
         xr[p] = ld4(a.x + (long long)(ok ? m : 0) * F + 4 * q4);
       }
@@ -657,9 +667,9 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
 //     the epilogue's own traffic;
 //   * the epilogue has its own 34 KB staging tile, no longer aliasing the weight buffers.
 // ---------------------------------------------------------------------------------------------------------
-template <int F>
-__global__ __launch_bounds__(512, 2) void gcfn_fused4_kernel(const GcfnFusedArgs a) {
-  constexpr int MT = 2, NW = 8, NT = 512;
+template <int F, int MT, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void gcfn_fused4_kernel(const GcfnFusedArgs a) {
+  constexpr int NT = 64 * NW;
   constexpr int GF_ROWS_OUT = 16 * MT - 2;
   constexpr int GF_TILE = NW * GF_ROWS_OUT;
   constexpr int EH = (16 * MT * NW) / 64;
@@ -686,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void gcfn_fused4_kernel(const GcfnFusedArgs
     unsigned loff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(loff));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 16; ++i) {
       if (i * NW >= nblk) break;
       const int blk = i * NW + w;
       if (blk < nblk) {
@@ -860,10 +870,19 @@ __global__ __launch_bounds__(512, 2) void gcfn_fused4_kernel(const GcfnFusedArgs
             const float wv0 = cs[2 * 16 + r], wv1 = cs[3 * 16 + r], wv2 = cs[4 * 16 + r];
             const float wg0 = cs[5 * 16 + r], wg1 = cs[6 * 16 + r], wg2 = cs[7 * 16 + r];
             const float cbv = cs[8 * 16 + r], cbg = cs[9 * 16 + r];
-            const float v0 = hv[0][r], v1 = hv[1][r], g0 = hg[0][r], g1 = hg[1][r];
-            const float pv[MT] = {dpp_ror1(v1), v0}, nv[MT] = {v1, dpp_rol1(v0)};
-            const float pg[MT] = {dpp_ror1(g1), g0}, ng[MT] = {g1, dpp_rol1(g0)};
-            const float cv[MT] = {v0, v1}, cg[MT] = {g0, g1};
+            float cv[MT], cg[MT], pv[MT], pg[MT], nv[MT], ng[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              cv[mt] = hv[mt][r];
+              cg[mt] = hg[mt][r];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              pv[mt] = mt > 0 ? cv[mt - 1] : dpp_ror1(cv[MT - 1]);
+              pg[mt] = mt > 0 ? cg[mt - 1] : dpp_ror1(cg[MT - 1]);
+              nv[mt] = mt + 1 < MT ? cv[mt + 1] : dpp_rol1(cv[0]);
+              ng[mt] = mt + 1 < MT ? cg[mt + 1] : dpp_rol1(cg[0]);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const float a0v = EDGE ? wv0 * f0[mt] : wv0, a2v = EDGE ? wv2 * f2[mt] : wv2;
@@ -908,7 +927,7 @@ __global__ __launch_bounds__(512, 2) void gcfn_fused4_kernel(const GcfnFusedArgs
     constexpr int Q = F / 4;                 // float4 per row
     constexpr int RPP = NT / Q;              // rows per pass
     constexpr int NP = 64 / RPP;
-    static_assert(64 % RPP == 0, "epilogue pass partition");
+    static_assert(64 % RPP == 0 && (16 * MT * NW) % 64 == 0 && 64 % (16 * MT) == 0, "epilogue pass partition");
     const int q4 = tid % Q, rr = tid / Q;
     const float4 b2 = ld4(a.b2 + 4 * q4), lsv = ld4(a.ls + 4 * q4);
 #pragma unroll 1
@@ -959,6 +978,14 @@ __global__ __launch_bounds__(512, 2) void gcfn_fused4_kernel(const GcfnFusedArgs
 #define SEPR_GF_MT 2    // v1 frame tiles per wave (1 -> 14 frames out of 16, 8 waves; 2 -> 30 of 32, 4 waves)
 #endif
 [[maybe_unused]] constexpr int GF_MT = SEPR_GF_MT, GF_NW = (SEPR_GF_MT == 1) ? 8 : 4;
+#ifndef SEPR_GF3_MT
+#define SEPR_GF3_MT 2   // v3 frame tiles per wave: 2 -> 4 waves x 30 frames (2 waves per SIMD), 1 -> 6 waves x 14 frames (3 per SIMD)
+#endif
+#ifndef SEPR_GF4_MT
+#define SEPR_GF4_MT 2   // v4 frame tiles per wave: 2 -> 8 waves x 30 frames (2 waves per SIMD, 256 registers each),
+#endif                  //                         4 -> 4 waves x 62 frames (1 wave per SIMD, 512 registers)
+[[maybe_unused]] constexpr int GF4_MT = SEPR_GF4_MT, GF4_NW = (SEPR_GF4_MT == 4) ? 4 : 8;
+[[maybe_unused]] constexpr int GF3_MT = SEPR_GF3_MT, GF3_NW = (SEPR_GF3_MT == 1) ? 6 : 4;
 
 int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream) {
   if (a.M <= 0) return SEPR_OK;
@@ -967,26 +994,26 @@ int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t strea
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
 #if SEPR_GF_VERSION == 4
-  constexpr int tile_rows = 8 * 30;
+  constexpr int tile_rows = GF4_NW * (16 * GF4_MT - 2);
   const int ntiles = (a.M + tile_rows - 1) / tile_rows;
   const int cap = persistent_grid() / 2;       // one workgroup per CU
   const int grid = ntiles < cap ? ntiles : cap;
   if (F == 128) {
-    hipLaunchKernelGGL((gcfn_fused4_kernel<128>), dim3(grid), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL((gcfn_fused4_kernel<128, GF4_MT, GF4_NW>), dim3(grid), dim3(64 * GF4_NW), 0, stream, a);
   } else if (F == 64) {
-    hipLaunchKernelGGL((gcfn_fused4_kernel<64>), dim3(grid), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL((gcfn_fused4_kernel<64, GF4_MT, GF4_NW>), dim3(grid), dim3(64 * GF4_NW), 0, stream, a);
   } else {
     return SEPR_EINVAL;
   }
 #elif SEPR_GF_VERSION == 3
-  constexpr int tile_rows = 4 * 30;
+  constexpr int tile_rows = GF3_NW * (16 * GF3_MT - 2);
   const int ntiles = (a.M + tile_rows - 1) / tile_rows;
   const int cap = persistent_grid();
   const int grid = ntiles < cap ? ntiles : cap;
   if (F == 128) {
-    hipLaunchKernelGGL((gcfn_fused3_kernel<128, 4>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gcfn_fused3_kernel<128, GF3_MT, GF3_NW>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
   } else if (F == 64) {
-    hipLaunchKernelGGL((gcfn_fused3_kernel<64, 4>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gcfn_fused3_kernel<64, GF3_MT, GF3_NW>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
   } else {
     return SEPR_EINVAL;
   }
