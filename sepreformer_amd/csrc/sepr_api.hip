@@ -4,6 +4,7 @@
 
 #include "sepr_gemm_epi.h"
 #include "sepr_pointwise.h"
+#include <stdlib.h>
 
 namespace sepr {
 
@@ -223,6 +224,15 @@ extern "C" int sepr_cla_fwd(const float* x, float* y, int n, int T, int F, int K
   return SEPR_OK;
 }
 
+// the bf16x3 attention kernel serves the bf16x3 arithmetic mode (packed q/k/v present); SEPR_ATTN_F32=1 keeps the f32 one
+static int relattn_x3(const sepr_ega_w* w) {
+  static const bool f32 = [] {
+    const char* e = getenv("SEPR_ATTN_F32");
+    return e && e[0] == '1';
+  }();
+  return (w->attn.x3_qkv.wp != nullptr && !f32) ? 1 : 0;
+}
+
 extern "C" int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const sepr_ega_w* w, void* ws,
                             size_t ws_bytes, sepr_stream_t stream) {
   if (!x || !y || !w || x == y || n <= 0 || T <= 0 || Tp <= 0 || F <= 0 || F % 32 != 0 || T % Tp != 0) return SEPR_EINVAL;
@@ -251,7 +261,7 @@ extern "C" int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int 
     a.W = w->attn.wqkv; a.bias = w->attn.bqkv; a.Y = qkv; a.ldc = 3 * F;
     SEPR_TRY(project(PRO_NORM, EPI_STORE, a, w->attn.x3_qkv, SEPR_SITE_ATTN_PROJ, st));
   }
-  SEPR_TRY(launch_relattn(qkv, o, n, Tp, F, H, w->pe_k, w->maxlen, st));   // (network.py:106-122)
+  SEPR_TRY(launch_relattn(qkv, o, n, Tp, F, H, w->pe_k, w->maxlen, relattn_x3(w), st));   // (network.py:106-122)
   {  // linear_out * LayerScale (no residual inside MHA)                    (network.py:124)
     GemmArgs a = gemm_args_zero();
     a.M = (int)Mp; a.N = F; a.K = F;

@@ -155,13 +155,223 @@ __global__ __launch_bounds__(256) void relattn_kernel(const float* __restrict__ 
   }
 }
 
-int launch_relattn(const float* QKV, float* O, int n, int Tp, int F, int H, const float* pe_k, int maxlen, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16x3 form of the same attention for dk = 16 (default arithmetic).  relattn_kernel above is VALU-bound: per 16 keys
+// a lane spends 64 FMAs + 16 LDS reads on the relative-position bias against 8 f32 MFMAs (PMC: 74 % VALU-active,
+// 31 % MFMA-busy).  Here all three products run on the bf16 MFMA with split operands (hi.hi + hi.lo + lo.hi):
+//   * keys are walked 32 at a time; S^T = K q^T is one K=32 MFMA step per 16 keys (dk = 16 fills half of K, the
+//     other half of the fragments is zero);
+//   * the relative-position term is a THIRD product, P^T[b][query] = band[b] . q for the 47 band rows a
+//     (16 queries x 32 keys) block can touch (3 row tiles), skewed through a per-wave LDS scratch:
+//     bias(query, key) = P[query][query - key + 31].  9 cheap MFMAs + 3 LDS writes + 8 LDS reads replace 128 FMAs;
+//   * O^T += V^T P: the 8 probabilities a lane holds (keys 4g+r of both 16-key halves) are exactly one K=32 B fragment
+//     when V^T is read with the matching key-slot order, so PV is 3 MFMAs per 32 keys with no data movement.
+// K, V^T and the band are split into bf16 hi/lo planes once per 64-key tile while they are staged into LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& l) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 hh = (__bf16)x[e];
+    h[e] = hh;
+    l[e] = (__bf16)(x[e] - (float)hh);
+  }
+}
+
+__global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict__ QKV, float* __restrict__ O, int Tp, int F,
+                                                        const float* __restrict__ pe, int maxlen, float inv_sqrt_dk) {
+  constexpr int DK = 16, QB = 64, KT = 64;
+  constexpr int KSB = 24;             // K / band row stride in bf16 (16 used + 8 pad: 48 B)
+  constexpr int VSB = KT + 8;         // V^T row stride in bf16 (144 B)
+  constexpr int NBAND = QB + KT - 1;
+  constexpr int PSK = 52;             // skew scratch row stride in floats (48 used)
+  __shared__ __attribute__((aligned(16))) __bf16 Kh[KT * KSB], Kl[KT * KSB];
+  __shared__ __attribute__((aligned(16))) __bf16 Vh[DK * VSB], Vl[DK * VSB];
+  __shared__ __attribute__((aligned(16))) __bf16 Bh[NBAND * KSB], Bl[NBAND * KSB];
+  __shared__ __attribute__((aligned(16))) float Psk[4 * 16 * PSK];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ii = lane & 15, g = lane >> 4;
+  const int i0 = blockIdx.x * QB, h = blockIdx.y, seq = blockIdx.z;
+  const int ld = 3 * F;
+  const float* base = QKV + (long long)seq * Tp * ld + h * DK;
+  const int i = i0 + 16 * w + ii;
+  const bool active = i < Tp;
+  const bool lowk = g < 2;            // lane groups 2,3 carry the zero half of the K = 32 fragments:
+  const int gk = g & 1;               // they read the (zeroed) 8-element pad at the end of every K / band row
+  const int go = 8 * (g < 2 ? g : 2);
+  for (int r = tid; r < KT; r += 256) {
+#pragma unroll
+    for (int e = 16; e < KSB; ++e) Kh[r * KSB + e] = Kl[r * KSB + e] = (__bf16)0.f;
+  }
+  for (int r = tid; r < NBAND; r += 256) {
+#pragma unroll
+    for (int e = 16; e < KSB; ++e) Bh[r * KSB + e] = Bl[r * KSB + e] = (__bf16)0.f;
+  }
+
+  // B fragments of this lane's query (scaled), shared by the q.k and the q.band products
+  bf16x8 qh, ql;
+  {
+    const float* qp = base + (long long)(active ? i : Tp - 1) * ld + 8 * gk;
+    const float4 a = ld4(qp), b = ld4(qp + 4);
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = lowk ? x[e] * inv_sqrt_dk : 0.f;
+      const __bf16 hh = (__bf16)v;
+      qh[e] = hh;
+      ql[e] = (__bf16)(v - (float)hh);
+    }
+  }
+  f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};       // O^T[d = 4g + r][query ii]
+  float mrun = -1e30f, lrun = 0.f;
+  float* const psk = Psk + (w * 16 + ii) * PSK;
+
+  // staging registers: one K and one V float4 per thread (64 keys x 16 d) and two band float4 (127 rows x 16 d)
+  const int sjj = tid / (DK / 4), sc4 = tid % (DK / 4);
+  float4 rk, rv, rb[2];
+  auto fetch = [&](int j0) {          // global -> registers for the key tile starting at j0
+    const int j = j0 + sjj;
+    rk = zero4();
+    rv = zero4();
+    if (j < Tp) {
+      const float* kp = base + (long long)j * ld + F + 4 * sc4;
+      rk = ld4(kp);
+      rv = ld4(kp + F);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u;
+      const int rr = idx / (DK / 4) < NBAND ? idx / (DK / 4) : NBAND - 1;
+      int rel = i0 - j0 - (KT - 1) + rr;                      // i - j for band row rr
+      rel = rel < -maxlen ? -maxlen : (rel > maxlen - 1 ? maxlen - 1 : rel);
+      rb[u] = ld4(pe + (long long)(rel + maxlen) * DK + 4 * (idx % (DK / 4)));
+    }
+  };
+  fetch(0);
+  for (int j0 = 0; j0 < Tp; j0 += KT) {
+    __syncthreads();   // previous tile fully consumed
+    // ---- registers -> LDS: K rows, V transposed and the band of the position table as bf16 hi / lo planes ----------
+    {
+      bf16x4 hh, ll;
+      split4(rk, hh, ll);
+      *reinterpret_cast<bf16x4*>(Kh + sjj * KSB + 4 * sc4) = hh;
+      *reinterpret_cast<bf16x4*>(Kl + sjj * KSB + 4 * sc4) = ll;
+      split4(rv, hh, ll);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Vh[(4 * sc4 + e) * VSB + sjj] = hh[e];
+        Vl[(4 * sc4 + e) * VSB + sjj] = ll[e];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = tid + 256 * u;
+        if (idx < NBAND * (DK / 4)) {
+          split4(rb[u], hh, ll);
+          *reinterpret_cast<bf16x4*>(Bh + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = hh;
+          *reinterpret_cast<bf16x4*>(Bl + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = ll;
+        }
+      }
+    }
+    __syncthreads();
+    if (j0 + KT < Tp) fetch(j0 + KT);   // the next tile's rows fly under this tile's arithmetic
+
+    const int npair = (Tp - j0 >= KT) ? KT / 32 : (Tp - j0 + 31) / 32;
+    for (int p = 0; p < npair; ++p) {
+      // ---- S^T[key = 16 s + 4g + r][query ii] for the two 16-key halves s ------------------------------------------
+      f32x4 sc[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int row = 32 * p + 16 * s + ii;
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + row * KSB + go);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + row * KSB + go);
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh, a, 0, 0, 0);
+        sc[s] = a;
+      }
+      // ---- relative-position term: P^T[b][query], band row of (query ql, key kl) is bb + b, b = ql - kl + 31 ---------
+      const int bb = 16 * w - 32 * p + 32;
+#pragma unroll
+      for (int tb = 0; tb < 3; ++tb) {
+        const int row = bb + 16 * tb + ii;                    // <= 126 except unused rows of the last tile
+        const int rc = row < NBAND ? row : NBAND - 1;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bh + rc * KSB + go);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + rc * KSB + go);
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, qh, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ql, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, qh, a, 0, 0, 0);
+        st4(psk + 16 * tb + 4 * g, make_float4(a[0], a[1], a[2], a[3]));   // rows b = 16 tb + 4g + r of this query
+      }
+      float sv[2][4];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int b0 = ii + 31 - 16 * s - 4 * g;              // b of key 16 s + 4g + 0; r steps down
+        const int jbase = j0 + 32 * p + 16 * s + 4 * g;
+        float bias[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[r] = psk[b0 - r];       // unconditional: the reads issue back to back
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[s][r] = (jbase + r < Tp) ? sc[s][r] + bias[r] : -1e30f;
+      }
+      float mx = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
+                       fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun, mx);
+      const float corr = __expf(mrun - mnew);
+      bf16x8 ph, pl;
+      float psum = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __expf(sv[s][r] - mnew);
+          psum += pv;
+          const __bf16 hh = (__bf16)pv;
+          ph[4 * s + r] = hh;
+          pl[4 * s + r] = (__bf16)(pv - (float)hh);
+        }
+      lrun = lrun * corr + psum;
+      mrun = mnew;
+      // ---- O^T[d][query] += V^T[d][key slots] . P[key slots][query]; slot e -> key 16 (e / 4) + 4g + e % 4 --------
+      o[0] *= corr; o[1] *= corr; o[2] *= corr; o[3] *= corr;
+      {
+        const __bf16* vh0 = Vh + ii * VSB + 32 * p + 4 * g;
+        const __bf16* vl0 = Vl + ii * VSB + 32 * p + 4 * g;
+        const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(vh0), a1 = *reinterpret_cast<const bf16x4*>(vh0 + 16);
+        const bf16x4 b0v = *reinterpret_cast<const bf16x4*>(vl0), b1v = *reinterpret_cast<const bf16x4*>(vl0 + 16);
+        const bf16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const bf16x8 vl = {b0v[0], b0v[1], b0v[2], b0v[3], b1v[0], b1v[1], b1v[2], b1v[3]};
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o, 0, 0, 0);
+      }
+    }
+  }
+  float ltot = lrun + __shfl_xor(lrun, 16, 64);
+  ltot += __shfl_xor(ltot, 32, 64);
+  if (active) {
+    const float inv = 1.0f / ltot;
+    st4(O + ((long long)seq * Tp + i) * F + h * DK + 4 * g, make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv));
+  }
+}
+
+int launch_relattn(const float* QKV, float* O, int n, int Tp, int F, int H, const float* pe_k, int maxlen, int x3,
+                   hipStream_t s) {
   if (n <= 0 || Tp <= 0) return SEPR_OK;
   if (H <= 0 || F % H != 0 || maxlen <= 0 || !pe_k || n > 65535) return SEPR_EINVAL;
   const int dk = F / H;
   const dim3 grid((Tp + 63) / 64, H, n);
   const float isd = 1.0f / sqrtf((float)dk);
-  if (dk == 16) {
+  if (dk == 16 && x3) {
+    hipLaunchKernelGGL(relattn_x3_kernel, grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd);
+  } else if (dk == 16) {
     hipLaunchKernelGGL((relattn_kernel<16>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd);
   } else if (dk == 32) {
     hipLaunchKernelGGL((relattn_kernel<32>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd);

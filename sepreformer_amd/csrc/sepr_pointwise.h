@@ -40,7 +40,7 @@ int launch_decoder(const float* O2, int nS, int S, int L, int N, int K, int stri
                    float* wav, int Tout, hipStream_t s);
 
 // EGA attention with relative-position bias.  QKV [n,Tp,3F] -> O [n,Tp,F]
-int launch_relattn(const float* QKV, float* O, int n, int Tp, int F, int H, const float* pe_k, int maxlen,
+int launch_relattn(const float* QKV, float* O, int n, int Tp, int F, int H, const float* pe_k, int maxlen, int x3,
                    hipStream_t s);
 
 }  // namespace sepr
