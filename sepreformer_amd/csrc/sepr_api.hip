@@ -393,30 +393,28 @@ extern "C" int sepr_outlayer_decoder_fwd(const float* x, int nS, int S, int Tsrc
   float* o1 = ar.f32(2LL * F * M);
   float* o2 = ar.f32((long long)N * M);
   if (!ar.ok()) return SEPR_EWORKSPACE;
-  {  // crop / upsample-gather rows, Linear F->4F, GLU                      (module.py:250-252, model.py:49)
+  // Both projections are per-frame maps, so for an upsampled head (idx != NULL) they run on the Tsrc source frames of
+  // every sequence, not on the L repeated ones; the decoder kernel applies idx, the ReLU mask and the encoder product
+  // while it reads the rows.  Without idx the row map is the crop of module.py:250.
+  const bool unique = idx != nullptr && Tsrc <= L;   // (a down-sampling map keeps the gather in the first projection)
+  const long long Mp = unique ? (long long)nS * Tsrc : M;
+  {  // Linear F->4F, GLU                                                   (module.py:250-252, model.py:49)
     GemmArgs a = gemm_args_zero();
-    a.M = (int)M; a.N = 4 * F; a.K = F;
-    a.A = x; a.lda = F; a.rows_out = L; a.rows_src = Tsrc; a.rows_valid = L; a.idx = idx;
+    a.M = (int)Mp; a.N = 4 * F; a.K = F;
+    a.A = x; a.lda = F;
+    if (!unique) { a.rows_out = L; a.rows_src = Tsrc; a.rows_valid = L; a.idx = idx; }
     a.W = w->w1; a.bias = w->b1; a.Y = o1; a.ldc = 2 * F;
     SEPR_TRY(project(PRO_PLAIN, EPI_GLU, a, w->x3_1, SEPR_SITE_OUT, st));
   }
-  {  // Linear 2F->N (+ ReLU(.) * encoder_output for the auxiliary heads)   (module.py:252-260, network.py:41)
+  {  // Linear 2F->N                                                        (module.py:252-256)
     GemmArgs a = gemm_args_zero();
-    a.M = (int)M; a.N = N; a.K = 2 * F;
+    a.M = (int)Mp; a.N = N; a.K = 2 * F;
     a.A = o1; a.lda = 2 * F; a.W = w->w2; a.bias = w->b2; a.Y = o2; a.ldc = N;
-    a.rows_out = 0;
-    if (enc) {
-      a.aux = enc; a.S = S;
-      // EPI_MASK reads rows_out as the per-sequence frame count; keep the A-side map an identity
-      GemmArgs m = a;
-      m.rows_out = L; m.rows_src = L; m.rows_valid = L;
-      SEPR_TRY(project(PRO_PLAIN, EPI_MASK, m, w->x3_2, SEPR_SITE_OUT, st));
-    } else {
-      SEPR_TRY(project(PRO_PLAIN, EPI_STORE, a, w->x3_2, SEPR_SITE_OUT, st));
-    }
+    SEPR_TRY(project(PRO_PLAIN, EPI_STORE, a, w->x3_2, SEPR_SITE_OUT, st));
   }
+  // ReLU(.) * encoder_output for the auxiliary heads (module.py:257-260, network.py:41) + ConvTranspose1d (:278-283)
   const int Tout = (L - 1) * stride + K;
-  SEPR_TRY(launch_decoder(o2, nS, S, L, N, K, stride, w->wdec, wav, Tout, st));   // (module.py:278-283)
+  SEPR_TRY(launch_decoder(o2, nS, S, L, N, K, stride, w->wdec, wav, Tout, unique ? idx : nullptr, Tsrc, enc, st));
   return SEPR_OK;
 }
 

@@ -36,8 +36,8 @@ int launch_encoder(const float* wav, int B, int T, int L, const float* w, int N,
                    float* E, double* part, hipStream_t s);
 
 // decoder: ConvTranspose1d(N->1,K,stride) of O2 [nS,L,N] -> wav [S,B,Tout] (overlap-add in LDS)
-int launch_decoder(const float* O2, int nS, int S, int L, int N, int K, int stride, const float* wdec,
-                   float* wav, int Tout, hipStream_t s);
+int launch_decoder(const float* O2, int nS, int S, int L, int N, int K, int stride, const float* wdec, float* wav,
+                   int Tout, const int* idx, int Tsrc, const float* enc, hipStream_t s);
 
 // EGA attention with relative-position bias.  QKV [n,Tp,3F] -> O [n,Tp,F]
 int launch_relattn(const float* QKV, float* O, int n, int Tp, int F, int H, const float* pe_k, int maxlen, int x3,

@@ -732,9 +732,14 @@ int launch_encoder(const float* wav, int B, int T, int L, const float* w, int N,
 // ---------------------------------------------------------------------------------------------------
 constexpr int DEC_ROWS = 64, DEC_HB = 3, DEC_FT = DEC_ROWS - DEC_HB;
 
+// Auxiliary heads (model.py:47-52): the stage output is nearest-upsampled to L frames BEFORE the per-frame
+// OutputLayer, i.e. every source frame is pushed through both projections 2-16 times.  The projections are per-row
+// maps, so they run once per SOURCE frame; the upsampling (idx), the ReLU mask and the product with the encoder
+// frame (network.py:41) happen here, where the rows are read: x = max(O2[seq, idx[l]], 0) * enc[b, l].
 template <int K>
 __global__ __launch_bounds__(TPB) void decoder_kernel(const float* __restrict__ O2, int S, int B, int L, int N, int stride,
-                                                     const float* __restrict__ wdec, float* __restrict__ wav, int Tout) {
+                                                     const float* __restrict__ wdec, float* __restrict__ wav, int Tout,
+                                                     const int* __restrict__ idx, int Tsrc, const float* __restrict__ enc) {
   static_assert(K == 16, "one 16-tap MFMA tile");
   __shared__ __attribute__((aligned(16))) float Ds[DEC_ROWS * K];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -744,13 +749,20 @@ __global__ __launch_bounds__(TPB) void decoder_kernel(const float* __restrict__ 
   // tile row r <-> frame l0 - hb + r; this lane's frame
   const int l = l0 - hb + 16 * w + fi;
   const bool valid = (l >= 0 && l < L);
-  const float* xrow = O2 + ((long long)seq * L + (valid ? l : 0)) * N + 4 * fg;
+  const int lc = valid ? l : 0;
+  const int src = idx ? idx[lc] : lc;
+  const float* xrow = O2 + ((long long)seq * (idx ? Tsrc : L) + src) * N + 4 * fg;
+  const float* erow = enc ? enc + ((long long)(seq / S) * L + lc) * N + 4 * fg : nullptr;
   const float* wrow = wdec + (long long)fi * N + 4 * fg;     // tap fi
   f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int steps = N / 16;
   for (int cc = 0; cc < steps; ++cc) {
     float4 x = ld4(xrow + 16 * cc);
     const float4 wv = ld4(wrow + 16 * cc);
+    if (erow) {
+      const float4 e = ld4(erow + 16 * cc);
+      x = make_float4(fmaxf(x.x, 0.f) * e.x, fmaxf(x.y, 0.f) * e.y, fmaxf(x.z, 0.f) * e.z, fmaxf(x.w, 0.f) * e.w);
+    }
     if (!valid) x = zero4();
     d = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, x.x, d, 0, 0, 0);
     d = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, x.y, d, 0, 0, 0);
@@ -776,13 +788,14 @@ __global__ __launch_bounds__(TPB) void decoder_kernel(const float* __restrict__ 
 }
 
 int launch_decoder(const float* O2, int nS, int S, int L, int N, int K, int stride, const float* wdec, float* wav,
-                   int Tout, hipStream_t s) {
+                   int Tout, const int* idx, int Tsrc, const float* enc, hipStream_t s) {
   if (nS <= 0 || L <= 0) return SEPR_EINVAL;
   if (K != 16 || stride < 4 || stride > 16 || N > 4096 || N % 16 != 0 || S <= 0 || nS % S != 0) return SEPR_EINVAL;
   if ((K - 1) / stride > DEC_HB) return SEPR_EINVAL;
   const int hb = (K - 1) / stride;
   const int tiles = (L + hb + DEC_FT - 1) / DEC_FT;
-  hipLaunchKernelGGL((decoder_kernel<16>), dim3(tiles, nS), dim3(TPB), 0, s, O2, S, nS / S, L, N, stride, wdec, wav, Tout);
+  hipLaunchKernelGGL((decoder_kernel<16>), dim3(tiles, nS), dim3(TPB), 0, s, O2, S, nS / S, L, N, stride, wdec, wav, Tout,
+                     idx, Tsrc, enc);
   SEPR_CHECK_LAUNCH("decoder_kernel");
   return SEPR_OK;
 }
