@@ -8,6 +8,8 @@ current-stream handle only.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, List, Optional, Tuple
 
@@ -44,6 +46,12 @@ class SeparatorEngine:
         self._ws: Optional[torch.Tensor] = None
         self._idx_cache: Dict[Tuple[int, int], torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
+        # the speaker splits of the skip connections and the auxiliary heads depend on nothing downstream of their
+        # input, so they are enqueued on a side stream and fill the CUs that the small launches of the deeper
+        # stages leave idle (SEPR_OVERLAP=0: everything on one stream)
+        self.overlap = os.environ.get("SEPR_OVERLAP", "1") != "0"
+        self._side: Optional[torch.cuda.Stream] = None
+        self._ws2: Optional[torch.Tensor] = None
 
     # ---- plumbing ---------------------------------------------------------------------------------
     def _stream(self) -> int:
@@ -73,6 +81,15 @@ class SeparatorEngine:
         ``forward`` calls this itself; tests call it before driving single blocks."""
         self._st = self._stream()
         self._wsargs = self._workspace(self.workspace_bytes(B, L_, Lp))
+        self._side_on = self.overlap and not torch.cuda.is_current_stream_capturing()
+        if self._side_on:
+            c, lib = self.cfg, self.lib
+            need = max(lib.sepr_workspace_bytes(L.OP_SPKSPLIT, B, Lp, 0, c.feat, c.enc_channels, c.num_spks),
+                       lib.sepr_workspace_bytes(L.OP_OUTLAYER, B * c.num_spks, L_, 0, c.feat, c.enc_channels, c.num_spks))
+            if self._ws2 is None or self._ws2.numel() < need:
+                self._ws2 = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
 
     def _new(self, *shape) -> torch.Tensor:
         return torch.empty(shape, dtype=torch.float32, device=self.device)
@@ -119,10 +136,28 @@ class SeparatorEngine:
         L.check(self.lib.sepr_downconv_fwd(x.data_ptr(), y.data_ptr(), n, T, self.cfg.feat, K, C.byref(w), self._st), "sepr_downconv_fwd")
         return y, To
 
-    def spksplit(self, x, w, B, T):
+    def _aside(self, fn, *inputs):
+        """Run ``fn(wsargs, stream_handle)`` on the side stream once ``inputs`` (produced on the main stream) are ready."""
+        if not self._side_on:
+            return fn(self._wsargs, self._st)
+        main = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            out = fn((self._ws2.data_ptr(), self._ws2.numel()), self._side.cuda_stream)
+        for t in inputs:
+            t.record_stream(self._side)          # freed on the main stream while the side stream may still read it
+        out.record_stream(main)                   # consumed (and freed) on the main stream after join()
+        return out
+
+    def _join(self):
+        if self._side_on:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+
+    def spksplit(self, x, w, B, T, wsargs=None, st=None):
         S = self.cfg.num_spks
         y = self._new(B * S, T, self.cfg.feat)
-        L.check(self.lib.sepr_spksplit_fwd(x.data_ptr(), y.data_ptr(), B, S, T, self.cfg.feat, GN_EPS, C.byref(w), *self._wsargs, self._st), "sepr_spksplit_fwd")
+        L.check(self.lib.sepr_spksplit_fwd(x.data_ptr(), y.data_ptr(), B, S, T, self.cfg.feat, GN_EPS, C.byref(w),
+                                           *(wsargs or self._wsargs), st or self._st), "sepr_spksplit_fwd")
         return y
 
     def fuse(self, lo, skip, wb, n, T):
@@ -130,14 +165,14 @@ class SeparatorEngine:
         L.check(self.lib.sepr_fuse_fwd(lo.data_ptr(), skip.data_ptr(), y.data_ptr(), n, T, self.cfg.feat, C.byref(wb), self._st), "sepr_fuse_fwd")
         return y
 
-    def head(self, x, w, nS, Tsrc, L_, idx, enc, B):
+    def head(self, x, w, nS, Tsrc, L_, idx, enc, B, wsargs=None, st=None):
         c = self.cfg
         Tout = (L_ - 1) * c.enc_stride + c.enc_kernel
         wav = self._new(c.num_spks, B, Tout)
         L.check(self.lib.sepr_outlayer_decoder_fwd(
             x.data_ptr(), nS, c.num_spks, Tsrc, L_, None if idx is None else idx.data_ptr(),
             None if enc is None else enc.data_ptr(), c.feat, c.enc_channels, c.enc_kernel, c.enc_stride,
-            C.byref(w), wav.data_ptr(), *self._wsargs, self._st), "sepr_outlayer_decoder_fwd")
+            C.byref(w), wav.data_ptr(), *(wsargs or self._wsargs), st or self._st), "sepr_outlayer_decoder_fwd")
         return wav
 
     # ---- latency mode: the whole forward as one hipGraph ----------------------------------------------
@@ -207,7 +242,7 @@ class SeparatorEngine:
                 cur = self.local_block(cur, st["l"][j], B, Tc)
             if taps is not None:
                 taps[f"enc{i}.skip_pre_split"] = cur
-            skips.append((self.spksplit(cur, pk.splits[i], B, Tc), Tc))
+            skips.append((self._aside(lambda ws, sh, x_=cur, i_=i, T_=Tc: self.spksplit(x_, pk.splits[i_], B, T_, ws, sh), cur), Tc))
             cur, Tc = self.downconv(cur, st["down"], B, Tc)
         if Tc != Tp:
             raise RuntimeError(f"internal: bottleneck length {Tc} != pooled length {Tp}")
@@ -217,12 +252,14 @@ class SeparatorEngine:
         if taps is not None:
             taps["bottleneck"] = cur
         cur = self.spksplit(cur, pk.splits[R], B, Tc)
+        self._join()                                                  # the skip splits
 
         # temporal expanding part                                     (module.py:207-215)
         nS = B * S
-        stage_outs: List[Tuple[torch.Tensor, int]] = []
+        aux: List[torch.Tensor] = []
         for i in range(R):
-            stage_outs.append((cur, Tc))
+            if with_aux:                                              # auxiliary head of this stage's input (model.py:47-52)
+                aux.append(self._aside(lambda ws, sh, x_=cur, i_=i, T_=Tc: self.head(x_, pk.out_aux[i_], nS, T_, L_, self._idx(T_, L_), enc, B, ws, sh), cur, enc))
             skip, Ts = skips[R - 1 - i]
             if Ts != 2 * Tc:
                 raise RuntimeError(f"internal: skip length {Ts} != 2 x {Tc}")
@@ -240,8 +277,5 @@ class SeparatorEngine:
 
         # output layer + decoder, main and auxiliary heads            (model.py:42-52)
         wav = self.head(cur, pk.out_main, nS, Tc, L_, None, None, B)
-        aux = []
-        if with_aux:
-            for i, (so, Ti) in enumerate(stage_outs):
-                aux.append(self.head(so, pk.out_aux[i], nS, Ti, L_, self._idx(Ti, L_), enc, B))
+        self._join()                                                  # the auxiliary heads
         return wav, aux
