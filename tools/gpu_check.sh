@@ -12,12 +12,15 @@ lscpu | grep -E "Model name|Socket|Core|Thread|^CPU\(s\)" >> $OUT/device.txt
 echo "== smoke" | tee $OUT/summary.txt
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/summary.txt
 tail -3 $OUT/smoke.log | tee -a $OUT/summary.txt
-for grp in test_linear_core test_blocks "test_e2e_golden or test_e2e_pit or test_intermediate" "test_ragged or test_no_padding or test_error or test_weights or test_groupnorm" test_full_size; do
+for grp in test_linear_core test_blocks "test_e2e_golden or test_e2e_pit or test_intermediate" "test_ragged or test_no_padding or test_error or test_weights or test_groupnorm or test_graph" test_full_size; do
   name=$(echo "$grp" | tr ' ' '_' | cut -c1-40)
   timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "$grp" -p no:cacheprovider > "$OUT/pytest_$name.log" 2>&1
   echo "pytest [$grp] rc=$?" | tee -a $OUT/summary.txt
   tail -15 "$OUT/pytest_$name.log" | grep -E "passed|failed|error|Error|dB" | tail -8 | tee -a $OUT/summary.txt
 done
+timeout 600 python -m pytest tests/test_criterion.py tests/test_infer.py -m gpu -q -p no:cacheprovider > "$OUT/pytest_criterion_infer.log" 2>&1
+echo "pytest [criterion + infer] rc=$?" | tee -a $OUT/summary.txt
+tail -3 "$OUT/pytest_criterion_infer.log" | grep -E "passed|failed|error" | tee -a $OUT/summary.txt
 echo "== bench" | tee -a $OUT/summary.txt
 timeout 600 python bench.py --steps $STEPS --warmup 2 > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
 cat $OUT/bench.log | tee -a $OUT/summary.txt
