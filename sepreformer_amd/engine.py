@@ -52,6 +52,7 @@ class SeparatorEngine:
         self.overlap = os.environ.get("SEPR_OVERLAP", "1") != "0"
         self._side: Optional[torch.cuda.Stream] = None
         self._ws2: Optional[torch.Tensor] = None
+        self._held: list = []
 
     # ---- plumbing ---------------------------------------------------------------------------------
     def _stream(self) -> int:
@@ -137,21 +138,26 @@ class SeparatorEngine:
         return y, To
 
     def _aside(self, fn, *inputs):
-        """Run ``fn(wsargs, stream_handle)`` on the side stream once ``inputs`` (produced on the main stream) are ready."""
+        """Run ``fn(wsargs, stream_handle)`` on the side stream once ``inputs`` (produced on the main stream) are ready.
+
+        Lifetime rules instead of ``record_stream`` (which defers every free and made the allocator's reserved pool
+        grow by gigabytes per step): the inputs are kept referenced until ``_join`` (the main stream then waits for
+        the side stream, so freeing them afterwards is ordered), and the outputs live in the side stream's pool,
+        whose next allocation can only happen after the next ``wait_stream(main)`` below, i.e. after every main-stream
+        consumer of the previous forward has been enqueued ahead of it."""
         if not self._side_on:
             return fn(self._wsargs, self._st)
         main = torch.cuda.current_stream(self.device)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             out = fn((self._ws2.data_ptr(), self._ws2.numel()), self._side.cuda_stream)
-        for t in inputs:
-            t.record_stream(self._side)          # freed on the main stream while the side stream may still read it
-        out.record_stream(main)                   # consumed (and freed) on the main stream after join()
+        self._held.extend(inputs)
         return out
 
     def _join(self):
         if self._side_on:
             torch.cuda.current_stream(self.device).wait_stream(self._side)
+            self._held.clear()
 
     def spksplit(self, x, w, B, T, wsargs=None, st=None):
         S = self.cfg.num_spks
