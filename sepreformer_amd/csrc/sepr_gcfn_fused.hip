@@ -348,6 +348,9 @@ struct bool_c { static constexpr bool value = V; };
 #ifndef SEPR_GF3_UPFIRST
 #define SEPR_GF3_UPFIRST 1   // 1: both up-projections before both convolutions (the next chunk copy gets one more conv to land; ~1 %)
 #endif
+#ifndef SEPR_GF3_PRIO
+#define SEPR_GF3_PRIO 0
+#endif
 template <int F, int MT, int NW>
 __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
   static_assert(MT == 1 || MT == 2, "frame tiles per wave");
@@ -507,7 +510,8 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
               hg[mt] = (f32x4){bg.x, bg.y, bg.z, bg.w};
             }
           }
-#pragma unroll
+          if (SEPR_GF3_PRIO) __builtin_amdgcn_s_setprio(1);   // MFMA phases win the issue arbitration over the
+#pragma unroll                                                 // other workgroup's VALU phases
           for (int g = 0; g < 2 * KS; ++g) {
             if (g + RD < 2 * KS) ld_up(j, g + RD, fb[(g + RD) % (RD + 1)]);
             __builtin_amdgcn_sched_barrier(0);
@@ -531,6 +535,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
             }
             __builtin_amdgcn_sched_barrier(0);
           }
+          if (SEPR_GF3_PRIO) __builtin_amdgcn_s_setprio(0);
           if (j == 0) {                            // the second tile pair's first fragments arrive under the conv
 #pragma unroll
             for (int g = 0; g < RD; ++g) ld_up(1, g, fb[g]);
@@ -584,6 +589,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
             }
         }
         // ---- down-projection K step of this chunk -----------------------------------------------------------
+        if (SEPR_GF3_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ft = 0; ft < FT; ++ft) {
           if (ft + RD < FT) ld_dn(ft + RD, fb[(ft + RD) % (RD + 1)]);
@@ -598,6 +604,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
           for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[mt], acc[ft][mt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (SEPR_GF3_PRIO) __builtin_amdgcn_s_setprio(0);
         dma_barrier();                             // down-projection fragments consumed; chunk c+1's up-projection
         if (c + 1 < NCH && !(SEPR_GF_ABL & 2)) dma_w2(c + 1);            // fragments have landed
       }
