@@ -87,7 +87,7 @@ using namespace sepr;
 
 extern "C" int sepr_version(void) { return SEPR_VERSION; }
 extern "C" const char* sepr_build_info(void) {
-  return "libsepr_hip gfx950 f32-mfma(16x16x4) tile128x128x32 " __DATE__ " " __TIME__;
+  return "libsepr_hip gfx950 bf16x3+f32 MFMA, fused GCFN/CLA/SpkAttn/EGA-gate " __DATE__ " " __TIME__;
 }
 extern "C" const char* sepr_last_hip_error(void) { return g_err; }
 

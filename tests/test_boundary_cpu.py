@@ -281,3 +281,116 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+# ---- packed layouts of the other fused kernels: decode them and redo the block in fp64 -----------------------------------------
+def _unfrag(fr):
+    """``[R][KS][2][64][8]`` bf16 fragments -> fp64 ``[R*16, KS*32]`` (hi + lo), the inverse of pack._split_frag."""
+    R, KS = fr.shape[0], fr.shape[1]
+    w = (fr[:, :, 0].double() + fr[:, :, 1].double()).view(R, KS, 4, 16, 8)      # [t, ks, g, i, e]
+    return w.permute(0, 3, 1, 2, 4).reshape(R * 16, KS * 32)
+
+
+def _unkslot(w2p):
+    """``[C][FT][2][64][8]`` k-slot-ordered fragments -> fp64 ``[FT*16, C*32]``."""
+    C, FT = w2p.shape[0], w2p.shape[1]
+    w = (w2p[:, :, 0].double() + w2p[:, :, 1].double()).view(C, FT, 4, 16, 8)    # [c, ft, g, i, e]
+    out = torch.zeros(FT * 16, C * 32, dtype=torch.float64)
+    for g in range(4):
+        for e in range(8):
+            n = 4 * g + e if e < 4 else 16 + 4 * g + e - 4
+            out[:, n::32] = w[:, :, g, :, e].permute(1, 2, 0).reshape(FT * 16, C)
+    return out
+
+
+def _chunks(wp, ntile, KS):
+    """byte tensor ``[nch, frag + 4096]`` -> (fragments ``[nch, ntile, KS, 2, 64, 8]`` bf16, constants ``[nch, 1024]`` fp32)."""
+    nfrag = ntile * KS * 2 * 64 * 8 * 2
+    assert wp.dtype == torch.uint8 and wp.shape[1] == nfrag + 4096
+    fr = wp[:, :nfrag].contiguous().view(torch.bfloat16).view(wp.shape[0], ntile, KS, 2, 64, 8)
+    return fr, wp[:, nfrag:].contiguous().view(torch.float32).view(wp.shape[0], 1024)
+
+
+@pytest.fixture(scope="module")
+def base_sd():
+    cfg = VARIANTS["SepReformer_Base_WSJ0"]
+    return cfg, synth_state_dict(cfg, 0)
+
+
+def _ln0(x):
+    return (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+
+
+def test_pack_cla_fused_layout(base_sd):
+    from sepreformer_amd.pack import pack_cla_fused, BN_EPS
+    cfg, sd = base_sd
+    p, F = "separator.enc_stages.0.l_block_1.block.cla", cfg.feat
+    s = sd[p + ".BN.weight"].double() / torch.sqrt(sd[p + ".BN.running_var"].double() + BN_EPS)
+    w2 = (sd[p + ".linear2.weight"].double() * s[:, None]).float()
+    b2 = ((sd[p + ".linear2.bias"].double() - sd[p + ".BN.running_mean"].double()) * s + sd[p + ".BN.bias"].double()).float()
+    w1p, w2p, w3p = pack_cla_fused(sd[p + ".linear1.weight"], sd[p + ".linear1.bias"], sd[p + ".layer_norm.weight"],
+                                   sd[p + ".layer_norm.bias"], w2, b2, sd[p + ".linear3.1.weight"])
+    KS = F // 32
+    f1, c1 = _chunks(w1p, 4, KS)
+    f2, c2 = _chunks(w2p, 4, KS)
+    assert f1.shape[0] == F // 32 and f2.shape[0] == 2 * F // 64 and tuple(w3p.shape) == (2 * F // 32, F // 16, 2, 64, 8)
+    W1, B1 = torch.zeros(2 * F, F, dtype=torch.float64), torch.zeros(2 * F, dtype=torch.float64)
+    for c in range(F // 32):
+        rows = _unfrag(f1[c])                                               # tiles v0 v1 g0 g1
+        for t, base in enumerate([32 * c, 32 * c + 16, F + 32 * c, F + 32 * c + 16]):
+            W1[base:base + 16], B1[base:base + 16] = rows[16 * t:16 * t + 16], c1[c, 16 * t:16 * t + 16].double()
+    W2, B2 = torch.zeros(2 * F, F, dtype=torch.float64), torch.zeros(2 * F, dtype=torch.float64)
+    for c in range(2 * F // 64):
+        W2[64 * c:64 * c + 64], B2[64 * c:64 * c + 64] = _unfrag(f2[c]), c2[c, :64].double()
+    W3 = _unkslot(w3p)
+    x = torch.randn(2, 150, F, dtype=torch.float64)
+    u = _ln0(x) @ W1.t() + B1
+    u = u[..., :F] * torch.sigmoid(u[..., F:])
+    cconv = torch.nn.functional.conv1d(u.permute(0, 2, 1), sd[p + ".dw_conv_1d.weight"].double(), sd[p + ".dw_conv_1d.bias"].double(),
+                                       padding=32, groups=F).permute(0, 2, 1)
+    h = torch.nn.functional.gelu(cconv @ W2.t() + B2)
+    y = x + (h @ W3.t() + sd[p + ".linear3.1.bias"].double()) * sd[p + ".Layer_scale.layer_scale"].double()
+    assert orc.agreement_db(y.float(), orc.cla(sd, p, x.float())) > 95
+
+
+def test_pack_spk_fused_layout(base_sd):
+    from sepreformer_amd.pack import pack_spk_fused
+    cfg, sd = base_sd
+    p, F, H = "separator.dec_stages.0.spk_attn_1.self_attn", cfg.feat, cfg.heads
+    wqkv = torch.cat([sd[f"{p}.linear_{n}.weight"] for n in "qkv"], 0)
+    bqkv = torch.cat([sd[f"{p}.linear_{n}.bias"] for n in "qkv"], 0)
+    w1p, w2p = pack_spk_fused(wqkv, bqkv, sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"], sd[p + ".linear_out.weight"])
+    KS = F // 32
+    f1, c1 = _chunks(w1p, 6, KS)
+    assert f1.shape[0] == F // 32 and tuple(w2p.shape) == (F // 32, F // 16, 2, 64, 8)
+    W, Bq = torch.zeros(3 * F, F, dtype=torch.float64), torch.zeros(3 * F, dtype=torch.float64)
+    for c in range(F // 32):
+        rows = _unfrag(f1[c])                                               # tiles q(2c) q(2c+1) k(2c) k(2c+1) v(2c) v(2c+1)
+        for t in range(6):
+            base = (t // 2) * F + 16 * (2 * c + (t & 1))
+            W[base:base + 16], Bq[base:base + 16] = rows[16 * t:16 * t + 16], c1[c, 16 * t:16 * t + 16].double()
+    Wo = _unkslot(w2p)
+    x = torch.randn(5, 2, F, dtype=torch.float64)                           # [frames, speakers, F]
+    qkv = _ln0(x) @ W.t() + Bq
+    q, k, v = (t_.view(5, 2, H, F // H).permute(0, 2, 1, 3) for t_ in qkv.split(F, -1))       # [n, H, S, dk]
+    att = torch.softmax(q @ k.transpose(-1, -2) / (F // H) ** 0.5, -1) @ v
+    o = att.permute(0, 2, 1, 3).reshape(5, 2, F)
+    y = x + (o @ Wo.t() + sd[p + ".linear_out.bias"].double()) * sd[p + ".Layer_scale.layer_scale"].double()
+    want = x.float() + orc.mha(sd, p, x.float(), None, H)
+    assert orc.agreement_db(y.float(), want) > 95
+
+
+def test_pack_gate_fused_layout(base_sd):
+    from sepreformer_amd.pack import pack_gate_fused
+    cfg, sd = base_sd
+    p, F = "separator.enc_stages.0.g_block_1.block.ega", cfg.feat
+    wp = pack_gate_fused(sd[p + ".block.linear.1.weight"], sd[p + ".block.linear.1.bias"], sd[p + ".block.linear.0.weight"],
+                         sd[p + ".block.linear.0.bias"])
+    fr, cst = _chunks(wp, 4, F // 32)
+    W = torch.cat([_unfrag(fr[c]) for c in range(F // 64)], 0)
+    b = torch.cat([cst[c, :64].double() for c in range(F // 64)], 0)
+    x = torch.randn(3, 40, F, dtype=torch.float64)
+    got = _ln0(x) @ W.t() + b
+    ln = torch.nn.functional.layer_norm(x, (F,), sd[p + ".block.linear.0.weight"].double(), sd[p + ".block.linear.0.bias"].double(), 1e-5)
+    want = ln @ sd[p + ".block.linear.1.weight"].double().t() + sd[p + ".block.linear.1.bias"].double()
+    assert orc.agreement_db(got.float(), want.float()) > 95
