@@ -50,281 +50,9 @@ __device__ __forceinline__ float dpp_rol1(float v) {   // lane i <- lane (i+1) m
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x12f, 0xf, 0xf, false));
 }
 
-template <int F, int MT, int NW>
-__global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused_kernel(const GcfnFusedArgs a) {
-  constexpr int NT = 64 * NW;            // threads
-  constexpr int GF_ROWS_OUT = 16 * MT - 2;
-  constexpr int GF_TILE = NW * GF_ROWS_OUT;
-  constexpr int EH = (16 * MT * NW) / 64; // epilogue passes of 64 frames through LDS
-  constexpr int KS = F / 32;             // K steps of the up-projection
-  constexpr int NCH = 3 * F / 32;        // hidden chunks (32 value + 32 gate channels each)
-  constexpr int FT = F / 16;             // 16-channel output tiles of the down-projection
-  constexpr int W1F_U4 = 4 * KS * 2 * 64; // uint4 of up-projection fragments per chunk
-  constexpr int CS_U4 = 256;              // + 4 KB of per-channel constants (bias, conv taps) of the chunk
-  constexpr int W1_U4 = W1F_U4 + CS_U4;   // uint4 per chunk of w1p
-  constexpr int W2_U4 = FT * 2 * 64;      // uint4 per chunk of w2p
-  constexpr int OS = F + 4;              // epilogue staging row stride (floats)
-  // LDS: up-projection fragments | down-projection fragments | two constants blocks (chunk parity: the block
-  // of chunk c+1 is copied while the conv of chunk c still reads its own)
-  __shared__ __attribute__((aligned(16))) uint4 wl[W1F_U4 + W2_U4 + 2 * CS_U4];
-  static_assert(sizeof(uint4) * (W1F_U4 + W2_U4) >= sizeof(float) * 64 * OS, "epilogue staging must fit");
-  static_assert(W1F_U4 % NT == 0 && CS_U4 % NT == 0 && W2_U4 % NT == 0 && W1F_U4 / NT <= 16 && (16 * MT * NW) % 64 == 0, "copy / epilogue partition");
-  const uint4* const w1s = wl;
-  const uint4* const w2s = wl + W1F_U4;
-  uint4* const csl = wl + W1F_U4 + W2_U4;
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int fi = lane & 15, fg = lane >> 4;
-  const int ntiles = (a.M + GF_TILE - 1) / GF_TILE;
-  const uint4* const W1g = static_cast<const uint4*>(a.w1p);
-  const uint4* const W2g = static_cast<const uint4*>(a.w2p);
-
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // ---- this wave's 32 frames: load, LayerNorm statistics, split -------------------------------------
-    const int mw0 = tile * GF_TILE + w * GF_ROWS_OUT - 1;       // wave row 0 (halo)
-    bf16x8 xh[MT][KS], xl[MT][KS];
-    int trow[MT];                                                // frame index inside its sequence
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = mw0 + 16 * mt + fi;
-      const bool valid = (m >= 0 && m < a.M);
-      trow[mt] = valid ? m % a.T : -2;
-      const float* xp = a.x + (long long)(valid ? m : 0) * F + 8 * fg;
-      float v[KS][8];
-      float s = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const float4 p = ld4(xp + 32 * ks), q = ld4(xp + 32 * ks + 4);
-        v[ks][0] = p.x; v[ks][1] = p.y; v[ks][2] = p.z; v[ks][3] = p.w;
-        v[ks][4] = q.x; v[ks][5] = q.y; v[ks][6] = q.z; v[ks][7] = q.w;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += v[ks][e];
-      }
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      const float mean = s * (1.0f / F);
-      float d = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float c = v[ks][e] - mean;
-          d = fmaf(c, c, d);
-        }
-      d += __shfl_xor(d, 16, 64);
-      d += __shfl_xor(d, 32, 64);
-      const float rstd = valid ? 1.0f / sqrtf(d * (1.0f / F) + a.eps) : 0.f;   // invalid frames: exactly zero
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 h, l;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xn = (v[ks][e] - mean) * rstd;
-          const __bf16 hh = (__bf16)xn;
-          h[e] = hh;
-          l[e] = (__bf16)(xn - (float)hh);
-        }
-        xh[mt][ks] = h;
-        xl[mt][ks] = l;
-      }
-    }
-    f32x4 acc[FT][MT];
-#pragma unroll
-    for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // zero-padding flags of the depthwise conv at sequence starts / ends
-    float f0[MT], f2[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      f0[mt] = (trow[mt] == 0) ? 0.f : 1.f;
-      f2[mt] = (trow[mt] == a.T - 1) ? 0.f : 1.f;
-    }
-
-    // ---- weight chunks: global (fragment order) -> LDS by LDS-DMA (global_load_lds, 1 KiB per wave
-    // instruction, no VGPRs).  The copies are asynchronous: the up-projection fragments of chunk c+1 land under
-    // the conv + down-projection of chunk c, the down-projection fragments of chunk c+1 under the
-    // up-projection of chunk c+1; __syncthreads() (which drains vmcnt) is the only wait.
-    // (address = wave-uniform 64-bit base in SGPRs + one 32-bit per-lane byte offset; the offset is laundered
-    //  through an empty asm so the compiler cannot hoist a dozen 64-bit per-lane addresses out of the chunk
-    //  loop and spill them)
-    auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {
-      unsigned loff = (unsigned)lane * 16u;
-      asm volatile("" : "+v"(loff));
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (i >= nblk) break;
-        const int blk = i * NW + w;
-        const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
-      }
-    };
-    auto dma_w1 = [&](int c) {
-      dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / NT);
-      dma(W1g + (long long)c * W1_U4 + W1F_U4, csl + (c & 1) * CS_U4, CS_U4 / NT);
-    };
-    auto dma_w2 = [&](int c) { dma(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / NT); };
-    // hipcc only drains vmcnt at a barrier when it can SEE an LDS-DMA in flight on that path; the copies here
-    // are loop-carried, so every barrier that publishes DMA data carries its own explicit wait.
-    auto dma_barrier = [&]() {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    };
-    __syncthreads();   // the previous tile's epilogue staging is fully consumed
-    dma_w1(0);
-    dma_w2(0);
-    dma_barrier();     // chunk 0 landed
-    for (int c = 0; c < NCH; ++c) {
-      bf16x8 gh[MT], gw[MT];          // gated values (bf16 hi / lo) in down-projection k-slot order, per frame tile
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {   // the chunk's two 16-channel (value, gate) tile pairs
-        // ---- up-projection: h[channel 4fg+r of tile][frame fi] ---------------------------------------
-        f32x4 hv[MT], hg[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          hv[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          hg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          {
-            const uint4 uh = w1s[((j * KS + ks) * 2 + 0) * 64 + lane], ul = w1s[((j * KS + ks) * 2 + 1) * 64 + lane];
-            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&uh), wlo = *reinterpret_cast<const bf16x8*>(&ul);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hv[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hv[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hv[mt], 0, 0, 0);
-          }
-          {
-            const uint4 uh = w1s[(((2 + j) * KS + ks) * 2 + 0) * 64 + lane], ul = w1s[(((2 + j) * KS + ks) * 2 + 1) * 64 + lane];
-            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&uh), wlo = *reinterpret_cast<const bf16x8*>(&ul);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hg[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hg[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hg[mt], 0, 0, 0);
-          }
-        }
-        if (j == 1) {
-          dma_barrier();                         // every wave has read its up-projection fragments of chunk c;
-                                                 // this chunk's down-projection fragments have landed
-          if (c + 1 < NCH) dma_w1(c + 1);        // lands under the conv + down-projection below
-        }
-        // ---- + bias, depthwise k=3 conv along frames (DPP row), GLU ------------------------------------
-        // per-channel constants of the chunk ride along with the weight fragments (LDS, scalar reads per
-        // channel: keeping all eleven float4s live cost 44 registers)
-        const float* cs = reinterpret_cast<const float*>(csl + (c & 1) * CS_U4) + j * 160 + 4 * fg;
-        float gl[MT][4];                                  // gated values [frame tile][channel r]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float hval[MT], hgat[MT];
-          const float b1v = cs[0 * 16 + r], b1g = cs[1 * 16 + r];
-          const float wv0 = cs[2 * 16 + r], wv1 = cs[3 * 16 + r], wv2 = cs[4 * 16 + r];
-          const float wg0 = cs[5 * 16 + r], wg1 = cs[6 * 16 + r], wg2 = cs[7 * 16 + r];
-          const float cbv = cs[8 * 16 + r], cbg = cs[9 * 16 + r];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            hval[mt] = hv[mt][r] + b1v;
-            hgat[mt] = hg[mt][r] + b1g;
-          }
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            // previous / next frame: the neighbouring lane of the DPP row, the adjacent tile at the seams
-            float pv = dpp_ror1(hval[mt]), pg = dpp_ror1(hgat[mt]);
-            float nx = dpp_rol1(hval[mt]), ng = dpp_rol1(hgat[mt]);
-            if (mt > 0) {
-              const float sv = dpp_ror1(hval[mt - 1]), sg = dpp_ror1(hgat[mt - 1]);   // lane 0 <- previous tile, frame 15
-              pv = (fi == 0) ? sv : pv;
-              pg = (fi == 0) ? sg : pg;
-            }
-            if (mt + 1 < MT) {
-              const float sv = dpp_rol1(hval[mt + 1]), sg = dpp_rol1(hgat[mt + 1]);   // lane 15 <- next tile, frame 0
-              nx = (fi == 15) ? sv : nx;
-              ng = (fi == 15) ? sg : ng;
-            }
-            const float val = fmaf(wv2 * f2[mt], nx, fmaf(wv1, hval[mt], fmaf(wv0 * f0[mt], pv, cbv)));
-            const float gat = fmaf(wg2 * f2[mt], ng, fmaf(wg1, hgat[mt], fmaf(wg0 * f0[mt], pg, cbg)));
-            gl[mt][r] = val * sigmoid_f(gat);
-          }
-        }
-        // ---- the 4 gated channels of tile j are k-slots 4j..4j+3 of this chunk's down-projection step ---
-        // (kept per j in gsl; after both j the 8 slots form the B fragment)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const __bf16 hh = (__bf16)gl[mt][r];
-            gh[mt][4 * j + r] = hh;
-            gw[mt][4 * j + r] = (__bf16)(gl[mt][r] - (float)hh);
-          }
-      }
-      // ---- down-projection K step of this chunk ---------------------------------------------------------
-#pragma unroll
-      for (int ft = 0; ft < FT; ++ft) {
-        const uint4 uh = w2s[(ft * 2 + 0) * 64 + lane], ul = w2s[(ft * 2 + 1) * 64 + lane];
-        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&uh), wlo = *reinterpret_cast<const bf16x8*>(&ul);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[mt], acc[ft][mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gw[mt], acc[ft][mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[mt], acc[ft][mt], 0, 0, 0);
-      }
-      dma_barrier();                             // down-projection fragments consumed; chunk c+1's up-projection
-      if (c + 1 < NCH) dma_w2(c + 1);            // fragments have landed
-    }
-
-    // ---- epilogue: y = x + ls * (acc + b2), two waves at a time through LDS ---------------------------------
-    float* const Os = reinterpret_cast<float*>(wl);
-    constexpr int WPP = 64 / (16 * MT);   // waves per 64-frame epilogue pass
-#pragma unroll 1
-    for (int half = 0; half < EH; ++half) {
-      if (half > 0) __syncthreads();   // previous pass fully stored (the chunk loop ended on a barrier)
-      if (w / WPP == half) {
-        float* base = Os + (w % WPP) * (16 * MT) * OS;
-#pragma unroll
-        for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 v = acc[ft][mt];
-            st4(base + (16 * mt + fi) * OS + 16 * ft + 4 * fg, make_float4(v[0], v[1], v[2], v[3]));
-          }
-      }
-      __syncthreads();
-      {
-#pragma clang fp contract(off)
-        constexpr int Q = F / 4;                 // float4 per row
-        constexpr int RPP = NT / Q;              // rows per pass
-        const int q4 = tid % Q, rr = tid / Q;
-        const float4 b2 = ld4(a.b2 + 4 * q4), lsv = ld4(a.ls + 4 * q4);
-#pragma unroll
-        for (int p = 0; p < (64 + RPP - 1) / RPP; ++p) {
-          const int row = rr + p * RPP;          // 0..63: WPP waves x 16*MT frames
-          if (row >= 64) break;
-          const int ww = WPP * half + row / (16 * MT), lr = row % (16 * MT);
-          const int m = tile * GF_TILE + ww * GF_ROWS_OUT - 1 + lr;
-          if (lr >= 1 && lr <= GF_ROWS_OUT && m < a.M) {
-            const float4 o = ld4(Os + row * OS + 4 * q4);
-            const float4 xr = ld4(a.x + (long long)m * F + 4 * q4);
-            st4(a.y + (long long)m * F + 4 * q4,
-                make_float4(fmaf(o.x + b2.x, lsv.x, xr.x), fmaf(o.y + b2.y, lsv.y, xr.y),
-                            fmaf(o.z + b2.z, lsv.z, xr.z), fmaf(o.w + b2.w, lsv.w, xr.w)));
-          }
-        }
-      }
-    }
-  }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------
-// Version 3 of the fused kernel: same tiling, LDS layout and barrier structure as gcfn_fused_kernel above, with
-// the per-wave instruction stream reworked (v1 profile: 4.7 VALU instructions per MFMA, every MFMA group waiting
-// on the LDS read issued right in front of it):
+// gcfn_fused3_kernel (the default).  Its predecessor (git history: gcfn_fused_kernel, frame = 16*mt + fi) spent 4.7
+// VALU instructions per MFMA and waited on every LDS fragment read; what changed:
 //  * frames are INTERLEAVED over the two frame tiles (frame = 2*fi + mt instead of 16*mt + fi): the previous /
 //    next frame of a lane's tile-0 / tile-1 value is the lane's own other register, the remaining neighbour is one
 //    DPP row rotation, and the two rotation wrap-arounds land exactly on the two halo frames whose outputs are
@@ -381,7 +109,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
   const uint4* const W1g = static_cast<const uint4*>(a.w1p);
   const uint4* const W2g = static_cast<const uint4*>(a.w2p);
 
-  // ---- weight chunks: global -> LDS by LDS-DMA, same protocol as gcfn_fused_kernel ---------------------------
+  // ---- weight chunks: global -> LDS by LDS-DMA, 1 KiB per wave instruction ---------------------------
   auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {   // nblk 1 KiB blocks, dealt round-robin to the waves
     unsigned loff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(loff));
@@ -979,12 +707,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gcfn_fused4_kernel(const Gcfn
 }
 
 #ifndef SEPR_GF_VERSION
-#define SEPR_GF_VERSION 3   // 1: gcfn_fused_kernel, 3: gcfn_fused3_kernel, 4: gcfn_fused4_kernel
+#define SEPR_GF_VERSION 3   // 3: gcfn_fused3_kernel (default), 4: gcfn_fused4_kernel (one workgroup per CU; measured slower)
 #endif
-#ifndef SEPR_GF_MT
-#define SEPR_GF_MT 2    // v1 frame tiles per wave (1 -> 14 frames out of 16, 8 waves; 2 -> 30 of 32, 4 waves)
-#endif
-[[maybe_unused]] constexpr int GF_MT = SEPR_GF_MT, GF_NW = (SEPR_GF_MT == 1) ? 8 : 4;
 #ifndef SEPR_GF3_MT
 #define SEPR_GF3_MT 2   // v3 frame tiles per wave: 2 -> 4 waves x 30 frames (2 waves per SIMD), 1 -> 6 waves x 14 frames (3 per SIMD)
 #endif
@@ -1021,24 +745,6 @@ int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t strea
     hipLaunchKernelGGL((gcfn_fused3_kernel<128, GF3_MT, GF3_NW>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
   } else if (F == 64) {
     hipLaunchKernelGGL((gcfn_fused3_kernel<64, GF3_MT, GF3_NW>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
-  } else {
-    return SEPR_EINVAL;
-  }
-#else
-  constexpr int tile_rows = GF_NW * (16 * GF_MT - 2);
-  const int ntiles = (a.M + tile_rows - 1) / tile_rows;
-  static const int cap = [] {   // SEPR_GF_GRID: "tiles" -> one tile per workgroup, k -> k workgroups per CU
-    const char* e = getenv("SEPR_GF_GRID");
-    if (!e || !e[0]) return persistent_grid();
-    if (e[0] == 't') return 0;
-    const int k = atoi(e);
-    return k > 0 ? persistent_grid() / 2 * k : persistent_grid();
-  }();
-  const int grid = (cap <= 0 || ntiles < cap) ? ntiles : cap;
-  if (F == 128) {
-    hipLaunchKernelGGL((gcfn_fused_kernel<128, GF_MT, GF_NW>), dim3(grid), dim3(64 * GF_NW), 0, stream, a);
-  } else if (F == 64) {
-    hipLaunchKernelGGL((gcfn_fused_kernel<64, GF_MT, GF_NW>), dim3(grid), dim3(64 * GF_NW), 0, stream, a);
   } else {
     return SEPR_EINVAL;
   }
