@@ -258,6 +258,18 @@ int sepr_pit_sisnr_fwd(const float* est, const float* tgt, const float* mix, int
                        double eps_loss, double eps_i, double clamp_min, float* loss, int* loss_perm,
                        float* sisnri, int* sisnri_perm, void* ws, size_t ws_bytes, sepr_stream_t stream);
 
+/* PIT_SISNR_mag.__call__, utils/implements/criterions.py:148-176 with the conv-STFT of :43-113: per utterance
+ *   loss[b] = min over permutations of sum_s -20 log10(eps + |M(c t_p(s))| / (|M(est_s) - M(c t_p(s))| + eps)),
+ * M = sqrt(re^2 + im^2 + 1e-10) of the STFT of the zero-mean signal (frame_len-point DFT kernel `dft`, hop
+ * frame_shift, zero padding to a multiple of the hop, no centre padding), c = max(<e~,t~> / (|t~|^2 + eps), 1e-2),
+ * norms over bins and frames.  est, tgt [S,B,T]; dft [(frame_len + 2 rounded up to 4), frame_len] row-major = the
+ * reference's STFTBase.K (real rows, then imaginary rows, then zero rows); loss [B]; perm [B,S] or NULL.
+ * mel_opt = false only.  Workspace: sepr_pit_sisnr_mag_workspace(S, B, T, frame_len, frame_shift). */
+size_t sepr_pit_sisnr_mag_workspace(int S, int B, int T, int frame_len, int frame_shift);
+int sepr_pit_sisnr_mag_fwd(const float* est, const float* tgt, int S, int B, int T, const float* dft,
+                           int frame_len, int frame_shift, double eps, float* loss, int* perm, void* ws,
+                           size_t ws_bytes, sepr_stream_t stream);
+
 /* ---- opt-in kernel timer (bench.py roofline) ------------------------------------------------- */
 /* Sites a projection launch can be attributed to. */
 enum {

@@ -76,3 +76,53 @@ def pit_sisnri(estims: List[Tensor], targets: List[Tensor], mixture: Tensor, eps
     B = x.shape[0]
     per_best = pscore[idx, torch.arange(B)]                          # [B, S]
     return torch.sum(best_sum) / B, per_best, torch.tensor(perms)[idx]
+
+
+def stft_kernel(frame_len: int, frame_hop: int) -> Tensor:
+    """STFTBase._init_kernel, criterions.py:43-61 ('hann' window): ``[frame_len + 2, 1, frame_len]``."""
+    N = frame_len
+    W = torch.hann_window(frame_len)                                  # :48
+    if N // 4 == frame_hop:                                           # :49-51
+        W = (2 / 3) ** 0.5 * W
+    elif N // 2 == frame_hop:                                         # :52-53
+        W = W ** 0.5
+    S = 0.5 * (N * N / frame_hop) ** 0.5                              # :54
+    K = torch.fft.rfft(torch.eye(N) / S, dim=1)[:frame_len]           # :57
+    K = torch.stack((torch.real(K), torch.imag(K)), dim=2)            # :58
+    K = torch.transpose(K, 0, 2) * W                                  # :59
+    return torch.reshape(K, (N + 2, 1, frame_len))                    # :60
+
+
+def stft_mag(x: Tensor, K: Tensor, frame_shift: int) -> Tensor:
+    """STFT.forward for ``[N, S]`` input, magnitude only (criterions.py:88-113)."""
+    from math import ceil
+    n_frame = ceil(x.shape[-1] / frame_shift)                         # :90
+    len_padded = n_frame * frame_shift
+    x = torch.cat((x, torch.zeros(x.shape[0], len_padded - x.shape[-1], dtype=x.dtype)), dim=-1)   # :94
+    c = torch.nn.functional.conv1d(x.unsqueeze(1), K.to(x.dtype), stride=frame_shift, padding=0)    # :97
+    r, i = torch.chunk(c, 2, dim=1)                                   # :99
+    return (r ** 2 + i ** 2 + 1.0e-10) ** 0.5                         # :112
+
+
+def pit_sisnr_mag(estims: List[Tensor], targets: List[Tensor], frame_length: int = 512, frame_shift: int = 128,
+                  eps: float = 1.0e-12, dtype: torch.dtype = torch.float32) -> Tuple[Tensor, Tensor, Tensor]:
+    """PIT_SISNR_mag.__call__ (criterions.py:148-176, mel_opt False) -> (mean loss, per-utterance loss [B], perm [B,S])."""
+    S = len(estims)
+    K = stft_kernel(frame_length, frame_shift)
+    est = [e.to(dtype) for e in estims]
+    tgt = [t.to(dtype) for t in targets]
+    perms = list(permutations(range(S)))
+    pscore = []
+    for p in perms:
+        tot = 0
+        for s, t in enumerate(p):                                     # :154-166
+            mix_zm = est[s] - torch.mean(est[s], dim=-1, keepdim=True)
+            src_zm = tgt[t] - torch.mean(tgt[t], dim=-1, keepdim=True)
+            scale = torch.sum(mix_zm * src_zm, dim=-1, keepdim=True) / (_l2norm(src_zm, keepdim=True) ** 2 + eps)
+            src_zm = torch.clamp(scale, min=1e-2) * src_zm
+            m_mix, m_src = stft_mag(mix_zm, K, frame_shift), stft_mag(src_zm, K, frame_shift)
+            tot = tot + (-20 * torch.log10(eps + _l2norm(_l2norm(m_src)) / (_l2norm(_l2norm(m_mix - m_src)) + eps)))
+        pscore.append(tot)
+    pscore = torch.stack(pscore)
+    min_perutt, idx = torch.min(pscore, dim=0)
+    return torch.sum(min_perutt) / est[0].shape[0], min_perutt, torch.tensor(perms)[idx]

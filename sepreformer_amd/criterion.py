@@ -64,6 +64,50 @@ def pit_sisnr(estims: _TensorList, targets: _TensorList, mixture: torch.Tensor =
     return {"loss": loss, "loss_perm": loss_perm, "sisnri": sisnri, "sisnri_perm": sisnri_perm}
 
 
+def stft_kernel(frame_len: int, frame_hop: int, window: str = "hann") -> torch.Tensor:
+    """The reference's conv-STFT kernel (``STFTBase._init_kernel``, criterions.py:43-61) as a ``[frame_len + 2 (padded to
+    a multiple of 4), frame_len]`` matrix: windowed, scaled real DFT rows, then imaginary rows, then zero rows.  A
+    constant of the criterion (built on the host once, like the reference does in ``__post_init__``)."""
+    if window != "hann":
+        raise NotImplementedError("only the 'hann' window is configured by the reference")
+    N = frame_len
+    W = torch.hann_window(frame_len)
+    if N // 4 == frame_hop:
+        W = (2 / 3) ** 0.5 * W
+    elif N // 2 == frame_hop:
+        W = W ** 0.5
+    S = 0.5 * (N * N / frame_hop) ** 0.5
+    K = torch.fft.rfft(torch.eye(N) / S, dim=1)[:frame_len]                 # [N, N/2+1]
+    K = torch.stack((torch.real(K), torch.imag(K)), dim=2)                  # [N, N/2+1, 2]
+    K = torch.transpose(K, 0, 2) * W                                         # [2, N/2+1, N]
+    K = torch.reshape(K, (N + 2, frame_len))
+    pad = (-(N + 2)) % 4
+    return torch.cat([K, torch.zeros(pad, frame_len)], 0).to(torch.float32).contiguous()
+
+
+def pit_sisnr_mag(estims: _TensorList, targets: _TensorList, dft: torch.Tensor, frame_len: int, frame_shift: int,
+                  eps: float = 1.0e-12):
+    """Per-utterance PIT_SISNR_mag loss ``[B]`` and its permutation ``[B,S]`` (one moment pass, one f32-MFMA STFT
+    projection over all 2S waveforms, one pair-sum pass)."""
+    est, tgt = _stack(estims, "estims"), _stack(targets, "target_attr")
+    if est.shape != tgt.shape:
+        raise RuntimeError(f"estims {tuple(est.shape)} and targets {tuple(tgt.shape)} differ")
+    S, B, T = est.shape
+    dev = est.device
+    lib = L.load()
+    with torch.cuda.device(dev):
+        nbytes = lib.sepr_pit_sisnr_mag_workspace(S, B, T, frame_len, frame_shift)
+        if nbytes == 0:
+            raise RuntimeError(f"unsupported PIT_SISNR_mag problem: num_spks={S}, batch={B}, samples={T}")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        perm = torch.empty(B, S, dtype=torch.int32, device=dev)
+        L.check(lib.sepr_pit_sisnr_mag_fwd(est.data_ptr(), tgt.data_ptr(), S, B, T, dft.data_ptr(), frame_len, frame_shift, eps,
+                                           loss.data_ptr(), perm.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           torch.cuda.current_stream(dev).cuda_stream), "sepr_pit_sisnr_mag_fwd")
+    return {"loss": loss, "perm": perm}
+
+
 class _Base:
     def __init__(self, device, num_spks: int, scale_inv: bool = True):
         if not scale_inv:
@@ -95,3 +139,36 @@ class PIT_SISNRi(_Base):
         per = out["sisnri"]
         mean = torch.sum(per) / kwargs["input_sizes"].shape[0]                    # reference :255-257
         return mean, (per[0] if per.shape[0] == 1 else per)
+
+
+class PIT_SISNR_mag:
+    """``PIT_SISNR_mag(device, frame_length, frame_shift, window, num_stages, num_spks, scale_inv, mel_opt)`` of the
+    reference (criterions.py:117-176): ``__call__(estims=..., idx=..., input_sizes=..., target_attr=...)`` -> scalar loss.
+    ``idx`` selects one of ``num_stages`` identical STFT layers in the reference; there is one kernel matrix here."""
+
+    def __init__(self, device, frame_length: int, frame_shift: int, window: str, num_stages: int, num_spks: int,
+                 scale_inv: bool = True, mel_opt: bool = False):
+        if not scale_inv or mel_opt:
+            raise NotImplementedError("only scale_inv=True, mel_opt=False (what every shipped config uses) is built")
+        self.device = torch.device(device)
+        self.frame_length, self.frame_shift, self.window = frame_length, frame_shift, window
+        self.num_stages, self.num_spks, self.scale_inv, self.mel_opt = num_stages, num_spks, scale_inv, mel_opt
+        self._dft = stft_kernel(frame_length, frame_shift, window)
+        if self.device.type == "cuda":
+            self._dft = self._dft.to(self.device)
+
+    def __repr__(self):
+        return (f"<PIT_SISNR_mag(device={self.device!r}, frame_length={self.frame_length}, frame_shift={self.frame_shift}, "
+                f"window={self.window!r}, num_stages={self.num_stages}, num_spks={self.num_spks}, scale_inv=True, mel_opt=False)>")
+
+    def __call__(self, **kwargs) -> torch.Tensor:
+        estims, targets = kwargs["estims"], kwargs["target_attr"]
+        if not 0 <= int(kwargs["idx"]) < self.num_stages:
+            raise IndexError("idx out of range")                                    # self.stft[idx] in the reference
+        n = estims.shape[0] if isinstance(estims, torch.Tensor) else len(estims)
+        if n != self.num_spks:
+            raise RuntimeError(f"expected {self.num_spks} estimates, got {n}")
+        if self._dft.device.type != "cuda":
+            raise RuntimeError("PIT_SISNR_mag was built for a non-HIP device (no CPU fallback exists)")
+        out = pit_sisnr_mag(estims, targets, self._dft, self.frame_length, self.frame_shift)
+        return torch.sum(out["loss"]) / kwargs["input_sizes"].shape[0]             # reference :175-176

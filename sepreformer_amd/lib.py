@@ -77,6 +77,8 @@ SIGNATURES = {
     "sepr_groupnorm_stats": (_i, [_fp, _i, _ll, _f, _fp, _fp, _sz, _fp]),
     "sepr_linear_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
     "sepr_linear_x3_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
+    "sepr_pit_sisnr_mag_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "sepr_pit_sisnr_mag_fwd": (_i, [_fp, _fp, _i, _i, _i, _fp, _i, _i, C.c_double, _fp, _fp, _fp, _sz, _fp]),
     "sepr_pit_sisnr_fwd": (_i, [_fp, _fp, _fp, _i, _i, _i, C.c_double, C.c_double, C.c_double, _fp, _fp, _fp, _fp,
                                 _fp, _sz, _fp]),
     "sepr_prof_start": (_i, [_i, _i]),

@@ -123,3 +123,65 @@ def test_device_error_codes():
     rc = lib.sepr_pit_sisnr_fwd(y.data_ptr(), y.data_ptr(), None, 2, 2, 64, 1e-8, 1e-15, -30.0, loss.data_ptr(), None, loss.data_ptr(),
                                 None, loss.data_ptr(), 4096, torch.cuda.current_stream().cuda_stream)
     assert rc == L.SEPR_EINVAL                                     # improvements requested without a mixture
+
+
+# ---- PIT_SISNR_mag (conv-STFT magnitude loss) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["s2", "s3"])
+def test_mag_oracle_matches_reference_values(golden, tag):
+    g, src, est, _ = _case(golden, tag)
+    mean, per_utt, perm = co.pit_sisnr_mag(est, src)
+    assert abs(float(mean) - float(g[f"{tag}.mag_mean"])) < 1e-4
+    assert np.allclose(per_utt.numpy(), g[f"{tag}.mag_per_utt"], atol=1e-4)
+    assert np.array_equal(perm.numpy(), g[f"{tag}.mag_perm"])
+
+
+def test_stft_kernel_matches_oracle_and_is_unitary_like():
+    from sepreformer_amd.criterion import stft_kernel
+    K = stft_kernel(512, 128)
+    assert tuple(K.shape) == (516, 512) and torch.equal(K[:514], co.stft_kernel(512, 128)[:, 0, :]) and not K[514:].any()
+    # a windowed sinusoid at bin 32 concentrates its energy there
+    t = torch.arange(512, dtype=torch.float32)
+    spec = K @ torch.cos(2 * torch.pi * 32 * t / 512)
+    mag = (spec[:257] ** 2 + spec[257:514] ** 2).sqrt()
+    assert int(mag.argmax()) == 32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["s2", "s3"])
+def test_device_mag_matches_oracle_and_reference(golden, tag):
+    """Tolerance: the STFT runs on the f32 MFMA (exact fp32 products, different summation order than aten's conv1d) and
+    the pair sums in fp64: 5e-3 dB against the fp32 oracle / reference values, 2e-3 dB against its fp64 evaluation."""
+    from sepreformer_amd.criterion import PIT_SISNR_mag, pit_sisnr_mag, stft_kernel
+    g, src, est, _ = _case(golden, tag)
+    dev = torch.device("cuda:0")
+    S, B = len(est), est[0].shape[0]
+    out = pit_sisnr_mag([e.to(dev) for e in est], [s.to(dev) for s in src], stft_kernel(512, 128).to(dev), 512, 128)
+    _, per64, perm64 = co.pit_sisnr_mag(est, src, dtype=torch.float64)
+    assert np.allclose(out["loss"].cpu().numpy(), per64.numpy(), atol=2e-3)
+    assert np.array_equal(out["perm"].cpu().numpy(), perm64.numpy())
+    assert np.allclose(out["loss"].cpu().numpy(), g[f"{tag}.mag_per_utt"], atol=5e-3)
+    crit = PIT_SISNR_mag(dev, 512, 128, "hann", 4, S, True, False)
+    loss = crit(estims=[e.to(dev) for e in est], idx=2, input_sizes=torch.full((B,), est[0].shape[1]), target_attr=[s.to(dev) for s in src])
+    assert abs(float(loss) - float(g[f"{tag}.mag_mean"])) < 5e-3
+    with pytest.raises(IndexError):
+        crit(estims=[e.to(dev) for e in est], idx=4, input_sizes=torch.full((B,), 1), target_attr=[s.to(dev) for s in src])
+
+
+@pytest.mark.gpu
+def test_device_mag_full_batch_and_errors():
+    from sepreformer_amd import lib as L
+    from sepreformer_amd.criterion import pit_sisnr_mag, stft_kernel
+    from sepreformer_amd.synth import synth_sources
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(synth_sources(32, 32000, seed=11)).permute(1, 0, 2).contiguous()
+    g_ = torch.Generator().manual_seed(6)
+    est = torch.stack([src[1], src[0]], 0) * 0.9 + 0.01 * torch.randn(src.shape, generator=g_)
+    dft = stft_kernel(512, 128).to(dev)
+    a = pit_sisnr_mag(est.to(dev), src.to(dev), dft, 512, 128)
+    b = pit_sisnr_mag(est.to(dev), src.to(dev), dft, 512, 128)
+    assert torch.equal(a["loss"], b["loss"]) and (a["perm"].cpu() == torch.tensor([1, 0])).all()
+    _, per64, _ = co.pit_sisnr_mag(list(est), list(src), dtype=torch.float64)
+    assert np.allclose(a["loss"].cpu().numpy(), per64.numpy(), atol=2e-3)
+    with pytest.raises(RuntimeError):                                           # shorter than one frame
+        pit_sisnr_mag(est[..., :300].contiguous().to(dev), src[..., :300].contiguous().to(dev), dft, 512, 128)
+    assert L.load().sepr_pit_sisnr_mag_workspace(4, 2, 4000, 512, 128) == 0    # S > 3
