@@ -737,6 +737,26 @@ int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t strea
     return SEPR_EINVAL;
   }
 #elif SEPR_GF_VERSION == 3
+  // Small launches (fewer 120-frame tiles than workgroup slots, e.g. batch 1 or the bottleneck stage) take the
+  // 14-frame-wave instantiation: 1.4x more, shorter tiles.  A frame's arithmetic does not depend on the tiling, so the
+  // result is bit-identical; for large launches the 30-frame form is 1.7x faster per frame (weight re-use).
+  static const int small_rows = [] {
+    const char* e = getenv("SEPR_GF_SMALL_ROWS");
+    return e && e[0] ? atoi(e) : 30000;
+  }();
+  if (GF3_MT == 2 && a.M < small_rows) {
+    constexpr int tile_rows = 6 * 14;
+    const int ntiles = (a.M + tile_rows - 1) / tile_rows;
+    const int cap = persistent_grid();
+    const int grid = ntiles < cap ? ntiles : cap;
+    if (F == 128) {
+      hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6>), dim3(grid), dim3(384), 0, stream, a);
+    } else if (F == 64) {
+      hipLaunchKernelGGL((gcfn_fused3_kernel<64, 1, 6>), dim3(grid), dim3(384), 0, stream, a);
+    } else {
+      return SEPR_EINVAL;
+    }
+  } else {
   constexpr int tile_rows = GF3_NW * (16 * GF3_MT - 2);
   const int ntiles = (a.M + tile_rows - 1) / tile_rows;
   const int cap = persistent_grid();
@@ -747,6 +767,7 @@ int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t strea
     hipLaunchKernelGGL((gcfn_fused3_kernel<64, GF3_MT, GF3_NW>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
   } else {
     return SEPR_EINVAL;
+  }
   }
 #endif
   // algorithmic FLOPs of the block: both projections + the depthwise conv
