@@ -147,7 +147,7 @@ def main():
         main_out = torch.stack([a[0:1] for a in out[0]], 0).cpu()
         parity_db = round(agreement_db(main_out, torch.from_numpy(g["main"])), 1)
 
-    launches_per_step = 56                      # GCFN launches per forward incl. aux heads (upper bound; sizes the event pool)
+    launches_per_step = 56 * 4                  # GCFN launches per forward (56) x sub-batch pipelines; sizes the event pool
     L.check(lib.sepr_prof_start(L.SITE_GCFN_UP, launches_per_step * max(args.steps, 1) + 8), "sepr_prof_start")
     sdist.barrier()
     torch.cuda.synchronize(dev)
@@ -169,7 +169,13 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_gcfn_up.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                pmc_rec = json.load(f)
+            traffic = pmc_rec.get("hbm_bytes_per_launch")
+            ratio = pmc_rec.get("traffic_over_algorithmic")
+            if ratio and precision == "bf16x3" and fl.value > 0 and n_l.value > 0:
+                # PMC bytes per algorithmic byte (measured on full-batch launches) x this run's algorithmic bytes per launch
+                rows_l = fl.value / (18.0 * cfg.feat * cfg.feat + 36.0 * cfg.feat) / n_l.value
+                traffic = round(ratio * rows_l * 8.0 * cfg.feat)
         n_launch = max(n_l.value, 1)
         if precision == "fp32":
             dtype = "f32"
@@ -201,6 +207,26 @@ def main():
                     "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
         roof.update({"launches": int(n_l.value), "avg_launch_ms": round(ms.value / n_launch, 4),
                      "algorithmic_gflop_per_launch": round(fl.value / 1e9 / n_launch, 3)})
+        if getattr(model, "pipelines", 1) > 1 and B >= 8 * model.pipelines:
+            # the timed region runs the batch as `pipelines` half-size sub-batches on separate streams: launches of the
+            # same kernel overlap on the device, so each one's event-to-event duration includes the time it shares
+            # the CUs with its twin.  The figures of the kernel running ALONE (one pipeline, 2 untimed steps) go
+            # next to them; `value` always comes from the timed region above.
+            model.pipelines, saved = 1, model.pipelines
+            L.check(lib.sepr_prof_start(L.SITE_GCFN_UP, launches_per_step * 2 + 8), "sepr_prof_start")
+            step(); step()
+            torch.cuda.synchronize(dev)
+            n2, ms2, fl2 = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
+            L.check(lib.sepr_prof_stop(C.byref(n2), C.byref(ms2), C.byref(fl2)), "sepr_prof_stop")
+            model.pipelines = saved
+            if ms2.value > 0 and n2.value > 0:
+                scale = 3.0 * (18.0 * cfg.feat * cfg.feat) / (18.0 * cfg.feat * cfg.feat + 36.0 * cfg.feat) if precision == "bf16x3" else 1.0
+                peak = BF16_MFMA_PEAK_TFLOPS if precision == "bf16x3" else FP32_MFMA_PEAK_TFLOPS
+                tf = scale * (fl2.value / 1e12) / (ms2.value / 1e3)
+                roof["exclusive"] = {"achieved": round(tf, 1), "frac": round(tf / peak, 4), "launches": int(n2.value),
+                                     "avg_launch_ms": round(ms2.value / n2.value, 4),
+                                     "note": "same kernel, single pipeline (launches do not share the device)"}
+            roof["pipelines"] = saved
         rec = {
             "metric": METRIC, "value": round(utt_per_s, 3), "unit": "utt/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
