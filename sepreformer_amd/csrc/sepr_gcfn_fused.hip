@@ -742,7 +742,7 @@ int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t strea
   // result is bit-identical; for large launches the 30-frame form is 1.7x faster per frame (weight re-use).
   static const int small_rows = [] {
     const char* e = getenv("SEPR_GF_SMALL_ROWS");
-    return e && e[0] ? atoi(e) : 30000;
+    return e && e[0] ? atoi(e) : 17000;
   }();
   if (GF3_MT == 2 && a.M < small_rows) {
     constexpr int tile_rows = 6 * 14;
