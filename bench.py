@@ -198,7 +198,7 @@ def main():
             mfma_tf = 3.0 * rows * 18.0 * F * F / 1e12 / sec if sec > 0 else 0.0
             gbs = rows * 8.0 * F / 1e9 / sec if sec > 0 else 0.0
             dtype = "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)"
-            roof = {"kernel": "gcfn_fused3_kernel<128,4> (whole GCFN block in one launch: LayerNorm, F->6F bf16x3 MFMA, "
+            roof = {"kernel": "gcfn_fused3_kernel<128,2,4> (and its <128,1,6> instantiation for launches under 17000 rows; whole GCFN block in one launch: LayerNorm, F->6F bf16x3 MFMA, "
                               "depthwise conv k=3 + GLU, 3F->F bf16x3 MFMA, LayerScale, residual)",
                     "bound": "mfma", "achieved": round(mfma_tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(mfma_tf / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
