@@ -79,14 +79,23 @@ struct bool_c { static constexpr bool value = V; };
 #ifndef SEPR_GF3_PRIO
 #define SEPR_GF3_PRIO 0
 #endif
+#ifndef SEPR_GF3_XCH
+#define SEPR_GF3_XCH 1
+#endif
 template <int F, int MT, int NW>
 __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
   static_assert(MT == 1 || MT == 2, "frame tiles per wave");
   constexpr int RD = SEPR_GF3_RING;      // LDS fragment read-ahead, in MFMA groups
   constexpr bool UF = SEPR_GF3_UPFIRST != 0;
   constexpr int NT = 64 * NW;
-  constexpr int GF_ROWS_OUT = 16 * MT - 2;
-  constexpr int GF_TILE = NW * GF_ROWS_OUT;
+  // XCH: the waves of a workgroup cover 16*MT*NW CONTIGUOUS frames and hand each other the conv's neighbour frame at
+  // the wave seams through LDS (published by the barrier the chunk already has after the up-projections), so only the
+  // two frames at the workgroup's ends are recomputed halo: 126 outputs per 128 frames instead of 120, and - what
+  // matters more - 64000 x 2^k rows are then just under 512 x 2^k tiles, i.e. full launch rounds instead of
+  // "one round + a 4 % tail" (534 tiles on 512 slots).  Without XCH every wave carries its own two halo frames.
+  constexpr bool XCH = (SEPR_GF3_XCH != 0) && MT == 2 && UF;
+  constexpr int WSTR = XCH ? 16 * MT : 16 * MT - 2;            // frames a wave advances
+  constexpr int GF_TILE = XCH ? NW * 16 * MT - 2 : NW * (16 * MT - 2);   // output frames per workgroup tile
   constexpr int EH = (16 * MT * NW + 63) / 64;   // epilogue passes of up to 64 frames
   constexpr int KS = F / 32;
   constexpr int NCH = 3 * F / 32;
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
   constexpr int W2_U4 = FT * 2 * 64;
   constexpr int OS = F + 4;
   __shared__ __attribute__((aligned(16))) uint4 wl[W1F_U4 + W2_U4 + 2 * CS_U4];
+  __shared__ __attribute__((aligned(16))) float xch[XCH ? NW * 2 * 2 * 2 * 16 : 4];   // [wave][first|last frame][j][v|g][16 ch]
   static_assert(sizeof(uint4) * (W1F_U4 + W2_U4) >= sizeof(float) * 64 * OS, "epilogue staging must fit");
   static_assert(W1F_U4 / 64 <= 16 * NW, "copy partition");
   const uint4* const w1s = wl;
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     dma_w1(0);
     dma_w2(0);
     // ---- this wave's 32 frames (lane fi holds frames 2*fi and 2*fi+1): load, LayerNorm, split --------------
-    const int mw0 = tile * GF_TILE + w * GF_ROWS_OUT - 1;       // wave frame 0 (halo)
+    const int mw0 = tile * GF_TILE + w * WSTR - 1;              // wave frame 0 (tile frame 0 is halo)
     bf16x8 xh[MT][KS], xl[MT][KS];
     float f0[MT], f2[MT];                                        // conv zero-padding flags (sequence start / end)
     bool edge_lane = false;
@@ -268,6 +278,21 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
 #pragma unroll
             for (int g = 0; g < RD; ++g) ld_up(1, g, fb[g]);
           } else {
+            if (XCH) {   // this wave's first / last frame of both tile pairs for the neighbouring waves' conv
+#pragma unroll
+              for (int jx = 0; jx < 2; ++jx) {
+                float* e0 = xch + ((w * 2 + 0) * 2 + jx) * 32 + 4 * fg;
+                float* e1 = xch + ((w * 2 + 1) * 2 + jx) * 32 + 4 * fg;
+                if (fi == 0) {
+                  st4(e0, make_float4(hvA[jx][0][0], hvA[jx][0][1], hvA[jx][0][2], hvA[jx][0][3]));
+                  st4(e0 + 16, make_float4(hgA[jx][0][0], hgA[jx][0][1], hgA[jx][0][2], hgA[jx][0][3]));
+                }
+                if (fi == 15) {
+                  st4(e1, make_float4(hvA[jx][MT - 1][0], hvA[jx][MT - 1][1], hvA[jx][MT - 1][2], hvA[jx][MT - 1][3]));
+                  st4(e1 + 16, make_float4(hgA[jx][MT - 1][0], hgA[jx][MT - 1][1], hgA[jx][MT - 1][2], hgA[jx][MT - 1][3]));
+                }
+              }
+            }
             dma_barrier();                         // every wave has read its up-projection fragments of chunk c;
                                                    // this chunk's down-projection fragments have landed
             if (c + 1 < NCH && !(SEPR_GF_ABL & 2)) dma_w1(c + 1);        // lands under the conv + down-projection below
@@ -279,6 +304,16 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
           // ---- depthwise k=3 conv along frames, GLU ---------------------------------------------------------
           // frame 2*fi+mt: tile 0's previous frame is the left lane's tile-1 value, its next frame the lane's own
           // tile-1 value (and mirrored for tile 1); the rotations wrap onto the two halo frames only.
+          float xpv[4] = {0.f, 0.f, 0.f, 0.f}, xpg[4] = {0.f, 0.f, 0.f, 0.f}, xnv[4] = {0.f, 0.f, 0.f, 0.f}, xng[4] = {0.f, 0.f, 0.f, 0.f};
+          if (XCH) {   // last frame of the wave before, first frame of the wave after (the tile's two end frames are halo)
+            const int wp = w > 0 ? w - 1 : 0, wn = w + 1 < NW ? w + 1 : NW - 1;
+            const float4 a0 = ld4(xch + ((wp * 2 + 1) * 2 + j) * 32 + 4 * fg), a1 = ld4(xch + ((wp * 2 + 1) * 2 + j) * 32 + 16 + 4 * fg);
+            const float4 b0 = ld4(xch + ((wn * 2 + 0) * 2 + j) * 32 + 4 * fg), b1 = ld4(xch + ((wn * 2 + 0) * 2 + j) * 32 + 16 + 4 * fg);
+            xpv[0] = a0.x; xpv[1] = a0.y; xpv[2] = a0.z; xpv[3] = a0.w;
+            xpg[0] = a1.x; xpg[1] = a1.y; xpg[2] = a1.z; xpg[3] = a1.w;
+            xnv[0] = b0.x; xnv[1] = b0.y; xnv[2] = b0.z; xnv[3] = b0.w;
+            xng[0] = b1.x; xng[1] = b1.y; xng[2] = b1.z; xng[3] = b1.w;
+          }
           float gl[MT][4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -297,6 +332,12 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
               pg[mt] = mt > 0 ? cg[mt - 1] : dpp_ror1(cg[MT - 1]);
               nv[mt] = mt + 1 < MT ? cv[mt + 1] : dpp_rol1(cv[0]);
               ng[mt] = mt + 1 < MT ? cg[mt + 1] : dpp_rol1(cg[0]);
+            }
+            if (XCH) {   // wave seams: the rotation wrapped around; take the neighbouring wave's frame instead
+              pv[0] = fi == 0 ? xpv[r] : pv[0];
+              pg[0] = fi == 0 ? xpg[r] : pg[0];
+              nv[MT - 1] = fi == 15 ? xnv[r] : nv[MT - 1];
+              ng[MT - 1] = fi == 15 ? xng[r] : ng[MT - 1];
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -359,8 +400,10 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
       for (int p = 0; p < NP; ++p) {
         const int row = rr + p * RPP;          // 0..63: WPP waves x 16*MT frames
         const int ww = WPP * half + row / (16 * MT), lr = row % (16 * MT);
-        const int m = tile * GF_TILE + ww * GF_ROWS_OUT - 1 + lr;
-        const bool ok = row < 64 && ww < NW && lr >= 1 && lr <= GF_ROWS_OUT && m < a.M;
+        const int bf = ww * WSTR + lr;                           // frame inside the workgroup tile (0 = halo)
+        const int m = tile * GF_TILE - 1 + bf;
+        const bool ok = row < 64 && ww < NW && m < a.M &&
+                        (XCH ? (bf >= 1 && bf <= GF_TILE) : (lr >= 1 && lr <= 16 * MT - 2));
         mrow[p] = ok ? m : -1;
         xr[p] = ld4(a.x + (long long)(ok ? m : 0) * F + 4 * q4);
       }
@@ -757,7 +800,7 @@ int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t strea
       return SEPR_EINVAL;
     }
   } else {
-  constexpr int tile_rows = GF3_NW * (16 * GF3_MT - 2);
+  constexpr int tile_rows = (SEPR_GF3_XCH && GF3_MT == 2 && SEPR_GF3_UPFIRST) ? GF3_NW * 16 * GF3_MT - 2 : GF3_NW * (16 * GF3_MT - 2);
   const int ntiles = (a.M + tile_rows - 1) / tile_rows;
   const int cap = persistent_grid();
   const int grid = ntiles < cap ? ntiles : cap;

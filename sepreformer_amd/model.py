@@ -50,7 +50,7 @@ class Model(torch.nn.Module):
         # returned tensors are then static buffers that the next same-shape call overwrites
         self.use_graphs = os.environ.get("SEPR_GRAPHS", "0") == "1"
         # throughput mode for batches: the batch as N independent pipelines on N streams (engine.forward_split)
-        self.pipelines = int(os.environ.get("SEPR_PIPELINES", "2"))
+        self.pipelines = int(os.environ.get("SEPR_PIPELINES", "1"))
         # projection arithmetic: "fp32" = exact f32 MFMA; "bf16x3" = split-fp32 on the bf16 MFMA (3 MFMAs per
         # product, ~100 dB agreement with fp32, 5x less matrix time).  Default from SEPR_PRECISION.
         self.precision = precision or os.environ.get("SEPR_PRECISION", DEFAULT_PRECISION)
