@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
-"""Throughput of the SepReformer-Base separator forward on MI355X.
+"""Throughput of the SepReformer separator on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W         # N > 1 without a launcher: re-executes itself under
+                                                          # torch.distributed.run (one rank per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one full ``Model.forward`` (main + the 4 auxiliary heads, exactly what the reference's
-forward evaluates, model.py:38-54) over one batch of 32 synthetic 4 s / 8 kHz two-speaker mixtures
-already resident in HBM (BASELINE.json configs[1]).  With N ranks every rank runs its own batch of 32
-(weak scaling, configs[2]); there is no collective on the data path - only the timing max-reduce.
-Rank 0 prints ONE JSON line.
+Inference (default, BASELINE.json configs[1] / configs[2]): a "step" is one full ``Model.forward`` (main + the 4
+auxiliary heads, exactly what the reference's forward evaluates, model.py:38-54) over one batch of 32 synthetic
+4 s / 8 kHz two-speaker mixtures already resident in HBM, followed by the PIT SI-SNR / SI-SNRi metric of the separated
+waveforms against the known sources on the device (what the reference's test loop computes per utterance,
+engine.py:131) and the 3-scalar RCCL all-reduce of ``[sum SI-SNR, sum SI-SNRi, count]`` - the only collective of the
+path (north_star: "RCCL over xGMI for the optional PIT/SI-SNR reduction").  With N ranks every rank runs its own
+batch of 32 (weak scaling); there is no collective on the data path.  ``--variant SepReformer_Large_DM_WHAMR``
+measures BASELINE configs[3]; ``--mode train`` measures configs[4] (forward + criteria + backward + clip + AdamW,
+gradient all-reduce over RCCL).  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      dominant kernel = the fused GCFN block (gcfn_fused_kernel, ~1/3 of the step; 56 launches per
-                forward with the aux heads): default precision bf16x3 -> bound "mfma" against the dense bf16 MFMA
-                peak, achieved = 3 x algorithmic projection FLOPs (the split-fp32 products) / launch time
-                measured with hipEvents on the launch stream inside the timed region; the fp32-equivalent rate
-                and the HBM-side rate ride along.  With --precision fp32 the dominant kernel is the f32-MFMA
-                GCFN up-projection (gemm_kernel<PRO_NORM,EPI_DWGLU,1>) against the 157.3 TFLOP/s f32 peak.
-  cpu_baseline  the oracle (CPU restatement of the reference, same aten op sequence; kind "port")
-                timed on this host's cores on a bounded sample (B=1, one warm-up + best of 3).
+  roofline      dominant kernel = the GCFN block's kernel (fused for Base: ~40 % of the step, 56 launches per forward).
+                ``achieved`` = ALGORITHMIC fp32 FLOPs of the launches / their hipEvent durations (measured on the launch
+                stream inside the timed region), ``frac`` = achieved / the dense bf16 MFMA peak.  The default
+                arithmetic (bf16x3: every fp32 product = 3 bf16 MFMAs) caps that fraction at ``ceiling`` = 1/3;
+                ``mfma_pipe_frac`` = 3 x achieved / peak is the share of the matrix pipe actually issued.
+                ``traffic`` = HBM bytes per launch from rocprofv3 PMC counters; ``traffic_source`` says where from.
+  cpu_baseline  the oracle (CPU restatement of the reference, same aten op sequence; kind "port") timed on this host's
+                cores on a bounded sample (B=1 best of 3 per thread count; B=8 once when the time budget allows).
 """
 from __future__ import annotations
 
@@ -27,6 +32,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,15 +40,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 METRIC = "utterances/sec (4 s, 8 kHz, 2-spk) SepReformer-Base at 1/2/4/8 MI355X"
-VARIANT = "SepReformer_Base_WSJ0"
+DEFAULT_VARIANT = "SepReformer_Base_WSJ0"
 SAMPLES = 32000
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA, same table (2495 TF measured)
 HBM_PEAK_GBS = 8000.0                  # HBM3E spec (6.29 TB/s measured copy), same table
-GFLOP_PER_UTT_MAIN, GFLOP_PER_UTT_FULL = 164.87, 182.16   # SURVEY.md section 8d (4 s, Base)
+# algorithmic GFLOP per 4 s utterance (main heads, with the 4 aux heads): SURVEY.md section 8d
+GFLOP_PER_UTT = {"SepReformer_Base_WSJ0": (164.87, 182.16), "SepReformer_Large_DM_WHAMR": (633.3, 684.14),
+                 "SepReformer_Large_DM_WSJ0": (633.3, 684.14), "SepReformer_Large_DM_WHAM": (633.3, 684.14)}
 
 
 def physical_cores() -> int:
@@ -64,88 +70,147 @@ def physical_cores() -> int:
         return os.cpu_count() or 1
 
 
-def cpu_baseline(cfg, max_threads: int):
-    """Oracle forward on the host cores, bounded sample: B=1, 4 s.  aten's intra-op threading stops
-    scaling (and then regresses) long before a 2-socket host is full for these small ops, so the thread
-    count is swept and the FASTEST setting is reported (1 warm-up + best of 2 per setting, ~20-30 s)."""
+def cpu_baseline(cfg, max_threads: int, budget_s: float = 45.0):
+    """Oracle forward on the host cores, bounded sample (SURVEY.md section 8d protocol within a time budget): B=1 x 4 s
+    with 1 warm-up + best of 3 per thread count (aten's intra-op threading stops scaling long before a 2-socket host
+    is full for these small ops, so the count is swept and the FASTEST setting reported), then B=8 once at that count
+    if the budget allows."""
+    import torch
     from oracle import sepreformer_oracle as orc
     from sepreformer_amd.synth import synth_mixture, synth_state_dict
     sd = synth_state_dict(cfg, 0)
-    x = synth_mixture(1, SAMPLES, seed=1234)
-    sweep, results = sorted({t for t in (8, 16, 32, 64, max_threads) if t <= max_threads}), {}
-    t_budget = time.perf_counter() + 45.0
+    x = synth_mixture(8, SAMPLES, seed=1234)
+    sweep, results = sorted({t for t in (8, 16, 32, max_threads) if t <= max_threads}), {}
+    t_end = time.perf_counter() + budget_s
     with torch.inference_mode():
         for th in sweep:
-            if time.perf_counter() > t_budget and results:
+            if time.perf_counter() > t_end - 8.0 and results:
                 break
             torch.set_num_threads(th)
-            orc.model_forward(sd, cfg, x)
+            orc.model_forward(sd, cfg, x[:1])
             best = float("inf")
-            for _ in range(2):
+            for _ in range(3):
                 t0 = time.perf_counter()
-                orc.model_forward(sd, cfg, x)
+                orc.model_forward(sd, cfg, x[:1])
                 best = min(best, time.perf_counter() - t0)
             results[th] = best
-    th = min(results, key=results.get)
-    return {"value": round(1.0 / results[th], 4), "unit": "utt/s", "cores": th, "kind": "port",
-            "sample": f"oracle.model_forward (main + aux heads), B=1 x {SAMPLES} samples, fp32, 1 warm-up + best of 2 "
-                      f"per thread count; seconds by threads: " + ", ".join(f"{k}:{v:.2f}" for k, v in results.items())
-                      + f"; host has {physical_cores()} physical / {os.cpu_count()} logical cores"}
+        th = min(results, key=results.get)
+        b8 = None
+        if time.perf_counter() + 9.0 * results[th] < t_end:
+            torch.set_num_threads(th)
+            t0 = time.perf_counter()
+            orc.model_forward(sd, cfg, x)
+            b8 = time.perf_counter() - t0
+    rec = {"value": round(1.0 / results[th], 4), "unit": "utt/s", "cores": th, "kind": "port",
+           "sample": f"oracle.model_forward (main + aux heads), fp32; B=1 x {SAMPLES} samples: 1 warm-up + best of 3 per "
+                     f"thread count, seconds by threads: " + ", ".join(f"{k}:{v:.2f}" for k, v in results.items())
+                     + (f"; B=8 once at {th} threads: {b8:.2f} s = {8.0 / b8:.3f} utt/s" if b8 else "; B=8 skipped (time budget)")
+                     + f"; host has {physical_cores()} physical / {os.cpu_count()} logical cores"}
+    if b8:
+        rec["value_b8"] = round(8.0 / b8, 4)
+    return rec
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (default 32; 4 in train mode)")
+    ap.add_argument("--variant", default=DEFAULT_VARIANT, help="model variant (models/<variant>/configs.yaml)")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary heads (NOT the reference's forward)")
-    ap.add_argument("--no-alt-precision", action="store_true", help="skip the second-precision side measurement")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=None,
+    ap.add_argument("--no-alt-precision", action="store_true", help="skip the second-precision / latency side measurements")
+    ap.add_argument("--no-metric", action="store_true", help="skip the per-step PIT SI-SNR metric + RCCL reduction")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default=None,
                     help="projection arithmetic (default: the package default / SEPR_PRECISION)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: run N ranks of this script under torch.distributed.run."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if args.mode == "train":
+        from sepreformer_amd import train_bench
+        return train_bench.main(args)
+
+    import torch
     from sepreformer_amd import dist as sdist
     from sepreformer_amd import lib as L
     from sepreformer_amd.config import VARIANTS
+    from sepreformer_amd.criterion import pit_sisnr
     from sepreformer_amd.model import Model
-    from sepreformer_amd.synth import synth_mixture
+    from sepreformer_amd.synth import synth_sources
 
     rank, world, local = sdist.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the separator path)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     lib = L.load()
 
-    cfg = VARIANTS[VARIANT]
+    variant = args.variant
+    cfg = VARIANTS[variant]
     model = Model.from_config(cfg, init_seed=0, precision=args.precision).load_synthetic_(0).eval().to(dev)
     precision = model.precision
     model.compute_aux = not args.no_aux
-    B = args.batch
+    B = args.batch or 32
     # each rank separates its own utterances: seeds 1234 + global utterance index
-    x = synth_mixture(B, SAMPLES, seed=1234 + rank * B).to(dev)
+    src = torch.from_numpy(synth_sources(B, SAMPLES, seed=1234 + rank * B)).to(dev)        # [B, 2, T]
+    x = src.sum(1).contiguous()
+    tgt = src.permute(1, 0, 2).contiguous()                                                 # [S, B, T]
+    metric_acc = torch.zeros(3, dtype=torch.float64, device=dev)
+    count = torch.tensor(float(B), dtype=torch.float64, device=dev)
 
     def step():
-        return model(x)
+        out = model(x)
+        if not args.no_metric:
+            # the reference's test-loop metric on the device (engine.py:131) + the path's only collective
+            est = torch.stack(out[0], 0)
+            m = pit_sisnr(est, tgt[..., : est.shape[-1]], mixture=x[..., : est.shape[-1]])
+            acc = torch.stack([-m["loss"].double().sum(), m["sisnri"].double().sum(), count])
+            metric_acc.copy_(sdist.reduce_metric_sums(acc))
+        return out
 
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize(dev)
 
-    # parity gate in the same run (rank 0's utterance 0 is the committed golden)
-    parity_db = None
-    if rank == 0:
+    # parity gates in the same run (rank 0): utterance 0 against the committed golden waveform, and the north_star gate
+    # |PIT SI-SNR(hip) - PIT SI-SNR(reference)| per utterance over the whole batch (reference values: tests/golden)
+    parity_db = pit_delta = None
+    if rank == 0 and variant == DEFAULT_VARIANT:
         import numpy as np
-        from oracle.sepreformer_oracle import agreement_db
+        from oracle.sepreformer_oracle import agreement_db, pit_si_snr_db
         g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_base_4s.npz"))
         if args.warmup == 0:
             out = step()
         main_out = torch.stack([a[0:1] for a in out[0]], 0).cpu()
         parity_db = round(agreement_db(main_out, torch.from_numpy(g["main"])), 1)
+        gate = os.path.join(ROOT, "tests", "golden", "pit_gate_base_b32.npz")
+        if os.path.exists(gate):
+            ref_pit = np.load(gate)["ref_pit_db"]
+            nb = min(B, len(ref_pit))
+            T_ = out[0][0].shape[-1]
+            got = pit_si_snr_db([a[:nb].cpu() for a in out[0]], [src[:nb, 0, :T_].cpu(), src[:nb, 1, :T_].cpu()])
+            pit_delta = float((got - torch.from_numpy(ref_pit[:nb])).abs().max())
 
     launches_per_step = 56 * 4                  # GCFN launches per forward (56) x sub-batch pipelines; sizes the event pool
     L.check(lib.sepr_prof_start(L.SITE_GCFN_UP, launches_per_step * max(args.steps, 1) + 8), "sepr_prof_start")
@@ -160,92 +225,92 @@ def main():
     n_l, ms, fl = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
     L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
     elapsed = sdist.max_over_ranks(elapsed, dev)
+    rccl_ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
 
     if rank == 0:
+        F = cfg.feat
         utt_per_s = world * B * args.steps / elapsed
-        gflop = GFLOP_PER_UTT_MAIN if args.no_aux else GFLOP_PER_UTT_FULL
-        achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
-        traffic = None
+        gflop = GFLOP_PER_UTT.get(variant, (0.0, 0.0))[0 if args.no_aux else 1]
+        n_launch = max(n_l.value, 1)
+        sec = ms.value / 1e3
+        algo_tf = (fl.value / 1e12) / sec if sec > 0 else 0.0            # algorithmic fp32 FLOPs / launch time
+        fused = precision == "bf16x3" and F in (64, 128)
+        # rows per launch: the fused kernel reports 18F^2 + 36F FLOPs per row (both projections + the conv), the generic
+        # up-projection 2 * 6F * F per row
+        rows = fl.value / (18.0 * F * F + 36.0 * F) if fused else fl.value / (12.0 * F * F)
+        algo_bytes_launch = rows / n_launch * 8.0 * F if fused else None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_gcfn_up.json")
-        if os.path.exists(pmc):
+        if fused and variant == DEFAULT_VARIANT and os.path.exists(pmc):
             with open(pmc) as f:
                 pmc_rec = json.load(f)
-            traffic = pmc_rec.get("hbm_bytes_per_launch")
             ratio = pmc_rec.get("traffic_over_algorithmic")
-            if ratio and precision == "bf16x3" and fl.value > 0 and n_l.value > 0:
-                # PMC bytes per algorithmic byte (measured on full-batch launches) x this run's algorithmic bytes per launch
-                rows_l = fl.value / (18.0 * cfg.feat * cfg.feat + 36.0 * cfg.feat) / n_l.value
-                traffic = round(ratio * rows_l * 8.0 * cfg.feat)
-        n_launch = max(n_l.value, 1)
+            if ratio and algo_bytes_launch:
+                # PMC bytes per algorithmic byte (rocprofv3 FETCH_SIZE / WRITE_SIZE passes on full-batch launches,
+                # tools/pmc_traffic.sh) x this run's algorithmic bytes per launch
+                traffic = round(ratio * algo_bytes_launch)
+                traffic_src = ("static: profiles/pmc_gcfn_up.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                               f"tools/pmc_traffic.sh, collected {pmc_rec.get('collected', 'in round 1')}); not re-measured in this run")
         if precision == "fp32":
             dtype = "f32"
-            roof = {"kernel": "gemm_kernel<PRO_NORM,EPI_DWGLU,1> (GCFN F->6F projection: LayerNorm prologue, f32 MFMA, "
-                              "depthwise-conv+GLU epilogue)",
-                    "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic}
+            peak, mult, ceiling = FP32_MFMA_PEAK_TFLOPS, 1.0, 1.0
+            kern = ("gemm_kernel<PRO_NORM,EPI_DWGLU,1> (GCFN F->6F projection: LayerNorm prologue, f32 MFMA, "
+                    "depthwise-conv+GLU epilogue)")
         else:
-            # the fused GCFN kernel (one launch per GCFN block: LayerNorm, F->6F, depthwise conv + GLU, 3F->F,
-            # LayerScale, residual).  Per frame row it moves 8F bytes of HBM (read x, write y, fp32) and issues
-            # 3 bf16 MFMA products per algorithmic multiply-add (split-fp32): 3 * 18F^2 * 2 / 8F = 864 bf16 FLOP
-            # per HBM byte at F=128, far above the machine balance (2500 TF / 8 TB/s = 312), so the bf16 matrix
-            # pipe is the roof.  achieved = bf16 MFMA FLOP/s actually required by the arithmetic (3 x the
-            # algorithmic projection FLOPs) over the HIP-event launch time; the fp32-equivalent algorithmic rate
-            # and the HBM-side rate are reported next to it.
-            F = cfg.feat
-            flop_row = 18.0 * F * F + 36.0 * F            # what launch_gcfn_fused reports per row
-            rows = fl.value / flop_row
-            sec = ms.value / 1e3
-            mfma_tf = 3.0 * rows * 18.0 * F * F / 1e12 / sec if sec > 0 else 0.0
+            mult = 3.0 if precision == "bf16x3" else 1.0
+            peak, ceiling = BF16_MFMA_PEAK_TFLOPS, 1.0 / mult
+            dtype = ("bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)"
+                     if precision == "bf16x3" else "bf16 operands, fp32 accumulate")
+            kern = ("gcfn_fused3_kernel<F,2,4> (and its <F,1,6> instantiation for launches under 17000 rows; whole GCFN block in "
+                    "one launch: LayerNorm, F->6F MFMA, depthwise conv k=3 + GLU, 3F->F MFMA, LayerScale, residual)"
+                    if fused else
+                    "gemm_x3_kernel<PRO_NORM,EPI_DWGLU,1> (GCFN F->6F projection of the generic path: LayerNorm prologue, "
+                    "bf16x3 MFMA, depthwise-conv+GLU epilogue)")
+        # matrix FLOPs only (the conv's 36F per row ride on the VALU) for the pipe-occupancy figure
+        mfma_tf = mult * (rows * 18.0 * F * F if fused else fl.value) / 1e12 / sec if sec > 0 else 0.0
+        roof = {"kernel": kern, "bound": "mfma", "achieved": round(algo_tf, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(algo_tf / peak, 4), "frac_algorithmic": round(algo_tf / peak, 4),
+                "mfma_pipe_frac": round(mfma_tf / peak, 4), "ceiling": round(ceiling, 4),
+                "frac_of_ceiling": round(algo_tf / peak / ceiling, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "launches": int(n_l.value), "avg_launch_ms": round(ms.value / n_launch, 4),
+                "algorithmic_gflop_per_launch": round(fl.value / 1e9 / n_launch, 3)}
+        if algo_bytes_launch:
             gbs = rows * 8.0 * F / 1e9 / sec if sec > 0 else 0.0
-            dtype = "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)"
-            roof = {"kernel": "gcfn_fused3_kernel<128,2,4> (and its <128,1,6> instantiation for launches under 17000 rows; whole GCFN block in one launch: LayerNorm, F->6F bf16x3 MFMA, "
-                              "depthwise conv k=3 + GLU, 3F->F bf16x3 MFMA, LayerScale, residual)",
-                    "bound": "mfma", "achieved": round(mfma_tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(mfma_tf / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": round(rows / n_launch * 8.0 * F),
-                    "algorithmic_fp32_tflops": round(achieved, 2),
-                    "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
-        roof.update({"launches": int(n_l.value), "avg_launch_ms": round(ms.value / n_launch, 4),
-                     "algorithmic_gflop_per_launch": round(fl.value / 1e9 / n_launch, 3)})
-        if getattr(model, "pipelines", 1) > 1 and B >= 8 * model.pipelines:
-            # the timed region runs the batch as `pipelines` half-size sub-batches on separate streams: launches of the
-            # same kernel overlap on the device, so each one's event-to-event duration includes the time it shares
-            # the CUs with its twin.  The figures of the kernel running ALONE (one pipeline, 2 untimed steps) go
-            # next to them; `value` always comes from the timed region above.
-            model.pipelines, saved = 1, model.pipelines
-            L.check(lib.sepr_prof_start(L.SITE_GCFN_UP, launches_per_step * 2 + 8), "sepr_prof_start")
-            step(); step()
-            torch.cuda.synchronize(dev)
-            n2, ms2, fl2 = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
-            L.check(lib.sepr_prof_stop(C.byref(n2), C.byref(ms2), C.byref(fl2)), "sepr_prof_stop")
-            model.pipelines = saved
-            if ms2.value > 0 and n2.value > 0:
-                scale = 3.0 * (18.0 * cfg.feat * cfg.feat) / (18.0 * cfg.feat * cfg.feat + 36.0 * cfg.feat) if precision == "bf16x3" else 1.0
-                peak = BF16_MFMA_PEAK_TFLOPS if precision == "bf16x3" else FP32_MFMA_PEAK_TFLOPS
-                tf = scale * (fl2.value / 1e12) / (ms2.value / 1e3)
-                roof["exclusive"] = {"achieved": round(tf, 1), "frac": round(tf / peak, 4), "launches": int(n2.value),
-                                     "avg_launch_ms": round(ms2.value / n2.value, 4),
-                                     "note": "same kernel, single pipeline (launches do not share the device)"}
-            roof["pipelines"] = saved
+            roof.update({"algorithmic_bytes_per_launch": round(algo_bytes_launch), "hbm_gbs": round(gbs, 1),
+                         "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
+        cfg_idx = {DEFAULT_VARIANT: 1 if world == 1 else 2, "SepReformer_Large_DM_WHAMR": 3}.get(variant)
+        acc = metric_acc.cpu()
         rec = {
-            "metric": METRIC, "value": round(utt_per_s, 3), "unit": "utt/s", "n_gpus": world,
+            "metric": METRIC if variant == DEFAULT_VARIANT else METRIC.replace("SepReformer-Base", variant),
+            "value": round(utt_per_s, 3), "unit": "utt/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": f"{VARIANT} inference, batch={B} per GPU, 4 s @ 8 kHz, 2 speakers "
-                                   f"(BASELINE.json configs[{1 if world == 1 else 2}])",
+            "config": {"workload": f"{variant} inference, batch={B} per GPU, 4 s @ 8 kHz, 2 speakers"
+                                   + (f" (BASELINE.json configs[{cfg_idx}])" if cfg_idx else ""),
                        "batch_per_gpu": B, "samples": SAMPLES, "aux_heads": not args.no_aux, "precision": precision,
-                       "weights": "synthetic seed 0 (O(1) LayerScale)", "parallelism": f"utterance-sharded x{world}"},
+                       "weights": "synthetic seed 0 (O(1) LayerScale)", "parallelism": f"utterance-sharded x{world}",
+                       "step": "Model.forward (main + aux heads)" + ("" if args.no_metric else
+                               " + device PIT SI-SNR/SI-SNRi of the batch + 3-scalar all-reduce")},
             "parity_db_vs_golden": parity_db,
+            "pit_si_snr_max_abs_delta_db": None if pit_delta is None else float(f"{pit_delta:.3e}"),
+            "rccl_ranks": rccl_ranks, "collective_backend": backend,
+            "reduced_metric": None if args.no_metric else {
+                "utterances": int(acc[2].item()), "mean_pit_si_snr_db": round(float(acc[0] / acc[2]) / cfg.num_spks, 4),
+                "mean_si_snri_db": round(float(acc[1] / acc[2]) / cfg.num_spks, 4),
+                "note": "sum over ranks of the last step's per-utterance metric (random weights: values are not a quality claim)"},
             # whole-forward algorithmic rate per GPU (fp32-equivalent FLOPs of the reference's op list) and the
-            # fraction of the matrix pipe it needs in this arithmetic (bf16x3 issues 3 bf16 MFMA FLOPs per FLOP)
+            # fraction of the matrix pipe it needs in this arithmetic
             "model_tflops": round(utt_per_s * gflop / 1e3 / world, 2),
-            "model_mfma_frac": round(utt_per_s * gflop / 1e3 / world * (3.0 / BF16_MFMA_PEAK_TFLOPS if precision == "bf16x3"
-                                                                         else 1.0 / FP32_MFMA_PEAK_TFLOPS), 4),
+            "model_frac_algorithmic": round(utt_per_s * gflop / 1e3 / world / peak, 4),
+            "model_mfma_frac": round(utt_per_s * gflop / 1e3 / world * mult / peak, 4),
             "roofline": roof,
         }
-        if world == 1 and not args.no_alt_precision:
+        if world == 1 and not args.no_alt_precision and variant == DEFAULT_VARIANT:
+            from oracle.sepreformer_oracle import agreement_db
             # the other projection arithmetic on the same workload (2 timed steps): exact f32 MFMA vs bf16x3
-            alt = "fp32" if precision == "bf16x3" else "bf16x3"
+            alt = "fp32" if precision != "fp32" else "bf16x3"
             model.precision = alt
             step(); torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
@@ -259,9 +324,8 @@ def main():
                                                                               torch.from_numpy(g["main"])), 1)}
             model.precision = precision
         if world == 1 and not args.no_alt_precision:
-            # single-utterance latency: B=1 x 4 s, eager launches vs the captured hipGraph
+            # single-utterance latency: B=1 x 4 s through the PUBLIC call, model(x)
             x1 = x[:1].contiguous()
-            eng = model.engine()
 
             def med_ms(fn, reps=15):
                 ts = []
@@ -273,13 +337,17 @@ def main():
                     ts.append(time.perf_counter() - t)
                 return round(1e3 * sorted(ts)[len(ts) // 2], 3)
 
-            eng.forward(x1, with_aux=True)
-            eager = med_ms(lambda: eng.forward(x1, with_aux=True))
-            eng.forward_graphed(x1, with_aux=True)
-            graphed = med_ms(lambda: eng.forward_graphed(x1, with_aux=True))
-            rec["latency_b1"] = {"unit": "ms per 4 s utterance (batch 1, full forward incl. aux heads)",
+            model(x1)
+            eager = med_ms(lambda: model(x1))
+            model.use_graphs = True
+            try:
+                model(x1)
+                graphed = med_ms(lambda: model(x1))
+            finally:
+                model.use_graphs = False
+            rec["latency_b1"] = {"unit": "ms per 4 s utterance (batch 1, model(x): full forward incl. aux heads)",
                                  "eager": eager, "hipgraph": graphed}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and variant == DEFAULT_VARIANT:
             threads = int(os.environ.get("SEPR_CPU_THREADS", str(physical_cores())))
             rec["cpu_baseline"] = cpu_baseline(cfg, threads)
             rec["speedup_vs_cpu"] = round(utt_per_s / rec["cpu_baseline"]["value"], 1)

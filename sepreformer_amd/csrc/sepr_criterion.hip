@@ -95,7 +95,12 @@ __global__ __launch_bounds__(64) void pit_finalize_kernel(const double* __restri
   const double n = (double)T;
   double zz[NV];                                        // zero-mean energies
 #pragma unroll
-  for (int i = 0; i < NV; ++i) zz[i] = q[NV + i] - q[i] * q[i] / n;
+  for (int i = 0; i < NV; ++i) {
+    // sum(x^2) - sum(x)^2/n of a constant (DC-only) signal can cancel to a slightly negative number; the
+    // reference subtracts the mean first, so its energies are >= 0: clamp, or sqrt() would return NaN
+    const double e = q[NV + i] - q[i] * q[i] / n;
+    zz[i] = e > 0.0 ? e : 0.0;
+  }
   double snr_l[S][S], snr_i[S][S], snr_x[S];
 #pragma unroll
   for (int k = 0; k < S; ++k) {
@@ -213,7 +218,8 @@ __global__ __launch_bounds__(64) void mag_scales_kernel(const double* __restrict
 #pragma unroll
     for (int k = 0; k < S; ++k) {
       const double et = q[2 * NV + s * S + k] - q[s] * q[S + k] / n;
-      const double tt = q[NV + S + k] - q[S + k] * q[S + k] / n;
+      double tt = q[NV + S + k] - q[S + k] * q[S + k] / n;
+      tt = tt > 0.0 ? tt : 0.0;                        // cancellation on a DC-only target (see pit_finalize_kernel)
       const double sc = et / (tt + eps);
       scales[(b * S + s) * S + k] = (float)(sc < 1e-2 ? 1e-2 : sc);             // torch.clamp(scale, min=1e-2)
     }

@@ -434,331 +434,11 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Version 4: the v3 wave program in a software-pipelined workgroup.  Ablations of v3 (profiles/r01_v9_*): of its
-// time 17 % is the per-tile prologue/epilogue, 16 % waiting for weight chunks to land, 13 % its three barriers per
-// chunk.  Here ONE 8-wave workgroup owns a CU and 138 KB of LDS:
-//   * both weight buffers are doubled (2 x 52 KB): the LDS-DMA of chunk c+1 is issued at the top of chunk c and has
-//     the whole chunk to land; ONE barrier per chunk (it publishes chunk c and retires chunk c-1's buffers);
-//   * the copy of the NEXT tile's chunk 0 is issued at the top of the last chunk, and the next tile's frames are
-//     requested (into the registers the bf16 frames just vacated) before the epilogue, so both latencies fly under
-//     the epilogue's own traffic;
-//   * the epilogue has its own 34 KB staging tile, no longer aliasing the weight buffers.
-// ---------------------------------------------------------------------------------------------------------
-template <int F, int MT, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 4) void gcfn_fused4_kernel(const GcfnFusedArgs a) {
-  constexpr int NT = 64 * NW;
-  constexpr int GF_ROWS_OUT = 16 * MT - 2;
-  constexpr int GF_TILE = NW * GF_ROWS_OUT;
-  constexpr int EH = (16 * MT * NW) / 64;
-  constexpr int KS = F / 32;
-  constexpr int NCH = 3 * F / 32;
-  constexpr int FT = F / 16;
-  constexpr int W1F_U4 = 4 * KS * 2 * 64;
-  constexpr int CS_U4 = 256;
-  constexpr int W1_U4 = W1F_U4 + CS_U4;          // global chunk stride of w1p (fragments + constants)
-  constexpr int W2_U4 = FT * 2 * 64;
-  constexpr int BUF_U4 = W1_U4 + W2_U4;          // one LDS weight buffer: [w1 fragments | constants | w2 fragments]
-  constexpr int OS = F + 4;
-  static_assert(NCH % 2 == 0, "the next tile's chunk 0 goes to buffer 0 while the last chunk reads buffer 1");
-  __shared__ __attribute__((aligned(16))) uint4 wl[2 * BUF_U4];
-  __shared__ __attribute__((aligned(16))) float Os[64 * OS];
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int fi = lane & 15, fg = lane >> 4;
-  const int ntiles = (a.M + GF_TILE - 1) / GF_TILE;
-  const uint4* const W1g = static_cast<const uint4*>(a.w1p);
-  const uint4* const W2g = static_cast<const uint4*>(a.w2p);
-
-  auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {   // nblk 1 KiB blocks, dealt round-robin to the waves
-    unsigned loff = (unsigned)lane * 16u;
-    asm volatile("" : "+v"(loff));
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if (i * NW >= nblk) break;
-      const int blk = i * NW + w;
-      if (blk < nblk) {
-        const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
-      }
-    }
-  };
-  auto dma_chunk = [&](int c) {                   // chunk c -> buffer c & 1
-    uint4* buf = wl + (c & 1) * BUF_U4;
-    dma(W1g + (long long)c * W1_U4, buf, W1_U4 / 64);
-    dma(W2g + (long long)c * W2_U4, buf + W1_U4, W2_U4 / 64);
-  };
-  // frames of a tile, raw fp32 in B-fragment order (lane = frame MT*fi + mt, 8 channels per K step and lane group)
-  auto load_rows = [&](int tile, float (&v)[MT][KS][8]) {
-    const int mw0 = tile * GF_TILE + w * GF_ROWS_OUT - 1;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = mw0 + MT * fi + mt;
-      const bool valid = (m >= 0 && m < a.M);
-      const float* xp = a.x + (long long)(valid ? m : 0) * F + 8 * fg;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const float4 p = ld4(xp + 32 * ks), q = ld4(xp + 32 * ks + 4);
-        v[mt][ks][0] = p.x; v[mt][ks][1] = p.y; v[mt][ks][2] = p.z; v[mt][ks][3] = p.w;
-        v[mt][ks][4] = q.x; v[mt][ks][5] = q.y; v[mt][ks][6] = q.z; v[mt][ks][7] = q.w;
-      }
-    }
-  };
-
-#ifndef SEPR_GF4_PREFETCH_ROWS
-#define SEPR_GF4_PREFETCH_ROWS 0   // 1: request the next tile's frames before the epilogue (needs 64 more live registers;
-#endif                             //    hipcc spills them right after the loads, which exposes the latency it was to hide)
-  float xraw[MT][KS][8];
-  int tile = blockIdx.x;
-  if (tile < ntiles) {
-    if (SEPR_GF4_PREFETCH_ROWS) load_rows(tile, xraw);
-    dma_chunk(0);
-  }
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int next_tile = tile + gridDim.x;
-    if (!SEPR_GF4_PREFETCH_ROWS) load_rows(tile, xraw);
-    // ---- LayerNorm + split of this tile's frames (already in registers) ------------------------------------------
-    const int mw0 = tile * GF_TILE + w * GF_ROWS_OUT - 1;       // wave frame 0 (halo)
-    bf16x8 xh[MT][KS], xl[MT][KS];
-    float f0[MT], f2[MT];
-    bool edge_lane = false;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = mw0 + MT * fi + mt;
-      const bool valid = (m >= 0 && m < a.M);
-      const int trow = valid ? m % a.T : -2;
-      f0[mt] = (trow == 0) ? 0.f : 1.f;
-      f2[mt] = (trow == a.T - 1) ? 0.f : 1.f;
-      edge_lane = edge_lane || trow == 0 || trow == a.T - 1;
-      float s = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += xraw[mt][ks][e];
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      const float mean = s * (1.0f / F);
-      float d = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float c = xraw[mt][ks][e] - mean;
-          d = fmaf(c, c, d);
-        }
-      d += __shfl_xor(d, 16, 64);
-      d += __shfl_xor(d, 32, 64);
-      const float rstd = valid ? 1.0f / sqrtf(d * (1.0f / F) + a.eps) : 0.f;   // invalid frames: exactly zero
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 h, l;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xn = (xraw[mt][ks][e] - mean) * rstd;
-          const __bf16 hh = (__bf16)xn;
-          h[e] = hh;
-          l[e] = (__bf16)(xn - (float)hh);
-        }
-        xh[mt][ks] = h;
-        xl[mt][ks] = l;
-      }
-    }
-    const bool edge = __builtin_amdgcn_ballot_w64(edge_lane) != 0ull;   // wave-uniform
-    f32x4 acc[FT][MT];
-#pragma unroll
-    for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto chunks = [&](auto edge_c) {
-      constexpr bool EDGE = decltype(edge_c)::value;
-      for (int c = 0; c < NCH; ++c) {
-        // chunk c has landed (every wave waits for its own copies, the barrier publishes them) and every wave is
-        // done with chunk c-1, whose buffers the next copy overwrites
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (c + 1 < NCH) {
-          dma_chunk(c + 1);
-        } else if (next_tile < ntiles) {
-          dma_chunk(0);                          // NCH is even: the last chunk reads buffer 1
-        }
-        const uint4* const w1s = wl + (c & 1) * BUF_U4;
-        const uint4* const w2s = w1s + W1_U4;
-        auto ld_up = [&](int j, int g, uint4 (&d)[2]) {   // g = 2*ks + (0 value tile | 1 gate tile)
-          const uint4* p = w1s + ((((g & 1) * 2 + j) * KS + (g >> 1)) * 2) * 64 + lane;
-          d[0] = p[0];
-          d[1] = p[64];
-        };
-        auto ld_dn = [&](int ft, uint4 (&d)[2]) {
-          const uint4* p = w2s + (ft * 2) * 64 + lane;
-          d[0] = p[0];
-          d[1] = p[64];
-        };
-        bf16x8 gh[MT], gw[MT];          // gated values (bf16 hi / lo) in down-projection k-slot order
-        uint4 fb[3][2];                 // fragment ring: two MFMA groups in flight ahead of the one being multiplied
-        ld_up(0, 0, fb[0]);
-        ld_up(0, 1, fb[1]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float* cs = reinterpret_cast<const float*>(w1s + W1F_U4) + j * 160 + 4 * fg;
-          f32x4 hv[MT], hg[MT];
-          {
-            const float4 bv = ld4(cs), bg = ld4(cs + 16);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              hv[mt] = (f32x4){bv.x, bv.y, bv.z, bv.w};
-              hg[mt] = (f32x4){bg.x, bg.y, bg.z, bg.w};
-            }
-          }
-#pragma unroll
-          for (int g = 0; g < 2 * KS; ++g) {
-            if (g + 2 < 2 * KS) ld_up(j, g + 2, fb[(g + 2) % 3]);
-            __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[g % 3][0]);
-            const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[g % 3][1]);
-            const int ks = g >> 1;
-            if ((g & 1) == 0) {
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hv[mt], 0, 0, 0);
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hv[mt], 0, 0, 0);
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hv[mt], 0, 0, 0);
-            } else {
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hg[mt], 0, 0, 0);
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hg[mt], 0, 0, 0);
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hg[mt], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if (j == 0) {
-            ld_up(1, 0, fb[0]);
-            ld_up(1, 1, fb[1]);
-          } else {
-            ld_dn(0, fb[0]);
-            ld_dn(1, fb[1]);
-          }
-          float gl[MT][4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float wv0 = cs[2 * 16 + r], wv1 = cs[3 * 16 + r], wv2 = cs[4 * 16 + r];
-            const float wg0 = cs[5 * 16 + r], wg1 = cs[6 * 16 + r], wg2 = cs[7 * 16 + r];
-            const float cbv = cs[8 * 16 + r], cbg = cs[9 * 16 + r];
-            float cv[MT], cg[MT], pv[MT], pg[MT], nv[MT], ng[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              cv[mt] = hv[mt][r];
-              cg[mt] = hg[mt][r];
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              pv[mt] = mt > 0 ? cv[mt - 1] : dpp_ror1(cv[MT - 1]);
-              pg[mt] = mt > 0 ? cg[mt - 1] : dpp_ror1(cg[MT - 1]);
-              nv[mt] = mt + 1 < MT ? cv[mt + 1] : dpp_rol1(cv[0]);
-              ng[mt] = mt + 1 < MT ? cg[mt + 1] : dpp_rol1(cg[0]);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              const float a0v = EDGE ? wv0 * f0[mt] : wv0, a2v = EDGE ? wv2 * f2[mt] : wv2;
-              const float a0g = EDGE ? wg0 * f0[mt] : wg0, a2g = EDGE ? wg2 * f2[mt] : wg2;
-              const float val = fmaf(a2v, nv[mt], fmaf(wv1, cv[mt], fmaf(a0v, pv[mt], cbv)));
-              const float gat = fmaf(a2g, ng[mt], fmaf(wg1, cg[mt], fmaf(a0g, pg[mt], cbg)));
-              gl[mt][r] = val * sigmoid_f(gat);
-            }
-          }
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const __bf16 hh = (__bf16)gl[mt][r];
-              gh[mt][4 * j + r] = hh;
-              gw[mt][4 * j + r] = (__bf16)(gl[mt][r] - (float)hh);
-            }
-        }
-#pragma unroll
-        for (int ft = 0; ft < FT; ++ft) {
-          if (ft + 2 < FT) ld_dn(ft + 2, fb[(ft + 2) % 3]);
-          __builtin_amdgcn_sched_barrier(0);
-          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[ft % 3][0]);
-          const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[ft % 3][1]);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[mt], acc[ft][mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gw[mt], acc[ft][mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[mt], acc[ft][mt], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    };
-    if (edge) chunks(bool_c<true>{}); else chunks(bool_c<false>{});
-
-    // ---- the next tile's frames: requested now, consumed after the epilogue --------------------------------------
-    if (SEPR_GF4_PREFETCH_ROWS && next_tile < ntiles) load_rows(next_tile, xraw);
-
-    // ---- epilogue: y = x + ls * (acc + b2), two waves at a time through the staging tile ---------------------------
-    constexpr int WPP = 64 / (16 * MT);   // waves per 64-frame epilogue pass
-    constexpr int Q = F / 4;                 // float4 per row
-    constexpr int RPP = NT / Q;              // rows per pass
-    constexpr int NP = 64 / RPP;
-    static_assert(64 % RPP == 0 && (16 * MT * NW) % 64 == 0 && 64 % (16 * MT) == 0, "epilogue pass partition");
-    const int q4 = tid % Q, rr = tid / Q;
-    const float4 b2 = ld4(a.b2 + 4 * q4), lsv = ld4(a.ls + 4 * q4);
-#pragma unroll 1
-    for (int half = 0; half < EH; ++half) {
-      __syncthreads();                 // previous pass (or the previous tile's last pass) fully read
-      float4 xr[NP];
-      int mrow[NP];
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int row = rr + p * RPP;          // 0..63: WPP waves x 16*MT frames
-        const int ww = WPP * half + row / (16 * MT), lr = row % (16 * MT);
-        const int m = tile * GF_TILE + ww * GF_ROWS_OUT - 1 + lr;
-        const bool ok = lr >= 1 && lr <= GF_ROWS_OUT && m < a.M;
-        mrow[p] = ok ? m : -1;
-        xr[p] = ld4(a.x + (long long)(ok ? m : 0) * F + 4 * q4);
-      }
-      if (w / WPP == half) {
-        float* base = Os + (w % WPP) * (16 * MT) * OS;
-#pragma unroll
-        for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 v = acc[ft][mt];
-            st4(base + (MT * fi + mt) * OS + 16 * ft + 4 * fg, make_float4(v[0], v[1], v[2], v[3]));
-          }
-      }
-      __syncthreads();
-      {
-#pragma clang fp contract(off)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          if (mrow[p] >= 0) {
-            const float4 o = ld4(Os + (rr + p * RPP) * OS + 4 * q4);
-            st4(a.y + (long long)mrow[p] * F + 4 * q4,
-                make_float4(fmaf(o.x + b2.x, lsv.x, xr[p].x), fmaf(o.y + b2.y, lsv.y, xr[p].y),
-                            fmaf(o.z + b2.z, lsv.z, xr[p].z), fmaf(o.w + b2.w, lsv.w, xr[p].w)));
-          }
-        }
-      }
-    }
-  }
-}
-
-#ifndef SEPR_GF_VERSION
-#define SEPR_GF_VERSION 3   // 3: gcfn_fused3_kernel (default), 4: gcfn_fused4_kernel (one workgroup per CU; measured slower)
-#endif
+// (A one-workgroup-per-CU, software-pipelined variant of this kernel - "v4", 8 waves, doubled weight buffers, one
+//  barrier per chunk - was measured 10 % slower and removed in round 2; it lives in git history at 7cf5a73.)
 #ifndef SEPR_GF3_MT
 #define SEPR_GF3_MT 2   // v3 frame tiles per wave: 2 -> 4 waves x 30 frames (2 waves per SIMD), 1 -> 6 waves x 14 frames (3 per SIMD)
 #endif
-#ifndef SEPR_GF4_MT
-#define SEPR_GF4_MT 2   // v4 frame tiles per wave: 2 -> 8 waves x 30 frames (2 waves per SIMD, 256 registers each),
-#endif                  //                         4 -> 4 waves x 62 frames (1 wave per SIMD, 512 registers)
-[[maybe_unused]] constexpr int GF4_MT = SEPR_GF4_MT, GF4_NW = (SEPR_GF4_MT == 4) ? 4 : 8;
 [[maybe_unused]] constexpr int GF3_MT = SEPR_GF3_MT, GF3_NW = (SEPR_GF3_MT == 1) ? 6 : 4;
 
 int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream) {
@@ -767,19 +447,6 @@ int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t strea
   if (a.x == a.y) return SEPR_EINVAL;   // halo frames of a tile are outputs of its neighbours
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
-#if SEPR_GF_VERSION == 4
-  constexpr int tile_rows = GF4_NW * (16 * GF4_MT - 2);
-  const int ntiles = (a.M + tile_rows - 1) / tile_rows;
-  const int cap = persistent_grid() / 2;       // one workgroup per CU
-  const int grid = ntiles < cap ? ntiles : cap;
-  if (F == 128) {
-    hipLaunchKernelGGL((gcfn_fused4_kernel<128, GF4_MT, GF4_NW>), dim3(grid), dim3(64 * GF4_NW), 0, stream, a);
-  } else if (F == 64) {
-    hipLaunchKernelGGL((gcfn_fused4_kernel<64, GF4_MT, GF4_NW>), dim3(grid), dim3(64 * GF4_NW), 0, stream, a);
-  } else {
-    return SEPR_EINVAL;
-  }
-#elif SEPR_GF_VERSION == 3
   // Small launches (fewer 120-frame tiles than workgroup slots, e.g. batch 1 or the bottleneck stage) take the
   // 14-frame-wave instantiation: 1.4x more, shorter tiles.  A frame's arithmetic does not depend on the tiling, so the
   // result is bit-identical; for large launches the 30-frame form is 1.7x faster per frame (weight re-use).
@@ -812,7 +479,6 @@ int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t strea
     return SEPR_EINVAL;
   }
   }
-#endif
   // algorithmic FLOPs of the block: both projections + the depthwise conv
   if (timed) prof_end(slot, (double)a.M * (2.0 * F * 6 * F + 2.0 * 3 * 6 * F + 2.0 * 3 * F * F), stream);
   SEPR_CHECK_LAUNCH("gcfn_fused_kernel");

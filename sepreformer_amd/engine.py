@@ -223,6 +223,8 @@ class SeparatorEngine:
         for st in self._peer_streams:
             main.wait_stream(st)
         if errors:
+            for p in self._peers:                    # peers that did not raise themselves still hold their inputs
+                p._release_held()
             raise errors[0]
         wav = torch.cat([r[0] for r in results], dim=1)
         aux = [torch.cat([r[1][j] for r in results], dim=1) for j in range(len(results[0][1]))]
@@ -259,6 +261,20 @@ class SeparatorEngine:
     @torch.no_grad()
     def forward(self, x: torch.Tensor, with_aux: bool = True, taps: Optional[dict] = None):
         """x ``[B,T]`` fp32 on the HIP device -> (wav ``[S,B,T']``, list of R aux ``[S,B,T']`` or ``[]``)."""
+        try:
+            return self._forward(x, with_aux, taps)
+        except BaseException:
+            # a launch that raised mid-forward must not leave the side-stream inputs (encoder output, stage
+            # activations: hundreds of MB at B=32) referenced until the next successful forward
+            self._release_held()
+            raise
+
+    def _release_held(self):
+        if getattr(self, "_side_on", False) and self._side is not None and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+        self._held.clear()
+
+    def _forward(self, x: torch.Tensor, with_aux: bool = True, taps: Optional[dict] = None):
         c, pk, lib = self.cfg, self.pk, self.lib
         if x.dim() != 2:
             raise RuntimeError("Input can only be 2 dimensional: [batch, samples]")

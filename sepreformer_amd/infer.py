@@ -55,9 +55,12 @@ def peak_normalise(x: np.ndarray, peak: float) -> np.ndarray:
 
 
 def write_wav(path: str, x: np.ndarray, fs: int) -> None:
-    """float waveform -> PCM16 file (soundfile's default subtype for .wav, which the reference relies on)."""
+    """float waveform -> PCM16 file (soundfile's default subtype for .wav, which the reference relies on).
+    libsndfile's float -> short conversion is ``lrint(x * 0x7FFF)`` (normalised floats, round-half-even); the
+    same scale is used here so the written files are sample-identical to the reference's ``sf.write`` output
+    (the harness peak-normalises to 0.9, reference engine.py:168-172, so nothing clips; the clip is a guard)."""
     from scipy.io import wavfile
-    pcm = np.clip(np.round(np.asarray(x, dtype=np.float64) * 32768.0), -32768, 32767).astype(np.int16)
+    pcm = np.clip(np.rint(np.asarray(x, dtype=np.float64) * 32767.0), -32768, 32767).astype(np.int16)
     wavfile.write(path, fs, pcm)
 
 

@@ -18,8 +18,11 @@ batch-statistics BatchNorm, autograd through the kernels) is a later row of SURV
 """
 from __future__ import annotations
 
+import itertools
 import os
-from typing import List, Optional, Tuple
+import threading
+import weakref
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -30,6 +33,17 @@ from .params import build_param_tree
 
 
 DEFAULT_PRECISION = "bf16x3"
+
+# (device index, precision, weights key, id of the owning module) -> PackedModel; see Model._packed
+_PACK_CACHE: Dict[tuple, PackedModel] = {}
+_PACK_LOCK = threading.Lock()
+_UIDS = itertools.count(1)
+
+
+def _evict_packed(uid: int) -> None:
+    with _PACK_LOCK:
+        for k in [k for k in _PACK_CACHE if k[3] == uid]:
+            del _PACK_CACHE[k]
 
 
 class Model(torch.nn.Module):
@@ -44,7 +58,12 @@ class Model(torch.nn.Module):
         self.num_spks = num_spks
         self._kinds = build_param_tree(self, self.cfg, seed=init_seed)
         self._engine: Optional[SeparatorEngine] = None
-        self._engine_key = None
+        self._pack_epoch = 0
+        # replicas made by torch.nn.parallel.replicate share this list (shallow __dict__ copy) and reach the original
+        # module - whose parameters carry the version counters - through it
+        self._origin = [weakref.ref(self)]
+        self._uid = next(_UIDS)                      # cache key component (ids are recycled, uids are not)
+        weakref.finalize(self, _evict_packed, self._uid)
         self.compute_aux = True    # the reference evaluates the aux heads in every forward (model.py:47-52)
         # latency mode: replay the forward from a captured hipGraph per input shape (engine.forward_graphed); the
         # returned tensors are then static buffers that the next same-shape call overwrites
@@ -68,24 +87,84 @@ class Model(torch.nn.Module):
         self.load_state_dict(synth_state_dict(self.cfg, seed), strict=True)
         return self
 
-    def _weights_key(self):
-        # packed copies are caches keyed by (storage, version): optimizer steps / load_state_dict bump
-        # ``_version``, ``.to()`` changes ``data_ptr``
-        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+    # ---- packed-weight cache ------------------------------------------------------------------------
+    def _flat_tensors(self) -> List[torch.Tensor]:
+        """Every tensor of the state_dict, in ``param_rows`` order, resolved by attribute walk - works on the
+        replicas ``torch.nn.parallel.replicate`` builds too (their parameters are plain attributes, not
+        ``_parameters`` entries, so ``state_dict()`` / ``parameters()`` do not see them)."""
+        flat = None if self._is_replica_module() else self.__dict__.get("_flat")
+        if flat is None:
+            flat = []
+            for name in self._kinds:
+                node = self
+                for part in name.split("."):
+                    node = getattr(node, part)
+                flat.append(node)
+            if not self._is_replica_module():
+                self.__dict__["_flat"] = flat
+        return flat
 
-    def engine(self) -> SeparatorEngine:
-        dev = next(self.parameters()).device
+    def _is_replica_module(self) -> bool:
+        return bool(getattr(self, "_is_replica", False))
+
+    def _apply(self, fn, *a, **k):          # .to() / .cuda() / .float(): storages move
+        self.__dict__.pop("_flat", None)
+        return super()._apply(fn, *a, **k)
+
+    def invalidate_packed(self) -> None:
+        """Force a re-pack on the next forward.  Needed only after mutations the version counters cannot see
+        (``p.data.copy_()``, ``p.data.mul_()``, re-assigned ``nn.Parameter`` objects)."""
+        self.__dict__.pop("_flat", None)
+        self._pack_epoch += 1
+
+    def _weights_key(self):
+        """Cheap identity of the current weights: packed copies are caches keyed by it.  In-place updates
+        (optimizer steps, ``load_state_dict``, ``p.add_()``) bump a tensor's ``_version`` so the sum changes;
+        ``.to()`` changes the storages (``_apply`` drops the cached list).  ~0.14 ms for Base (1390 tensors)
+        against 2.8 ms for materialising the state_dict; ``.data`` mutations are invisible to it - call
+        ``invalidate_packed()`` after those."""
+        flat = self._flat_tensors()
+        return (flat[0].data_ptr(), flat[-1].data_ptr(), len(flat), sum(t._version for t in flat), self._pack_epoch)
+
+    def _packed(self, dev: torch.device) -> PackedModel:
+        """Packed weights for ``dev``, shared process-wide: keyed by (device, precision, identity of the ORIGINAL
+        module's weights), so the replicas that ``torch.nn.parallel.data_parallel`` rebuilds on every forward
+        (reference engine.py:64,98,130,167 with several device ids) hit the copy packed by an earlier replica on the
+        same device instead of re-packing ~750 tensors per call."""
+        origin = self._origin[0]() if self._is_replica_module() else self
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), self.precision,
+               (origin if origin is not None else self)._weights_key(), self._uid)
+        with _PACK_LOCK:
+            pk = _PACK_CACHE.get(key)
+            if pk is not None:
+                return pk
+        names = list(self._kinds)
+        sd = {n: t.detach() for n, t in zip(names, self._flat_tensors())}
+        with torch.cuda.device(dev):
+            pk = PackedModel(self.cfg, sd, self.precision)
+        with _PACK_LOCK:
+            stale = [k for k in _PACK_CACHE if k[0] == key[0] and k[3] == key[3] and k[1] == key[1] and k != key]
+            for k in stale:                              # older weight versions of the same module on this device
+                del _PACK_CACHE[k]
+            _PACK_CACHE[key] = pk
+        return pk
+
+    def engine(self, device: Optional[torch.device] = None) -> SeparatorEngine:
+        dev = device if device is not None else self._flat_tensors()[0].device
         if dev.type != "cuda":
             raise RuntimeError(
                 "sepreformer_amd.Model computes on an MI355X (HIP) device only; move the module with "
                 ".to('cuda'). There is deliberately no CPU fallback (the CPU restatement lives in oracle/ "
                 "and is test infrastructure).")
-        key = (dev, self.precision, self._weights_key())
-        if self._engine is None or self._engine_key != key:
-            sd = {k: v.detach() for k, v in self.state_dict(keep_vars=True).items()}
+        pk = self._packed(dev)
+        if self._is_replica_module():
+            # replicas are throw-away objects driven by one Python thread each (parallel_apply): a private engine
+            # (workspace, side stream) per call keeps the threads independent
             with torch.cuda.device(dev):
-                self._engine = SeparatorEngine(self.cfg, PackedModel(self.cfg, sd, self.precision), dev)
-            self._engine_key = key
+                return SeparatorEngine(self.cfg, pk, dev)
+        if self._engine is None or self._engine.pk is not pk:
+            with torch.cuda.device(dev):
+                self._engine = SeparatorEngine(self.cfg, pk, dev)
         return self._engine
 
     # ---- forward -------------------------------------------------------------------------------------
@@ -99,7 +178,7 @@ class Model(torch.nn.Module):
             raise RuntimeError("Expected [batch, samples] input")
         if not x.is_cuda:
             raise RuntimeError("input tensor is not on the HIP device (no CPU fallback exists)")
-        eng = self.engine()
+        eng = self.engine(x.device if self._is_replica_module() else None)
         with torch.cuda.device(x.device):
             if self.use_graphs:
                 wav, aux = eng.forward_graphed(x.to(torch.float32), with_aux=self.compute_aux)

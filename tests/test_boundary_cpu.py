@@ -394,3 +394,46 @@ def test_pack_gate_fused_layout(base_sd):
     ln = torch.nn.functional.layer_norm(x, (F,), sd[p + ".block.linear.0.weight"].double(), sd[p + ".block.linear.0.bias"].double(), 1e-5)
     want = ln @ sd[p + ".block.linear.1.weight"].double().t() + sd[p + ".block.linear.1.bias"].double()
     assert orc.agreement_db(got.float(), want.float()) > 95
+
+
+def test_weights_key_and_replica_walk():
+    """Packed weights are caches keyed by a cheap identity of the weights (data_ptr + version sum): in-place updates and
+    ``invalidate_packed`` change it, and the tensors are found by attribute walk so that the parameter-less replicas
+    of ``torch.nn.parallel.replicate`` (reference engine.py:64 with several device ids) resolve them too."""
+    import torch
+    from sepreformer_amd.config import VARIANTS
+    from sepreformer_amd.model import Model
+    m = Model.from_config(VARIANTS["tiny"], init_seed=0)
+    k0 = m._weights_key()
+    assert m._weights_key() == k0
+    with torch.no_grad():
+        m.out_layer.end_conv1x1._modules["2"].bias.add_(1.0)
+    k1 = m._weights_key()
+    assert k1 != k0
+    m.out_layer.end_conv1x1._modules["2"].bias.data.mul_(2.0)      # invisible to version counters ...
+    assert m._weights_key() == k1
+    m.invalidate_packed()                                          # ... hence the explicit switch
+    assert m._weights_key() != k1
+    m.load_state_dict(m.state_dict())
+    assert m._weights_key() != k1
+    names = list(m.state_dict().keys())
+    flat = m._flat_tensors()
+    assert len(flat) == len(names) and all(a is b for a, b in zip(flat, m.state_dict(keep_vars=True).values()))
+    # emulate replicate(): shallow module copies, parameters re-attached as plain tensors
+    mods = list(m.modules())
+    idx = {mm: i for i, mm in enumerate(mods)}
+    reps = [mm._replicate_for_data_parallel() for mm in mods]
+    for i, mm in enumerate(mods):
+        for key, ch in mm._modules.items():
+            setattr(reps[i], key, reps[idx[ch]])
+        for key, p in mm._parameters.items():
+            setattr(reps[i], key, p.detach().clone())
+        for key, b in mm._buffers.items():
+            setattr(reps[i], key, b.clone())
+    rep = reps[0]
+    assert rep._is_replica_module() and len(list(rep.parameters())) == 0
+    rflat = rep._flat_tensors()
+    assert len(rflat) == len(flat) and all(torch.equal(a, b) for a, b in zip(rflat, flat))
+    assert rep._origin[0]() is m and rep._uid == m._uid
+    with pytest.raises(RuntimeError, match="HIP"):
+        rep(torch.zeros(1, 400))                                   # still no CPU fallback

@@ -185,3 +185,27 @@ def test_device_mag_full_batch_and_errors():
     with pytest.raises(RuntimeError):                                           # shorter than one frame
         pit_sisnr_mag(est[..., :300].contiguous().to(dev), src[..., :300].contiguous().to(dev), dft, 512, 128)
     assert L.load().sepr_pit_sisnr_mag_workspace(4, 2, 4000, 512, 128) == 0    # S > 3
+
+
+@pytest.mark.gpu
+def test_device_constant_signals_stay_finite():
+    """DC-only targets / mixtures: sum(x^2) - sum(x)^2/n cancels to ~0 (possibly slightly negative) in the moment form;
+    the reference subtracts the mean first so its energies are exactly >= 0 and its loss is finite."""
+    from sepreformer_amd.criterion import pit_sisnr
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B, T = 3, 8000
+    est = [torch.randn(B, T), torch.randn(B, T)]
+    src = [torch.full((B, T), 0.3), torch.randn(B, T)]                 # target 0 is a constant
+    src[0][1] = 1.0e3                                                  # large DC: worst cancellation
+    mix = torch.full((B, T), -0.7)                                     # constant mixture
+    out = pit_sisnr([e.to(dev) for e in est], [s.to(dev) for s in src], mixture=mix.to(dev))
+    for k in ("loss", "sisnri"):
+        assert torch.isfinite(out[k]).all(), (k, out[k])
+    mean64, per64, _ = co.pit_sisnr_time(est, src, dtype=torch.float64)
+    assert torch.isfinite(per64).all()
+    got = out["loss"].cpu().numpy()
+    assert np.allclose(got[[0, 2]], per64.numpy()[[0, 2]], atol=1e-2)
+    # utterance 1 (DC of 1e3): the exact value is eps-dominated (-20 log10(1e-8) for the constant target); the
+    # moment form carries ~1e-6 of fp64 cancellation noise there, so only its magnitude is pinned
+    assert abs(got[1] - per64.numpy()[1]) < 10.0

@@ -84,3 +84,20 @@ def test_shard_range_properties():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def test_bench_self_launches_ranks():
+    """`python bench.py --gpus 2` without a launcher must start two ranks itself (the driver invokes bench.py directly).
+    Here there is no GPU, so every rank stops at the "needs an MI355X" check - which proves the ranks were started with
+    the torchrun environment (WORLD_SIZE=2) instead of dying at an argument check."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stderr[-2000:]
+        return
+    assert r.returncode != 0
+    txt = r.stdout + r.stderr
+    assert "WORLD_SIZE" not in txt or "but WORLD_SIZE" not in txt
+    assert "needs an MI355X" in txt or "invalid device ordinal" in txt or "device" in txt.lower(), txt[-2000:]

@@ -26,7 +26,8 @@ def test_load_pad_normalise_write(tmp_path, golden):
     p = str(tmp_path / "o.wav")
     infer.write_wav(p, y, 8000)
     back = infer.load_wav(p, 8000)
-    assert back.shape == x.shape and np.abs(back - y).max() <= 0.5 / 32768 + 1e-7      # PCM16 rounding
+    # libsndfile convention: written as rint(y * 32767), read back as pcm / 32768
+    assert back.shape == x.shape and np.array_equal(back, (np.rint(y.astype(np.float64) * 32767.0) / 32768.0).astype(np.float32))
     stereo = str(tmp_path / "st.wav")
     from scipy.io import wavfile
     wavfile.write(stereo, 8000, np.stack([np.full(8, 1000, np.int16), np.full(8, 3000, np.int16)], 1))
@@ -49,7 +50,8 @@ def test_separate_file_matches_reference_golden(tmp_path, golden):
         w = infer.load_wav(written[1 + i], 8000)
         assert w.shape[0] == 73593 and abs(np.abs(w).max() - 0.9) < 1e-3
         ref = 0.9 * want[i].numpy() / np.abs(want[i].numpy()).max()
-        assert np.abs(w - ref).max() < 2.0 / 32768                                 # same file the reference would write
+        ref_file = np.rint(ref.astype(np.float64) * 32767.0) / 32768.0               # what sf.write + a PCM16 read-back give
+        assert np.abs(w - ref_file).max() <= 1.0 / 32768 + 1e-9                    # same file up to one LSB of rounding
 
 
 @pytest.mark.gpu
