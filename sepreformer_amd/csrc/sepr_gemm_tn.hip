@@ -1,0 +1,269 @@
+// Weight-gradient contraction of the training path:  G[N][K] (+)= sum_m A[m][n] * B'[m][k]   (see sepr_train.h)
+//
+// Every parameter gradient of a projection is this "TN" product: the contraction runs over the M = batch x frames
+// rows (up to 512 000) while N and K are small (16 .. 1024), the transpose of the forward projection's shape.
+// Design (gfx950, wave64):
+//   * one workgroup (4 waves) owns a 128 x 128 tile of G for a contiguous slice of the rows; the slices of one tile
+//     are written as partial tiles to the workspace and summed in slice order by a second kernel (no atomics:
+//     bit-reproducible gradients);
+//   * a wave holds a 64 x 64 quadrant as 4 x 4 MFMA accumulators.  The MFMA contraction index is the ROW index m, so
+//     both operands are needed "m-fastest": the staging threads read 8 consecutive rows x 4 columns (row-contiguous
+//     512-byte segments per 32 lanes), transpose in registers and write one 16-byte [column][8 rows] vector per plane,
+//     which is exactly the fragment a lane later reads (16 lanes x 16 B, conflict-free at an 80-byte row stride);
+//   * bf16x3 arithmetic like the forward projections (sepr_gemm_x3.h): both operands are activations here, so both are
+//     split into bf16 hi/lo while staging; products hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+//     The exact mode uses v_mfma_f32_16x16x4_f32 on fp32 LDS tiles (no transpose needed: one k per lane group);
+//   * the B prologue replays what the forward projection did to its input (normalise with saved statistics, concat,
+//     crop / nearest-upsample / overlapping-frame row maps), so no normalised or gathered copy is ever materialised;
+//   * the column sums of A (bias gradients) ride along in the staging registers.
+#include "sepr_train.h"
+
+namespace sepr {
+
+typedef __bf16 tn_bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int TN_T = 128;          // tile edge (both n and k)
+constexpr int TN_SLAB = 32;        // rows per staging step
+constexpr int TN_LDM = 40;         // bf16 elements per LDS row of the x3 planes (32 rows + pad: 80 B)
+constexpr int TN_LDF = TN_T + 4;   // floats per LDS row of the f32 tiles
+constexpr int TN_THREADS = 256;
+
+struct TnPlan {
+  int tn, tk, nsplit, rows_per_split;
+};
+inline TnPlan tn_plan(int M, int N, int K) {
+  TnPlan p;
+  p.tn = (N + TN_T - 1) / TN_T;
+  p.tk = (K + TN_T - 1) / TN_T;
+  const int tiles = p.tn * p.tk;
+  int ns = 1024 / tiles;
+  if (ns < 1) ns = 1;
+  const int max_by_rows = (M + 4 * TN_SLAB - 1) / (4 * TN_SLAB);   // at least 128 rows per slice
+  if (ns > max_by_rows) ns = max_by_rows;
+  if (ns < 1) ns = 1;
+  int rps = (M + ns - 1) / ns;
+  rps = (rps + TN_SLAB - 1) / TN_SLAB * TN_SLAB;
+  p.nsplit = (M + rps - 1) / rps;
+  p.rows_per_split = rps;
+  return p;
+}
+
+template <bool X3>
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part,
+                                                               float* __restrict__ cpart) {
+  // x3: [A_hi, A_lo, B_hi, B_lo][128][40] bf16 = 40 960 B;  f32: [A, B][32][132] fp32 = 33 792 B
+  __shared__ __attribute__((aligned(16))) unsigned char smem[X3 ? 4 * TN_T * TN_LDM * 2 : 2 * TN_SLAB * TN_LDF * 4];
+  __shared__ float csum_s[4][TN_T];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int tile = blockIdx.x % (p.tn * p.tk), split = blockIdx.x / (p.tn * p.tk);
+  const int n0 = (tile / p.tk) * TN_T, k0 = (tile % p.tk) * TN_T;
+  const int m_beg = split * p.rows_per_split;
+  const int m_end = min(a.M, m_beg + p.rows_per_split);
+
+  // ---- staging role: threads 0..127 stage A, 128..255 stage B; each 8 rows x 4 columns per slab ----
+  const bool roleA = tid < 128;
+  const int t7 = tid & 127;
+  const int cg = t7 & 31, mg = t7 >> 5;
+  const int col = (roleA ? n0 : k0) + 4 * cg;
+  const bool col_ok = col < (roleA ? a.N : a.K);
+  float4 r[8];
+  float4 csum = zero4();
+
+  auto load_slab = [&](int mb) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int m = mb + 8 * mg + e;
+      r[e] = zero4();
+      if (m < m_end && col_ok) {
+        if (roleA) {
+          r[e] = ld4(a.A + (long long)m * a.lda + col);
+        } else {
+          long long off = (long long)m * a.ldb;
+          long long srow = m;
+          bool valid = true;
+          if (a.rows_out > 0) {
+            const int seq = m / a.rows_out;
+            const int rr = m - seq * a.rows_out;
+            valid = rr < a.rows_valid;
+            const int rs = valid ? ((a.idx ? a.idx[rr] : rr) >> a.b_shift) : 0;
+            off = (long long)seq * a.seq_stride + (long long)rs * a.ldb;
+            srow = seq;
+          }
+          if (valid) {
+            float4 v;
+            if (a.B2 && col >= a.ksplit) v = ld4(a.B2 + (long long)m * a.ldb2 + (col - a.ksplit));
+            else v = ld4(a.B + off + col);
+            if (a.stats) {
+              const long long si = a.stat_seq ? srow : m;
+              const float mean = a.stats[2 * si], rstd = a.stats[2 * si + 1];
+              v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd; v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
+            }
+            r[e] = v;
+          }
+        }
+      }
+    }
+  };
+  auto store_slab = [&]() {
+#pragma clang fp contract(off)
+    if (roleA) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { csum.x += r[e].x; csum.y += r[e].y; csum.z += r[e].z; csum.w += r[e].w; }
+    }
+    if (X3) {
+      unsigned short* hi = reinterpret_cast<unsigned short*>(smem) + (roleA ? 0 : 2) * TN_T * TN_LDM;
+      unsigned short* lo = hi + TN_T * TN_LDM;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        tn_bf16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = j == 0 ? r[e].x : (j == 1 ? r[e].y : (j == 2 ? r[e].z : r[e].w));
+          const __bf16 vh = (__bf16)v;
+          h[e] = vh;
+          l[e] = (__bf16)(v - (float)vh);
+        }
+        *reinterpret_cast<tn_bf16x8*>(hi + (4 * cg + j) * TN_LDM + 8 * mg) = h;
+        *reinterpret_cast<tn_bf16x8*>(lo + (4 * cg + j) * TN_LDM + 8 * mg) = l;
+      }
+    } else {
+      float* dst = reinterpret_cast<float*>(smem) + (roleA ? 0 : 1) * TN_SLAB * TN_LDF;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) st4(dst + (8 * mg + e) * TN_LDF + 4 * cg, r[e]);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (m_beg < m_end) load_slab(m_beg);
+  for (int mb = m_beg; mb < m_end; mb += TN_SLAB) {
+    __syncthreads();            // every wave is done reading the previous slab
+    store_slab();
+    __syncthreads();
+    if (mb + TN_SLAB < m_end) load_slab(mb + TN_SLAB);
+    if (X3) {
+      const unsigned short* Ahi = reinterpret_cast<const unsigned short*>(smem);
+      const unsigned short* Alo = Ahi + TN_T * TN_LDM;
+      const unsigned short* Bhi = Alo + TN_T * TN_LDM;
+      const unsigned short* Blo = Bhi + TN_T * TN_LDM;
+      tn_bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ra = (wm * 64 + t * 16 + fi) * TN_LDM + 8 * fg;
+        const int rb = (wn * 64 + t * 16 + fi) * TN_LDM + 8 * fg;
+        ah[t] = *reinterpret_cast<const tn_bf16x8*>(Ahi + ra);
+        al[t] = *reinterpret_cast<const tn_bf16x8*>(Alo + ra);
+        bh[t] = *reinterpret_cast<const tn_bf16x8*>(Bhi + rb);
+        bl[t] = *reinterpret_cast<const tn_bf16x8*>(Blo + rb);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh[kt], acc[nt][kt], 0, 0, 0);
+          acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl[kt], acc[nt][kt], 0, 0, 0);
+          acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh[kt], acc[nt][kt], 0, 0, 0);
+        }
+    } else {
+      const float* As = reinterpret_cast<const float*>(smem);
+      const float* Bs = As + TN_SLAB * TN_LDF;
+#pragma unroll
+      for (int kk = 0; kk < TN_SLAB / 4; ++kk) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          av[t] = As[(4 * kk + fg) * TN_LDF + wm * 64 + t * 16 + fi];
+          bv[t] = Bs[(4 * kk + fg) * TN_LDF + wn * 64 + t * 16 + fi];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+            acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv[kt], acc[nt][kt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- partial tile -> workspace: part[split][n][k] ----
+  float* pt = part + (long long)split * a.N * a.K;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = k0 + wn * 64 + kt * 16 + fi;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int n = n0 + wm * 64 + nt * 16 + 4 * fg + rr;
+        if (n < a.N && k < a.K) pt[(long long)n * a.K + k] = acc[nt][kt][rr];
+      }
+    }
+  // ---- column sums of A (bias gradient): only the k0 == 0 tile of each row block reports them ----
+  if (cpart && k0 == 0) {
+    __syncthreads();
+    if (roleA) {
+      csum_s[mg][4 * cg + 0] = csum.x; csum_s[mg][4 * cg + 1] = csum.y;
+      csum_s[mg][4 * cg + 2] = csum.z; csum_s[mg][4 * cg + 3] = csum.w;
+    }
+    __syncthreads();
+    if (tid < TN_T && n0 + tid < a.N)
+      cpart[(long long)split * a.N + n0 + tid] = (csum_s[0][tid] + csum_s[1][tid]) + (csum_s[2][tid] + csum_s[3][tid]);
+  }
+}
+
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart, int nsplit,
+                                                       int N, int K, float* __restrict__ G, int ldg, int accumulate,
+                                                       float* __restrict__ colsum, int colsum_acc) {
+  const long long total = (long long)N * K;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total + N; i += (long long)gridDim.x * 256) {
+    if (i < total) {
+      float s = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) s += part[(long long)sp * total + i];
+      const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+      float* g = G + (long long)n * ldg + k;
+      *g = accumulate ? *g + s : s;
+    } else if (colsum) {
+      const int n = (int)(i - total);
+      float s = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) s += cpart[(long long)sp * N + n];
+      colsum[n] = colsum_acc ? colsum[n] + s : s;
+    }
+  }
+}
+}  // namespace
+
+size_t tn_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const TnPlan p = tn_plan(M, N, K);
+  return align_up((size_t)p.nsplit * ((size_t)N * K + N) * sizeof(float));
+}
+
+int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (a.M <= 0) return SEPR_OK;
+  if (!a.A || !a.B || !a.G || a.N <= 0 || a.K <= 0 || (a.N % 4) || (a.K % 4) || (a.lda % 4) || (a.ldb % 4)) return SEPR_EINVAL;
+  if (a.B2 && ((a.ksplit % 4) || (a.ldb2 % 4))) return SEPR_EINVAL;
+  const TnPlan p = tn_plan(a.M, a.N, a.K);
+  const size_t need = tn_workspace_bytes(a.M, a.N, a.K);
+  if (!ws || ws_bytes < need) return SEPR_EWORKSPACE;
+  float* part = static_cast<float*>(ws);
+  float* cpart = part + (size_t)p.nsplit * a.N * a.K;
+  const int grid = p.tn * p.tk * p.nsplit;
+  if (x3)
+    hipLaunchKernelGGL((gemm_tn_kernel<true>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<false>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
+  const long long total = (long long)a.N * a.K + a.N;
+  const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
+                     a.colsum, a.colsum_accumulate);
+  SEPR_CHECK_LAUNCH("gemm_tn_kernel");
+  return SEPR_OK;
+}
+
+}  // namespace sepr

@@ -1,0 +1,130 @@
+// Training path: launchers shared by the block-level train / backward entry points of
+// sepr_train_api.hip.  Kernels live in sepr_gemm_tn.hip (weight-gradient contraction), sepr_train_pw.hip (row-wise and
+// element-wise forward/backward pieces, statistics, finishers) and sepr_train_attn.hip (attention forward with stored
+// probabilities and its backward).
+#pragma once
+#include "sepr_gemm_epi.h"
+
+namespace sepr {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// G[N][K] (+)= sum_m A[m][n] * B'[m][k]      ("TN" contraction over the M = batch x frames rows: every weight gradient)
+//   A  : fp32 rows, leading dimension lda (upstream gradient of the projection's output)
+//   B' : prologue(B): optional (b - mean) * rstd normalisation (LayerNorm / GroupNorm input of the projection), optional
+//        two-source concat, optional row map (crop / nearest upsample / overlapping frames) - the same maps the forward
+//        projection applies to its input
+//   colsum[N] (+)= sum_m A[m][n]              (bias gradient, optional)
+// Deterministic: the M range is split over workgroups, partial tiles go to the workspace and are summed in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TnArgs {
+  int M, N, K;
+  const float* A;
+  int lda;
+  const float* B;
+  int ldb;
+  const float* B2;   // concat: k >= ksplit reads B2[m * ldb2 + (k - ksplit)] (never row-mapped)
+  int ldb2, ksplit;
+  // row map of B.  rows_out == 0: source row = m.  Else m -> (seq = m / rows_out, r = m % rows_out); the row is zero
+  // unless r < rows_valid; source offset = seq * seq_stride + ((idx ? idx[r] : r) >> b_shift) * ldb.
+  int rows_out, rows_valid, b_shift;
+  long long seq_stride;
+  const int* idx;
+  const float* stats;   // normalisation: (mean, rstd) per row (stat_seq == 0) or per sequence (stat_seq == 1); null = none
+  int stat_seq;
+  float* G;
+  int ldg;
+  int accumulate;       // 1: G += result, 0: G = result
+  float* colsum;        // [N] or null
+  int colsum_accumulate;
+};
+inline TnArgs tn_args_zero() {
+  TnArgs a;
+  __builtin_memset(&a, 0, sizeof(a));
+  return a;
+}
+size_t tn_workspace_bytes(int M, int N, int K);
+// x3 != 0: bf16x3 split arithmetic (3 bf16 MFMAs per product), else exact f32 MFMA
+int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream_t s);
+
+// ---- row-wise / element-wise pieces (sepr_train_pw.hip) -------------------------------------------------------------
+// dx[m][f] = (dres ? dres[m][f] : 0) + rstd_m * (dxh[m][f] - mean_f(dxh[m]) - xh[m][f] * mean_f(dxh[m] * xh[m])),
+// xh = (x - mean_m) * rstd_m  (LayerNorm backward w.r.t. its input, affine already folded into dxh);
+// optional pooled add: dx[m] += padd[(m / T) * Tp + (m % T) / fac] * (1 / fac)   (adaptive_avg_pool1d backward)
+int launch_ln_bwd(const float* dxh, const float* x, const float* stats, const float* dres, const float* padd, int T, int Tp,
+                  int fac, float* dx, long long M, int F, hipStream_t s);
+// GLU over the last dim: a [M][2H] -> y [M][H] = a[:, :H] * sigmoid(a[:, H:]); backward da from dy and a
+int launch_glu_fwd(const float* a, float* y, long long M, int H, hipStream_t s);
+int launch_glu_bwd(const float* dy, const float* a, float* da, long long M, int H, hipStream_t s);
+// GCFN middle backward: h1 [n,T,2C] (pre-conv hidden: C value channels then C gate channels), dg [n,T,C] ->
+// dh1 [n,T,2C]; depthwise k=3 weight / bias gradients accumulated into dw_g [2C][3] (parameter layout) and db_g [2C].
+int launch_gcfn_mid_bwd(const float* h1, const float* dg, float* dh1, int n, int T, int C, const float* dw_w, const float* dw_b,
+                        float* dw_g, float* db_g, void* ws, size_t ws_bytes, hipStream_t s);
+size_t gcfn_mid_bwd_ws(int n, int T, int C);
+// depthwise conv weight gradient, stride 1, 'same' zero padding: dw[c][k] += sum_{seq,t} dy[t][c] * x[t + k - K/2][c];
+// db[c] += sum dy.  x, dy [n,T,C]; dw in parameter layout [C][K]
+int launch_dwconv_wgrad(const float* x, const float* dy, int n, int T, int C, int K, float* dw_g, float* db_g, void* ws,
+                        size_t ws_bytes, hipStream_t s);
+size_t dwconv_wgrad_ws(int n, int T, int C, int K);
+// per-channel batch statistics of z [M][C] (train-mode BatchNorm1d): stats[0][C] = mean, stats[1][C] = rstd (biased var,
+// eps inside); running_mean / running_var (unbiased) updated with `momentum` when non-null
+int launch_colstats(const float* z, long long M, int C, float eps, float momentum, float* stats, float* run_mean, float* run_var,
+                    void* ws, size_t ws_bytes, hipStream_t s);
+size_t colstats_ws(long long M, int C);
+// y = gelu(gamma * (z - mean) * rstd + beta)   (BatchNorm apply + exact GELU)
+int launch_bn_gelu_fwd(const float* z, const float* stats, const float* g, const float* b, float* y, long long M, int C,
+                       hipStream_t s);
+// backward of the above w.r.t. z, plus dgamma / dbeta accumulation
+int launch_bn_gelu_bwd(const float* dy, const float* z, const float* stats, const float* g, const float* b, float* dz, float* dg_g,
+                       float* db_g, long long M, int C, void* ws, size_t ws_bytes, hipStream_t s);
+// EGA gate: y = x + sigmoid(zg) * att[(m / T) * Tp + (m % T) / fac]
+int launch_gate_fwd(const float* x, const float* zg, const float* att, float* y, int n, int T, int Tp, int F, hipStream_t s);
+// dzg = dy * att_up * sigmoid'(zg) [M][F]; datt[Mp][F] = sum over the fac frames of a pooled frame of dy * sigmoid(zg)
+int launch_gate_bwd(const float* dy, const float* zg, const float* att, float* dzg, float* datt, int n, int T, int Tp, int F,
+                    hipStream_t s);
+// attention across the S speakers of each frame, backward: qkv, dO -> dqkv
+int launch_spkmix_bwd(const float* QKV, const float* dO, float* dQKV, int B, int S, int T, int F, int H, hipStream_t s);
+// fusion conv backward glue: dcat [n,T,2F] -> dlo [n,T/2,F] (sum of the two frames that read it), dskip [n,T,F];
+// acc_* != 0: add into the destination
+int launch_unfuse(const float* dcat, float* dlo, float* dskip, int n, int T, int F, hipStream_t s);
+// GroupNorm(1 group) backward over (T, F) of each sequence.  v = pre-norm input [n,T,F], dy upstream.
+// dv written with the channel-split inverted when S > 0: sequence q = b*S + s, frame t -> dv[(b*T + t) * S*F + s*F + f]
+int launch_gn_bwd(const float* dy, const float* v, const float* stats, const float* g, float* dv, float* dg_g, float* db_g, int n,
+                  int T, int F, int S, void* ws, size_t ws_bytes, hipStream_t s);
+size_t gn_bwd_ws(int n, int T, int F);
+// y = gn(v): out-of-place GroupNorm apply (the train path keeps v)
+int launch_gn_apply_oop(const float* v, const float* stats, const float* g, const float* b, float* y, int n, int T, int F,
+                        hipStream_t s);
+// DownConv (train): c = depthwise K stride-2 conv + bias [n,To,F]; backward dx from dc, weight / bias gradients
+int launch_downconv_pre(const float* x, float* c, int n, int T, int To, int F, int K, const float* w, const float* b, hipStream_t s);
+int launch_downconv_bwd(const float* x, const float* dc, float* dx, int n, int T, int To, int F, int K, const float* w, float* dw_g,
+                        float* db_g, void* ws, size_t ws_bytes, hipStream_t s);
+size_t downconv_bwd_ws(int n, int T, int F, int K);
+// y (+)= a   (gradient accumulation where two consumers read one tensor)
+int launch_add_inplace(float* y, const float* a, long long count, hipStream_t s);
+// y = x + ls[f] * v  /  plain scaled copies used by the dropout-enabled paths
+int launch_res_ls(const float* x, const float* v, const float* ls, float* y, long long M, int F, hipStream_t s);
+// inverted dropout with a counter-based generator: y[i] = keep(seed, offset + i) ? x[i] / (1 - p) : 0 (in place allowed)
+int launch_dropout(const float* x, float* y, long long count, float p, unsigned long long seed, unsigned long long offset,
+                   hipStream_t s);
+
+// ---- parameter-gradient finishers -------------------------------------------------------------------------------------
+// projection behind a normalisation whose affine was folded into it:  y = ((xh * g + b) . W^T + bias)
+//   dWh [N][K] = sum dy xh, s [N] = sum dy   ->   dW += dWh * g_k + s_n * b_k;  dbias += s;
+//   dg_k += sum_n W[n][k] dWh[n][k];  db_k += sum_n s[n] W[n][k]
+int launch_finish_norm_linear(const float* dWh, const float* s, const float* W, const float* g, const float* b, float* dW_g,
+                              float* dbias_g, float* dg_g, float* db_g, int N, int K, hipStream_t st);
+// projection followed by LayerScale:  y = ls * (v . W^T + bias)
+//   Gr [N][K] = sum dy v, s [N] = sum dy  ->  dW += ls_n Gr;  dbias += ls_n s_n;  dls_n += sum_k W[n][k] Gr[n][k] + bias_n s_n
+int launch_finish_linear_ls(const float* Gr, const float* s, const float* W, const float* bias, const float* ls, float* dW_g,
+                            float* dbias_g, float* dls_g, int N, int K, hipStream_t st);
+
+// ---- attention with stored probabilities (sepr_train_attn.hip) ----------------------------------------------------
+size_t relattn_train_ws(int n, int Tp, int F, int H);
+// QKV [n,Tp,3F] -> O [n,Tp,F]; P [n,H,Tp,Tp] = softmax probabilities (saved for the backward)
+int launch_relattn_train_fwd(const float* QKV, float* O, float* P, int n, int Tp, int F, int H, const float* pe_k, int maxlen,
+                             hipStream_t s);
+// dO [n,Tp,F] -> dQKV [n,Tp,3F]; dpe [2*maxlen][dk] accumulated
+int launch_relattn_bwd(const float* QKV, const float* P, const float* O, const float* dO, float* dQKV, float* dpe_g, int n, int Tp,
+                       int F, int H, const float* pe_k, int maxlen, void* ws, size_t ws_bytes, hipStream_t s);
+
+}  // namespace sepr
