@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SEPR_VERSION 100 /* major*10000 + minor*100 + patch */
+#define SEPR_VERSION 200 /* major*10000 + minor*100 + patch */
 
 #define SEPR_OK 0
 #define SEPR_EINVAL (-1)     /* bad shape / unsupported size / null pointer */
@@ -269,6 +269,181 @@ size_t sepr_pit_sisnr_mag_workspace(int S, int B, int T, int frame_len, int fram
 int sepr_pit_sisnr_mag_fwd(const float* est, const float* tgt, int S, int B, int T, const float* dft,
                            int frame_len, int frame_shift, double eps, float* loss, int* perm, void* ws,
                            size_t ws_bytes, sepr_stream_t stream);
+
+/* ================================================================================================================= */
+/* Training path: train-mode forward twins that keep what the backward needs, and the       */
+/* backward of every block.  The reference trains through torch.autograd over the same modules (engine.py:50-83:     */
+/* data_parallel forward, PIT losses, backward, clip_grad_norm_, AdamW); here each block has an explicit backward.   */
+/*                                                                                                                   */
+/* Conventions (in addition to the ones at the top of this header)                                                   */
+/*   - a block's train_fwd writes its saved-for-backward tensors into a caller-provided context buffer `ctx` of       */
+/*     sepr_train_ctx_bytes(op, ...) bytes; the matching _bwd reads the same buffer (the caller keeps it and the      */
+/*     block's input x alive in between); `ws` is scratch of sepr_train_ws_bytes(op, ...) bytes;                      */
+/*   - parameter gradients are ACCUMULATED (+=) into fp32 buffers laid out exactly like the reference parameters      */
+/*     (e.g. depthwise.weight [C,1,K]); the caller zeroes them once per step; activation gradients are overwritten;   */
+/*   - a projection travels as sepr_lin: exact-f32 form (w: fp32 [N][K] row-major) or bf16x3 form (wp: pack_x3         */
+/*     fragments), never both; b may be NULL.  The host packs, per weight version, the forward form and the            */
+/*     transposed form the input gradient needs, with LayerNorm / GroupNorm affines and LayerScale folded in           */
+/*     (sepreformer_amd/train_pack.py); the raw parameters ride along for the gradient finishers;                      */
+/*   - train-mode BatchNorm uses batch statistics over (sequences x frames) and updates running_mean / running_var     */
+/*     in place (momentum 0.1, unbiased variance), like torch.nn.BatchNorm1d (network.py:167, module.py:69);          */
+/*   - dropout (network.py:55,57,87,121,124,171): inverted dropout from a counter-based generator keyed by             */
+/*     (seed, element index); p_drop = 0 disables it exactly; the backward regenerates the masks from the same seed.  */
+/* ================================================================================================================= */
+typedef struct { const float* w; const void* wp; const float* b; } sepr_lin;
+typedef unsigned long long sepr_u64;
+
+/* GCFN, modules/network.py:46-66 */
+typedef struct {
+  sepr_lin up;      /* [6F,F]  net1.1.weight * ln_gamma, net1.1.bias + W . ln_beta */
+  sepr_lin up_t;    /* [F,6F]  (net1.1.weight * ln_gamma)^T */
+  sepr_lin down;    /* [F,3F]  net2.2 */
+  sepr_lin down_t;  /* [3F,F]  (layer_scale * net2.2.weight)^T */
+  const float* dw_w; /* [3,6F] tap-major */
+  const float* dw_b; /* [6F] */
+  const float* ls;   /* [F] */
+  const float* w1; const float* ln_g; const float* ln_b; const float* w2; const float* b2;   /* raw parameters */
+} sepr_gcfn_tw;
+typedef struct { float* ln_g; float* ln_b; float* w1; float* b1; float* dw_w; float* dw_b; float* w2; float* b2; float* ls; } sepr_gcfn_grad;
+
+/* CLA, modules/network.py:159-187 (BatchNorm NOT folded: batch statistics) */
+typedef struct {
+  sepr_lin l1, l1_t;   /* [2F,F] linear1 * ln_gamma (+ beta in the bias); [F,2F] transpose */
+  const float* dw_w;   /* [K,F] tap-major */
+  const float* dw_wf;  /* [K,F] tap-major, taps reversed (input gradient of the 'same' conv) */
+  const float* dw_b;   /* [F] */
+  const float* zeros;  /* [>= 2F] zeros */
+  sepr_lin l2, l2_t;   /* [2F,F] linear2; [F,2F] linear2^T */
+  const float* bn_g; const float* bn_b; float* bn_rm; float* bn_rv;   /* BN affine; running stats (updated in place) */
+  sepr_lin l3, l3_t;   /* [F,2F] linear3.1; [2F,F] (layer_scale * linear3.1.weight)^T */
+  const float* ls;
+  const float* w1; const float* ln_g; const float* ln_b; const float* w3; const float* b3;   /* raw parameters */
+} sepr_cla_tw;
+typedef struct { float* ln_g; float* ln_b; float* w1; float* b1; float* dw_w; float* dw_b; float* w2; float* b2; float* bn_g; float* bn_b;
+                 float* w3; float* b3; float* ls; } sepr_cla_grad;
+
+/* MultiHeadAttention, modules/network.py:69-124 */
+typedef struct {
+  sepr_lin qkv, qkv_t;  /* [3F,F] stacked q/k/v * ln_gamma; [F,3F] transpose */
+  sepr_lin out, out_t;  /* [F,F] linear_out; (layer_scale * linear_out.weight)^T */
+  const float* ls;
+  const float* wqkv; const float* ln_g; const float* ln_b; const float* wo; const float* bo;   /* raw (wqkv stacked [3F,F]) */
+} sepr_mha_tw;
+typedef struct { float* ln_g; float* ln_b; float* wq; float* bq; float* wk; float* bk; float* wv; float* bv; float* wo; float* bo; float* ls; } sepr_mha_grad;
+
+/* EGA, modules/network.py:126-155 */
+typedef struct {
+  sepr_mha_tw attn;
+  sepr_lin gate, gate_t;  /* [F,F] block.linear.1 * gamma; transpose */
+  const float* gate_w; const float* gate_ln_g; const float* gate_ln_b;   /* raw */
+  const float* pe_k; int maxlen;
+} sepr_ega_tw;
+typedef struct { sepr_mha_grad attn; float* gate_ln_g; float* gate_ln_b; float* gate_w; float* gate_b; float* pe_k; } sepr_ega_grad;
+
+/* DownConvLayer, modules/module.py:63-78 */
+typedef struct { const float* w /* [K,F] tap-major */; const float* b; const float* bn_g; const float* bn_b; float* bn_rm; float* bn_rv; } sepr_down_tw;
+typedef struct { float* w /* [F,1,K] */; float* b; float* bn_g; float* bn_b; } sepr_down_grad;
+
+/* SpkSplitStage, modules/module.py:110-125 */
+typedef struct { sepr_lin l1, l1_t, l2, l2_t; const float* gn_g; const float* gn_b; } sepr_split_tw;
+typedef struct { float* w1; float* b1; float* w2; float* b2; float* gn_g; float* gn_b; } sepr_split_grad;
+
+/* fusion conv, modules/module.py:187,212-214 */
+typedef struct { sepr_lin l, l_t; } sepr_fuse_tw;
+typedef struct { float* w; float* b; } sepr_fuse_grad;
+
+/* OutputLayer + AudioDecoder, modules/module.py:237-283 */
+typedef struct { sepr_lin l1, l1_t, l2, l2_t; const float* wdec /* [K,N] tap-major */; } sepr_out_tw;
+typedef struct { float* w1; float* b1; float* w2; float* b2; float* wdec /* [N,1,K] */; } sepr_out_grad;
+
+/* AudioEncoder + FeatureProjector, modules/module.py:12-35.  The projector runs on the exact-f32 core with the GroupNorm
+ * affine in its prologue (as in inference: padded frames must come out exactly zero), only its input gradient uses a
+ * folded, transposed form. */
+typedef struct {
+  const float* w_enc;      /* [K,N] tap-major */
+  const float* proj_w;     /* [F,N] feature_projector.conv1d.weight */
+  const float* gn_g; const float* gn_b;   /* [N] feature_projector.norm */
+  sepr_lin proj_t;         /* [N,F] (conv1d.weight * gn_gamma)^T */
+  const float* ones;       /* [>= N] ones */
+} sepr_front_tw;
+typedef struct { float* w_enc /* [N,1,K] */; float* gn_g; float* gn_b; float* proj_w; } sepr_front_grad;
+
+enum { SEPR_TOP_GCFN = 0, SEPR_TOP_CLA, SEPR_TOP_EGA, SEPR_TOP_SPKATTN, SEPR_TOP_DOWN, SEPR_TOP_SPLIT, SEPR_TOP_FUSE, SEPR_TOP_OUT,
+       SEPR_TOP_FRONT, SEPR_TOP_COUNT };
+/* n sequences of T frames (Tp: pooled frames for EGA, source frames for OUT, padded frames Lp for FRONT), width F, encoder
+ * channels N, S speakers, K = depthwise taps where the op has them (CLA 65, DOWN 5; else ignored). */
+size_t sepr_train_ctx_bytes(int op, int n, int T, int Tp, int F, int N, int S, int H);
+size_t sepr_train_ws_bytes(int op, int n, int T, int Tp, int F, int N, int S, int H, int K);
+
+int sepr_gcfn_train_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, void* ctx, size_t ctx_bytes, void* ws,
+                        size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream);
+int sepr_gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, const sepr_gcfn_tw* w, const sepr_gcfn_grad* g,
+                  const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream);
+
+int sepr_cla_train_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_cla_tw* w, void* ctx, size_t ctx_bytes, void* ws,
+                       size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream);
+int sepr_cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int K, const sepr_cla_tw* w, const sepr_cla_grad* g,
+                 const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream);
+
+int sepr_ega_train_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const sepr_ega_tw* w, void* ctx, size_t ctx_bytes,
+                       void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream);
+int sepr_ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, int F, int H, const sepr_ega_tw* w,
+                 const sepr_ega_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed,
+                 sepr_stream_t stream);
+
+int sepr_spkattn_train_fwd(const float* x, float* y, int nS, int S, int T, int F, int H, const sepr_mha_tw* w, void* ctx,
+                           size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream);
+int sepr_spkattn_bwd(const float* x, const float* dy, float* dx, int nS, int S, int T, int F, int H, const sepr_mha_tw* w,
+                     const sepr_mha_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed,
+                     sepr_stream_t stream);
+
+int sepr_downconv_train_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_down_tw* w, void* ctx, size_t ctx_bytes,
+                            void* ws, size_t ws_bytes, sepr_stream_t stream);
+int sepr_downconv_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int K, const sepr_down_tw* w,
+                      const sepr_down_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, sepr_stream_t stream);
+
+int sepr_spksplit_train_fwd(const float* x, float* y, int B, int S, int T, int F, float gn_eps, const sepr_split_tw* w, void* ctx,
+                            size_t ctx_bytes, void* ws, size_t ws_bytes, sepr_stream_t stream);
+/* dx_accumulate != 0: dx += (the skip tensors are also read by the DownConv of their stage) */
+int sepr_spksplit_bwd(const float* x, const float* dy, float* dx, int dx_accumulate, int B, int S, int T, int F, const sepr_split_tw* w,
+                      const sepr_split_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, sepr_stream_t stream);
+
+/* forward is sepr_fuse_fwd with w->l; backward: dlo [n,T/2,F], dskip [n,T,F] */
+int sepr_fuse_bwd(const float* lo, const float* skip, const float* dy, float* dlo, float* dskip, int n, int T, int F,
+                  const sepr_fuse_tw* w, const sepr_fuse_grad* g, void* ws, size_t ws_bytes, sepr_stream_t stream);
+
+int sepr_outlayer_decoder_train_fwd(const float* x, int nS, int S, int Tsrc, int L, const int* idx, const float* enc, int F, int N,
+                                    int K, int stride, const sepr_out_tw* w, float* wav, void* ctx, size_t ctx_bytes, void* ws,
+                                    size_t ws_bytes, sepr_stream_t stream);
+/* dwav [S,B,Tout] -> dx [nS,Tsrc,F] (dx_accumulate: +=; rows of the main head beyond L get zero), denc [B,L,N] += for the
+ * masked (auxiliary) heads; idx_start [Tsrc+1]: first output frame mapped to each source frame (inverse of idx) */
+int sepr_outlayer_decoder_bwd(const float* x, const float* dwav, float* dx, int dx_accumulate, float* denc, int nS, int S, int Tsrc,
+                              int L, const int* idx, const int* idx_start, const float* enc, int F, int N, int K, int stride,
+                              const sepr_out_tw* w, const sepr_out_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes,
+                              sepr_stream_t stream);
+
+/* encoder + projector: wav [B,T] -> enc [B,L,N] (kept by the caller: the auxiliary heads read it), out [B,Lp,F] */
+int sepr_front_train_fwd(const float* wav, int B, int T, int N, int K, int stride, int F, int Lp, float gn_eps, const sepr_front_tw* w,
+                         float* enc, float* out, void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, sepr_stream_t stream);
+/* dout [B,Lp,F]; denc_aux [B,L,N] or NULL = gradient the auxiliary heads sent into enc (overwritten: used as scratch) */
+int sepr_front_bwd(const float* wav, const float* enc, const float* dout, float* denc_aux, int B, int T, int N, int K, int stride, int F,
+                   int Lp, const sepr_front_tw* w, const sepr_front_grad* g, const void* ctx, size_t ctx_bytes, void* ws,
+                   size_t ws_bytes, sepr_stream_t stream);
+
+/* G[N][K] (+)= sum_m A[m][n] B[m][k]: the weight-gradient contraction on its own (tests, roofline bench).  x3 != 0: bf16x3. */
+size_t sepr_linear_wgrad_workspace(int M, int N, int K);
+int sepr_linear_wgrad(const float* A, const float* B, float* G, float* colsum, int M, int N, int K, int accumulate, int x3, void* ws,
+                      size_t ws_bytes, sepr_stream_t stream);
+
+/* PIT_SISNR_time backward (criterions.py:191-217): d(sum_b loss[b] * gl[b]) / d est.  est, tgt, dest [S,B,T]; perm from the forward. */
+int sepr_pit_sisnr_bwd(const float* est, const float* tgt, const int* perm, const float* gl, int S, int B, int T, double eps,
+                       double clamp_min, float* dest, void* ws, size_t ws_bytes, sepr_stream_t stream);
+/* PIT_SISNR_mag backward (criterions.py:148-176).  dft_t [frame_len][ldd]: the transpose of the first frame_len + 2 rows of
+ * `dft`, zero padded to ldd = frame_len + 2 rounded up to a multiple of 32 columns. */
+int sepr_pit_sisnr_mag_bwd(const float* est, const float* tgt, const int* perm, const float* gl, int S, int B, int T, const float* dft,
+                           const float* dft_t, int frame_len, int frame_shift, double eps, float* dest, void* ws, size_t ws_bytes,
+                           sepr_stream_t stream);
+size_t sepr_pit_sisnr_mag_bwd_workspace(int S, int B, int T, int frame_len, int frame_shift);
 
 /* ---- opt-in kernel timer (bench.py roofline) ------------------------------------------------- */
 /* Sites a projection launch can be attributed to. */

@@ -43,10 +43,15 @@ def _ln(sd: SD, p: str, x: Tensor) -> Tensor:
     return TF.layer_norm(x, (w.shape[0],), w, sd[p + ".bias"], 1e-5)
 
 
+# train-mode switch (oracle/train_oracle.py): BatchNorm1d then uses batch statistics over (batch, frames) and updates the
+# running statistics in place with momentum 0.1, exactly what the reference modules do under model.train()
+BN_TRAINING = False
+
+
 def _bn_eval(sd: SD, p: str, x: Tensor) -> Tensor:
-    # BatchNorm1d in eval mode: running statistics, eps 1e-5 (torch default)
+    # BatchNorm1d: eval mode = running statistics; eps 1e-5, momentum 0.1 (torch defaults; network.py:167, module.py:69)
     return TF.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
-                         sd[p + ".weight"], sd[p + ".bias"], False, 0.1, 1e-5)
+                         sd[p + ".weight"], sd[p + ".bias"], BN_TRAINING, 0.1, 1e-5)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -9,8 +9,12 @@ Mirrors ``utils/implements/criterions.py`` of the reference (SURVEY.md section 8
 
 ``estims`` / ``target_attr`` are lists of ``[B,T]`` tensors (or one ``[S,B,T]`` tensor) on the HIP device.  The
 arithmetic is one pass over the waveforms in ``csrc/sepr_criterion.hip`` through ``sepr_pit_sisnr_fwd``; there is no
-CPU implementation here (the CPU restatement is ``oracle/criterion_oracle.py``, test infrastructure).  Forward
-only: the returned tensors carry no autograd graph (backward is section 8f-2).
+CPU implementation here (the CPU restatement is ``oracle/criterion_oracle.py``, test infrastructure).
+
+Training: when an estimate requires grad, ``PIT_SISNR_time`` / ``PIT_SISNR_mag`` return an
+autograd-connected scalar; their backward is ``sepr_pit_sisnr_bwd`` / ``sepr_pit_sisnr_mag_bwd`` (closed form from the same
+moments; the STFT adjoint is one more projection with the transposed DFT kernel), the permutation chosen in the forward
+is held fixed, as ``torch.min`` does in the reference.
 """
 from __future__ import annotations
 
@@ -21,6 +25,72 @@ import torch
 from . import lib as L
 
 _TensorList = Union[torch.Tensor, Sequence[torch.Tensor]]
+
+
+def _needs_grad(x: _TensorList) -> bool:
+    if not torch.is_grad_enabled():
+        return False
+    return x.requires_grad if isinstance(x, torch.Tensor) else any(t.requires_grad for t in x)
+
+
+def _stack_g(x: _TensorList) -> torch.Tensor:
+    """Stack keeping the autograd graph (the training criteria differentiate through this)."""
+    t = x if isinstance(x, torch.Tensor) else torch.stack(list(x), dim=0)
+    return t.to(torch.float32).contiguous()
+
+
+class _PitTimeFn(torch.autograd.Function):
+    """sum_b w_b * loss_b of PIT_SISNR_time with d/d est from sepr_pit_sisnr_bwd (criterions.py:191-217)."""
+
+    @staticmethod
+    def forward(ctx, est, tgt, eps, clamp_min):
+        out = pit_sisnr(est, tgt, eps_loss=eps, clamp_min=clamp_min)
+        ctx.save_for_backward(est, tgt, out["loss_perm"])
+        ctx.consts = (eps, clamp_min)
+        return out["loss"]
+
+    @staticmethod
+    def backward(ctx, gl):
+        est, tgt, perm = ctx.saved_tensors
+        eps, clamp_min = ctx.consts
+        S, B, T = est.shape
+        lib = L.load()
+        with torch.cuda.device(est.device):
+            nbytes = lib.sepr_workspace_bytes(L.OP_PIT, B, T, 0, 0, 0, S) + 16 * B * S + 512
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=est.device)
+            dest = torch.empty_like(est)
+            glc = gl.detach().to(torch.float32).contiguous()
+            L.check(lib.sepr_pit_sisnr_bwd(est.data_ptr(), tgt.data_ptr(), perm.data_ptr(), glc.data_ptr(), S, B, T, eps, clamp_min,
+                                           dest.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(est.device).cuda_stream),
+                    "sepr_pit_sisnr_bwd")
+        return dest, None, None, None
+
+
+class _PitMagFn(torch.autograd.Function):
+    """Per-utterance PIT_SISNR_mag loss with d/d est from sepr_pit_sisnr_mag_bwd (criterions.py:148-176)."""
+
+    @staticmethod
+    def forward(ctx, est, tgt, dft, dft_t, frame_len, frame_shift, eps):
+        out = pit_sisnr_mag(est, tgt, dft, frame_len, frame_shift, eps)
+        ctx.save_for_backward(est, tgt, out["perm"], dft, dft_t)
+        ctx.consts = (frame_len, frame_shift, eps)
+        return out["loss"]
+
+    @staticmethod
+    def backward(ctx, gl):
+        est, tgt, perm, dft, dft_t = ctx.saved_tensors
+        frame_len, frame_shift, eps = ctx.consts
+        S, B, T = est.shape
+        lib = L.load()
+        with torch.cuda.device(est.device):
+            nbytes = lib.sepr_pit_sisnr_mag_bwd_workspace(S, B, T, frame_len, frame_shift)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=est.device)
+            dest = torch.empty_like(est)
+            glc = gl.detach().to(torch.float32).contiguous()
+            L.check(lib.sepr_pit_sisnr_mag_bwd(est.data_ptr(), tgt.data_ptr(), perm.data_ptr(), glc.data_ptr(), S, B, T, dft.data_ptr(),
+                                               dft_t.data_ptr(), frame_len, frame_shift, eps, dest.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               torch.cuda.current_stream(est.device).cuda_stream), "sepr_pit_sisnr_mag_bwd")
+        return dest, None, None, None, None, None, None
 
 
 def _stack(x: _TensorList, what: str) -> torch.Tensor:
@@ -127,6 +197,9 @@ class PIT_SISNR_time(_Base):
     def __call__(self, **kwargs) -> torch.Tensor:
         estims, targets = kwargs["estims"], kwargs["target_attr"]
         self._check(estims)
+        if _needs_grad(estims):                                                   # training: autograd-connected (engine.py:70,75)
+            loss = _PitTimeFn.apply(_stack_g(estims), _stack(targets, "target_attr"), 1.0e-8, -30.0)
+            return torch.sum(loss) / kwargs["input_sizes"].shape[0]
         out = pit_sisnr(estims, targets)
         return torch.sum(out["loss"]) / kwargs["input_sizes"].shape[0]           # reference :216-217
 
@@ -154,8 +227,12 @@ class PIT_SISNR_mag:
         self.frame_length, self.frame_shift, self.window = frame_length, frame_shift, window
         self.num_stages, self.num_spks, self.scale_inv, self.mel_opt = num_stages, num_spks, scale_inv, mel_opt
         self._dft = stft_kernel(frame_length, frame_shift, window)
+        ldd = (frame_length + 2 + 31) // 32 * 32                                   # K of the adjoint projection (include/sepr.h)
+        self._dft_t = torch.zeros(frame_length, ldd)
+        self._dft_t[:, : frame_length + 2] = self._dft[: frame_length + 2].t()
         if self.device.type == "cuda":
             self._dft = self._dft.to(self.device)
+            self._dft_t = self._dft_t.to(self.device).contiguous()
 
     def __repr__(self):
         return (f"<PIT_SISNR_mag(device={self.device!r}, frame_length={self.frame_length}, frame_shift={self.frame_shift}, "
@@ -170,5 +247,9 @@ class PIT_SISNR_mag:
             raise RuntimeError(f"expected {self.num_spks} estimates, got {n}")
         if self._dft.device.type != "cuda":
             raise RuntimeError("PIT_SISNR_mag was built for a non-HIP device (no CPU fallback exists)")
+        if _needs_grad(estims):                                                     # training (engine.py:68,75)
+            loss = _PitMagFn.apply(_stack_g(estims), _stack(targets, "target_attr"), self._dft, self._dft_t, self.frame_length,
+                                   self.frame_shift, 1.0e-12)
+            return torch.sum(loss) / kwargs["input_sizes"].shape[0]
         out = pit_sisnr_mag(estims, targets, self._dft, self.frame_length, self.frame_shift)
         return torch.sum(out["loss"]) / kwargs["input_sizes"].shape[0]             # reference :175-176

@@ -370,7 +370,7 @@ extern "C" int sepr_spksplit_fwd(const float* x, float* y, int B, int S, int T, 
 
 extern "C" int sepr_fuse_fwd(const float* lo, const float* skip, float* y, int n, int T, int F, const sepr_fuse_w* w,
                              sepr_stream_t stream) {
-  if (!lo || !skip || !y || !w || !w->w || !w->b || n <= 0 || T <= 0 || (T & 1) || F <= 0 || F % 32 != 0) return SEPR_EINVAL;
+  if (!lo || !skip || !y || !w || (!w->w && !w->x3.wp) || n <= 0 || T <= 0 || (T & 1) || F <= 0 || F % 32 != 0) return SEPR_EINVAL;
   const long long M = (long long)n * T;
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
   GemmArgs a = gemm_args_zero();

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
     if (kt > 0 || blockIdx.x != (unsigned)a.M) return;   // timing ablation: no global loads after setup
 #endif
     const int k = kt * GEMM_BK + 4 * c4;
-    if (PRO == PRO_NORM) {
+    if (PRO == PRO_NORM && a.gamma) {   // gamma == NULL: affine already folded into W / bias (training path)
       g4 = ld4(a.gamma + k);
       b4 = ld4(a.beta + k);
     }

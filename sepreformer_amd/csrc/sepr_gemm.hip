@@ -65,7 +65,7 @@ int launch_gemm(int pro, int epi, const GemmArgs& a, int site, hipStream_t strea
   if (!a.A || !a.W || !a.Y) return SEPR_EINVAL;
   if ((a.lda % 4) != 0 || (a.ldc % 4) != 0) return SEPR_EINVAL;
   if (pro == PRO_CAT2 && (!a.A2 || (a.ksplit % GEMM_BK) != 0 || (a.lda2 % 4) != 0)) return SEPR_EINVAL;
-  if (pro == PRO_NORM && (!a.stats || !a.gamma || !a.beta)) return SEPR_EINVAL;
+  if (pro == PRO_NORM && (!a.stats || (a.gamma != nullptr) != (a.beta != nullptr))) return SEPR_EINVAL;
   // staging addresses are 32-bit element offsets from the bases
   {
     const long long src_rows = a.rows_out > 0 ? ((long long)(a.M + a.rows_out - 1) / a.rows_out) * a.rows_src : a.M;

@@ -79,7 +79,9 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
       r[e] = zero4();
       if (m < m_end && col_ok) {
         if (roleA) {
-          r[e] = ld4(a.A + (long long)m * a.lda + col);
+          bool valid = true;
+          if (a.mask_a && a.rows_out > 0) valid = (m % a.rows_out) < a.rows_valid;
+          if (valid) r[e] = ld4(a.A + (long long)m * a.lda + col);
         } else {
           long long off = (long long)m * a.ldb;
           long long srow = m;

@@ -29,6 +29,7 @@ struct TnArgs {
   int rows_out, rows_valid, b_shift;
   long long seq_stride;
   const int* idx;
+  int mask_a;           // 1: rows of A that the row map declares invalid (r >= rows_valid) count as zero too (colsum)
   const float* stats;   // normalisation: (mean, rstd) per row (stat_seq == 0) or per sequence (stat_seq == 1); null = none
   int stat_seq;
   float* G;
@@ -106,6 +107,22 @@ int launch_res_ls(const float* x, const float* v, const float* ls, float* y, lon
 // inverted dropout with a counter-based generator: y[i] = keep(seed, offset + i) ? x[i] / (1 - p) : 0 (in place allowed)
 int launch_dropout(const float* x, float* y, long long count, float p, unsigned long long seed, unsigned long long offset,
                    hipStream_t s);
+
+// ---- waveform ends (encoder / decoder) -------------------------------------------------------------------------------
+// dwav [S,B,Tout] -> dwp [B*S,Tout] (sequence order b*S + s, the order of every decoder-side tensor)
+int launch_permute_sb(const float* dwav, float* dwp, int S, int B, int Tout, hipStream_t s);
+// ConvTranspose1d backward w.r.t. its input: dm[(seq,l)][n] = sum_k dwp[seq][stride*l + k] * wdec[k][n]
+int launch_dec_bwd_dm(const float* dwp, const float* wdec, float* dm, int nS, int L, int N, int K, int stride, int Tout, hipStream_t s);
+// auxiliary heads (module.py:257-260): m[(seq,l)][n] = relu(o2[(seq, idx[l])][n]) * enc[(seq / S, l)][n]
+int launch_aux_m(const float* o2, const float* enc, const int* idx, float* m, int nS, int S, int Tsrc, int L, int N, hipStream_t s);
+// do2[(seq,src)][n] = (o2 > 0) * sum_{l in [start[src], start[src+1])} dm[(seq,l)][n] * enc[(seq / S, l)][n]
+int launch_aux_mask_bwd(const float* dm, const float* o2, const float* enc, const int* idx_start, float* do2, int nS, int S, int Tsrc,
+                        int L, int N, hipStream_t s);
+// denc[(b,l)][n] += sum_s dm[(b*S+s, l)][n] * relu(o2[(b*S+s, idx[l])][n])
+int launch_aux_denc(const float* dm, const float* o2, const int* idx, float* denc, int nS, int S, int Tsrc, int L, int N, hipStream_t s);
+// encoder: de[(b,l)][n] = (de + add) * gelu'(sum_k w[k][n] wav[b][stride*l + k])   (in place; add may be null)
+int launch_enc_bwd_pre(float* de, const float* add, const float* wav, const float* w, int B, int T, int L, int N, int K, int stride,
+                       hipStream_t s);
 
 // ---- parameter-gradient finishers -------------------------------------------------------------------------------------
 // projection behind a normalisation whose affine was folded into it:  y = ((xh * g + b) . W^T + bias)

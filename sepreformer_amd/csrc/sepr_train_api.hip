@@ -1,0 +1,877 @@
+// extern "C" entry points of the training path (include/sepr.h, "Training path"): per block a train-mode forward that keeps
+// what the backward needs in a caller-provided context buffer, and the backward.  Each is a fixed sequence of launches
+// on the caller's stream: projections on the forward projection cores (sepr_gemm.h / sepr_gemm_x3.h) with transposed,
+// affine-folded weights for the input gradients, the TN contraction (sepr_gemm_tn.hip) for the weight gradients, and
+// the row-wise pieces of sepr_train_pw.hip / sepr_train_attn.hip.
+//
+// Layout of a block's context and scratch is defined ONCE, by the block's own implementation running in "dry" mode
+// (Carve::dry): sepr_train_ctx_bytes / sepr_train_ws_bytes replay the same carving without launching anything.
+#include <string.h>
+
+#include "sepr_pointwise.h"
+#include "sepr_train.h"
+
+namespace sepr {
+namespace {
+
+const float LN_EPS_T = 1e-5f, BN_EPS_T = 1e-5f, BN_MOM = 0.1f;
+
+struct Carve {
+  char* base;
+  size_t size, off;
+  bool dry;
+  Carve(void* p, size_t n, bool d) : base(static_cast<char*>(p)), size(n), off(0), dry(d) {}
+  void* take(size_t bytes) {
+    const size_t o = align_up(off);
+    off = o + bytes;
+    if (dry) return reinterpret_cast<void*>(0x1000);   // never dereferenced
+    if (!base || off > size) return nullptr;
+    return base + o;
+  }
+  float* f32(size_t count) { return static_cast<float*>(take(count * sizeof(float))); }
+  bool ok() const { return dry || (base != nullptr && off <= size); }
+  size_t need() const { return align_up(off); }
+};
+
+int lin(int pro, int epi, GemmArgs& a, const sepr_lin& l, int site, hipStream_t st) {
+  a.W = l.w;
+  a.Wp = l.wp;
+  a.bias = l.b;
+  if (l.wp) return launch_gemm_x3(pro, epi, a, site, st);
+  if (!l.w) return SEPR_EINVAL;
+  return launch_gemm(pro, epi, a, site, st);
+}
+// y[M][N] = a[M][K] . W^T (+ bias); residual add when R != null (y = . + R)
+int plain(const float* A, int lda, float* Y, int ldc, long long M, int N, int K, const sepr_lin& l, const float* R, hipStream_t st) {
+  GemmArgs a = gemm_args_zero();
+  a.M = (int)M; a.N = N; a.K = K;
+  a.A = A; a.lda = lda; a.Y = Y; a.ldc = ldc; a.R = R;
+  return lin(PRO_PLAIN, R ? EPI_RES : EPI_STORE, a, l, SEPR_SITE_NONE, st);
+}
+// y = xh . W^T + bias with xh = (x - mean) * rstd from per-row stats (affine folded into W / bias)
+int normed(const float* X, int lda, const float* stats, float* Y, int ldc, long long M, int N, int K, const sepr_lin& l,
+           hipStream_t st) {
+  GemmArgs a = gemm_args_zero();
+  a.M = (int)M; a.N = N; a.K = K;
+  a.A = X; a.lda = lda; a.stats = stats; a.Y = Y; a.ldc = ldc;
+  return lin(PRO_NORM, EPI_STORE, a, l, SEPR_SITE_NONE, st);
+}
+// G[N][K] = sum_m A[m][n] B[m][k] (B optionally normalised with per-row stats), colsum[N]
+int wgrad(const float* A, int lda, const float* B, int ldb, const float* stats, float* G, float* colsum, long long M, int N, int K,
+          int accumulate, bool x3, void* ws, size_t wsb, hipStream_t st) {
+  TnArgs t = tn_args_zero();
+  t.M = (int)M; t.N = N; t.K = K;
+  t.A = A; t.lda = lda; t.B = B; t.ldb = ldb; t.stats = stats;
+  t.G = G; t.ldg = K; t.accumulate = accumulate;
+  t.colsum = colsum; t.colsum_accumulate = accumulate;
+  return launch_gemm_tn(t, x3 ? 1 : 0, ws, wsb, st);
+}
+bool rows_ok(long long M) { return M > 0 && M <= 0x7fffffffLL / 8; }
+// distinct generator streams per dropout site of one block call
+sepr_u64 site_off(int site) { return (sepr_u64)site << 44; }
+
+// =====================================================================================================================
+// GCFN  (network.py:46-66)
+// =====================================================================================================================
+struct GcfnCtx { float *stats, *h1, *g; };
+GcfnCtx gcfn_ctx(Carve& c, long long M, int F) {
+  GcfnCtx k;
+  k.stats = c.f32(2 * M);
+  k.h1 = c.f32(6LL * F * M);
+  k.g = c.f32(3LL * F * M);
+  return k;
+}
+int gcfn_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, Carve& cx, Carve& ws, float p, sepr_u64 seed,
+             hipStream_t st) {
+  const long long M = (long long)n * T;
+  GcfnCtx k = gcfn_ctx(cx, M, F);
+  float* out = p > 0.f ? ws.f32((long long)F * M) : nullptr;
+  if (cx.dry) return SEPR_OK;
+  if (!cx.ok()) return SEPR_EWORKSPACE;
+  if (!ws.ok()) return SEPR_EWORKSPACE;
+  SEPR_TRY(launch_rowstats(x, k.stats, M, F, LN_EPS_T, st));
+  SEPR_TRY(normed(x, F, k.stats, k.h1, 6 * F, M, 6 * F, F, w->up, st));                       // network.py:61
+  SEPR_TRY(launch_dwglu(k.h1, k.g, n, T, F, w->dw_w, w->dw_b, st));                            // :62-65 (conv, GLU)
+  if (p > 0.f) {
+    SEPR_TRY(launch_dropout(k.g, k.g, 3LL * F * M, p, seed, site_off(0), st));                 // net2[1]
+    SEPR_TRY(plain(k.g, 3 * F, out, F, M, F, 3 * F, w->down, nullptr, st));                    // net2[2]
+    SEPR_TRY(launch_dropout(out, out, (long long)F * M, p, seed, site_off(1), st));            // net2[3]
+    SEPR_TRY(launch_res_ls(x, out, w->ls, y, M, F, st));                                       // :66
+  } else {
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = F; a.K = 3 * F;
+    a.A = k.g; a.lda = 3 * F; a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
+    SEPR_TRY(lin(PRO_PLAIN, EPI_RES, a, w->down, SEPR_SITE_NONE, st));
+  }
+  return SEPR_OK;
+}
+int gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, const sepr_gcfn_tw* w, const sepr_gcfn_grad* g, Carve& cx,
+             Carve& ws, float p, sepr_u64 seed, hipStream_t st) {
+  const long long M = (long long)n * T;
+  GcfnCtx k = gcfn_ctx(cx, M, F);
+  float* dyp = p > 0.f ? ws.f32((long long)F * M) : nullptr;
+  float* Gr = ws.f32(3LL * F * F);
+  float* s2 = ws.f32(F);
+  float* dg = ws.f32(3LL * F * M);
+  float* dh1 = ws.f32(6LL * F * M);
+  float* dWh = ws.f32(6LL * F * F);
+  float* s1 = ws.f32(6 * F);
+  float* dxh = ws.f32((long long)F * M);
+  const size_t tnb = tn_workspace_bytes((int)M, 6 * F, F) > tn_workspace_bytes((int)M, F, 3 * F) ? tn_workspace_bytes((int)M, 6 * F, F)
+                                                                                                   : tn_workspace_bytes((int)M, F, 3 * F);
+  void* tnw = ws.take(tnb);
+  const size_t midb = gcfn_mid_bwd_ws(n, T, 3 * F);
+  void* midw = ws.take(midb);
+  if (ws.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  const bool x3 = w->up.wp != nullptr;
+  const float* dyq = dy;
+  if (p > 0.f) {
+    SEPR_TRY(launch_dropout(dy, dyp, (long long)F * M, p, seed, site_off(1), st));
+    dyq = dyp;
+  }
+  // net2.2 + LayerScale: raw contraction, then dW2 / db2 / dls
+  SEPR_TRY(wgrad(dyq, F, k.g, 3 * F, nullptr, Gr, s2, M, F, 3 * F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_linear_ls(Gr, s2, w->w2, w->b2, w->ls, g->w2, g->b2, g->ls, F, 3 * F, st));
+  SEPR_TRY(plain(dyq, F, dg, 3 * F, M, 3 * F, F, w->down_t, nullptr, st));
+  if (p > 0.f) SEPR_TRY(launch_dropout(dg, dg, 3LL * F * M, p, seed, site_off(0), st));
+  // GLU + depthwise conv
+  SEPR_TRY(launch_gcfn_mid_bwd(k.h1, dg, dh1, n, T, 3 * F, w->dw_w, w->dw_b, g->dw_w, g->dw_b, midw, midb, st));
+  // net1: LayerNorm-folded projection
+  SEPR_TRY(wgrad(dh1, 6 * F, x, F, k.stats, dWh, s1, M, 6 * F, F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_norm_linear(dWh, s1, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 6 * F, F, st));
+  SEPR_TRY(plain(dh1, 6 * F, dxh, F, M, F, 6 * F, w->up_t, nullptr, st));
+  SEPR_TRY(launch_ln_bwd(dxh, x, k.stats, dy, nullptr, 0, 0, 0, dx, M, F, st));
+  return SEPR_OK;
+}
+
+// =====================================================================================================================
+// CLA  (network.py:159-187), train-mode BatchNorm
+// =====================================================================================================================
+struct ClaCtx { float *stats, *a, *u, *c, *z, *bn, *d; };
+ClaCtx cla_ctx(Carve& cx, long long M, int F) {
+  ClaCtx k;
+  k.stats = cx.f32(2 * M);
+  k.a = cx.f32(2LL * F * M);    // linear1 output (pre-GLU)
+  k.u = cx.f32((long long)F * M);
+  k.c = cx.f32((long long)F * M);
+  k.z = cx.f32(2LL * F * M);    // linear2 output (pre-BatchNorm)
+  k.bn = cx.f32(4 * F);         // batch mean [2F], rstd [2F]
+  k.d = cx.f32(2LL * F * M);    // gelu(bn(z)) (post-dropout input of linear3 when p > 0 ... dropout sits after linear3)
+  return k;
+}
+int cla_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_cla_tw* w, Carve& cx, Carve& ws, float p, sepr_u64 seed,
+            hipStream_t st) {
+  const long long M = (long long)n * T;
+  ClaCtx k = cla_ctx(cx, M, F);
+  const size_t csb = colstats_ws(M, 2 * F);
+  void* csw = ws.take(csb);
+  float* out = p > 0.f ? ws.f32((long long)F * M) : nullptr;
+  if (cx.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  SEPR_TRY(launch_rowstats(x, k.stats, M, F, LN_EPS_T, st));
+  SEPR_TRY(normed(x, F, k.stats, k.a, 2 * F, M, 2 * F, F, w->l1, st));                        // network.py:175-176
+  SEPR_TRY(launch_glu_fwd(k.a, k.u, M, F, st));                                               // :177
+  SEPR_TRY(launch_dwconv_same(k.u, k.c, n, T, F, K, w->dw_w, w->dw_b, st));                   // :178-180
+  SEPR_TRY(plain(k.c, F, k.z, 2 * F, M, 2 * F, F, w->l2, nullptr, st));                       // :181
+  SEPR_TRY(launch_colstats(k.z, M, 2 * F, BN_EPS_T, BN_MOM, k.bn, w->bn_rm, w->bn_rv, csw, csb, st));   // :183 (batch statistics)
+  SEPR_TRY(launch_bn_gelu_fwd(k.z, k.bn, w->bn_g, w->bn_b, k.d, M, 2 * F, st));               // :183,185 (GELU)
+  if (p > 0.f) {
+    SEPR_TRY(plain(k.d, 2 * F, out, F, M, F, 2 * F, w->l3, nullptr, st));
+    SEPR_TRY(launch_dropout(out, out, (long long)F * M, p, seed, site_off(0), st));           // linear3[2]
+    SEPR_TRY(launch_res_ls(x, out, w->ls, y, M, F, st));
+  } else {
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = F; a.K = 2 * F;
+    a.A = k.d; a.lda = 2 * F; a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
+    SEPR_TRY(lin(PRO_PLAIN, EPI_RES, a, w->l3, SEPR_SITE_NONE, st));                          // :185-187
+  }
+  return SEPR_OK;
+}
+int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int K, const sepr_cla_tw* w, const sepr_cla_grad* g,
+            Carve& cx, Carve& ws, float p, sepr_u64 seed, hipStream_t st) {
+  const long long M = (long long)n * T;
+  ClaCtx k = cla_ctx(cx, M, F);
+  float* dyp = p > 0.f ? ws.f32((long long)F * M) : nullptr;
+  float* Gr = ws.f32(2LL * F * F);
+  float* s = ws.f32(2 * F);
+  float* dd = ws.f32(2LL * F * M);      // d(gelu out), later dz in place, later da
+  float* dc = ws.f32((long long)F * M);
+  float* du = ws.f32((long long)F * M);
+  float* dxh = dc;                      // dc is dead once du / the conv weight gradient are formed
+  const size_t tnb = tn_workspace_bytes((int)M, 2 * F, F);
+  void* tnw = ws.take(tnb);
+  const size_t csb = colstats_ws(M, 2 * F);
+  void* csw = ws.take(csb);
+  const size_t wgb = dwconv_wgrad_ws(n, T, F, K);
+  void* wgw = ws.take(wgb);
+  if (ws.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  const bool x3 = w->l1.wp != nullptr;
+  const float* dyq = dy;
+  if (p > 0.f) {
+    SEPR_TRY(launch_dropout(dy, dyp, (long long)F * M, p, seed, site_off(0), st));
+    dyq = dyp;
+  }
+  SEPR_TRY(wgrad(dyq, F, k.d, 2 * F, nullptr, Gr, s, M, F, 2 * F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_linear_ls(Gr, s, w->w3, w->b3, w->ls, g->w3, g->b3, g->ls, F, 2 * F, st));
+  SEPR_TRY(plain(dyq, F, dd, 2 * F, M, 2 * F, F, w->l3_t, nullptr, st));
+  SEPR_TRY(launch_bn_gelu_bwd(dd, k.z, k.bn, w->bn_g, w->bn_b, dd, g->bn_g, g->bn_b, M, 2 * F, csw, csb, st));   // dd := dz
+  SEPR_TRY(wgrad(dd, 2 * F, k.c, F, nullptr, g->w2, g->b2, M, 2 * F, F, 1, x3, tnw, tnb, st));                   // linear2 (direct)
+  SEPR_TRY(plain(dd, 2 * F, dc, F, M, F, 2 * F, w->l2_t, nullptr, st));
+  SEPR_TRY(launch_dwconv_wgrad(k.u, dc, n, T, F, K, g->dw_w, g->dw_b, wgw, wgb, st));
+  SEPR_TRY(launch_dwconv_same(dc, du, n, T, F, K, w->dw_wf, w->zeros, st));                   // correlation with reversed taps
+  SEPR_TRY(launch_glu_bwd(du, k.a, dd, M, F, st));                                             // dd := da [M][2F]
+  SEPR_TRY(wgrad(dd, 2 * F, x, F, k.stats, Gr, s, M, 2 * F, F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_norm_linear(Gr, s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, st));
+  SEPR_TRY(plain(dd, 2 * F, dxh, F, M, F, 2 * F, w->l1_t, nullptr, st));
+  SEPR_TRY(launch_ln_bwd(dxh, x, k.stats, dy, nullptr, 0, 0, 0, dx, M, F, st));
+  return SEPR_OK;
+}
+
+// =====================================================================================================================
+// MultiHeadAttention pieces shared by EGA and SpkAttention
+// =====================================================================================================================
+// d(linear_out * LayerScale): Graw / finish / dO = dy' . (ls * Wo)
+int mha_out_bwd(const float* dyq, const float* o, float* dO, long long M, int F, const sepr_mha_tw* w, const sepr_mha_grad* g, float* Gr,
+                float* s, bool x3, void* tnw, size_t tnb, hipStream_t st) {
+  SEPR_TRY(wgrad(dyq, F, o, F, nullptr, Gr, s, M, F, F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_linear_ls(Gr, s, w->wo, w->bo, w->ls, g->wo, g->bo, g->ls, F, F, st));
+  return plain(dyq, F, dO, F, M, F, F, w->out_t, nullptr, st);
+}
+// d(q/k/v projection behind the LayerNorm): dWh [3F][F] -> three finishers (shared dgamma / dbeta), dxh = dqkv . (Wqkv * gamma)
+int mha_qkv_bwd(const float* dqkv, const float* xin, const float* stats, float* dxh, long long M, int F, const sepr_mha_tw* w,
+                const sepr_mha_grad* g, float* dWh, float* s, bool x3, void* tnw, size_t tnb, hipStream_t st) {
+  SEPR_TRY(wgrad(dqkv, 3 * F, xin, F, stats, dWh, s, M, 3 * F, F, 0, x3, tnw, tnb, st));
+  float* gw[3] = {g->wq, g->wk, g->wv};
+  float* gb[3] = {g->bq, g->bk, g->bv};
+  for (int i = 0; i < 3; ++i)
+    SEPR_TRY(launch_finish_norm_linear(dWh + (long long)i * F * F, s + i * F, w->wqkv + (long long)i * F * F, w->ln_g, w->ln_b, gw[i],
+                                       gb[i], g->ln_g, g->ln_b, F, F, st));
+  return plain(dqkv, 3 * F, dxh, F, M, F, 3 * F, w->qkv_t, nullptr, st);
+}
+
+// =====================================================================================================================
+// EGA  (network.py:126-155)
+// =====================================================================================================================
+struct EgaCtx { float *stats, *stats_p, *xd, *qkv, *P, *o, *att, *zg; };
+EgaCtx ega_ctx(Carve& cx, int n, int T, int Tp, int F, int H) {
+  const long long M = (long long)n * T, Mp = (long long)n * Tp;
+  EgaCtx k;
+  k.stats = cx.f32(2 * M);
+  k.stats_p = cx.f32(2 * Mp);
+  k.xd = cx.f32((long long)F * Mp);
+  k.qkv = cx.f32(3LL * F * Mp);
+  k.P = cx.f32((long long)n * H * Tp * Tp);
+  k.o = cx.f32((long long)F * Mp);
+  k.att = cx.f32((long long)F * Mp);
+  k.zg = cx.f32((long long)F * M);
+  return k;
+}
+int ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const sepr_ega_tw* w, Carve& cx, Carve& ws, float p,
+            sepr_u64 seed, hipStream_t st) {
+  const long long M = (long long)n * T, Mp = (long long)n * Tp;
+  const int fac = T / Tp;
+  EgaCtx k = ega_ctx(cx, n, T, Tp, F, H);
+  float* tmp = p > 0.f ? ws.f32((long long)F * Mp) : nullptr;
+  if (cx.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  if (p > 0.f) return SEPR_EINVAL;   // attention-probability dropout is not built yet: run the EGA blocks with p_drop = 0
+  const float* xp = x;
+  if (fac > 1) {
+    SEPR_TRY(launch_pool(x, k.xd, n, Tp, fac, F, st));                                          // network.py:146
+    xp = k.xd;
+  }
+  SEPR_TRY(launch_rowstats(xp, k.stats_p, Mp, F, LN_EPS_T, st));
+  SEPR_TRY(normed(xp, F, k.stats_p, k.qkv, 3 * F, Mp, 3 * F, F, w->attn.qkv, st));             // :99-102
+  SEPR_TRY(launch_relattn_train_fwd(k.qkv, k.o, k.P, n, Tp, F, H, w->pe_k, w->maxlen, st));    // :106-122
+  {
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)Mp; a.N = F; a.K = F;
+    a.A = k.o; a.lda = F; a.Y = k.att; a.ldc = F; a.R = nullptr; a.ls = w->attn.ls;
+    SEPR_TRY(lin(PRO_PLAIN, EPI_RES, a, w->attn.out, SEPR_SITE_NONE, st));                      // :124
+  }
+  (void)tmp; (void)seed;
+  SEPR_TRY(launch_rowstats(x, k.stats, M, F, LN_EPS_T, st));
+  SEPR_TRY(normed(x, F, k.stats, k.zg, F, M, F, F, w->gate, st));                               // :132-134
+  SEPR_TRY(launch_gate_fwd(x, k.zg, k.att, y, n, T, Tp, F, st));                                // :135,151-153
+  return SEPR_OK;
+}
+int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, int F, int H, const sepr_ega_tw* w, const sepr_ega_grad* g,
+            Carve& cx, Carve& ws, float p, sepr_u64 seed, hipStream_t st) {
+  const long long M = (long long)n * T, Mp = (long long)n * Tp;
+  const int fac = T / Tp;
+  EgaCtx k = ega_ctx(cx, n, T, Tp, F, H);
+  float* dzg = ws.f32((long long)F * M);
+  float* datt = ws.f32((long long)F * Mp);
+  float* dO = ws.f32((long long)F * Mp);
+  float* dqkv = ws.f32(3LL * F * Mp);
+  float* dxh_p = ws.f32((long long)F * Mp);
+  float* dxd = ws.f32((long long)F * Mp);
+  float* dWh = ws.f32(3LL * F * F);
+  float* s = ws.f32(3 * F);
+  float* dxh = ws.f32((long long)F * M);
+  size_t tnb = tn_workspace_bytes((int)M, F, F);
+  if (tn_workspace_bytes((int)Mp, 3 * F, F) > tnb) tnb = tn_workspace_bytes((int)Mp, 3 * F, F);
+  void* tnw = ws.take(tnb);
+  const size_t atb = relattn_train_ws(n, Tp, F, H);
+  void* atw = ws.take(atb);
+  if (ws.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  if (p > 0.f) return SEPR_EINVAL;
+  (void)seed;
+  const bool x3 = w->gate.wp != nullptr;
+  const float* xp = fac > 1 ? k.xd : x;
+  // gate: y = x + sigmoid(zg) * up(att)
+  SEPR_TRY(launch_gate_bwd(dy, k.zg, k.att, dzg, datt, n, T, Tp, F, st));
+  // attention branch first (its input gradient is added while the gate branch's LayerNorm backward writes dx)
+  SEPR_TRY(mha_out_bwd(datt, k.o, dO, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, st));
+  SEPR_TRY(launch_relattn_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, atw, atb, st));
+  SEPR_TRY(mha_qkv_bwd(dqkv, xp, k.stats_p, dxh_p, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, st));
+  SEPR_TRY(launch_ln_bwd(dxh_p, xp, k.stats_p, nullptr, nullptr, 0, 0, 0, dxd, Mp, F, st));
+  // gate projection behind its own LayerNorm
+  SEPR_TRY(wgrad(dzg, F, x, F, k.stats, dWh, s, M, F, F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_norm_linear(dWh, s, w->gate_w, w->gate_ln_g, w->gate_ln_b, g->gate_w, g->gate_b, g->gate_ln_g, g->gate_ln_b, F, F,
+                                     st));
+  SEPR_TRY(plain(dzg, F, dxh, F, M, F, F, w->gate_t, nullptr, st));
+  // dx = dy + LN'(dxh) + avg-pool backward of dxd
+  SEPR_TRY(launch_ln_bwd(dxh, x, k.stats, dy, dxd, T, Tp, fac, dx, M, F, st));
+  return SEPR_OK;
+}
+
+// =====================================================================================================================
+// SpkAttention up to its feed-forward  (network.py:233-247)
+// =====================================================================================================================
+struct SpkCtx { float *stats, *qkv, *o; };
+SpkCtx spk_ctx(Carve& cx, long long M, int F) {
+  SpkCtx k;
+  k.stats = cx.f32(2 * M);
+  k.qkv = cx.f32(3LL * F * M);
+  k.o = cx.f32((long long)F * M);
+  return k;
+}
+int spk_fwd(const float* x, float* y, int nS, int S, int T, int F, int H, const sepr_mha_tw* w, Carve& cx, Carve& ws, float p,
+            sepr_u64 seed, hipStream_t st) {
+  const long long M = (long long)nS * T;
+  SpkCtx k = spk_ctx(cx, M, F);
+  float* out = p > 0.f ? ws.f32((long long)F * M) : nullptr;
+  if (cx.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  if (p > 0.f) return SEPR_EINVAL;   // (attention-probability dropout: see ega_fwd)
+  (void)out; (void)seed;
+  SEPR_TRY(launch_rowstats(x, k.stats, M, F, LN_EPS_T, st));
+  SEPR_TRY(normed(x, F, k.stats, k.qkv, 3 * F, M, 3 * F, F, w->qkv, st));
+  SEPR_TRY(launch_spkmix(k.qkv, k.o, nS / S, S, T, F, H, st));
+  GemmArgs a = gemm_args_zero();
+  a.M = (int)M; a.N = F; a.K = F;
+  a.A = k.o; a.lda = F; a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
+  return lin(PRO_PLAIN, EPI_RES, a, w->out, SEPR_SITE_NONE, st);
+}
+int spk_bwd(const float* x, const float* dy, float* dx, int nS, int S, int T, int F, int H, const sepr_mha_tw* w, const sepr_mha_grad* g,
+            Carve& cx, Carve& ws, float p, sepr_u64 seed, hipStream_t st) {
+  const long long M = (long long)nS * T;
+  SpkCtx k = spk_ctx(cx, M, F);
+  float* dO = ws.f32((long long)F * M);
+  float* dqkv = ws.f32(3LL * F * M);
+  float* dWh = ws.f32(3LL * F * F);
+  float* s = ws.f32(3 * F);
+  float* dxh = dO;                      // dO is dead after the speaker-mix backward
+  const size_t tnb = tn_workspace_bytes((int)M, 3 * F, F);
+  void* tnw = ws.take(tnb);
+  if (ws.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  if (p > 0.f) return SEPR_EINVAL;
+  (void)seed;
+  const bool x3 = w->qkv.wp != nullptr;
+  SEPR_TRY(mha_out_bwd(dy, k.o, dO, M, F, w, g, dWh, s, x3, tnw, tnb, st));
+  SEPR_TRY(launch_spkmix_bwd(k.qkv, dO, dqkv, nS / S, S, T, F, H, st));
+  SEPR_TRY(mha_qkv_bwd(dqkv, x, k.stats, dxh, M, F, w, g, dWh, s, x3, tnw, tnb, st));
+  return launch_ln_bwd(dxh, x, k.stats, dy, nullptr, 0, 0, 0, dx, M, F, st);
+}
+
+// =====================================================================================================================
+// DownConvLayer (module.py:63-78), train-mode BatchNorm
+// =====================================================================================================================
+struct DownCtx { float *c, *bn; };
+int down_To(int T, int K) { return (T + 2 * ((K - 1) / 2) - K) / 2 + 1; }
+DownCtx down_ctx(Carve& cx, int n, int To, int F) {
+  DownCtx k;
+  k.c = cx.f32((long long)n * To * F);
+  k.bn = cx.f32(2 * F);
+  return k;
+}
+int down_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_down_tw* w, Carve& cx, Carve& ws, hipStream_t st) {
+  const int To = down_To(T, K);
+  DownCtx k = down_ctx(cx, n, To, F);
+  const size_t csb = colstats_ws((long long)n * To, F);
+  void* csw = ws.take(csb);
+  if (cx.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  SEPR_TRY(launch_downconv_pre(x, k.c, n, T, To, F, K, w->w, w->b, st));                                        // module.py:74
+  SEPR_TRY(launch_colstats(k.c, (long long)n * To, F, BN_EPS_T, BN_MOM, k.bn, w->bn_rm, w->bn_rv, csw, csb, st));   // :75
+  return launch_bn_gelu_fwd(k.c, k.bn, w->bn_g, w->bn_b, y, (long long)n * To, F, st);                          // :75-76
+}
+int down_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int K, const sepr_down_tw* w, const sepr_down_grad* g,
+             Carve& cx, Carve& ws, hipStream_t st) {
+  const int To = down_To(T, K);
+  DownCtx k = down_ctx(cx, n, To, F);
+  float* dc = ws.f32((long long)n * To * F);
+  const size_t csb = colstats_ws((long long)n * To, F);
+  void* csw = ws.take(csb);
+  const size_t wgb = downconv_bwd_ws(n, T, F, K);
+  void* wgw = ws.take(wgb);
+  if (ws.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  SEPR_TRY(launch_bn_gelu_bwd(dy, k.c, k.bn, w->bn_g, w->bn_b, dc, g->bn_g, g->bn_b, (long long)n * To, F, csw, csb, st));
+  return launch_downconv_bwd(x, dc, dx, n, T, To, F, K, w->w, g->w, g->b, wgw, wgb, st);
+}
+
+// =====================================================================================================================
+// SpkSplitStage (module.py:110-125)
+// =====================================================================================================================
+struct SplitCtx { float *a, *z, *v, *stats; };
+SplitCtx split_ctx(Carve& cx, int B, int S, int T, int F) {
+  const long long M = (long long)B * T;
+  SplitCtx k;
+  k.a = cx.f32(4LL * F * S * M);     // linear.0 output (pre-GLU)
+  k.z = cx.f32(2LL * F * S * M);
+  k.v = cx.f32((long long)F * S * M);   // linear.2 output in [B*S, T, F] layout (pre-GroupNorm)
+  k.stats = cx.f32(2LL * B * S);
+  return k;
+}
+int split_fwd(const float* x, float* y, int B, int S, int T, int F, float eps, const sepr_split_tw* w, Carve& cx, Carve& ws,
+              hipStream_t st) {
+  const long long M = (long long)B * T;
+  SplitCtx k = split_ctx(cx, B, S, T, F);
+  const int n_out = B * S;
+  const long long count = (long long)T * F;
+  const int nchunk = gn_chunks(count);
+  double* part = static_cast<double*>(ws.take((size_t)n_out * nchunk * 2 * sizeof(double)));
+  if (cx.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  SEPR_TRY(plain(x, F, k.a, 4 * F * S, M, 4 * F * S, F, w->l1, nullptr, st));                   // module.py:114
+  SEPR_TRY(launch_glu_fwd(k.a, k.z, M, 2 * F * S, st));                                          // :115 (channel dim == last dim here)
+  {
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = F * S; a.K = 2 * F * S;
+    a.A = k.z; a.lda = 2 * F * S; a.Y = k.v; a.ldc = F; a.T = T; a.S = S; a.Fs = F;
+    SEPR_TRY(lin(PRO_PLAIN, EPI_SPLIT, a, w->l2, SEPR_SITE_NONE, st));                           // :116,123
+  }
+  SEPR_TRY(launch_gn_partial(k.v, part, n_out, count, nchunk, st));
+  SEPR_TRY(launch_gn_finalize(part, n_out, nchunk, count, eps, k.stats, st));
+  return launch_gn_apply_oop(k.v, k.stats, w->gn_g, w->gn_b, y, n_out, T, F, st);                // :124
+}
+int split_bwd(const float* x, const float* dy, float* dx, int dx_acc, int B, int S, int T, int F, const sepr_split_tw* w,
+              const sepr_split_grad* g, Carve& cx, Carve& ws, hipStream_t st) {
+  const long long M = (long long)B * T;
+  SplitCtx k = split_ctx(cx, B, S, T, F);
+  float* dv = ws.f32((long long)F * S * M);      // [M][S*F] (channel-split inverted)
+  float* dz = ws.f32(2LL * F * S * M);
+  float* da = ws.f32(4LL * F * S * M);
+  const size_t gnb = gn_bwd_ws(B * S, T, F);
+  void* gnw = ws.take(gnb);
+  size_t tnb = tn_workspace_bytes((int)M, F * S, 2 * F * S);
+  if (tn_workspace_bytes((int)M, 4 * F * S, F) > tnb) tnb = tn_workspace_bytes((int)M, 4 * F * S, F);
+  void* tnw = ws.take(tnb);
+  if (ws.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  const bool x3 = w->l1.wp != nullptr;
+  SEPR_TRY(launch_gn_bwd(dy, k.v, k.stats, w->gn_g, dv, g->gn_g, g->gn_b, B * S, T, F, S, gnw, gnb, st));
+  SEPR_TRY(wgrad(dv, F * S, k.z, 2 * F * S, nullptr, g->w2, g->b2, M, F * S, 2 * F * S, 1, x3, tnw, tnb, st));
+  SEPR_TRY(plain(dv, F * S, dz, 2 * F * S, M, 2 * F * S, F * S, w->l2_t, nullptr, st));
+  SEPR_TRY(launch_glu_bwd(dz, k.a, da, M, 2 * F * S, st));
+  SEPR_TRY(wgrad(da, 4 * F * S, x, F, nullptr, g->w1, g->b1, M, 4 * F * S, F, 1, x3, tnw, tnb, st));
+  return plain(da, 4 * F * S, dx, F, M, F, 4 * F * S, w->l1_t, dx_acc ? dx : nullptr, st);
+}
+
+}  // namespace
+}  // namespace sepr
+
+using namespace sepr;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// extern "C" wrappers
+// ---------------------------------------------------------------------------------------------------------------------
+#define SEPR_ST static_cast<hipStream_t>(stream)
+
+extern "C" int sepr_gcfn_train_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, void* ctx, size_t ctx_bytes,
+                                   void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream) {
+  if (!x || !y || !w || n <= 0 || T <= 0 || F <= 0 || F % 32 || !rows_ok((long long)n * T) || x == y) return SEPR_EINVAL;
+  Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
+  return gcfn_fwd(x, y, n, T, F, w, cx, wk, p_drop, seed, SEPR_ST);
+}
+extern "C" int sepr_gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, const sepr_gcfn_tw* w,
+                             const sepr_gcfn_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop,
+                             sepr_u64 seed, sepr_stream_t stream) {
+  if (!x || !dy || !dx || !w || !g || n <= 0 || T <= 0 || F <= 0 || F % 32 || !rows_ok((long long)n * T)) return SEPR_EINVAL;
+  Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
+  return gcfn_bwd(x, dy, dx, n, T, F, w, g, cx, wk, p_drop, seed, SEPR_ST);
+}
+extern "C" int sepr_cla_train_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_cla_tw* w, void* ctx, size_t ctx_bytes,
+                                  void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream) {
+  if (!x || !y || !w || n <= 0 || T <= 0 || F <= 0 || F % 64 || !rows_ok((long long)n * T) || x == y) return SEPR_EINVAL;
+  Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
+  return cla_fwd(x, y, n, T, F, K, w, cx, wk, p_drop, seed, SEPR_ST);
+}
+extern "C" int sepr_cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int K, const sepr_cla_tw* w,
+                            const sepr_cla_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop,
+                            sepr_u64 seed, sepr_stream_t stream) {
+  if (!x || !dy || !dx || !w || !g || n <= 0 || T <= 0 || F <= 0 || F % 64 || !rows_ok((long long)n * T)) return SEPR_EINVAL;
+  Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
+  return cla_bwd(x, dy, dx, n, T, F, K, w, g, cx, wk, p_drop, seed, SEPR_ST);
+}
+extern "C" int sepr_ega_train_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const sepr_ega_tw* w, void* ctx,
+                                  size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream) {
+  if (!x || !y || !w || x == y || n <= 0 || T <= 0 || Tp <= 0 || T % Tp || F <= 0 || F % 32 || H <= 0 || F % H ||
+      !rows_ok((long long)n * T))
+    return SEPR_EINVAL;
+  Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
+  return ega_fwd(x, y, n, T, Tp, F, H, w, cx, wk, p_drop, seed, SEPR_ST);
+}
+extern "C" int sepr_ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, int F, int H, const sepr_ega_tw* w,
+                            const sepr_ega_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop,
+                            sepr_u64 seed, sepr_stream_t stream) {
+  if (!x || !dy || !dx || !w || !g || n <= 0 || T <= 0 || Tp <= 0 || T % Tp || F <= 0 || F % 32 || H <= 0 || F % H ||
+      !rows_ok((long long)n * T))
+    return SEPR_EINVAL;
+  Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
+  return ega_bwd(x, dy, dx, n, T, Tp, F, H, w, g, cx, wk, p_drop, seed, SEPR_ST);
+}
+extern "C" int sepr_spkattn_train_fwd(const float* x, float* y, int nS, int S, int T, int F, int H, const sepr_mha_tw* w, void* ctx,
+                                      size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream) {
+  if (!x || !y || !w || nS <= 0 || S <= 0 || nS % S || T <= 0 || F <= 0 || F % 32 || H <= 0 || F % H || !rows_ok((long long)nS * T))
+    return SEPR_EINVAL;
+  Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
+  return spk_fwd(x, y, nS, S, T, F, H, w, cx, wk, p_drop, seed, SEPR_ST);
+}
+extern "C" int sepr_spkattn_bwd(const float* x, const float* dy, float* dx, int nS, int S, int T, int F, int H, const sepr_mha_tw* w,
+                                const sepr_mha_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop,
+                                sepr_u64 seed, sepr_stream_t stream) {
+  if (!x || !dy || !dx || !w || !g || nS <= 0 || S <= 0 || nS % S || T <= 0 || F <= 0 || F % 32 || H <= 0 || F % H ||
+      !rows_ok((long long)nS * T))
+    return SEPR_EINVAL;
+  Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
+  return spk_bwd(x, dy, dx, nS, S, T, F, H, w, g, cx, wk, p_drop, seed, SEPR_ST);
+}
+extern "C" int sepr_downconv_train_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_down_tw* w, void* ctx,
+                                       size_t ctx_bytes, void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  if (!x || !y || !w || n <= 0 || T <= 0 || F <= 0 || F % 4 || K <= 0 || !(K & 1)) return SEPR_EINVAL;
+  Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
+  return down_fwd(x, y, n, T, F, K, w, cx, wk, SEPR_ST);
+}
+extern "C" int sepr_downconv_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int K, const sepr_down_tw* w,
+                                 const sepr_down_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes,
+                                 sepr_stream_t stream) {
+  if (!x || !dy || !dx || !w || !g || n <= 0 || T <= 0 || F <= 0 || F % 4 || K <= 0 || !(K & 1)) return SEPR_EINVAL;
+  Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
+  return down_bwd(x, dy, dx, n, T, F, K, w, g, cx, wk, SEPR_ST);
+}
+extern "C" int sepr_spksplit_train_fwd(const float* x, float* y, int B, int S, int T, int F, float gn_eps, const sepr_split_tw* w,
+                                       void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  if (!x || !y || !w || B <= 0 || S <= 0 || T <= 0 || F <= 0 || F % 32 || !rows_ok((long long)B * T * S)) return SEPR_EINVAL;
+  Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
+  return split_fwd(x, y, B, S, T, F, gn_eps, w, cx, wk, SEPR_ST);
+}
+extern "C" int sepr_spksplit_bwd(const float* x, const float* dy, float* dx, int dx_accumulate, int B, int S, int T, int F,
+                                 const sepr_split_tw* w, const sepr_split_grad* g, const void* ctx, size_t ctx_bytes, void* ws,
+                                 size_t ws_bytes, sepr_stream_t stream) {
+  if (!x || !dy || !dx || !w || !g || B <= 0 || S <= 0 || T <= 0 || F <= 0 || F % 32 || !rows_ok((long long)B * T * S)) return SEPR_EINVAL;
+  Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
+  return split_bwd(x, dy, dx, dx_accumulate, B, S, T, F, w, g, cx, wk, SEPR_ST);
+}
+
+extern "C" size_t sepr_linear_wgrad_workspace(int M, int N, int K) { return tn_workspace_bytes(M, N, K); }
+extern "C" int sepr_linear_wgrad(const float* A, const float* B, float* G, float* colsum, int M, int N, int K, int accumulate, int x3,
+                                 void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  if (!A || !B || !G || M <= 0) return SEPR_EINVAL;
+  return wgrad(A, N, B, K, nullptr, G, colsum, M, N, K, accumulate, x3 != 0, ws, ws_bytes, SEPR_ST);
+}
+
+// =====================================================================================================================
+// fusion conv, OutputLayer + decoder, encoder + projector, sizing
+// =====================================================================================================================
+namespace sepr {
+namespace {
+
+int fuse_bwd(const float* lo, const float* skip, const float* dy, float* dlo, float* dskip, int n, int T, int F, const sepr_fuse_tw* w,
+             const sepr_fuse_grad* g, Carve& ws, hipStream_t st) {
+  const long long M = (long long)n * T;
+  float* dcat = ws.f32(2LL * F * M);
+  const size_t tnb = tn_workspace_bytes((int)M, F, 2 * F);
+  void* tnw = ws.take(tnb);
+  if (ws.dry) return SEPR_OK;
+  if (!ws.ok()) return SEPR_EWORKSPACE;
+  TnArgs t = tn_args_zero();                       // dW [F][2F] += sum dy [up2(lo) | skip]   (module.py:212-214)
+  t.M = (int)M; t.N = F; t.K = 2 * F;
+  t.A = dy; t.lda = F;
+  t.B = lo; t.ldb = F; t.rows_out = T; t.rows_valid = T; t.b_shift = 1; t.seq_stride = (long long)(T / 2) * F;
+  t.B2 = skip; t.ldb2 = F; t.ksplit = F;
+  t.G = g->w; t.ldg = 2 * F; t.accumulate = 1; t.colsum = g->b; t.colsum_accumulate = 1;
+  SEPR_TRY(launch_gemm_tn(t, w->l.wp != nullptr, tnw, tnb, st));
+  SEPR_TRY(plain(dy, F, dcat, 2 * F, M, 2 * F, F, w->l_t, nullptr, st));
+  return launch_unfuse(dcat, dlo, dskip, n, T, F, st);
+}
+
+struct OutCtx { float *a1, *o1, *o2; };
+OutCtx out_ctx(Carve& cx, long long Mp, int F, int N) {
+  OutCtx k;
+  k.a1 = cx.f32(4LL * F * Mp);
+  k.o1 = cx.f32(2LL * F * Mp);
+  k.o2 = cx.f32((long long)N * Mp);
+  return k;
+}
+int out_fwd(const float* x, int nS, int S, int Tsrc, int L, const int* idx, const float* enc, int F, int N, int K, int stride,
+            const sepr_out_tw* w, float* wav, Carve& cx, hipStream_t st) {
+  const long long Mp = idx ? (long long)nS * Tsrc : (long long)nS * L;
+  OutCtx k = out_ctx(cx, Mp, F, N);
+  if (cx.dry) return SEPR_OK;
+  if (!cx.ok()) return SEPR_EWORKSPACE;
+  {  // Linear F->4F on the frames the head reads (main: the crop of module.py:250; aux: the source frames)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)Mp; a.N = 4 * F; a.K = F;
+    a.A = x; a.lda = F; a.Y = k.a1; a.ldc = 4 * F;
+    if (!idx) { a.rows_out = L; a.rows_src = Tsrc; a.rows_valid = L; }
+    SEPR_TRY(lin(PRO_PLAIN, EPI_STORE, a, w->l1, SEPR_SITE_NONE, st));
+  }
+  SEPR_TRY(launch_glu_fwd(k.a1, k.o1, Mp, 2 * F, st));                                       // module.py:246 (GLU)
+  SEPR_TRY(plain(k.o1, 2 * F, k.o2, N, Mp, N, 2 * F, w->l2, nullptr, st));                   // :247
+  const int Tout = (L - 1) * stride + K;
+  return launch_decoder(k.o2, nS, S, L, N, K, stride, w->wdec, wav, Tout, idx, Tsrc, enc, st);   // :257-260, :278-283
+}
+int out_bwd(const float* x, const float* dwav, float* dx, int dx_acc, float* denc, int nS, int S, int Tsrc, int L, const int* idx,
+            const int* idx_start, const float* enc, int F, int N, int K, int stride, const sepr_out_tw* w, const sepr_out_grad* g,
+            Carve& cx, Carve& ws, hipStream_t st) {
+  const bool aux = idx != nullptr;
+  const long long Mp = aux ? (long long)nS * Tsrc : (long long)nS * L, ML = (long long)nS * L;
+  const int Tout = (L - 1) * stride + K;
+  OutCtx k = out_ctx(cx, Mp, F, N);
+  float* dwp = ws.f32((long long)nS * Tout);
+  float* dm = ws.f32((long long)N * ML);
+  float* mt = ws.f32(aux ? (long long)N * ML : 4);
+  float* do2 = aux ? ws.f32((long long)N * Mp) : dm;
+  float* do1 = ws.f32(2LL * F * Mp);
+  float* da1 = ws.f32(4LL * F * Mp);
+  size_t tnb = tn_workspace_bytes((int)ML, N, K);
+  if (tn_workspace_bytes((int)Mp, N, 2 * F) > tnb) tnb = tn_workspace_bytes((int)Mp, N, 2 * F);
+  if (tn_workspace_bytes((int)Mp, 4 * F, F) > tnb) tnb = tn_workspace_bytes((int)Mp, 4 * F, F);
+  void* tnw = ws.take(tnb);
+  if (ws.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  if (aux && (!idx_start || !enc || !denc)) return SEPR_EINVAL;
+  const bool x3 = w->l1.wp != nullptr;
+  SEPR_TRY(launch_permute_sb(dwav, dwp, S, nS / S, Tout, st));
+  SEPR_TRY(launch_dec_bwd_dm(dwp, w->wdec, dm, nS, L, N, K, stride, Tout, st));
+  const float* m = k.o2;
+  if (aux) {
+    SEPR_TRY(launch_aux_m(k.o2, enc, idx, mt, nS, S, Tsrc, L, N, st));
+    m = mt;
+  }
+  {  // decoder weight [N][1][K] += sum_rows m[row][n] * dwav_frame[row][k]
+    TnArgs t = tn_args_zero();
+    t.M = (int)ML; t.N = N; t.K = K;
+    t.A = m; t.lda = N;
+    t.B = dwp; t.ldb = stride; t.rows_out = L; t.rows_valid = L; t.seq_stride = Tout;
+    t.G = g->wdec; t.ldg = K; t.accumulate = 1;
+    SEPR_TRY(launch_gemm_tn(t, 0, tnw, tnb, st));      // exact core: K = 16, negligible work
+  }
+  if (aux) {
+    SEPR_TRY(launch_aux_mask_bwd(dm, k.o2, enc, idx_start, do2, nS, S, Tsrc, L, N, st));
+    SEPR_TRY(launch_aux_denc(dm, k.o2, idx, denc, nS, S, Tsrc, L, N, st));
+  }
+  SEPR_TRY(wgrad(do2, N, k.o1, 2 * F, nullptr, g->w2, g->b2, Mp, N, 2 * F, 1, x3, tnw, tnb, st));
+  SEPR_TRY(plain(do2, N, do1, 2 * F, Mp, 2 * F, N, w->l2_t, nullptr, st));
+  SEPR_TRY(launch_glu_bwd(do1, k.a1, da1, Mp, 2 * F, st));
+  {  // first projection: input rows = the frames the head read
+    TnArgs t = tn_args_zero();
+    t.M = (int)Mp; t.N = 4 * F; t.K = F;
+    t.A = da1; t.lda = 4 * F; t.B = x; t.ldb = F;
+    if (!aux) { t.rows_out = L; t.rows_valid = L; t.seq_stride = (long long)Tsrc * F; }
+    t.G = g->w1; t.ldg = F; t.accumulate = 1; t.colsum = g->b1; t.colsum_accumulate = 1;
+    SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
+  }
+  {  // dx over all Tsrc frames of every sequence (main head: frames >= L read nothing -> zero gradient)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)((long long)nS * Tsrc); a.N = F; a.K = 4 * F;
+    a.A = da1; a.lda = 4 * F; a.Y = dx; a.ldc = F; a.R = dx_acc ? dx : nullptr;
+    if (!aux) { a.rows_out = Tsrc; a.rows_src = L; a.rows_valid = L; }
+    SEPR_TRY(lin(PRO_PLAIN, dx_acc ? EPI_RES : EPI_STORE, a, w->l1_t, SEPR_SITE_NONE, st));
+  }
+  return SEPR_OK;
+}
+
+int front_fwd(const float* wav, int B, int T, int N, int K, int stride, int F, int Lp, float eps, const sepr_front_tw* w, float* enc,
+              float* out, Carve& cx, Carve& ws, hipStream_t st) {
+  const int L = (T - K) / stride + 1;
+  float* stats = cx.f32(2 * B);
+  const int ntile = encoder_tiles(L);
+  double* part = static_cast<double*>(ws.take((size_t)B * ntile * 2 * sizeof(double)));
+  if (cx.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  SEPR_TRY(launch_encoder(wav, B, T, L, w->w_enc, N, K, stride, enc, part, st));              // module.py:19-23
+  SEPR_TRY(launch_gn_finalize(part, B, ntile, (long long)L * N, eps, stats, st));
+  GemmArgs a = gemm_args_zero();                                                             // module.py:32-35, 220-234
+  a.M = B * Lp; a.N = F; a.K = N;
+  a.A = enc; a.lda = N; a.rows_out = Lp; a.rows_src = L; a.rows_valid = L;
+  a.stats = stats; a.stat_seq = 1; a.gamma = w->gn_g; a.beta = w->gn_b;
+  a.W = w->proj_w; a.bias = nullptr; a.Y = out; a.ldc = F;
+  return launch_gemm(PRO_NORM, EPI_STORE, a, SEPR_SITE_PROJECTOR, st);
+}
+int front_bwd(const float* wav, const float* enc, const float* dout, float* denc_aux, int B, int T, int N, int K, int stride, int F,
+              int Lp, const sepr_front_tw* w, const sepr_front_grad* g, Carve& cx, Carve& ws, hipStream_t st) {
+  const int L = (T - K) / stride + 1;
+  const long long ML = (long long)B * L;
+  float* stats = cx.f32(2 * B);
+  float* dWh = ws.f32((long long)F * N);
+  float* s = ws.f32(F);
+  float* deh = ws.f32((long long)N * ML);
+  float* de = ws.f32((long long)N * ML);
+  float* dump = ws.f32(2 * N);
+  size_t tnb = tn_workspace_bytes(B * Lp, F, N);
+  if (tn_workspace_bytes((int)ML, N, K) > tnb) tnb = tn_workspace_bytes((int)ML, N, K);
+  void* tnw = ws.take(tnb);
+  const size_t gnb = gn_bwd_ws(B, L, N);
+  void* gnw = ws.take(gnb);
+  if (ws.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  {  // projector weight: dWh [F][N] = sum over the valid frames of dout[m][f] * enc_hat[m][n]
+    TnArgs t = tn_args_zero();
+    t.M = B * Lp; t.N = F; t.K = N;
+    t.A = dout; t.lda = F; t.mask_a = 1;
+    t.B = enc; t.ldb = N; t.rows_out = Lp; t.rows_valid = L; t.seq_stride = (long long)L * N;
+    t.stats = stats; t.stat_seq = 1;
+    t.G = dWh; t.ldg = N; t.colsum = s;
+    SEPR_TRY(launch_gemm_tn(t, w->proj_t.wp != nullptr, tnw, tnb, st));
+  }
+  SEPR_TRY(launch_finish_norm_linear(dWh, s, w->proj_w, w->gn_g, w->gn_b, g->proj_w, nullptr, g->gn_g, g->gn_b, F, N, st));
+  {  // d enc_hat [B*L][N] = dout(valid rows) . (W * gamma)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)ML; a.N = N; a.K = F;
+    a.A = dout; a.lda = F; a.rows_out = L; a.rows_src = Lp; a.rows_valid = L;
+    a.Y = deh; a.ldc = N;
+    SEPR_TRY(lin(PRO_PLAIN, EPI_STORE, a, w->proj_t, SEPR_SITE_NONE, st));
+  }
+  // GroupNorm(1, N) backward over (L, N) of each sample (affine already folded: gamma = 1 here)
+  SEPR_TRY(hipMemsetAsync(dump, 0, 2 * N * sizeof(float), st) == hipSuccess ? SEPR_OK : SEPR_EHIP);
+  SEPR_TRY(launch_gn_bwd(deh, enc, stats, w->ones, de, dump, dump + N, B, L, N, 0, gnw, gnb, st));
+  // + gradient from the auxiliary heads' masks, through the GELU; then the encoder filters
+  SEPR_TRY(launch_enc_bwd_pre(de, denc_aux, wav, w->w_enc, B, T, L, N, K, stride, st));
+  TnArgs t = tn_args_zero();                       // w_enc [N][1][K] += sum dpre[m][n] * wav[b][stride*l + k]
+  t.M = (int)ML; t.N = N; t.K = K;
+  t.A = de; t.lda = N;
+  t.B = wav; t.ldb = stride; t.rows_out = L; t.rows_valid = L; t.seq_stride = T;
+  t.G = g->w_enc; t.ldg = K; t.accumulate = 1;
+  return launch_gemm_tn(t, 0, tnw, tnb, st);
+}
+
+}  // namespace
+}  // namespace sepr
+
+extern "C" int sepr_fuse_bwd(const float* lo, const float* skip, const float* dy, float* dlo, float* dskip, int n, int T, int F,
+                             const sepr_fuse_tw* w, const sepr_fuse_grad* g, void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  if (!lo || !skip || !dy || !dlo || !dskip || !w || !g || n <= 0 || T <= 0 || (T & 1) || F <= 0 || F % 32) return SEPR_EINVAL;
+  Carve wk(ws, ws_bytes, false);
+  return fuse_bwd(lo, skip, dy, dlo, dskip, n, T, F, w, g, wk, SEPR_ST);
+}
+extern "C" int sepr_outlayer_decoder_train_fwd(const float* x, int nS, int S, int Tsrc, int L, const int* idx, const float* enc, int F,
+                                               int N, int K, int stride, const sepr_out_tw* w, float* wav, void* ctx, size_t ctx_bytes,
+                                               void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  (void)ws; (void)ws_bytes;
+  if (!x || !w || !wav || nS <= 0 || S <= 0 || nS % S || Tsrc <= 0 || L <= 0 || F % 32 || N % 16) return SEPR_EINVAL;
+  if (!idx && L > Tsrc) return SEPR_EINVAL;
+  if (idx && (Tsrc > L || !enc)) return SEPR_EINVAL;
+  Carve cx(ctx, ctx_bytes, false);
+  return out_fwd(x, nS, S, Tsrc, L, idx, enc, F, N, K, stride, w, wav, cx, SEPR_ST);
+}
+extern "C" int sepr_outlayer_decoder_bwd(const float* x, const float* dwav, float* dx, int dx_accumulate, float* denc, int nS, int S,
+                                         int Tsrc, int L, const int* idx, const int* idx_start, const float* enc, int F, int N, int K,
+                                         int stride, const sepr_out_tw* w, const sepr_out_grad* g, const void* ctx, size_t ctx_bytes,
+                                         void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  if (!x || !dwav || !dx || !w || !g || nS <= 0 || S <= 0 || nS % S || Tsrc <= 0 || L <= 0 || F % 32 || N % 16) return SEPR_EINVAL;
+  if (!idx && L > Tsrc) return SEPR_EINVAL;
+  if (idx && Tsrc > L) return SEPR_EINVAL;
+  Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
+  return out_bwd(x, dwav, dx, dx_accumulate, denc, nS, S, Tsrc, L, idx, idx_start, enc, F, N, K, stride, w, g, cx, wk, SEPR_ST);
+}
+extern "C" int sepr_front_train_fwd(const float* wav, int B, int T, int N, int K, int stride, int F, int Lp, float gn_eps,
+                                    const sepr_front_tw* w, float* enc, float* out, void* ctx, size_t ctx_bytes, void* ws,
+                                    size_t ws_bytes, sepr_stream_t stream) {
+  if (!wav || !w || !enc || !out || B <= 0 || T < K || stride <= 0 || Lp < (T - K) / stride + 1) return SEPR_EINVAL;
+  Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
+  return front_fwd(wav, B, T, N, K, stride, F, Lp, gn_eps, w, enc, out, cx, wk, SEPR_ST);
+}
+extern "C" int sepr_front_bwd(const float* wav, const float* enc, const float* dout, float* denc_aux, int B, int T, int N, int K,
+                              int stride, int F, int Lp, const sepr_front_tw* w, const sepr_front_grad* g, const void* ctx,
+                              size_t ctx_bytes, void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  if (!wav || !enc || !dout || !w || !g || B <= 0 || T < K || stride <= 0) return SEPR_EINVAL;
+  Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
+  return front_bwd(wav, enc, dout, denc_aux, B, T, N, K, stride, F, Lp, w, g, cx, wk, SEPR_ST);
+}
+
+// ---- sizing: replay each block's carving in dry mode --------------------------------------------------------------
+static void train_sizes(int op, int n, int T, int Tp, int F, int N, int S, int H, int K, size_t* ctx_b, size_t* ws_b) {
+  Carve cf(nullptr, 0, true), wf(nullptr, 0, true), cb(nullptr, 0, true), wb(nullptr, 0, true);
+  const float p1 = 0.5f;      // size for the dropout-enabled layout (superset)
+  switch (op) {
+    case SEPR_TOP_GCFN:
+      gcfn_fwd(nullptr, nullptr, n, T, F, nullptr, cf, wf, p1, 0, nullptr);
+      gcfn_bwd(nullptr, nullptr, nullptr, n, T, F, nullptr, nullptr, cb, wb, p1, 0, nullptr);
+      break;
+    case SEPR_TOP_CLA:
+      cla_fwd(nullptr, nullptr, n, T, F, K, nullptr, cf, wf, p1, 0, nullptr);
+      cla_bwd(nullptr, nullptr, nullptr, n, T, F, K, nullptr, nullptr, cb, wb, p1, 0, nullptr);
+      break;
+    case SEPR_TOP_EGA:
+      ega_fwd(nullptr, nullptr, n, T, Tp, F, H, nullptr, cf, wf, p1, 0, nullptr);
+      ega_bwd(nullptr, nullptr, nullptr, n, T, Tp, F, H, nullptr, nullptr, cb, wb, p1, 0, nullptr);
+      break;
+    case SEPR_TOP_SPKATTN:
+      spk_fwd(nullptr, nullptr, n, S, T, F, H, nullptr, cf, wf, p1, 0, nullptr);
+      spk_bwd(nullptr, nullptr, nullptr, n, S, T, F, H, nullptr, nullptr, cb, wb, p1, 0, nullptr);
+      break;
+    case SEPR_TOP_DOWN:
+      down_fwd(nullptr, nullptr, n, T, F, K, nullptr, cf, wf, nullptr);
+      down_bwd(nullptr, nullptr, nullptr, n, T, F, K, nullptr, nullptr, cb, wb, nullptr);
+      break;
+    case SEPR_TOP_SPLIT:
+      split_fwd(nullptr, nullptr, n, S, T, F, 0.f, nullptr, cf, wf, nullptr);
+      split_bwd(nullptr, nullptr, nullptr, 0, n, S, T, F, nullptr, nullptr, cb, wb, nullptr);
+      break;
+    case SEPR_TOP_FUSE:
+      fuse_bwd(nullptr, nullptr, nullptr, nullptr, nullptr, n, T, F, nullptr, nullptr, wb, nullptr);
+      break;
+    case SEPR_TOP_OUT: {   // n = sequences (B*S), T = output frames L, Tp = source frames; aux layout when Tp < T... both sized
+      static int dummy_idx = 0;
+      for (int aux = 0; aux < 2; ++aux) {
+        if (aux && Tp > T) continue;
+        if (!aux && T > Tp) continue;
+        Carve c1(nullptr, 0, true), c2(nullptr, 0, true), w2(nullptr, 0, true);
+        out_fwd(nullptr, n, S, Tp, T, aux ? &dummy_idx : nullptr, nullptr, F, N, 16, 4, nullptr, nullptr, c1, nullptr);
+        out_bwd(nullptr, nullptr, nullptr, 0, nullptr, n, S, Tp, T, aux ? &dummy_idx : nullptr, nullptr, nullptr, F, N, 16, 4, nullptr,
+                nullptr, c2, w2, nullptr);
+        if (c1.need() > cf.off) cf.off = c1.need();
+        if (w2.need() > wb.off) wb.off = w2.need();
+      }
+      break;
+    }
+    case SEPR_TOP_FRONT: {   // n = B, T = samples, Tp = Lp
+      front_fwd(nullptr, n, T, N, 16, 4, F, Tp, 0.f, nullptr, nullptr, nullptr, cf, wf, nullptr);
+      front_bwd(nullptr, nullptr, nullptr, nullptr, n, T, N, 16, 4, F, Tp, nullptr, nullptr, cb, wb, nullptr);
+      break;
+    }
+    default: break;
+  }
+  *ctx_b = cf.need() > cb.need() ? cf.need() : cb.need();
+  *ws_b = (wf.need() > wb.need() ? wf.need() : wb.need()) + 1024;
+}
+extern "C" size_t sepr_train_ctx_bytes(int op, int n, int T, int Tp, int F, int N, int S, int H) {
+  if (n <= 0 || T <= 0 || F <= 0) return 0;
+  size_t c = 0, w = 0;
+  train_sizes(op, n, T, Tp, F, N, S, H > 0 ? H : 1, 65, &c, &w);
+  return c + 256;
+}
+extern "C" size_t sepr_train_ws_bytes(int op, int n, int T, int Tp, int F, int N, int S, int H, int K) {
+  if (n <= 0 || T <= 0 || F <= 0) return 0;
+  size_t c = 0, w = 0;
+  train_sizes(op, n, T, Tp, F, N, S, H > 0 ? H : 1, K > 0 ? K : 65, &c, &w);
+  return w;
+}

@@ -57,6 +57,57 @@ FuseW = _struct("FuseW", ["w", "b"], ["x3"])
 OutW = _struct("OutW", ["w1", "b1", "w2", "b2", "wdec"], ["x3_1", "x3_2"])
 
 _i, _f, _sz, _ll = C.c_int, C.c_float, C.c_size_t, C.c_longlong
+_u64, _d = C.c_ulonglong, C.c_double
+
+
+# ---- training path (include/sepr.h, "Training path") ----------------------------------------------------------------------
+class Lin(C.Structure):
+    """sepr_lin: one projection, exact-f32 form (w) or bf16x3 form (wp); b may be NULL."""
+    _fields_ = [("w", _fp), ("wp", _fp), ("b", _fp)]
+
+
+def _tstruct(name, spec):
+    """spec: list of field names; a name starting with '@' is a Lin, '#' an int, anything else a device pointer."""
+    fields = []
+    for f in spec:
+        if f.startswith("@"):
+            fields.append((f[1:], Lin))
+        elif f.startswith("#"):
+            fields.append((f[1:], C.c_int))
+        else:
+            fields.append((f, _fp))
+    return type(name, (C.Structure,), {"_fields_": fields})
+
+
+GcfnTW = _tstruct("GcfnTW", ["@up", "@up_t", "@down", "@down_t", "dw_w", "dw_b", "ls", "w1", "ln_g", "ln_b", "w2", "b2"])
+GcfnGrad = _tstruct("GcfnGrad", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "ls"])
+ClaTW = _tstruct("ClaTW", ["@l1", "@l1_t", "dw_w", "dw_wf", "dw_b", "zeros", "@l2", "@l2_t", "bn_g", "bn_b", "bn_rm", "bn_rv",
+                           "@l3", "@l3_t", "ls", "w1", "ln_g", "ln_b", "w3", "b3"])
+ClaGrad = _tstruct("ClaGrad", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "bn_g", "bn_b", "w3", "b3", "ls"])
+MhaTW = _tstruct("MhaTW", ["@qkv", "@qkv_t", "@out", "@out_t", "ls", "wqkv", "ln_g", "ln_b", "wo", "bo"])
+MhaGrad = _tstruct("MhaGrad", ["ln_g", "ln_b", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ls"])
+
+
+class EgaTW(C.Structure):
+    _fields_ = [("attn", MhaTW), ("gate", Lin), ("gate_t", Lin), ("gate_w", _fp), ("gate_ln_g", _fp), ("gate_ln_b", _fp),
+                ("pe_k", _fp), ("maxlen", C.c_int)]
+
+
+class EgaGrad(C.Structure):
+    _fields_ = [("attn", MhaGrad), ("gate_ln_g", _fp), ("gate_ln_b", _fp), ("gate_w", _fp), ("gate_b", _fp), ("pe_k", _fp)]
+
+
+DownTW = _tstruct("DownTW", ["w", "b", "bn_g", "bn_b", "bn_rm", "bn_rv"])
+DownGrad = _tstruct("DownGrad", ["w", "b", "bn_g", "bn_b"])
+SplitTW = _tstruct("SplitTW", ["@l1", "@l1_t", "@l2", "@l2_t", "gn_g", "gn_b"])
+SplitGrad = _tstruct("SplitGrad", ["w1", "b1", "w2", "b2", "gn_g", "gn_b"])
+FuseTW = _tstruct("FuseTW", ["@l", "@l_t"])
+FuseGrad = _tstruct("FuseGrad", ["w", "b"])
+OutTW = _tstruct("OutTW", ["@l1", "@l1_t", "@l2", "@l2_t", "wdec"])
+OutGrad = _tstruct("OutGrad", ["w1", "b1", "w2", "b2", "wdec"])
+FrontTW = _tstruct("FrontTW", ["w_enc", "proj_w", "gn_g", "gn_b", "@proj_t", "ones"])
+FrontGrad = _tstruct("FrontGrad", ["w_enc", "gn_g", "gn_b", "proj_w"])
+(TOP_GCFN, TOP_CLA, TOP_EGA, TOP_SPKATTN, TOP_DOWN, TOP_SPLIT, TOP_FUSE, TOP_OUT, TOP_FRONT) = range(9)
 
 # name -> (restype, argtypes); must list every symbol include/sepr.h declares (tests check this)
 SIGNATURES = {
@@ -81,6 +132,31 @@ SIGNATURES = {
     "sepr_pit_sisnr_mag_fwd": (_i, [_fp, _fp, _i, _i, _i, _fp, _i, _i, C.c_double, _fp, _fp, _fp, _sz, _fp]),
     "sepr_pit_sisnr_fwd": (_i, [_fp, _fp, _fp, _i, _i, _i, C.c_double, C.c_double, C.c_double, _fp, _fp, _fp, _fp,
                                 _fp, _sz, _fp]),
+    "sepr_train_ctx_bytes": (_sz, [_i] * 8),
+    "sepr_train_ws_bytes": (_sz, [_i] * 9),
+    "sepr_gcfn_train_fwd": (_i, [_fp, _fp, _i, _i, _i, C.POINTER(GcfnTW), _fp, _sz, _fp, _sz, _f, _u64, _fp]),
+    "sepr_gcfn_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, C.POINTER(GcfnTW), C.POINTER(GcfnGrad), _fp, _sz, _fp, _sz, _f, _u64, _fp]),
+    "sepr_cla_train_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, C.POINTER(ClaTW), _fp, _sz, _fp, _sz, _f, _u64, _fp]),
+    "sepr_cla_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, C.POINTER(ClaTW), C.POINTER(ClaGrad), _fp, _sz, _fp, _sz, _f, _u64, _fp]),
+    "sepr_ega_train_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _i, C.POINTER(EgaTW), _fp, _sz, _fp, _sz, _f, _u64, _fp]),
+    "sepr_ega_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(EgaTW), C.POINTER(EgaGrad), _fp, _sz, _fp, _sz, _f, _u64, _fp]),
+    "sepr_spkattn_train_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _i, C.POINTER(MhaTW), _fp, _sz, _fp, _sz, _f, _u64, _fp]),
+    "sepr_spkattn_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(MhaTW), C.POINTER(MhaGrad), _fp, _sz, _fp, _sz, _f, _u64, _fp]),
+    "sepr_downconv_train_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, C.POINTER(DownTW), _fp, _sz, _fp, _sz, _fp]),
+    "sepr_downconv_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, C.POINTER(DownTW), C.POINTER(DownGrad), _fp, _sz, _fp, _sz, _fp]),
+    "sepr_spksplit_train_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _f, C.POINTER(SplitTW), _fp, _sz, _fp, _sz, _fp]),
+    "sepr_spksplit_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(SplitTW), C.POINTER(SplitGrad), _fp, _sz, _fp, _sz, _fp]),
+    "sepr_fuse_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.POINTER(FuseTW), C.POINTER(FuseGrad), _fp, _sz, _fp]),
+    "sepr_outlayer_decoder_train_fwd": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, C.POINTER(OutTW), _fp, _fp, _sz, _fp, _sz, _fp]),
+    "sepr_outlayer_decoder_bwd": (_i, [_fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, C.POINTER(OutTW),
+                                       C.POINTER(OutGrad), _fp, _sz, _fp, _sz, _fp]),
+    "sepr_front_train_fwd": (_i, [_fp, _i, _i, _i, _i, _i, _i, _i, _f, C.POINTER(FrontTW), _fp, _fp, _fp, _sz, _fp, _sz, _fp]),
+    "sepr_front_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(FrontTW), C.POINTER(FrontGrad), _fp, _sz, _fp, _sz, _fp]),
+    "sepr_linear_wgrad_workspace": (_sz, [_i, _i, _i]),
+    "sepr_linear_wgrad": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _sz, _fp]),
+    "sepr_pit_sisnr_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _d, _d, _fp, _fp, _sz, _fp]),
+    "sepr_pit_sisnr_mag_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "sepr_pit_sisnr_mag_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _i, _i, _d, _fp, _fp, _sz, _fp]),
     "sepr_prof_start": (_i, [_i, _i]),
     "sepr_prof_stop": (_i, [C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

@@ -12,9 +12,12 @@ Boundary being mirrored:
   ``.parameters()`` behave as for any ``nn.Module``.
 
 The arithmetic is NOT here: ``forward`` hands the input to ``SeparatorEngine`` (HIP kernels through the
-C ABI).  There is no CPU implementation in this package; a CPU tensor raises.  ``train()`` mode (dropout,
-batch-statistics BatchNorm, autograd through the kernels) is a later row of SURVEY.md section 8f and raises
-``NotImplementedError`` rather than silently computing eval-mode numbers.
+C ABI).  There is no CPU implementation in this package; a CPU tensor raises.
+
+``train()`` mode (reference ``engine.py:50-83``): the forward goes through ``TrainEngine`` - batch-statistics
+BatchNorm with running-stat updates, dropout from a counter-based generator - inside ONE ``torch.autograd.Function``
+(``_SeparatorFn``): PyTorch is the autograd glue between the criterion and the parameters' ``.grad``, the backward of
+every block is an explicit ``sepr_*_bwd`` call, no per-op autograd graph exists.
 """
 from __future__ import annotations
 
@@ -29,7 +32,7 @@ import torch
 from .config import SepConfig
 from .engine import SeparatorEngine
 from .pack import PRECISIONS, PackedModel
-from .params import build_param_tree
+from .params import KINDS, build_param_tree
 
 
 DEFAULT_PRECISION = "bf16x3"
@@ -44,6 +47,52 @@ def _evict_packed(uid: int) -> None:
     with _PACK_LOCK:
         for k in [k for k in _PACK_CACHE if k[3] == uid]:
             del _PACK_CACHE[k]
+
+
+class _SeparatorFn(torch.autograd.Function):
+    """Whole-model forward / backward through the HIP training path.  Inputs: the module, the mixture, then every
+    parameter (so autograd routes the returned gradients into ``.grad``); outputs: main waveforms ``[S,B,T']`` and the R
+    auxiliary ones."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        from .train_engine import TrainEngine
+        from .train_pack import GradBuffer, TrainPack
+        dev = x.device
+        with torch.cuda.device(dev):
+            eng = model.__dict__.get("_train_engine")
+            if eng is None or eng.device != dev:
+                eng = TrainEngine(model.cfg, dev)
+                model.__dict__["_train_engine"] = eng
+            names = list(model._kinds)
+            flat = model._flat_tensors()
+            sd = {n: t.detach() for n, t in zip(names, flat)}
+            gb = GradBuffer(model.cfg, dev)                  # fresh zeros per step: autograd may keep views of it as .grad
+            tp = TrainPack(model.cfg, sd, gb, model.precision)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if model.dropout_p > 0.0 else 0
+            wav, aux, tape, dims = eng.forward(x.detach().to(torch.float32), tp, model.dropout_p, seed, with_aux=model.compute_aux)
+            torch._foreach_add_(tp.bn_counters, 1)           # BatchNorm.num_batches_tracked
+        model.invalidate_packed()                            # running statistics changed behind the version counters
+        ctx.state = (model, eng, tp, gb, tape, dims, len(aux))
+        return (wav, *aux)
+
+    @staticmethod
+    def backward(ctx, d_wav, *d_aux):
+        model, eng, tp, gb, tape, dims, n_aux = ctx.state
+        ctx.state = None
+        if tape is None:
+            raise RuntimeError("the HIP training path keeps one tape per forward: backward twice needs a second forward")
+        with torch.cuda.device(eng.device):
+            eng.backward(tape, dims, d_wav, list(d_aux), tp, model.dropout_p)
+            sync = model.grad_sync
+            if sync is not None:
+                sync(gb.flat)
+        grads = []
+        for name, kind in model._kinds.items():
+            if KINDS[kind]:
+                continue
+            grads.append(gb.view(name))
+        return (None, None, *grads)
 
 
 class Model(torch.nn.Module):
@@ -75,6 +124,10 @@ class Model(torch.nn.Module):
         self.precision = precision or os.environ.get("SEPR_PRECISION", DEFAULT_PRECISION)
         if self.precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {PRECISIONS}")
+        # train mode: dropout probability of the GCFN / CLA sites (configs.yaml dropout_rate; 0 disables exactly) and an
+        # optional callable applied to the flat gradient buffer at the end of backward (dist.GradSync: RCCL all-reduce)
+        self.dropout_p = float(self.cfg.dropout)
+        self.grad_sync = None
 
     # ---- weights -----------------------------------------------------------------------------------
     @classmethod
@@ -169,15 +222,13 @@ class Model(torch.nn.Module):
 
     # ---- forward -------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor):
-        if self.training:
-            raise NotImplementedError(
-                "train-mode forward/backward through the HIP kernels is not built yet (SURVEY.md section 8f-2); "
-                "call .eval()")
         if x.dim() == 1:
             # the reference advertises [T] input but fails in GroupNorm for it
             raise RuntimeError("Expected [batch, samples] input")
         if not x.is_cuda:
             raise RuntimeError("input tensor is not on the HIP device (no CPU fallback exists)")
+        if self.training:
+            return self._forward_train(x)
         eng = self.engine(x.device if self._is_replica_module() else None)
         with torch.cuda.device(x.device):
             if self.use_graphs:
@@ -186,6 +237,16 @@ class Model(torch.nn.Module):
                 wav, aux = eng.forward_split(x.to(torch.float32), with_aux=self.compute_aux, parts=self.pipelines)
             else:
                 wav, aux = eng.forward(x.to(torch.float32), with_aux=self.compute_aux)
+        T = x.shape[-1]
+        audio = [wav[s] for s in range(self.num_spks)]
+        audio_aux = [[a[s][..., :T] for s in range(self.num_spks)] for a in aux]
+        return audio, audio_aux
+
+    def _forward_train(self, x: torch.Tensor):
+        """Reference ``Model.forward`` under ``model.train()`` (engine.py:51,64): same return structure, autograd-connected."""
+        params = [t for t, kind in zip(self._flat_tensors(), self._kinds.values()) if not KINDS[kind]]
+        outs = _SeparatorFn.apply(self, x, *params)
+        wav, aux = outs[0], outs[1:]
         T = x.shape[-1]
         audio = [wav[s] for s in range(self.num_spks)]
         audio_aux = [[a[s][..., :T] for s in range(self.num_spks)] for a in aux]

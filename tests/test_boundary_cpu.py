@@ -271,7 +271,7 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="HIP"):
         m(torch.zeros(1, 400))
     m.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="HIP"):      # the training path is HIP-only too
         m(torch.zeros(1, 400))
 
 
@@ -437,3 +437,53 @@ def test_weights_key_and_replica_walk():
     assert rep._origin[0]() is m and rep._uid == m._uid
     with pytest.raises(RuntimeError, match="HIP"):
         rep(torch.zeros(1, 400))                                   # still no CPU fallback
+
+
+def _header_struct_fields(hdr: str, cname: str):
+    """Field (kind, name) list of a struct in include/sepr.h; handles several declarators per statement and comments."""
+    body = re.search(r"typedef struct \{((?:[^{}]|\{[^{}]*\})*)\} " + cname + ";", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for stmt in body.split(";"):
+        stmt = " ".join(stmt.split())
+        if not stmt:
+            continue
+        m = re.match(r"(const float\*|const void\*|float\*|int|sepr_lin|sepr_mha_tw|sepr_mha_grad)\s*(.*)", stmt)
+        assert m, (cname, stmt)
+        for decl in m.group(2).split(","):
+            out.append((m.group(1), decl.strip()))
+    return out
+
+
+def test_train_struct_layouts_match_header():
+    """ctypes mirrors of the training-path structs (lib.py) against include/sepr.h: same fields, same order, same size."""
+    hdr = open(os.path.join(ROOT, "include", "sepr.h")).read()
+    size = {"const float*": 8, "const void*": 8, "float*": 8, "int": 4, "sepr_lin": 24,
+            "sepr_mha_tw": ctypes.sizeof(L.MhaTW), "sepr_mha_grad": ctypes.sizeof(L.MhaGrad)}
+    pairs = [("sepr_lin", L.Lin), ("sepr_gcfn_tw", L.GcfnTW), ("sepr_gcfn_grad", L.GcfnGrad), ("sepr_cla_tw", L.ClaTW),
+             ("sepr_cla_grad", L.ClaGrad), ("sepr_mha_tw", L.MhaTW), ("sepr_mha_grad", L.MhaGrad), ("sepr_ega_tw", L.EgaTW),
+             ("sepr_ega_grad", L.EgaGrad), ("sepr_down_tw", L.DownTW), ("sepr_down_grad", L.DownGrad), ("sepr_split_tw", L.SplitTW),
+             ("sepr_split_grad", L.SplitGrad), ("sepr_fuse_tw", L.FuseTW), ("sepr_fuse_grad", L.FuseGrad), ("sepr_out_tw", L.OutTW),
+             ("sepr_out_grad", L.OutGrad), ("sepr_front_tw", L.FrontTW), ("sepr_front_grad", L.FrontGrad)]
+    for cname, cls in pairs:
+        fields = _header_struct_fields(hdr, cname)
+        assert [n for _, n in fields] == [f for f, _ in cls._fields_], cname
+        raw = sum(size[k] for k, _ in fields)
+        assert ctypes.sizeof(cls) == (raw + 7) // 8 * 8, (cname, ctypes.sizeof(cls), raw)
+    assert ctypes.sizeof(L.Lin) == 24
+
+
+def test_train_sizing_entries_run_without_a_device():
+    """sepr_train_ctx_bytes / sepr_train_ws_bytes replay each block's carving in dry mode: no launch, no device needed."""
+    lib = L.load()
+    for op in range(9):
+        c = lib.sepr_train_ctx_bytes(op, 4, 1000, 250, 128, 256, 2, 8)
+        w = lib.sepr_train_ws_bytes(op, 4, 1000, 250, 128, 256, 2, 8, 65 if op == L.TOP_CLA else 5)
+        assert c > 0 and w > 0, op
+    # a GCFN keeps the LayerNorm statistics, the 6F hidden tensor and the gated 3F tensor
+    n, T, F = 4, 1000, 128
+    want = n * T * (2 + 6 * F + 3 * F) * 4
+    got = lib.sepr_train_ctx_bytes(L.TOP_GCFN, n, T, 0, F, 256, 2, 8)
+    assert want <= got <= want + 4096
+    assert lib.sepr_train_ctx_bytes(L.TOP_GCFN, 0, T, 0, F, 256, 2, 8) == 0
+    assert lib.sepr_gcfn_bwd(None, None, None, 1, 8, 128, None, None, None, 0, None, 0, 0.0, 0, None) == L.SEPR_EINVAL

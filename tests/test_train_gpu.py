@@ -1,0 +1,546 @@
+"""Training path on the device against the train-mode oracle (torch.autograd over the CPU restatement,
+pinned to the imported reference by tests/golden/make_train_golden.py: every one of the 710 gradient tensors identical).
+
+Tolerances (floating point): every forward output and every gradient tensor must agree with the oracle to >= MIN_DB
+(80 dB, the same bar as the inference parity tests; exact-f32 mode is held to 100 dB where noted).  All measured values go
+to gpurun_out/train_parity_report.json.
+"""
+import dataclasses
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import criterion_oracle as co
+from oracle import sepreformer_oracle as orc
+from oracle import train_oracle as tor
+from sepreformer_amd import lib as L
+from sepreformer_amd.config import VARIANTS
+from sepreformer_amd.synth import synth_sources, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+MIN_DB = 80.0
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = {}
+PRECISIONS = ["fp32", "bf16x3"]
+
+
+def record(name, db):
+    REPORT[name] = round(float(db), 2)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "train_parity_report.json")
+    merged = {}
+    if os.path.exists(path):
+        try:
+            with open(path) as f:
+                merged = json.load(f)
+        except ValueError:
+            merged = {}
+    merged.update(REPORT)
+    with open(path, "w") as f:
+        json.dump(merged, f, indent=1, sort_keys=True)
+
+
+class Soft:
+    """Collects every disagreement of a test so that one device run shows all of them."""
+
+    def __init__(self, tag):
+        self.tag, self.bad = tag, []
+
+    def agree(self, name, got, want, min_db=MIN_DB):
+        got = got.detach().float().cpu()
+        want = want.detach().float().cpu()
+        if got.shape != want.shape:
+            self.bad.append(f"{name}: shape {tuple(got.shape)} != {tuple(want.shape)}")
+            return
+        if not torch.isfinite(got).all():
+            self.bad.append(f"{name}: non-finite values")
+            record(f"{self.tag}.{name}", -999)
+            return
+        db = orc.agreement_db(got, want) if float(want.abs().max()) > 0 else (999.0 if float(got.abs().max()) == 0 else -999.0)
+        record(f"{self.tag}.{name}", db)
+        if db < min_db:
+            self.bad.append(f"{name}: {db:.1f} dB < {min_db}")
+
+    def done(self):
+        assert not self.bad, f"[{self.tag}] " + "; ".join(self.bad[:40])
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def cl(x):  # [b, C, T] -> channel-last device tensor
+    return x.permute(0, 2, 1).contiguous().cuda()
+
+
+def cf(y):  # channel-last device tensor -> [b, C, T] host
+    return y.detach().cpu().permute(0, 2, 1)
+
+
+_cache = {}
+
+
+def setup(variant, precision):
+    """TrainEngine + TrainPack + GradBuffer over the synthetic weights of `variant` (dropout 0), and the host state_dict."""
+    from sepreformer_amd.train_engine import TrainEngine
+    from sepreformer_amd.train_pack import GradBuffer, TrainPack
+    key = (variant, precision)
+    if key not in _cache:
+        cfg = dataclasses.replace(VARIANTS[variant], dropout=0.0)
+        sd = synth_state_dict(cfg, 0)
+        dev = torch.device("cuda:0")
+        sdd = {k: v.to(dev) for k, v in sd.items()}
+        gb = GradBuffer(cfg, dev)
+        tp = TrainPack(cfg, sdd, gb, precision)
+        _cache[key] = (cfg, sd, sdd, gb, tp, TrainEngine(cfg, dev))
+    cfg, sd, sdd, gb, tp, eng = _cache[key]
+    gb.flat.zero_()
+    return cfg, sd, sdd, gb, tp, eng
+
+
+def check_param_grads(soft, gb, sdl, prefix, min_db=MIN_DB):
+    n = 0
+    for k, v in sdl.items():
+        if k.startswith(prefix) and v.requires_grad and v.grad is not None:
+            soft.agree("grad." + k[len(prefix):].lstrip("."), gb.view(k), v.grad, min_db)
+            n += 1
+    assert n > 0, prefix
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the weight-gradient contraction on its own
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("x3", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (4099, 768, 128), (257, 64, 512), (5000, 256, 16), (130, 192, 64), (33, 128, 384),
+                                   (70000, 128, 384), (1, 64, 64)])
+def test_wgrad_core(M, N, K, x3):
+    lib = L.load()
+    a, b = rnd(M, N, seed=1), rnd(M, K, seed=2)
+    ad, bd = a.cuda(), b.cuda()
+    G = torch.full((N, K), 7.0, device="cuda")
+    cs = torch.full((N,), -3.0, device="cuda")
+    ws = torch.empty(int(lib.sepr_linear_wgrad_workspace(M, N, K)) + 256, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.sepr_linear_wgrad(ad.data_ptr(), bd.data_ptr(), G.data_ptr(), cs.data_ptr(), M, N, K, 0, x3, ws.data_ptr(), ws.numel(), st), "wgrad")
+    want = (a.double().t() @ b.double()).float()
+    soft = Soft(f"wgrad.{M}x{N}x{K}.{'x3' if x3 else 'f32'}")
+    soft.agree("G", G, want, 85.0 if x3 else 110.0)
+    soft.agree("colsum", cs, a.double().sum(0).float(), 110.0)
+    # accumulate on top, and bitwise reproducibility (no atomics)
+    G2 = G.clone()
+    L.check(lib.sepr_linear_wgrad(ad.data_ptr(), bd.data_ptr(), G2.data_ptr(), cs.data_ptr(), M, N, K, 1, x3, ws.data_ptr(), ws.numel(), st), "wgrad")
+    soft.agree("G_accumulated", G2, 2 * want, 85.0 if x3 else 110.0)
+    G3 = torch.empty_like(G)
+    L.check(lib.sepr_linear_wgrad(ad.data_ptr(), bd.data_ptr(), G3.data_ptr(), None, M, N, K, 0, x3, ws.data_ptr(), ws.numel(), st), "wgrad")
+    assert torch.equal(G3, G)
+    soft.done()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# every block: train-mode forward and backward against autograd over the oracle's restatement of the same module
+# ---------------------------------------------------------------------------------------------------------------------
+BLOCK_VARIANTS = ["tiny", "SepReformer_Base_WSJ0"]
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("variant", BLOCK_VARIANTS)
+def test_gcfn_train(variant, precision):
+    cfg, sd, sdd, gb, tp, eng = setup(variant, precision)
+    F = cfg.feat
+    soft = Soft(f"{variant}.{precision}.gcfn")
+    p = "separator.enc_stages.0.g_block_1.block.gcfn"
+    for n, T in ((2, 37), (3, 300), (1, 1)):
+        gb.flat.zero_()
+        x, dy = rnd(n, T, F, seed=T), rnd(n, T, F, seed=T + 7)
+        y, rec = eng.block_fwd("gcfn", x.cuda(), tp.gcfn[0], n, T)
+        dx = eng.block_bwd(rec, dy.cuda())
+        sdl = tor.leaf_state(sd)
+        xl = x.clone().requires_grad_(True)
+        yo = orc.gcfn(sdl, p, xl)
+        yo.backward(dy)
+        soft.agree(f"T{T}.y", y, yo)
+        soft.agree(f"T{T}.dx", dx, xl.grad)
+        check_param_grads(soft, gb, sdl, p)
+    soft.done()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("variant", BLOCK_VARIANTS)
+def test_cla_train(variant, precision):
+    cfg, sd, sdd, gb, tp, eng = setup(variant, precision)
+    F = cfg.feat
+    soft = Soft(f"{variant}.{precision}.cla")
+    p = "separator.enc_stages.0.l_block_1.block.cla"
+    for n, T in ((2, 24), (2, 150), (3, 700)):
+        gb.flat.zero_()
+        rm0, rv0 = sdd[p + ".BN.running_mean"].clone(), sdd[p + ".BN.running_var"].clone()
+        x, dy = rnd(n, T, F, seed=T), rnd(n, T, F, seed=T + 7)
+        y, rec = eng.block_fwd("cla", x.cuda(), tp.cla[0], n, T)
+        dx = eng.block_bwd(rec, dy.cuda())
+        sdl = tor.leaf_state(sd)
+        xl = x.clone().requires_grad_(True)
+        orc.BN_TRAINING = True
+        try:
+            yo = orc.cla(sdl, p, xl)
+        finally:
+            orc.BN_TRAINING = False
+        yo.backward(dy)
+        soft.agree(f"T{T}.y", y, yo)
+        soft.agree(f"T{T}.dx", dx, xl.grad)
+        check_param_grads(soft, gb, sdl, p)
+        soft.agree(f"T{T}.running_mean", sdd[p + ".BN.running_mean"], sdl[p + ".BN.running_mean"], 100.0)
+        soft.agree(f"T{T}.running_var", sdd[p + ".BN.running_var"], sdl[p + ".BN.running_var"], 100.0)
+        sdd[p + ".BN.running_mean"].copy_(rm0)
+        sdd[p + ".BN.running_var"].copy_(rv0)
+    soft.done()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("variant", BLOCK_VARIANTS)
+def test_ega_train(variant, precision):
+    cfg, sd, sdd, gb, tp, eng = setup(variant, precision)
+    F, H = cfg.feat, cfg.heads
+    soft = Soft(f"{variant}.{precision}.ega")
+    p = "separator.enc_stages.0.g_block_1.block.ega"
+    for fac, Tp in ((1, 25), (4, 30), (2, 130), (16, 9)):      # Tp 130 > tiny's maxlen 40: clamped relative positions
+        gb.flat.zero_()
+        T = Tp * fac
+        x, dy = rnd(2, F, T, seed=fac), rnd(2, T, F, seed=fac + 7)
+        y, rec = eng.block_fwd("ega", cl(x), tp.ega[0], 2, T, Tp)
+        dx = eng.block_bwd(rec, dy.cuda())
+        sdl = tor.leaf_state(sd)
+        xl = x.clone().requires_grad_(True)
+        yo = orc.ega(sdl, p, xl, orc.rel_pos_k(sdl, Tp, cfg.maxlen), H)
+        yo.backward(dy)
+        soft.agree(f"fac{fac}.Tp{Tp}.y", y, yo)
+        soft.agree(f"fac{fac}.Tp{Tp}.dx", cf(dx), xl.grad)
+        check_param_grads(soft, gb, sdl, p)
+        soft.agree(f"fac{fac}.Tp{Tp}.grad.pe_k", gb.view("separator.pos_emb.pe_k.weight"), sdl["separator.pos_emb.pe_k.weight"].grad)
+    soft.done()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("variant", BLOCK_VARIANTS)
+def test_spkattn_train(variant, precision):
+    cfg, sd, sdd, gb, tp, eng = setup(variant, precision)
+    F, H, S = cfg.feat, cfg.heads, cfg.num_spks
+    soft = Soft(f"{variant}.{precision}.spkattn")
+    p = "separator.dec_stages.0.spk_attn_1.self_attn"
+    B, T = 3, 33
+    x, dy = rnd(B * S, T, F, seed=5), rnd(B * S, T, F, seed=6)
+    y, rec = eng.block_fwd("spk", x.cuda(), tp.spk[0], B * S, T)
+    dx = eng.block_bwd(rec, dy.cuda())
+    sdl = tor.leaf_state(sd)
+    xl = x.clone().requires_grad_(True)
+    xr = xl.view(B, S, T, F).permute(0, 2, 1, 3).reshape(B * T, S, F)          # network.py:241-243 in channel-last terms
+    yr = xr + orc.mha(sdl, p, xr, None, H)                                      # :244
+    yo = yr.view(B, T, S, F).permute(0, 2, 1, 3).reshape(B * S, T, F)           # :245-247
+    yo.backward(dy)
+    soft.agree("y", y, yo)
+    soft.agree("dx", dx, xl.grad)
+    check_param_grads(soft, gb, sdl, p)
+    soft.done()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("variant", BLOCK_VARIANTS)
+def test_downconv_split_fuse_train(variant, precision):
+    cfg, sd, sdd, gb, tp, eng = setup(variant, precision)
+    F, S = cfg.feat, cfg.num_spks
+    soft = Soft(f"{variant}.{precision}.plumbing")
+    # DownConv, train-mode BatchNorm (module.py:63-78)
+    p = "separator.enc_stages.0.downconv"
+    for T in (40, 41, 301):
+        gb.flat.zero_()
+        rm0, rv0 = sdd[p + ".BN.running_mean"].clone(), sdd[p + ".BN.running_var"].clone()
+        x = rnd(2, T, F, seed=T)
+        y, cx, To = eng.down_fwd(x.cuda(), tp.down[0], 2, T)
+        dy = rnd(2, To, F, seed=T + 1)
+        dx = eng.down_bwd(x.cuda(), cx, tp.down[0], dy.cuda(), 2, T)
+        sdl = tor.leaf_state(sd)
+        xl = x.clone().requires_grad_(True)
+        orc.BN_TRAINING = True
+        try:
+            yo = orc.down_conv(sdl, p, xl)
+        finally:
+            orc.BN_TRAINING = False
+        yo.backward(dy)
+        soft.agree(f"down.T{T}.y", y, yo)
+        soft.agree(f"down.T{T}.dx", dx, xl.grad)
+        check_param_grads(soft, gb, sdl, p)
+        sdd[p + ".BN.running_mean"].copy_(rm0)
+        sdd[p + ".BN.running_var"].copy_(rv0)
+    # SpkSplit + GroupNorm (module.py:110-125), with and without accumulation into dx
+    p = "separator.spk_split_blocks.0" if cfg.per_level_split else "separator.spk_split_block"
+    gb.flat.zero_()
+    B, T = 3, 129
+    x, dy = rnd(B, F, T, seed=9), rnd(B * S, F, T, seed=10)
+    xd = cl(x)
+    y, cx = eng.split_fwd(xd, tp.splits[0], B, T)
+    dx = torch.empty_like(xd)
+    eng.split_bwd(xd, cx, tp.splits[0], cl(dy), dx, False, B, T)
+    sdl = tor.leaf_state(sd)
+    xl = x.clone().requires_grad_(True)
+    yo = orc.spk_split(sdl, p, xl, S)
+    yo.backward(dy)
+    soft.agree("split.y", cf(y), yo)
+    soft.agree("split.dx", cf(dx), xl.grad)
+    check_param_grads(soft, gb, sdl, p)
+    base = rnd(B, T, F, seed=11).cuda()
+    dx2 = base.clone()
+    eng.split_bwd(xd, cx, tp.splits[0], cl(dy), dx2, True, B, T)
+    soft.agree("split.dx_accumulate", dx2 - base, dx, 90.0)
+    # fusion conv (module.py:212-214)
+    gb.flat.zero_()
+    lo, sk, dy = rnd(2 * S, F, 12, seed=12), rnd(2 * S, F, 24, seed=13), rnd(2 * S, F, 24, seed=14)
+    y = eng.fuse_fwd(cl(lo), cl(sk), tp.fuse[0], 2 * S, 24)
+    dlo, dsk = eng.fuse_bwd(cl(lo), cl(sk), tp.fuse[0], cl(dy), 2 * S, 24)
+    sdl = tor.leaf_state(sd)
+    lol, skl = lo.clone().requires_grad_(True), sk.clone().requires_grad_(True)
+    up = torch.nn.functional.interpolate(lol, size=24, mode="nearest")
+    yo = torch.nn.functional.conv1d(torch.cat([up, skl], 1), sdl["separator.simple_fusion.0.weight"], sdl["separator.simple_fusion.0.bias"])
+    yo.backward(dy)
+    soft.agree("fuse.y", cf(y), yo)
+    soft.agree("fuse.dlo", cf(dlo), lol.grad)
+    soft.agree("fuse.dskip", cf(dsk), skl.grad)
+    check_param_grads(soft, gb, sdl, "separator.simple_fusion.0")
+    soft.done()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("variant", BLOCK_VARIANTS)
+def test_front_and_heads_train(variant, precision):
+    cfg, sd, sdd, gb, tp, eng = setup(variant, precision)
+    F, S, N = cfg.feat, cfg.num_spks, cfg.enc_channels
+    soft = Soft(f"{variant}.{precision}.ends")
+    B, T = 3, 4 * 131 + 12
+    L_ = cfg.frames(T)
+    Lp = cfg.padded_frames(L_)
+    wav = rnd(B, T, seed=12, scale=0.1)
+    wd = wav.cuda()
+    # encoder + GroupNorm + projector + pad, with an extra gradient flowing into enc (as the auxiliary heads send one)
+    gb.flat.zero_()
+    enc, cur, ctx = eng.front_fwd(wd, tp, B, T, L_, Lp)
+    dcur, denc = rnd(B, F, Lp, seed=13), rnd(B, N, L_, seed=14)
+    denc_d = cl(denc)
+    eng.front_bwd(wd, enc, ctx, tp, cl(dcur), denc_d, B, T, Lp)
+    sdl = tor.leaf_state(sd)
+    e = orc.audio_encoder(sdl, wav, cfg.enc_stride)
+    pj = orc.pad_signal(orc.feature_projector(sdl, e), cfg.num_stages)
+    (pj * dcur).sum().backward(retain_graph=True)
+    e.backward(denc, retain_graph=True)
+    soft.agree("front.enc", cf(enc), e, 100.0)
+    soft.agree("front.proj", cf(cur), pj)
+    for k in ("audio_encoder.conv1d.weight", "feature_projector.norm.weight", "feature_projector.norm.bias", "feature_projector.conv1d.weight"):
+        soft.agree("front.grad." + k, gb.view(k), sdl[k].grad)
+    # main head: crop + OutputLayer + decoder (module.py:249-283)
+    gb.flat.zero_()
+    e_d = enc
+    z = rnd(B * S, F, Lp, seed=15)
+    zd = cl(z)
+    wav_o, cx = eng.head_fwd(zd, tp.out_main, B * S, Lp, L_, None, None)
+    dwav = rnd(S, B, wav_o.shape[-1], seed=16)
+    dz = torch.empty_like(zd)
+    eng.head_bwd(zd, cx, tp.out_main, dwav.cuda(), dz, False, None, B * S, Lp, L_, None, None)
+    sdl = tor.leaf_state(sd)
+    zl = z.clone().requires_grad_(True)
+    e_h = e.detach()
+    o = orc.output_layer(sdl, "out_layer", zl, e_h, S, False)
+    want = torch.stack([orc.audio_decoder(sdl["audio_decoder.weight"], o[s], cfg.enc_stride).reshape(B, -1) for s in range(S)], 0)
+    want.backward(dwav)
+    soft.agree("head_main.wav", wav_o, want)
+    soft.agree("head_main.dx", cf(dz), zl.grad)
+    check_param_grads(soft, gb, sdl, "out_layer.")
+    soft.agree("head_main.grad.decoder", gb.view("audio_decoder.weight"), sdl["audio_decoder.weight"].grad)
+    # auxiliary head: nearest upsample + OutputLayer + ReLU mask x encoder + decoder (model.py:47-52), accumulating into dx / denc
+    gb.flat.zero_()
+    Ts = 37
+    zs = rnd(B * S, F, Ts, seed=17)
+    zsd = cl(zs)
+    idx = eng._index(Ts, L_)
+    wav_a, cx = eng.head_fwd(zsd, tp.out_aux[1], B * S, Ts, L_, idx, e_d)
+    dwav = rnd(S, B, wav_a.shape[-1], seed=18)
+    base_dx, base_denc = rnd(B * S, Ts, F, seed=19).cuda(), rnd(B, L_, N, seed=20).cuda()
+    dzs, dencd = base_dx.clone(), base_denc.clone()
+    eng.head_bwd(zsd, cx, tp.out_aux[1], dwav.cuda(), dzs, True, dencd, B * S, Ts, L_, idx, e_d)
+    sdl = tor.leaf_state(sd)
+    zl = zs.clone().requires_grad_(True)
+    el = e.detach().clone().requires_grad_(True)
+    up = torch.nn.functional.interpolate(zl, size=L_, mode="nearest")
+    o = orc.output_layer(sdl, "out_layer_bn.1", up, el, S, True)
+    want = torch.stack([orc.audio_decoder(sdl["decoder_bn.1.weight"], o[s], cfg.enc_stride).reshape(B, -1) for s in range(S)], 0)
+    want.backward(dwav)
+    soft.agree("head_aux.wav", wav_a, want)
+    soft.agree("head_aux.dx", cf(dzs - base_dx), zl.grad)
+    soft.agree("head_aux.denc", cf(dencd - base_denc), el.grad)
+    check_param_grads(soft, gb, sdl, "out_layer_bn.1.")
+    soft.agree("head_aux.grad.decoder", gb.view("decoder_bn.1.weight"), sdl["decoder_bn.1.weight"].grad)
+    soft.done()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# criteria backward (criterions.py:148-217) against autograd over the criterion oracle
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,B,T", [(2, 6, 8000), (3, 4, 3001), (2, 2, 1500)])
+def test_criteria_backward(S, B, T):
+    from sepreformer_amd.criterion import PIT_SISNR_mag, PIT_SISNR_time
+    g = torch.Generator().manual_seed(S * 100 + B)
+    src = [0.1 * torch.randn(B, T, generator=g) + 0.01 * (s + 1) for s in range(S)]
+    perm = [torch.randperm(S, generator=g).tolist() for _ in range(B)]
+    est = [torch.stack([0.7 * src[perm[b][s]][b] + [0.3, 0.03, 0.001, 1.0][b % 4] * 0.1 * torch.randn(T, generator=g) + 0.02 for b in range(B)])
+           for s in range(S)]
+    sizes = torch.full((B,), T)
+    soft = Soft(f"criteria.S{S}.B{B}.T{T}")
+    dev = torch.device("cuda:0")
+    srcd = [s_.to(dev) for s_ in src]
+    # time-domain loss
+    estd = [e.to(dev).requires_grad_(True) for e in est]
+    loss = PIT_SISNR_time(dev, S, True)(estims=estd, input_sizes=sizes, target_attr=srcd)
+    loss.backward()
+    esto = [e.clone().double().requires_grad_(True) for e in est]
+    lo = co.pit_sisnr_time(esto, [s_.double() for s_ in src], dtype=torch.float64)[0]
+    lo.backward()
+    soft.agree("time.loss", loss.reshape(1), lo.reshape(1).float(), 100.0)
+    for s in range(S):
+        soft.agree(f"time.dest{s}", estd[s].grad, esto[s].grad.float())
+    # STFT-magnitude loss
+    estd = [e.to(dev).requires_grad_(True) for e in est]
+    loss = PIT_SISNR_mag(dev, 512, 128, "hann", 4, S, True, False)(estims=estd, idx=1, input_sizes=sizes, target_attr=srcd)
+    loss.backward()
+    esto = [e.clone().double().requires_grad_(True) for e in est]
+    lo = co.pit_sisnr_mag(esto, [s_.double() for s_ in src], 512, 128)[0]
+    lo.backward()
+    soft.agree("mag.loss", loss.reshape(1), lo.reshape(1).float(), 90.0)
+    for s in range(S):
+        soft.agree(f"mag.dest{s}", estd[s].grad, esto[s].grad.float(), 70.0)      # fp32 STFT on both ends of a cancellation
+    soft.done()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole training step behind the reference's surface: model.train(); loss.backward()
+# ---------------------------------------------------------------------------------------------------------------------
+def _train_step(variant, precision, x, src, with_reference_loss=True):
+    from sepreformer_amd.criterion import PIT_SISNR_mag, PIT_SISNR_time
+    from sepreformer_amd.model import Model
+    cfg = dataclasses.replace(VARIANTS[variant], dropout=0.0)
+    dev = torch.device("cuda:0")
+    m = Model.from_config(cfg, init_seed=0, precision=precision).load_synthetic_(0).to(dev)
+    m.train()
+    assert m.dropout_p == 0.0
+    sizes = torch.full((x.shape[0],), x.shape[1])
+    audio, aux = m(x.to(dev))
+    srcd = [s_.to(dev) for s_ in src]
+    l_time = PIT_SISNR_time(dev, cfg.num_spks, True)(estims=audio, input_sizes=sizes, target_attr=srcd)
+    crit_m = PIT_SISNR_mag(dev, 512, 128, "hann", cfg.num_stages, cfg.num_spks, True, False)
+    l_mag = [crit_m(estims=a, idx=i, input_sizes=sizes, target_attr=srcd) for i, a in enumerate(aux)]
+    loss = ((1 - 0.4) * l_time + 0.4 * sum(l_mag) / len(l_mag)) / cfg.num_spks          # reference engine.py:73-74
+    loss.backward()
+    return cfg, m, audio, aux, loss, l_time, l_mag
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_train_step_tiny_matches_reference(golden, precision):
+    """model.train(); loss.backward() on the tiny configuration against the REFERENCE's own training step (fixture made
+    by tests/golden/make_train_golden.py from the imported reference + its criteria) and, tensor by tensor, the pinned oracle."""
+    g = golden("train_tiny")
+    x = torch.from_numpy(g["x"])
+    src = [torch.from_numpy(g["src"][:, s].copy()) for s in range(2)]
+    cfg, m, audio, aux, loss, l_time, l_mag = _train_step("tiny", precision, x, src)
+    soft = Soft(f"train_step.tiny.{precision}")
+    soft.agree("main", torch.stack(list(audio), 0), torch.from_numpy(g["main"]))
+    soft.agree("aux", torch.stack([torch.stack(list(a), 0) for a in aux], 0), torch.from_numpy(g["aux"]))
+    assert abs(float(loss) - float(g["loss"])) < 2e-3, (float(loss), float(g["loss"]))
+    assert abs(float(l_time) - float(g["loss_time"])) < 2e-3
+    assert np.abs(np.asarray([float(v) for v in l_mag]) - g["loss_mag"]).max() < 5e-3
+    # the reference's gradient summaries (norm, sum, seeded projection) for every tensor
+    from sepreformer_amd.synth import _gen
+
+    def probe(name, shape):        # the seeded projection vectors of tests/golden/make_train_golden.py
+        return _gen(4242, name).normal(0.0, 1.0, size=tuple(shape)).astype(np.float32)
+
+    names = [str(n) for n in g["grad_names"]]
+    params = dict(m.named_parameters())
+    assert set(names) == set(params)
+    worst = 0.0
+    for i, k in enumerate(names):
+        gr = params[k].grad.detach().double().cpu()
+        nrm, sm, pr = g["grad_summary"][i]
+        got = np.array([float(gr.norm()), float(gr.sum()), float((gr * torch.from_numpy(probe(k, gr.shape)).double()).sum())])
+        dev_ = np.abs(got - np.array([nrm, sm, pr])).max() / (nrm + 1e-30)
+        worst = max(worst, dev_)
+        if dev_ > 2e-3:
+            soft.bad.append(f"summary {k}: relative deviation {dev_:.2e}")
+    record(f"train_step.tiny.{precision}.summary_worst_rel", worst)
+    # tensor by tensor against the oracle (identical to the reference: PINNING_train.json)
+    sdl = tor.leaf_state(synth_state_dict(cfg, 0))
+    o_audio, o_aux = tor.model_forward_train(sdl, cfg, x)
+    o_loss, _, _ = tor.train_loss(o_audio, o_aux, src)
+    o_loss.backward()
+    for k, p_ in params.items():
+        soft.agree("grad." + k, p_.grad, sdl[k].grad)
+    # BatchNorm bookkeeping
+    st = m.state_dict()
+    off = 0
+    for k in [str(n) for n in g["bn_names"]]:
+        n_el = st[k].numel()
+        soft.agree("bn." + k, st[k], torch.from_numpy(g["bn_after"][off:off + n_el]), 100.0)
+        off += n_el
+    assert int(st["separator.enc_stages.0.l_block_1.block.cla.BN.num_batches_tracked"]) == int(g["num_batches_tracked_after"])
+    soft.done()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_train_step_base_matches_oracle(precision):
+    """Base width (F = 128, 4 stages), 0.5 s, batch 2: loss and all 710 gradient tensors against the oracle."""
+    B, T = 2, 4000
+    srcn = synth_sources(B, T, seed=31)
+    src = [torch.from_numpy(srcn[:, s].copy()) for s in range(2)]
+    x = src[0] + src[1]
+    cfg, m, audio, aux, loss, l_time, l_mag = _train_step("SepReformer_Base_WSJ0", precision, x, src)
+    sdl = tor.leaf_state(synth_state_dict(cfg, 0))
+    o_audio, o_aux = tor.model_forward_train(sdl, cfg, x)
+    o_loss, _, _ = tor.train_loss(o_audio, o_aux, src)
+    o_loss.backward()
+    soft = Soft(f"train_step.base.{precision}")
+    soft.agree("main", torch.stack(list(audio), 0), torch.stack([a.detach() for a in o_audio], 0))
+    assert abs(float(loss) - float(o_loss)) < 5e-3, (float(loss), float(o_loss))
+    for k, p_ in m.named_parameters():
+        soft.agree("grad." + k, p_.grad, sdl[k].grad)
+    soft.done()
+
+
+def test_dropout_contract():
+    """p = 0 disables dropout exactly; p > 0: keep rate ~ 1 - p, survivors scaled by 1 / (1 - p), the same (seed, block) gives
+    the same mask in forward and backward (the gradient of a dropped element is zero), a different seed a different mask."""
+    cfg, sd, sdd, gb, tp, eng = setup("SepReformer_Base_WSJ0", "bf16x3")
+    F = cfg.feat
+    n, T = 4, 500
+    x, dy = rnd(n, T, F, seed=1).cuda(), rnd(n, T, F, seed=2).cuda()
+    y0, _ = eng.block_fwd("gcfn", x, tp.gcfn[0], n, T, 0, 0.0, 123)
+    y0b, _ = eng.block_fwd("gcfn", x, tp.gcfn[0], n, T, 0, 0.0, 456)
+    assert torch.equal(y0, y0b)
+    y1, rec1 = eng.block_fwd("gcfn", x, tp.gcfn[0], n, T, 0, 0.3, 123)
+    y1b, _ = eng.block_fwd("gcfn", x, tp.gcfn[0], n, T, 0, 0.3, 123)
+    y2, _ = eng.block_fwd("gcfn", x, tp.gcfn[0], n, T, 0, 0.3, 124)
+    assert torch.equal(y1, y1b) and not torch.equal(y1, y2) and not torch.equal(y1, y0)
+    # output dropout: the branch (y - x) is exactly zero where dropped
+    dropped = ((y1 - x) == 0).float().mean().item()
+    assert 0.25 < dropped < 0.35, dropped
+    # backward with the same record regenerates the same masks: finite, and deterministic
+    dx = eng.block_bwd(rec1, dy)
+    gb.flat.zero_()
+    dx2 = eng.block_bwd(rec1, dy)
+    assert torch.isfinite(dx).all() and torch.equal(dx, dx2)
+    # numerical check of the dropout-enabled block: directional derivative of sum(y * dy) along a random direction
+    v = rnd(n, T, F, seed=3).cuda()
+    eps = 1e-2
+    yp, _ = eng.block_fwd("gcfn", x + eps * v, tp.gcfn[0], n, T, 0, 0.3, 123)
+    ym, _ = eng.block_fwd("gcfn", x - eps * v, tp.gcfn[0], n, T, 0, 0.3, 123)
+    num = float(((yp - ym).double() * dy.double()).sum() / (2 * eps))
+    ana = float((dx.double() * v.double()).sum())
+    assert abs(num - ana) <= 2e-2 * max(1.0, abs(ana)), (num, ana)
