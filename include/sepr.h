@@ -450,7 +450,7 @@ size_t sepr_pit_sisnr_mag_bwd_workspace(int S, int B, int T, int frame_len, int 
 enum {
   SEPR_SITE_NONE = 0, SEPR_SITE_GCFN_UP, SEPR_SITE_GCFN_DOWN, SEPR_SITE_CLA, SEPR_SITE_ATTN_PROJ,
   SEPR_SITE_EGA_GATE, SEPR_SITE_SPLIT, SEPR_SITE_FUSE, SEPR_SITE_OUT, SEPR_SITE_PROJECTOR,
-  SEPR_SITE_LINEAR, SEPR_SITE_COUNT
+  SEPR_SITE_LINEAR, SEPR_SITE_WGRAD /* gemm_tn (training) */, SEPR_SITE_COUNT
 };
 /* Start bracketing every launch of `site` with hipEvents on its own stream (up to max_launches). */
 int sepr_prof_start(int site, int max_launches);

@@ -256,10 +256,13 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   float* part = static_cast<float*>(ws);
   float* cpart = part + (size_t)p.nsplit * a.N * a.K;
   const int grid = p.tn * p.tk * p.nsplit;
+  long long slot = -1;
+  const bool timed = prof_begin(SEPR_SITE_WGRAD, s, &slot);
   if (x3)
     hipLaunchKernelGGL((gemm_tn_kernel<true>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<false>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
+  if (timed) prof_end(slot, 2.0 * (double)a.M * (double)a.N * (double)a.K, s);
   const long long total = (long long)a.N * a.K + a.N;
   const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(tn_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,

@@ -7,6 +7,23 @@
 
 namespace sepr {
 
+// ---- dropout generator (shared by every dropout site of the training path) ---------------------------------------------
+// Counter-based: one 64-bit mix (splitmix64 finaliser) of (seed, element index) per element - stateless, so the backward
+// regenerates the mask of any element from the same (seed, index) without storing it.
+__device__ __forceinline__ unsigned long long sepr_mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ bool sepr_keep(unsigned long long seed, unsigned long long index, unsigned int thr) {
+  return (unsigned int)(sepr_mix64(seed ^ sepr_mix64(index)) >> 32) >= thr;
+}
+inline unsigned int sepr_drop_threshold(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 4294967295u : (unsigned int)t;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // G[N][K] (+)= sum_m A[m][n] * B'[m][k]      ("TN" contraction over the M = batch x frames rows: every weight gradient)
 //   A  : fp32 rows, leading dimension lda (upstream gradient of the projection's output)
@@ -82,8 +99,13 @@ int launch_gate_fwd(const float* x, const float* zg, const float* att, float* y,
 // dzg = dy * att_up * sigmoid'(zg) [M][F]; datt[Mp][F] = sum over the fac frames of a pooled frame of dy * sigmoid(zg)
 int launch_gate_bwd(const float* dy, const float* zg, const float* att, float* dzg, float* datt, int n, int T, int Tp, int F,
                     hipStream_t s);
-// attention across the S speakers of each frame, backward: qkv, dO -> dqkv
-int launch_spkmix_bwd(const float* QKV, const float* dO, float* dQKV, int B, int S, int T, int F, int H, hipStream_t s);
+// attention across the S speakers of each frame (train): forward with dropout on the probabilities, and backward qkv, dO -> dqkv
+int launch_spkmix_train_fwd(const float* QKV, float* O, int B, int S, int T, int F, int H, float p, unsigned long long seed,
+                            unsigned long long offset, hipStream_t s);
+int launch_spkmix_bwd(const float* QKV, const float* dO, float* dQKV, int B, int S, int T, int F, int H, float p, unsigned long long seed,
+                      unsigned long long offset, hipStream_t s);
+// y[m][f] = ls[f] * v[m][f]
+int launch_scale_cols(const float* v, const float* ls, float* y, long long M, int F, hipStream_t s);
 // fusion conv backward glue: dcat [n,T,2F] -> dlo [n,T/2,F] (sum of the two frames that read it), dskip [n,T,F];
 // acc_* != 0: add into the destination
 int launch_unfuse(const float* dcat, float* dlo, float* dskip, int n, int T, int F, hipStream_t s);
@@ -138,10 +160,13 @@ int launch_finish_linear_ls(const float* Gr, const float* s, const float* W, con
 // ---- attention with stored probabilities (sepr_train_attn.hip) ----------------------------------------------------
 size_t relattn_train_ws(int n, int Tp, int F, int H);
 // QKV [n,Tp,3F] -> O [n,Tp,F]; P [n,H,Tp,Tp] = softmax probabilities (saved for the backward)
-int launch_relattn_train_fwd(const float* QKV, float* O, float* P, int n, int Tp, int F, int H, const float* pe_k, int maxlen,
-                             hipStream_t s);
+// p > 0: inverted dropout on the probabilities that multiply V (P itself is stored undropped); element index of the
+// generator = offset + ((n*H + h) * Tp + i) * Tp + j
+int launch_relattn_train_fwd(const float* QKV, float* O, float* P, int n, int Tp, int F, int H, const float* pe_k, int maxlen, float p,
+                             unsigned long long seed, unsigned long long offset, hipStream_t s);
 // dO [n,Tp,F] -> dQKV [n,Tp,3F]; dpe [2*maxlen][dk] accumulated
 int launch_relattn_bwd(const float* QKV, const float* P, const float* O, const float* dO, float* dQKV, float* dpe_g, int n, int Tp,
-                       int F, int H, const float* pe_k, int maxlen, void* ws, size_t ws_bytes, hipStream_t s);
+                       int F, int H, const float* pe_k, int maxlen, float p, unsigned long long seed, unsigned long long offset, void* ws,
+                       size_t ws_bytes, hipStream_t s);
 
 }  // namespace sepr

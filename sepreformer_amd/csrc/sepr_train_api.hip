@@ -276,7 +276,6 @@ int ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const 
   float* tmp = p > 0.f ? ws.f32((long long)F * Mp) : nullptr;
   if (cx.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
-  if (p > 0.f) return SEPR_EINVAL;   // attention-probability dropout is not built yet: run the EGA blocks with p_drop = 0
   const float* xp = x;
   if (fac > 1) {
     SEPR_TRY(launch_pool(x, k.xd, n, Tp, fac, F, st));                                          // network.py:146
@@ -284,14 +283,17 @@ int ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const 
   }
   SEPR_TRY(launch_rowstats(xp, k.stats_p, Mp, F, LN_EPS_T, st));
   SEPR_TRY(normed(xp, F, k.stats_p, k.qkv, 3 * F, Mp, 3 * F, F, w->attn.qkv, st));             // :99-102
-  SEPR_TRY(launch_relattn_train_fwd(k.qkv, k.o, k.P, n, Tp, F, H, w->pe_k, w->maxlen, st));    // :106-122
-  {
+  SEPR_TRY(launch_relattn_train_fwd(k.qkv, k.o, k.P, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), st));   // :106-122
+  if (p > 0.f) {
+    SEPR_TRY(plain(k.o, F, tmp, F, Mp, F, F, w->attn.out, nullptr, st));                        // :124 linear_out
+    SEPR_TRY(launch_dropout(tmp, tmp, (long long)F * Mp, p, seed, site_off(1), st));            //      dropout
+    SEPR_TRY(launch_scale_cols(tmp, w->attn.ls, k.att, Mp, F, st));                             //      LayerScale
+  } else {
     GemmArgs a = gemm_args_zero();
     a.M = (int)Mp; a.N = F; a.K = F;
     a.A = k.o; a.lda = F; a.Y = k.att; a.ldc = F; a.R = nullptr; a.ls = w->attn.ls;
     SEPR_TRY(lin(PRO_PLAIN, EPI_RES, a, w->attn.out, SEPR_SITE_NONE, st));                      // :124
   }
-  (void)tmp; (void)seed;
   SEPR_TRY(launch_rowstats(x, k.stats, M, F, LN_EPS_T, st));
   SEPR_TRY(normed(x, F, k.stats, k.zg, F, M, F, F, w->gate, st));                               // :132-134
   SEPR_TRY(launch_gate_fwd(x, k.zg, k.att, y, n, T, Tp, F, st));                                // :135,151-153
@@ -318,15 +320,14 @@ int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, in
   void* atw = ws.take(atb);
   if (ws.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
-  if (p > 0.f) return SEPR_EINVAL;
-  (void)seed;
   const bool x3 = w->gate.wp != nullptr;
   const float* xp = fac > 1 ? k.xd : x;
   // gate: y = x + sigmoid(zg) * up(att)
   SEPR_TRY(launch_gate_bwd(dy, k.zg, k.att, dzg, datt, n, T, Tp, F, st));
+  if (p > 0.f) SEPR_TRY(launch_dropout(datt, datt, (long long)F * Mp, p, seed, site_off(1), st));   // attention-output dropout mask
   // attention branch first (its input gradient is added while the gate branch's LayerNorm backward writes dx)
   SEPR_TRY(mha_out_bwd(datt, k.o, dO, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, st));
-  SEPR_TRY(launch_relattn_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, atw, atb, st));
+  SEPR_TRY(launch_relattn_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), atw, atb, st));
   SEPR_TRY(mha_qkv_bwd(dqkv, xp, k.stats_p, dxh_p, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, st));
   SEPR_TRY(launch_ln_bwd(dxh_p, xp, k.stats_p, nullptr, nullptr, 0, 0, 0, dxd, Mp, F, st));
   // gate projection behind its own LayerNorm
@@ -357,10 +358,14 @@ int spk_fwd(const float* x, float* y, int nS, int S, int T, int F, int H, const 
   float* out = p > 0.f ? ws.f32((long long)F * M) : nullptr;
   if (cx.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
-  if (p > 0.f) return SEPR_EINVAL;   // (attention-probability dropout: see ega_fwd)
-  (void)out; (void)seed;
   SEPR_TRY(launch_rowstats(x, k.stats, M, F, LN_EPS_T, st));
   SEPR_TRY(normed(x, F, k.stats, k.qkv, 3 * F, M, 3 * F, F, w->qkv, st));
+  if (p > 0.f) {
+    SEPR_TRY(launch_spkmix_train_fwd(k.qkv, k.o, nS / S, S, T, F, H, p, seed, site_off(0), st));
+    SEPR_TRY(plain(k.o, F, out, F, M, F, F, w->out, nullptr, st));
+    SEPR_TRY(launch_dropout(out, out, (long long)F * M, p, seed, site_off(1), st));
+    return launch_res_ls(x, out, w->ls, y, M, F, st);
+  }
   SEPR_TRY(launch_spkmix(k.qkv, k.o, nS / S, S, T, F, H, st));
   GemmArgs a = gemm_args_zero();
   a.M = (int)M; a.N = F; a.K = F;
@@ -376,15 +381,19 @@ int spk_bwd(const float* x, const float* dy, float* dx, int nS, int S, int T, in
   float* dWh = ws.f32(3LL * F * F);
   float* s = ws.f32(3 * F);
   float* dxh = dO;                      // dO is dead after the speaker-mix backward
+  float* dyp = p > 0.f ? ws.f32((long long)F * M) : nullptr;
   const size_t tnb = tn_workspace_bytes((int)M, 3 * F, F);
   void* tnw = ws.take(tnb);
   if (ws.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
-  if (p > 0.f) return SEPR_EINVAL;
-  (void)seed;
   const bool x3 = w->qkv.wp != nullptr;
-  SEPR_TRY(mha_out_bwd(dy, k.o, dO, M, F, w, g, dWh, s, x3, tnw, tnb, st));
-  SEPR_TRY(launch_spkmix_bwd(k.qkv, dO, dqkv, nS / S, S, T, F, H, st));
+  const float* dyq = dy;
+  if (p > 0.f) {
+    SEPR_TRY(launch_dropout(dy, dyp, (long long)F * M, p, seed, site_off(1), st));
+    dyq = dyp;
+  }
+  SEPR_TRY(mha_out_bwd(dyq, k.o, dO, M, F, w, g, dWh, s, x3, tnw, tnb, st));
+  SEPR_TRY(launch_spkmix_bwd(k.qkv, dO, dqkv, nS / S, S, T, F, H, p, seed, site_off(0), st));
   SEPR_TRY(mha_qkv_bwd(dqkv, x, k.stats, dxh, M, F, w, g, dWh, s, x3, tnw, tnb, st));
   return launch_ln_bwd(dxh, x, k.stats, dy, nullptr, 0, 0, 0, dx, M, F, st);
 }

@@ -30,7 +30,8 @@ __device__ __forceinline__ int relidx(int i, int j, int maxlen) {
 template <int DK>
 __global__ __launch_bounds__(AT_THREADS) void relattn_train_fwd_kernel(const float* __restrict__ QKV, float* __restrict__ O,
                                                                       float* __restrict__ P, int Tp, int F, int H,
-                                                                      const float* __restrict__ pe, int maxlen, float isd) {
+                                                                      const float* __restrict__ pe, int maxlen, float isd, unsigned int thr,
+                                                                      float dscale, unsigned long long seed, unsigned long long offset) {
   extern __shared__ float sm[];
   float* sc = sm;                        // [AT_QT][Tp]
   float* qs = sm + AT_QT * Tp;           // [AT_QT][DK]
@@ -96,8 +97,10 @@ __global__ __launch_bounds__(AT_THREADS) void relattn_train_fwd_kernel(const flo
     const int d4 = tid % D4, row = (tid / D4) % AT_QT, part = tid / (D4 * AT_QT);
     constexpr int NPART = AT_THREADS / (D4 * AT_QT);
     float4 acc = zero4();
+    const unsigned long long rowoff = offset + ((unsigned long long)nh * Tp + (i0 + row)) * Tp;
     for (int j = part; j < Tp; j += NPART) {
-      const float p = sc[row * Tp + j];
+      float p = sc[row * Tp + j];
+      if (thr) p = sepr_keep(seed, rowoff + j, thr) ? p * dscale : 0.f;      // network.py:121 (dropout on the probabilities)
       const float4 v = ld4(base + (long long)j * 3 * F + 2 * F + 4 * d4);
       acc.x = fmaf(p, v.x, acc.x); acc.y = fmaf(p, v.y, acc.y); acc.z = fmaf(p, v.z, acc.z); acc.w = fmaf(p, v.w, acc.w);
     }
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(AT_THREADS) void relattn_bwd_rows_kernel(const floa
                                                                      const float* __restrict__ O, const float* __restrict__ dO,
                                                                      float* __restrict__ dQKV, float* __restrict__ dS,
                                                                      float* __restrict__ band, int NH, int Tp, int F, int H,
-                                                                     const float* __restrict__ pe, int maxlen, float isd) {
+                                                                     const float* __restrict__ pe, int maxlen, float isd, unsigned int thr,
+                                                                     float dscale, unsigned long long seed, unsigned long long offset) {
   extern __shared__ float sm[];
   float* sc = sm;                        // [AT_QT][Tp]   P, then dS
   float* qs = sm + AT_QT * Tp;           // [AT_QT][DK]
@@ -178,6 +182,7 @@ __global__ __launch_bounds__(AT_THREADS) void relattn_bwd_rows_kernel(const floa
           const float4 gv = ld4(gs + ii * DK + d);
           a = fmaf(gv.x, vj[d], a); a = fmaf(gv.y, vj[d + 1], a); a = fmaf(gv.z, vj[d + 2], a); a = fmaf(gv.w, vj[d + 3], a);
         }
+        if (thr) a = sepr_keep(seed, offset + ((unsigned long long)nh * Tp + (i0 + ii)) * Tp + j, thr) ? a * dscale : 0.f;
         const float ds = sc[ii * Tp + j] * (a - Ds[ii]) * isd;
         sc[ii * Tp + j] = ds;
         if (i0 + ii < Tp) dS[((long long)nh * Tp + i0 + ii) * Tp + j] = ds;
@@ -242,7 +247,8 @@ __global__ __launch_bounds__(AT_THREADS) void relattn_bwd_rows_kernel(const floa
 template <int DK>
 __global__ __launch_bounds__(AT_THREADS) void relattn_bwd_cols_kernel(const float* __restrict__ QKV, const float* __restrict__ P,
                                                                      const float* __restrict__ dS, const float* __restrict__ dO,
-                                                                     float* __restrict__ dQKV, int Tp, int F, int H) {
+                                                                     float* __restrict__ dQKV, int Tp, int F, int H, unsigned int thr,
+                                                                     float dscale, unsigned long long seed, unsigned long long offset) {
   constexpr int D4 = DK / 4;
   constexpr int NPART = AT_THREADS / (D4 * AT_QT);
   __shared__ float redk[NPART][AT_QT][DK], redv[NPART][AT_QT][DK];
@@ -256,7 +262,9 @@ __global__ __launch_bounds__(AT_THREADS) void relattn_bwd_cols_kernel(const floa
   if (j < Tp) {
     for (int i = part; i < Tp; i += NPART) {
       const long long e = ((long long)nh * Tp + i) * Tp + j;
-      const float p = P[e], s = dS[e];
+      float p = P[e];
+      const float s = dS[e];
+      if (thr) p = sepr_keep(seed, offset + (unsigned long long)e, thr) ? p * dscale : 0.f;
       const float4 qv = ld4(base + (long long)i * 3 * F + 4 * d4);
       const float4 gv = ld4(dO + ((long long)n * Tp + i) * F + h * DK + 4 * d4);
       ak.x = fmaf(s, qv.x, ak.x); ak.y = fmaf(s, qv.y, ak.y); ak.z = fmaf(s, qv.z, ak.z); ak.w = fmaf(s, qv.w, ak.w);
@@ -317,17 +325,21 @@ size_t relattn_train_ws(int n, int Tp, int F, int H) {
   return align_up((size_t)NH * Tp * Tp * sizeof(float)) + align_up((size_t)ngroups * ntiles * (Tp + AT_QT - 1) * DK * sizeof(float));
 }
 
-int launch_relattn_train_fwd(const float* QKV, float* O, float* P, int n, int Tp, int F, int H, const float* pe_k, int maxlen,
-                             hipStream_t s) {
+int launch_relattn_train_fwd(const float* QKV, float* O, float* P, int n, int Tp, int F, int H, const float* pe_k, int maxlen, float p,
+                             unsigned long long seed, unsigned long long offset, hipStream_t s) {
   if (n <= 0) return SEPR_OK;
-  if (!QKV || !O || !P || !pe_k || Tp <= 0 || Tp > AT_TPMAX || H <= 0 || F % H) return SEPR_EINVAL;
+  if (!QKV || !O || !P || !pe_k || Tp <= 0 || Tp > AT_TPMAX || H <= 0 || F % H || !(p >= 0.f) || !(p < 1.f)) return SEPR_EINVAL;
   const int DK = F / H;
   const float isd = 1.0f / sqrtf((float)DK);
+  const unsigned int thr = p > 0.f ? sepr_drop_threshold(p) : 0u;
+  const float dscale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   const dim3 grid(n * H, (Tp + AT_QT - 1) / AT_QT);
   if (DK == 16) {
-    hipLaunchKernelGGL((relattn_train_fwd_kernel<16>), grid, dim3(AT_THREADS), fwd_shm(Tp, 16), s, QKV, O, P, Tp, F, H, pe_k, maxlen, isd);
+    hipLaunchKernelGGL((relattn_train_fwd_kernel<16>), grid, dim3(AT_THREADS), fwd_shm(Tp, 16), s, QKV, O, P, Tp, F, H, pe_k, maxlen, isd, thr,
+                       dscale, seed, offset);
   } else if (DK == 32) {
-    hipLaunchKernelGGL((relattn_train_fwd_kernel<32>), grid, dim3(AT_THREADS), fwd_shm(Tp, 32), s, QKV, O, P, Tp, F, H, pe_k, maxlen, isd);
+    hipLaunchKernelGGL((relattn_train_fwd_kernel<32>), grid, dim3(AT_THREADS), fwd_shm(Tp, 32), s, QKV, O, P, Tp, F, H, pe_k, maxlen, isd, thr,
+                       dscale, seed, offset);
   } else {
     return SEPR_EINVAL;
   }
@@ -336,9 +348,13 @@ int launch_relattn_train_fwd(const float* QKV, float* O, float* P, int n, int Tp
 }
 
 int launch_relattn_bwd(const float* QKV, const float* P, const float* O, const float* dO, float* dQKV, float* dpe_g, int n, int Tp,
-                       int F, int H, const float* pe_k, int maxlen, void* ws, size_t ws_bytes, hipStream_t s) {
+                       int F, int H, const float* pe_k, int maxlen, float p, unsigned long long seed, unsigned long long offset, void* ws,
+                       size_t ws_bytes, hipStream_t s) {
   if (n <= 0) return SEPR_OK;
-  if (!QKV || !P || !O || !dO || !dQKV || !dpe_g || !pe_k || Tp <= 0 || Tp > AT_TPMAX || H <= 0 || F % H) return SEPR_EINVAL;
+  if (!QKV || !P || !O || !dO || !dQKV || !dpe_g || !pe_k || Tp <= 0 || Tp > AT_TPMAX || H <= 0 || F % H || !(p >= 0.f) || !(p < 1.f))
+    return SEPR_EINVAL;
+  const unsigned int thr = p > 0.f ? sepr_drop_threshold(p) : 0u;
+  const float dscale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   const int DK = F / H;
   if (DK != 16 && DK != 32) return SEPR_EINVAL;
   const int NH = n * H;
@@ -352,17 +368,19 @@ int launch_relattn_bwd(const float* QKV, const float* P, const float* O, const f
   const float isd = 1.0f / sqrtf((float)DK);
 #define SEPR_ROWS(DD, NO)                                                                                                         \
   hipLaunchKernelGGL((relattn_bwd_rows_kernel<DD, NO>), dim3(ngroups, ntiles), dim3(AT_THREADS), bwd_shm(Tp, DD), s, QKV, P, O, dO, \
-                     dQKV, dS, band, NH, Tp, F, H, pe_k, maxlen, isd)
+                     dQKV, dS, band, NH, Tp, F, H, pe_k, maxlen, isd, thr, dscale, seed, offset)
   if (DK == 16) {
     if (nown <= 8) SEPR_ROWS(16, 8);
     else if (nown <= 16) SEPR_ROWS(16, 16);
     else SEPR_ROWS(16, 32);
-    hipLaunchKernelGGL((relattn_bwd_cols_kernel<16>), dim3(NH, ntiles), dim3(AT_THREADS), 0, s, QKV, P, dS, dO, dQKV, Tp, F, H);
+    hipLaunchKernelGGL((relattn_bwd_cols_kernel<16>), dim3(NH, ntiles), dim3(AT_THREADS), 0, s, QKV, P, dS, dO, dQKV, Tp, F, H, thr,
+                       dscale, seed, offset);
   } else {
     if (nown <= 8) SEPR_ROWS(32, 8);
     else if (nown <= 16) SEPR_ROWS(32, 16);
     else SEPR_ROWS(32, 32);
-    hipLaunchKernelGGL((relattn_bwd_cols_kernel<32>), dim3(NH, ntiles), dim3(AT_THREADS), 0, s, QKV, P, dS, dO, dQKV, Tp, F, H);
+    hipLaunchKernelGGL((relattn_bwd_cols_kernel<32>), dim3(NH, ntiles), dim3(AT_THREADS), 0, s, QKV, P, dS, dO, dQKV, Tp, F, H, thr,
+                       dscale, seed, offset);
   }
 #undef SEPR_ROWS
   hipLaunchKernelGGL(relattn_band_reduce_kernel, dim3((2 * maxlen * DK + AT_THREADS - 1) / AT_THREADS), dim3(AT_THREADS), 0, s, band,

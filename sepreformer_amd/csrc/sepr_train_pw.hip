@@ -571,9 +571,12 @@ int launch_gate_bwd(const float* dy, const float* zg, const float* att, float* d
 // One thread per (frame, head): S <= 4 speakers, dk <= 32.  QKV rows are (b*S + s)*T + t, [q | k | v] of 3F.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-template <int S, int DK>
+// FWD = true: writes o (into dQKV's place: [rows][F]) instead of the gradients; dropout (thr > 0) applies to the
+// probabilities that multiply V: generator index = offset + ((frame * H + h) * S + s) * S + u
+template <int S, int DK, bool FWD>
 __global__ __launch_bounds__(TPB) void spkmix_bwd_kernel(const float* __restrict__ QKV, const float* __restrict__ dO,
-                                                        float* __restrict__ dQKV, long long frames, int T, int F, int H, float isd) {
+                                                        float* __restrict__ dQKV, long long frames, int T, int F, int H, float isd,
+                                                        unsigned int thr, float dscale, unsigned long long seed, unsigned long long offset) {
   const long long total = frames * H;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
     const long long fr = i / H;
@@ -588,14 +591,20 @@ __global__ __launch_bounds__(TPB) void spkmix_bwd_kernel(const float* __restrict
       const float* p = QKV + row[s] * 3 * F + h * DK;
 #pragma unroll
       for (int d = 0; d < DK; d += 4) {
-        const float4 a = ld4(p + d), bb = ld4(p + F + d), c = ld4(p + 2 * F + d), g = ld4(dO + row[s] * F + h * DK + d);
+        const float4 a = ld4(p + d), bb = ld4(p + F + d), c = ld4(p + 2 * F + d);
+        const float4 g = FWD ? zero4() : ld4(dO + row[s] * F + h * DK + d);
         q[s][d] = a.x; q[s][d + 1] = a.y; q[s][d + 2] = a.z; q[s][d + 3] = a.w;
         k[s][d] = bb.x; k[s][d + 1] = bb.y; k[s][d + 2] = bb.z; k[s][d + 3] = bb.w;
         v[s][d] = c.x; v[s][d + 1] = c.y; v[s][d + 2] = c.z; v[s][d + 3] = c.w;
         go[s][d] = g.x; go[s][d + 1] = g.y; go[s][d + 2] = g.z; go[s][d + 3] = g.w;
       }
     }
-    float P[S][S], dS_[S][S];
+    float P[S][S], dS_[S][S], Mk[S][S];     // Mk: dropout multiplier (0 or 1 / (1 - p)) of P[s][u]
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int u = 0; u < S; ++u)
+        Mk[s][u] = (thr == 0u || sepr_keep(seed, offset + (unsigned long long)((i * S + s) * S + u), thr)) ? dscale : 0.f;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       float sc[S], mx = -3.0e38f;
@@ -617,11 +626,27 @@ __global__ __launch_bounds__(TPB) void spkmix_bwd_kernel(const float* __restrict
         float a = 0.f;
 #pragma unroll
         for (int d = 0; d < DK; ++d) a = fmaf(go[s][d], v[u][d], a);
-        dP[u] = a;
-        dot = fmaf(a, P[s][u], dot);
+        dP[u] = a * Mk[s][u];
+        dot = fmaf(dP[u], P[s][u], dot);
       }
 #pragma unroll
       for (int u = 0; u < S; ++u) dS_[s][u] = P[s][u] * (dP[u] - dot) * isd;
+    }
+    if (FWD) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float* o = dQKV + row[s] * F + h * DK;
+#pragma unroll
+        for (int d = 0; d < DK; d += 4) {
+          float a[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int u = 0; u < S; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = fmaf(P[s][u] * Mk[s][u], v[u][d + j], a[j]);
+          st4(o + d, make_float4(a[0], a[1], a[2], a[3]));
+        }
+      }
+      continue;
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -635,7 +660,7 @@ __global__ __launch_bounds__(TPB) void spkmix_bwd_kernel(const float* __restrict
           for (int j = 0; j < 4; ++j) {
             dq[j] = fmaf(dS_[s][u], k[u][d + j], dq[j]);       // dq_s = sum_u dS[s][u] k_u
             dk_[j] = fmaf(dS_[u][s], q[u][d + j], dk_[j]);     // dk_s = sum_u dS[u][s] q_u
-            dv[j] = fmaf(P[u][s], go[u][d + j], dv[j]);        // dv_s = sum_u P[u][s] dO_u
+            dv[j] = fmaf(P[u][s] * Mk[u][s], go[u][d + j], dv[j]);   // dv_s = sum_u P_dropped[u][s] dO_u
           }
         st4(o + d, make_float4(dq[0], dq[1], dq[2], dq[3]));
         st4(o + F + d, make_float4(dk_[0], dk_[1], dk_[2], dk_[3]));
@@ -645,22 +670,37 @@ __global__ __launch_bounds__(TPB) void spkmix_bwd_kernel(const float* __restrict
   }
 }
 }  // namespace
-int launch_spkmix_bwd(const float* QKV, const float* dO, float* dQKV, int B, int S, int T, int F, int H, hipStream_t s) {
+static int spkmix_train_launch(bool fwd, const float* QKV, const float* dO, float* out, int B, int S, int T, int F, int H, float p,
+                               unsigned long long seed, unsigned long long offset, hipStream_t s) {
   if (B <= 0 || T <= 0) return SEPR_OK;
-  if (!QKV || !dO || !dQKV || H <= 0 || F % H) return SEPR_EINVAL;
+  if (!QKV || !out || (!fwd && !dO) || H <= 0 || F % H || !(p >= 0.f) || !(p < 1.f)) return SEPR_EINVAL;
   const int dk = F / H;
   const long long frames = (long long)B * T;
   const float isd = 1.0f / sqrtf((float)dk);
+  const unsigned int thr = p > 0.f ? sepr_drop_threshold(p) : 0u;
+  const float dscale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   const dim3 g(grid_for(frames * H, TPB, 1 << 16)), t(TPB);
-#define SEPR_SPKB(SS, DD) hipLaunchKernelGGL((spkmix_bwd_kernel<SS, DD>), g, t, 0, s, QKV, dO, dQKV, frames, T, F, H, isd)
+#define SEPR_SPKB(SS, DD)                                                                                                               \
+  do {                                                                                                                                  \
+    if (fwd) hipLaunchKernelGGL((spkmix_bwd_kernel<SS, DD, true>), g, t, 0, s, QKV, dO, out, frames, T, F, H, isd, thr, dscale, seed, offset); \
+    else hipLaunchKernelGGL((spkmix_bwd_kernel<SS, DD, false>), g, t, 0, s, QKV, dO, out, frames, T, F, H, isd, thr, dscale, seed, offset);    \
+  } while (0)
   if (S == 2 && dk == 16) SEPR_SPKB(2, 16);
   else if (S == 2 && dk == 32) SEPR_SPKB(2, 32);
   else if (S == 3 && dk == 16) SEPR_SPKB(3, 16);
   else if (S == 3 && dk == 32) SEPR_SPKB(3, 32);
   else return SEPR_EINVAL;
 #undef SEPR_SPKB
-  SEPR_CHECK_LAUNCH("spkmix_bwd_kernel");
+  SEPR_CHECK_LAUNCH("spkmix train kernel");
   return SEPR_OK;
+}
+int launch_spkmix_train_fwd(const float* QKV, float* O, int B, int S, int T, int F, int H, float p, unsigned long long seed,
+                            unsigned long long offset, hipStream_t s) {
+  return spkmix_train_launch(true, QKV, nullptr, O, B, S, T, F, H, p, seed, offset, s);
+}
+int launch_spkmix_bwd(const float* QKV, const float* dO, float* dQKV, int B, int S, int T, int F, int H, float p, unsigned long long seed,
+                      unsigned long long offset, hipStream_t s) {
+  return spkmix_train_launch(false, QKV, dO, dQKV, B, S, T, F, H, p, seed, offset, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -978,19 +1018,19 @@ __global__ __launch_bounds__(TPB) void res_ls_kernel(const float* __restrict__ x
     st4(y + 4 * i, make_float4(fmaf(b.x, l.x, a.x), fmaf(b.y, l.y, a.y), fmaf(b.z, l.z, a.z), fmaf(b.w, l.w, a.w)));
   }
 }
-// counter-based generator: one 64-bit mix (splitmix64 finaliser) of (seed, element index) per element
-__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-__global__ __launch_bounds__(TPB) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long count, float p,
+__global__ __launch_bounds__(TPB) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long count, unsigned int thr,
                                                      float scale, unsigned long long seed, unsigned long long offset) {
-  const unsigned int thr = (unsigned int)(p * 4294967296.0f < 4294967295.0f ? p * 4294967296.0f : 4294967295.0f);
-  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < count; i += (long long)gridDim.x * TPB) {
-    const unsigned long long r = mix64(seed ^ mix64(offset + (unsigned long long)i));
-    y[i] = ((unsigned int)(r >> 32) >= thr) ? x[i] * scale : 0.f;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < count; i += (long long)gridDim.x * TPB)
+    y[i] = sepr_keep(seed, offset + (unsigned long long)i, thr) ? x[i] * scale : 0.f;
+}
+__global__ __launch_bounds__(TPB) void scale_cols_kernel(const float* __restrict__ v, const float* __restrict__ ls, float* __restrict__ y,
+                                                        long long M, int F) {
+  const int f4 = F >> 2;
+  const long long total = M * f4;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int c = (int)(i % f4) * 4;
+    const float4 b = ld4(v + 4 * i), l = ld4(ls + c);
+    st4(y + 4 * i, make_float4(b.x * l.x, b.y * l.y, b.z * l.z, b.w * l.w));
   }
 }
 }  // namespace
@@ -1012,8 +1052,16 @@ int launch_dropout(const float* x, float* y, long long count, float p, unsigned 
                    hipStream_t s) {
   if (count <= 0) return SEPR_OK;
   if (!x || !y || !(p >= 0.f) || !(p < 1.f)) return SEPR_EINVAL;
-  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(count, TPB, 1 << 16)), dim3(TPB), 0, s, x, y, count, p, 1.0f / (1.0f - p), seed, offset);
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(count, TPB, 1 << 16)), dim3(TPB), 0, s, x, y, count, sepr_drop_threshold(p),
+                     1.0f / (1.0f - p), seed, offset);
   SEPR_CHECK_LAUNCH("dropout_kernel");
+  return SEPR_OK;
+}
+int launch_scale_cols(const float* v, const float* ls, float* y, long long M, int F, hipStream_t s) {
+  if (M <= 0) return SEPR_OK;
+  if (!v || !ls || !y || F % 4) return SEPR_EINVAL;
+  hipLaunchKernelGGL(scale_cols_kernel, dim3(grid_for(M * (F >> 2), TPB, 1 << 16)), dim3(TPB), 0, s, v, ls, y, M, F);
+  SEPR_CHECK_LAUNCH("scale_cols_kernel");
   return SEPR_OK;
 }
 

@@ -24,7 +24,7 @@ _ERR = {SEPR_EINVAL: "SEPR_EINVAL (bad shape / unsupported size / null pointer)"
 
 (OP_ENCODER, OP_GCFN, OP_CLA, OP_EGA, OP_SPKATTN, OP_SPKSPLIT, OP_OUTLAYER, OP_PIT) = range(8)
 (SITE_NONE, SITE_GCFN_UP, SITE_GCFN_DOWN, SITE_CLA, SITE_ATTN_PROJ, SITE_EGA_GATE, SITE_SPLIT, SITE_FUSE,
- SITE_OUT, SITE_PROJECTOR, SITE_LINEAR) = range(11)
+ SITE_OUT, SITE_PROJECTOR, SITE_LINEAR, SITE_WGRAD) = range(12)
 
 _fp = C.c_void_p  # device pointers travel as plain addresses
 

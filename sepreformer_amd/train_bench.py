@@ -1,0 +1,120 @@
+"""``bench.py --mode train``: one training step of the reference loop (engine.py:50-83) per "step" on the HIP training path.
+
+step = model.train() forward (main + 4 auxiliary heads, batch-statistics BatchNorm, dropout at the model's configured rate)
+       + PIT_SISNR_time on the main outputs + PIT_SISNR_mag on each auxiliary output + the 0.6 / 0.4 mix (engine.py:66-74)
+       + backward through every block (sepr_*_bwd) + RCCL all-reduce of the flat gradient buffer when N > 1
+       + clip_grad_norm_(5) + AdamW step (stock torch optimizer, as in the reference).
+Inputs: synthetic two-speaker mixtures with their sources as targets, resident in HBM.  ``value`` = utterances/s over all ranks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import time
+
+import torch
+
+FP32_MFMA_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS = 157.3, 2500.0
+GFLOP_FWD = {"SepReformer_Base_WSJ0": 182.16, "SepReformer_Large_DM_WHAMR": 684.14}     # per 4 s utterance, forward incl. aux heads
+
+
+def main(args):
+    from . import dist as sdist
+    from . import lib as L
+    from .config import VARIANTS
+    from .criterion import PIT_SISNR_mag, PIT_SISNR_time
+    from .model import Model
+    from .synth import synth_sources
+
+    rank, world, local = sdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the separator path)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    lib = L.load()
+    variant = args.variant
+    cfg = VARIANTS[variant]
+    precision = args.precision if args.precision in ("fp32", "bf16x3") else None
+    model = Model.from_config(cfg, init_seed=0, precision=precision).load_synthetic_(0).to(dev)
+    model.train()
+    sync = sdist.GradSync()
+    model.grad_sync = sync
+    B = args.batch or 4
+    samples = 32000
+    src = torch.from_numpy(synth_sources(B, samples, seed=4321 + rank * B)).to(dev)
+    x = src.sum(1).contiguous()
+    targets = [src[:, s].contiguous() for s in range(cfg.num_spks)]
+    sizes = torch.full((B,), samples)
+    crit_t = PIT_SISNR_time(dev, cfg.num_spks, True)
+    crit_m = PIT_SISNR_mag(dev, 512, 128, "hann", cfg.num_stages, cfg.num_spks, True, False)
+    params = list(model.parameters())
+    try:
+        opt = torch.optim.AdamW(params, lr=1.0e-4, weight_decay=1.0e-2, fused=True)
+    except (TypeError, RuntimeError):
+        opt = torch.optim.AdamW(params, lr=1.0e-4, weight_decay=1.0e-2)
+    last = {}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        audio, aux = model(x)
+        l_time = crit_t(estims=audio, input_sizes=sizes, target_attr=targets)
+        l_mag = [crit_m(estims=a, idx=i, input_sizes=sizes, target_attr=targets) for i, a in enumerate(aux)]
+        loss = ((1 - 0.4) * l_time + 0.4 * sum(l_mag) / len(l_mag)) / cfg.num_spks           # engine.py:72-74
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(params, 5.0)                                      # engine.py:76
+        opt.step()
+        last["loss"], last["gn"] = loss.detach(), gn
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    L.check(lib.sepr_prof_start(L.SITE_WGRAD, 400 * max(args.steps, 1) + 8), "sepr_prof_start")
+    sdist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    sdist.barrier()
+    elapsed = time.perf_counter() - t0
+    n_l, ms, fl = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
+    L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
+    elapsed = sdist.max_over_ranks(elapsed, dev)
+    if rank == 0:
+        utt_per_s = world * B * args.steps / elapsed
+        x3 = model.precision == "bf16x3"
+        peak = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
+        mult = 3.0 if x3 else 1.0
+        sec = ms.value / 1e3
+        algo_tf = fl.value / 1e12 / sec if sec > 0 else 0.0
+        gflop = 3.0 * GFLOP_FWD.get(variant, 0.0)                      # forward + input gradients + weight gradients
+        rec = {
+            "metric": f"training utterances/sec (4 s, 8 kHz, 2-spk) {variant}: forward + PIT SI-SNR losses + backward + clip + AdamW",
+            "value": round(utt_per_s, 3), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate); fp32 master weights, "
+                      "gradients and optimizer state") if x3 else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{variant} training step, batch={B} per GPU, 4 s @ 8 kHz, 2 speakers (BASELINE.json configs[4])",
+                       "batch_per_gpu": B, "samples": samples, "precision": model.precision, "dropout": model.dropout_p,
+                       "dropout_sites": "all the reference's sites: GCFN x2, CLA, attention probabilities + attention output (EGA and speaker attention)",
+                       "optimizer": type(opt).__name__ + (" (fused)" if getattr(opt, "defaults", {}).get("fused") else ""),
+                       "clip_norm": 5.0, "parallelism": f"data-parallel x{world}, flat-buffer RCCL all-reduce"},
+            "loss": round(float(last["loss"]), 4), "grad_norm": round(float(last["gn"]), 4),
+            "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+            "allreduce_bytes_per_step": (sync.bytes // max(sync.calls, 1)) if sync.calls else 0,
+            "model_tflops": round(utt_per_s * gflop / 1e3 / world, 2),
+            "model_frac_algorithmic": round(utt_per_s * gflop / 1e3 / world / peak, 4),
+            "roofline": {"kernel": "gemm_tn_kernel (weight-gradient contraction G[N][K] = sum_m dY[m][n] X[m][k], all projections)",
+                         "bound": "mfma", "achieved": round(algo_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(algo_tf / peak, 4),
+                         "frac_algorithmic": round(algo_tf / peak, 4), "mfma_pipe_frac": round(mult * algo_tf / peak, 4),
+                         "ceiling": round(1.0 / mult, 4), "traffic": None, "launches": int(n_l.value),
+                         "avg_launch_ms": round(ms.value / max(n_l.value, 1), 4)},
+        }
+        print(json.dumps(rec), flush=True)
+    sdist.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()

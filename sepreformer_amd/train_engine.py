@@ -82,11 +82,11 @@ class TrainEngine:
         elif kind == "ega":
             cx = self._ctx(L.TOP_EGA, n, Tc, Tp)
             L.check(lib.sepr_ega_train_fwd(xin.data_ptr(), y.data_ptr(), n, Tc, Tp, F, H, C.byref(w[0]), cx.data_ptr(), cx.numel(),
-                                           *self._wsfor(L.TOP_EGA, n, Tc, Tp), 0.0, seed, st), "sepr_ega_train_fwd")
+                                           *self._wsfor(L.TOP_EGA, n, Tc, Tp), p_drop, seed, st), "sepr_ega_train_fwd")
         elif kind == "spk":
             cx = self._ctx(L.TOP_SPKATTN, n, Tc)
             L.check(lib.sepr_spkattn_train_fwd(xin.data_ptr(), y.data_ptr(), n, S, Tc, F, H, C.byref(w[0]), cx.data_ptr(), cx.numel(),
-                                               *self._wsfor(L.TOP_SPKATTN, n, Tc), 0.0, seed, st), "sepr_spkattn_train_fwd")
+                                               *self._wsfor(L.TOP_SPKATTN, n, Tc), p_drop, seed, st), "sepr_spkattn_train_fwd")
         else:
             raise ValueError(kind)
         return y, (kind, xin, cx, w, n, Tc, seed, Tp, p_drop)
@@ -107,10 +107,10 @@ class TrainEngine:
                     "sepr_cla_bwd")
         elif kind == "ega":
             L.check(lib.sepr_ega_bwd(xin.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, Tc, Tp, F, H, C.byref(w[0]), C.byref(w[1]),
-                                     cx.data_ptr(), cx.numel(), *self._wsfor(L.TOP_EGA, n, Tc, Tp), 0.0, seed, st), "sepr_ega_bwd")
+                                     cx.data_ptr(), cx.numel(), *self._wsfor(L.TOP_EGA, n, Tc, Tp), p_drop, seed, st), "sepr_ega_bwd")
         else:
             L.check(lib.sepr_spkattn_bwd(xin.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, S, Tc, F, H, C.byref(w[0]), C.byref(w[1]),
-                                         cx.data_ptr(), cx.numel(), *self._wsfor(L.TOP_SPKATTN, n, Tc), 0.0, seed, st), "sepr_spkattn_bwd")
+                                         cx.data_ptr(), cx.numel(), *self._wsfor(L.TOP_SPKATTN, n, Tc), p_drop, seed, st), "sepr_spkattn_bwd")
         return dx
 
     def split_fwd(self, xin, w, B, Tc):

@@ -101,3 +101,48 @@ def test_bench_self_launches_ranks():
     txt = r.stdout + r.stderr
     assert "WORLD_SIZE" not in txt or "but WORLD_SIZE" not in txt
     assert "needs an MI355X" in txt or "invalid device ordinal" in txt or "device" in txt.lower(), txt[-2000:]
+
+
+def _gradsync_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from sepreformer_amd import dist as sd
+    from sepreformer_amd.config import VARIANTS
+    from sepreformer_amd.train_pack import GradBuffer
+    sd.init_from_env("gloo")
+    gb = GradBuffer(VARIANTS["tiny"], torch.device("cpu"))
+    g = torch.Generator().manual_seed(100 + rank)
+    gb.flat.copy_(torch.randn(gb.numel, generator=g))
+    sync = sd.GradSync()
+    sync(gb.flat)
+    np.savez(os.path.join(out_dir, f"g{rank}.npz"), w=gb.view("separator.simple_fusion.0.weight").numpy(), calls=sync.calls, nbytes=sync.bytes,
+             numel=gb.numel)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_sync(tmp_path):
+    """Training DP (BASELINE configs[4]): the flat gradient buffer of every rank is replaced by the mean over ranks in ONE
+    all-reduce; parameter views into the buffer see the averaged values."""
+    sys.path.insert(0, ROOT)
+    from sepreformer_amd.config import VARIANTS
+    from sepreformer_amd.train_pack import GradBuffer
+    world = 2
+    mp.spawn(_gradsync_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    gb = GradBuffer(VARIANTS["tiny"], torch.device("cpu"))
+    flats = [torch.randn(gb.numel, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    gb.flat.copy_(sum(flats) / world)
+    want = gb.view("separator.simple_fusion.0.weight").numpy()
+    for r in range(world):
+        got = np.load(tmp_path / f"g{r}.npz")
+        assert np.allclose(got["w"], want, atol=1e-6)
+        assert int(got["calls"]) == 1 and int(got["nbytes"]) == 4 * gb.numel
+    # layout contract of the flat buffer: parameter order, 256-byte aligned slices, exact shapes
+    names = [n for n, _ in Model_param_names()]
+    assert list(gb.offsets) == names
+    assert all(off % 64 == 0 for off, _ in gb.offsets.values())
+
+
+def Model_param_names():
+    from sepreformer_amd.config import VARIANTS
+    from sepreformer_amd.model import Model
+    return list(Model.from_config(VARIANTS["tiny"], init_seed=0).named_parameters())

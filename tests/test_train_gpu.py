@@ -103,13 +103,31 @@ def setup(variant, precision):
     return cfg, sd, sdd, gb, tp, eng
 
 
+# Parameters whose gradient is identically zero in exact arithmetic: a bias in front of a train-mode BatchNorm (the batch mean
+# removes it: CLA dw_conv_1d.bias and linear2.bias, DownConv down_conv.bias) and the key bias of an attention (softmax is
+# invariant to a per-query constant).  Autograd and the HIP backward both return rounding noise there, so the check is on
+# magnitude (noise << the gradients that matter), not on agreement.
+STRUCTURAL_ZERO = ("linear_k.bias", "dw_conv_1d.bias", "cla.linear2.bias", "down_conv.bias")
+
+
+def agree_grad(soft, name, key, got, want, scale, min_db=MIN_DB):
+    if key.endswith(STRUCTURAL_ZERO):
+        noise_ref, noise_got = float(want.detach().abs().max()), float(got.detach().abs().max())
+        record(f"{soft.tag}.{name}.structural_zero_rel", noise_got / (scale + 1e-30))
+        if not (noise_ref <= 1e-3 * scale):
+            soft.bad.append(f"{name}: reference gradient {noise_ref:.2e} is not ~0 against scale {scale:.2e}")
+        if not (noise_got <= 1e-3 * scale):
+            soft.bad.append(f"{name}: gradient {noise_got:.2e} should be ~0 against scale {scale:.2e}")
+        return
+    soft.agree(name, got, want, min_db)
+
+
 def check_param_grads(soft, gb, sdl, prefix, min_db=MIN_DB):
-    n = 0
-    for k, v in sdl.items():
-        if k.startswith(prefix) and v.requires_grad and v.grad is not None:
-            soft.agree("grad." + k[len(prefix):].lstrip("."), gb.view(k), v.grad, min_db)
-            n += 1
-    assert n > 0, prefix
+    items = [(k, v) for k, v in sdl.items() if k.startswith(prefix) and v.requires_grad and v.grad is not None]
+    assert items, prefix
+    scale = max(float(v.grad.abs().max()) for _, v in items)
+    for k, v in items:
+        agree_grad(soft, "grad." + k[len(prefix):].lstrip("."), k, gb.view(k), v.grad, scale, min_db)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -417,7 +435,9 @@ def test_criteria_backward(S, B, T):
     lo.backward()
     soft.agree("mag.loss", loss.reshape(1), lo.reshape(1).float(), 90.0)
     for s in range(S):
-        soft.agree(f"mag.dest{s}", estd[s].grad, esto[s].grad.float(), 70.0)      # fp32 STFT on both ends of a cancellation
+        # fp32 STFT products on both ends of the M_e - M_s cancellation (estimates 60 dB close to their targets are in the
+        # batch); the reference evaluates the same expression in fp32
+        soft.agree(f"mag.dest{s}", estd[s].grad, esto[s].grad.float(), 60.0)
     soft.done()
 
 
@@ -471,6 +491,8 @@ def test_train_step_tiny_matches_reference(golden, precision):
         gr = params[k].grad.detach().double().cpu()
         nrm, sm, pr = g["grad_summary"][i]
         got = np.array([float(gr.norm()), float(gr.sum()), float((gr * torch.from_numpy(probe(k, gr.shape)).double()).sum())])
+        if k.endswith(STRUCTURAL_ZERO):
+            continue
         dev_ = np.abs(got - np.array([nrm, sm, pr])).max() / (nrm + 1e-30)
         worst = max(worst, dev_)
         if dev_ > 2e-3:
@@ -481,8 +503,9 @@ def test_train_step_tiny_matches_reference(golden, precision):
     o_audio, o_aux = tor.model_forward_train(sdl, cfg, x)
     o_loss, _, _ = tor.train_loss(o_audio, o_aux, src)
     o_loss.backward()
+    gscale = max(float(v.grad.abs().max()) for v in sdl.values() if v.requires_grad)
     for k, p_ in params.items():
-        soft.agree("grad." + k, p_.grad, sdl[k].grad)
+        agree_grad(soft, "grad." + k, k, p_.grad, sdl[k].grad, gscale)
     # BatchNorm bookkeeping
     st = m.state_dict()
     off = 0
@@ -509,8 +532,9 @@ def test_train_step_base_matches_oracle(precision):
     soft = Soft(f"train_step.base.{precision}")
     soft.agree("main", torch.stack(list(audio), 0), torch.stack([a.detach() for a in o_audio], 0))
     assert abs(float(loss) - float(o_loss)) < 5e-3, (float(loss), float(o_loss))
+    gscale = max(float(v.grad.abs().max()) for v in sdl.values() if v.requires_grad)
     for k, p_ in m.named_parameters():
-        soft.agree("grad." + k, p_.grad, sdl[k].grad)
+        agree_grad(soft, "grad." + k, k, p_.grad, sdl[k].grad, gscale)
     soft.done()
 
 
@@ -536,11 +560,19 @@ def test_dropout_contract():
     gb.flat.zero_()
     dx2 = eng.block_bwd(rec1, dy)
     assert torch.isfinite(dx).all() and torch.equal(dx, dx2)
-    # numerical check of the dropout-enabled block: directional derivative of sum(y * dy) along a random direction
+    # numerical check of every dropout-enabled block kind (all the reference's sites: GCFN x2, CLA, attention probabilities and
+    # attention output of EGA / speaker attention): directional derivative of sum(y * dy) along a random direction, same masks
     v = rnd(n, T, F, seed=3).cuda()
     eps = 1e-2
-    yp, _ = eng.block_fwd("gcfn", x + eps * v, tp.gcfn[0], n, T, 0, 0.3, 123)
-    ym, _ = eng.block_fwd("gcfn", x - eps * v, tp.gcfn[0], n, T, 0, 0.3, 123)
-    num = float(((yp - ym).double() * dy.double()).sum() / (2 * eps))
-    ana = float((dx.double() * v.double()).sum())
-    assert abs(num - ana) <= 2e-2 * max(1.0, abs(ana)), (num, ana)
+    for kind, w, Tp in (("gcfn", tp.gcfn[0], 0), ("cla", tp.cla[0], 0), ("ega", tp.ega[0], T // 4), ("spk", tp.spk[0], 0)):
+        y_, rec = eng.block_fwd(kind, x, w, n, T, Tp, 0.3, 77)
+        y_b, _ = eng.block_fwd(kind, x, w, n, T, Tp, 0.3, 77)
+        y_0, _ = eng.block_fwd(kind, x, w, n, T, Tp, 0.0, 77)
+        assert torch.equal(y_, y_b) and not torch.equal(y_, y_0), kind
+        dxk = eng.block_bwd(rec, dy)
+        yp, _ = eng.block_fwd(kind, x + eps * v, w, n, T, Tp, 0.3, 77)
+        ym, _ = eng.block_fwd(kind, x - eps * v, w, n, T, Tp, 0.3, 77)
+        num = float(((yp - ym).double() * dy.double()).sum() / (2 * eps))
+        ana = float((dxk.double() * v.double()).sum())
+        record(f"dropout.fd.{kind}.rel_dev", abs(num - ana) / max(1.0, abs(ana)))
+        assert abs(num - ana) <= 2e-2 * max(1.0, abs(ana)), (kind, num, ana)
