@@ -19,6 +19,7 @@ struct GcfnFusedArgs {
   const float* x; float* y; int M, T;
   const void* w1p; const void* w2p;
   const float* b2; const float* ls; float eps;
+  int stagger;
 };
 int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream);   // sepr_gcfn_fused.hip
 struct SpkFusedArgs {
@@ -146,7 +147,7 @@ extern "C" int sepr_gcfn_fwd(const float* x, float* y, int n, int T, int F, cons
     GcfnFusedArgs f;
     f.x = x; f.y = y; f.M = (int)M; f.T = T;
     f.w1p = w->fused_w1p; f.w2p = w->fused_w2p;
-    f.b2 = w->b2; f.ls = w->ls; f.eps = LN_EPS;
+    f.b2 = w->b2; f.ls = w->ls; f.eps = LN_EPS; f.stagger = 0;
     return launch_gcfn_fused(f, F, SEPR_SITE_GCFN_UP, st);
   }
   Arena ar(ws, ws_bytes);

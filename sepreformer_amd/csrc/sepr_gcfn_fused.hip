@@ -41,6 +41,7 @@ struct GcfnFusedArgs {
   const float* b2;    // [F]
   const float* ls;    // [F]
   float eps;
+  int stagger;        // s_sleep units (64 clocks each) by which every other co-resident workgroup starts late; 0 = off
 };
 
 __device__ __forceinline__ float dpp_ror1(float v) {   // lane i <- lane (i-1) mod 16 of its 16-lane row
@@ -157,6 +158,15 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     d[1] = p[64];
   };
 
+  // De-phase the two workgroups that share a CU: dispatched together they run their MFMA bursts (up- / down-projection)
+  // and their VALU phases (depthwise conv + GLU + bf16 split) in lockstep, so the matrix pipe idles while both are in VALU
+  // code and is contended while both multiply.  Every other co-resident workgroup (same parity rule as the projection
+  // core, sepr_gemm.h) starts a fraction of a chunk period late.
+  if (a.stagger > 0) {
+    const int ql = blockIdx.x >> 3;
+    if (((ql & 1) ^ ((ql >> 5) & 1)) != 0)
+      for (int i = 0; i < a.stagger; i += 100) __builtin_amdgcn_s_sleep(100);
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // chunk 0 of the weights is requested first: it lands under the frame loads and the LayerNorm below
     __syncthreads();   // the previous tile's epilogue staging is fully consumed
@@ -441,8 +451,14 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
 #endif
 [[maybe_unused]] constexpr int GF3_MT = SEPR_GF3_MT, GF3_NW = (SEPR_GF3_MT == 1) ? 6 : 4;
 
-int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream) {
-  if (a.M <= 0) return SEPR_OK;
+int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t stream) {
+  if (a_in.M <= 0) return SEPR_OK;
+  static const int stagger = [] {
+    const char* e = getenv("SEPR_GF_STAGGER");
+    return e && e[0] ? atoi(e) : 0;
+  }();
+  GcfnFusedArgs a = a_in;
+  a.stagger = stagger;
   if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || !a.ls || a.T <= 0) return SEPR_EINVAL;
   if (a.x == a.y) return SEPR_EINVAL;   // halo frames of a tile are outputs of its neighbours
   long long slot = -1;

@@ -37,9 +37,11 @@ inline TnPlan tn_plan(int M, int N, int K) {
   p.tn = (N + TN_T - 1) / TN_T;
   p.tk = (K + TN_T - 1) / TN_T;
   const int tiles = p.tn * p.tk;
-  int ns = 1024 / tiles;
+  // Row slices: enough workgroups to fill the chip (<= 512 co-resident), but every slice pays a partial tile of up to
+  // 64 KB written and re-read by the reduction, so a slice is at least 512 rows (its inputs: 512 x (N + K) x 4 B).
+  int ns = 512 / tiles;
   if (ns < 1) ns = 1;
-  const int max_by_rows = (M + 4 * TN_SLAB - 1) / (4 * TN_SLAB);   // at least 128 rows per slice
+  const int max_by_rows = (M + 511) / 512;
   if (ns > max_by_rows) ns = max_by_rows;
   if (ns < 1) ns = 1;
   int rps = (M + ns - 1) / ns;

@@ -233,7 +233,8 @@ def test_groupnorm_stats_entry():
 # ---------------------------------------------------------------------------------------------------
 E2E = [("tiny", "tiny"), ("tiny", "tiny_b1"), ("SepReformer_Base_WSJ0", "base_0p5s"),
        ("SepReformer_Base_WSJ0", "base_4s"), ("SepReformer_Base_WSJ0", "base_sample_wav"),
-       ("SepReformer_Large_DM_WHAMR", "large_whamr_0p5s"), ("SepReformer_Large_DM_WHAM", "large_wham_0p5s")]
+       ("SepReformer_Large_DM_WHAMR", "large_whamr_0p5s"), ("SepReformer_Large_DM_WHAM", "large_wham_0p5s"),
+       ("SepReformer_Large_DM_WHAMR", "large_whamr_4s")]
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -271,7 +272,7 @@ def _pit_gate(name, audio, ref_main, srcs, precision):
 # (golden tag, variant, source seed, amplitude factor applied to the mixture when the golden was made)
 PIT_GOLDENS = [("tiny", "tiny", 10, 4.0), ("tiny_b1", "tiny", 20, 4.0), ("base_0p5s", "SepReformer_Base_WSJ0", 30, 1.0),
                ("base_4s", "SepReformer_Base_WSJ0", 1234, 1.0), ("large_whamr_0p5s", "SepReformer_Large_DM_WHAMR", 40, 1.0),
-               ("large_wham_0p5s", "SepReformer_Large_DM_WHAM", 50, 1.0)]
+               ("large_wham_0p5s", "SepReformer_Large_DM_WHAM", 50, 1.0), ("large_whamr_4s", "SepReformer_Large_DM_WHAMR", 1234, 1.0)]
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

@@ -444,7 +444,7 @@ def test_criteria_backward(S, B, T):
 # ---------------------------------------------------------------------------------------------------------------------
 # the whole training step behind the reference's surface: model.train(); loss.backward()
 # ---------------------------------------------------------------------------------------------------------------------
-def _train_step(variant, precision, x, src, with_reference_loss=True):
+def _train_step(variant, precision, x, src, aux_loss=True):
     from sepreformer_amd.criterion import PIT_SISNR_mag, PIT_SISNR_time
     from sepreformer_amd.model import Model
     cfg = dataclasses.replace(VARIANTS[variant], dropout=0.0)
@@ -458,7 +458,10 @@ def _train_step(variant, precision, x, src, with_reference_loss=True):
     l_time = PIT_SISNR_time(dev, cfg.num_spks, True)(estims=audio, input_sizes=sizes, target_attr=srcd)
     crit_m = PIT_SISNR_mag(dev, 512, 128, "hann", cfg.num_stages, cfg.num_spks, True, False)
     l_mag = [crit_m(estims=a, idx=i, input_sizes=sizes, target_attr=srcd) for i, a in enumerate(aux)]
-    loss = ((1 - 0.4) * l_time + 0.4 * sum(l_mag) / len(l_mag)) / cfg.num_spks          # reference engine.py:73-74
+    if aux_loss:
+        loss = ((1 - 0.4) * l_time + 0.4 * sum(l_mag) / len(l_mag)) / cfg.num_spks      # reference engine.py:73-74
+    else:
+        loss = l_time / cfg.num_spks
     loss.backward()
     return cfg, m, audio, aux, loss, l_time, l_mag
 
@@ -517,24 +520,44 @@ def test_train_step_tiny_matches_reference(golden, precision):
     soft.done()
 
 
+@pytest.mark.parametrize("aux_loss", [True, False])
 @pytest.mark.parametrize("precision", PRECISIONS)
-def test_train_step_base_matches_oracle(precision):
-    """Base width (F = 128, 4 stages), 0.5 s, batch 2: loss and all 710 gradient tensors against the oracle."""
+def test_train_step_base_matches_oracle(precision, aux_loss):
+    """Base width (F = 128, 4 stages), 0.5 s, batch 2: loss and all 710 gradient tensors against the oracle.
+
+    Two losses.  ``aux_loss=False``: PIT_SISNR_time on the main outputs only - every op on that path is smooth, and every
+    gradient tensor must agree to >= 80 dB in both arithmetic modes.  ``aux_loss=True``: the reference's full training loss
+    (engine.py:66-74), whose auxiliary heads multiply by ReLU(.) (module.py:257-260, network.py:41).  A ReLU gate is
+    discontinuous in the forward activation: a forward deviation of relative size e flips a fraction ~e of the gates, and
+    each flipped gate changes its element's gradient by O(1), so two implementations whose forwards agree to e can only
+    agree to ~sqrt(e) on everything upstream of an auxiliary head - measured 84 dB in exact-f32 mode (e ~ 1e-7 between the
+    MFMA fmaf chain and aten's CPU summation order) and 50-65 dB in bf16x3 mode (e ~ 1e-5).  That is a property of the loss,
+    not of the backward kernels (every block's backward agrees to >= 97 dB on identical inputs, tests above), so the bar for
+    the full loss is 80 dB in f32 mode and 45 dB in bf16x3 mode, while the last decoder stage and the main head - downstream of
+    every auxiliary head - keep the 80 dB bar in both modes."""
     B, T = 2, 4000
     srcn = synth_sources(B, T, seed=31)
     src = [torch.from_numpy(srcn[:, s].copy()) for s in range(2)]
     x = src[0] + src[1]
-    cfg, m, audio, aux, loss, l_time, l_mag = _train_step("SepReformer_Base_WSJ0", precision, x, src)
+    cfg, m, audio, aux, loss, l_time, l_mag = _train_step("SepReformer_Base_WSJ0", precision, x, src, aux_loss)
     sdl = tor.leaf_state(synth_state_dict(cfg, 0))
     o_audio, o_aux = tor.model_forward_train(sdl, cfg, x)
-    o_loss, _, _ = tor.train_loss(o_audio, o_aux, src)
+    if aux_loss:
+        o_loss, _, _ = tor.train_loss(o_audio, o_aux, src)
+    else:
+        o_loss = co.pit_sisnr_time(o_audio, src)[0] / cfg.num_spks
     o_loss.backward()
-    soft = Soft(f"train_step.base.{precision}")
+    soft = Soft(f"train_step.base.{precision}.{'full' if aux_loss else 'main'}")
     soft.agree("main", torch.stack(list(audio), 0), torch.stack([a.detach() for a in o_audio], 0))
     assert abs(float(loss) - float(o_loss)) < 5e-3, (float(loss), float(o_loss))
-    gscale = max(float(v.grad.abs().max()) for v in sdl.values() if v.requires_grad)
+    gscale = max(float(v.grad.abs().max()) for v in sdl.values() if v.requires_grad and v.grad is not None)
+    relaxed = 45.0 if (aux_loss and precision == "bf16x3") else MIN_DB
     for k, p_ in m.named_parameters():
-        agree_grad(soft, "grad." + k, k, p_.grad, sdl[k].grad, gscale)
+        if sdl[k].grad is None:                       # auxiliary-head parameters under the main-only loss
+            assert p_.grad is None or float(p_.grad.abs().max()) == 0.0, k
+            continue
+        downstream = k.startswith(("separator.dec_stages.3.", "out_layer.", "audio_decoder."))
+        agree_grad(soft, "grad." + k, k, p_.grad, sdl[k].grad, gscale, MIN_DB if downstream else relaxed)
     soft.done()
 
 
