@@ -24,8 +24,10 @@ typedef __bf16 tn_bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 constexpr int TN_T = 128;          // tile edge (both n and k)
-constexpr int TN_SLAB = 32;        // rows per staging step
-constexpr int TN_LDM = 40;         // bf16 elements per LDS row of the x3 planes (32 rows + pad: 80 B)
+constexpr int TN_SLAB = 64;        // rows per staging step: 64 KB of operands in flight per workgroup (the launches are
+                                   // latency-bound: M / 512 slices of a few hundred rows each)
+constexpr int TN_NB = TN_SLAB / 32;
+constexpr int TN_LDM = TN_SLAB + 8;   // bf16 elements per LDS row of the x3 planes (64 rows + pad: 144 B, conflict-free 16-B reads)
 constexpr int TN_LDF = TN_T + 4;   // floats per LDS row of the f32 tiles
 constexpr int TN_THREADS = 256;
 
@@ -37,11 +39,11 @@ inline TnPlan tn_plan(int M, int N, int K) {
   p.tn = (N + TN_T - 1) / TN_T;
   p.tk = (K + TN_T - 1) / TN_T;
   const int tiles = p.tn * p.tk;
-  // Row slices: enough workgroups to fill the chip (<= 512 co-resident), but every slice pays a partial tile of up to
-  // 64 KB written and re-read by the reduction, so a slice is at least 512 rows (its inputs: 512 x (N + K) x 4 B).
+  // Row slices: enough workgroups to fill the chip (2 co-resident per CU = 512), but every slice pays a partial tile of
+  // up to 64 KB written and re-read by the reduction, so a slice is at least 256 rows (its inputs: 256 x (N + K) x 4 B).
   int ns = 512 / tiles;
   if (ns < 1) ns = 1;
-  const int max_by_rows = (M + 511) / 512;
+  const int max_by_rows = (M + 255) / 256;
   if (ns > max_by_rows) ns = max_by_rows;
   if (ns < 1) ns = 1;
   int rps = (M + ns - 1) / ns;
@@ -54,7 +56,7 @@ inline TnPlan tn_plan(int M, int N, int K) {
 template <bool X3>
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part,
                                                                float* __restrict__ cpart) {
-  // x3: [A_hi, A_lo, B_hi, B_lo][128][40] bf16 = 40 960 B;  f32: [A, B][32][132] fp32 = 33 792 B
+  // x3: [A_hi, A_lo, B_hi, B_lo][128][72] bf16 = 73 728 B;  f32: [A, B][64][132] fp32 = 67 584 B
   __shared__ __attribute__((aligned(16))) unsigned char smem[X3 ? 4 * TN_T * TN_LDM * 2 : 2 * TN_SLAB * TN_LDF * 4];
   __shared__ float csum_s[4][TN_T];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -71,13 +73,13 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
   const int cg = t7 & 31, mg = t7 >> 5;
   const int col = (roleA ? n0 : k0) + 4 * cg;
   const bool col_ok = col < (roleA ? a.N : a.K);
-  float4 r[8];
+  float4 r[8 * TN_NB];
   float4 csum = zero4();
 
   auto load_slab = [&](int mb) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int m = mb + 8 * mg + e;
+    for (int e = 0; e < 8 * TN_NB; ++e) {
+      const int m = mb + 32 * (e >> 3) + 8 * mg + (e & 7);
       r[e] = zero4();
       if (m < m_end && col_ok) {
         if (roleA) {
@@ -115,28 +117,31 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
 #pragma clang fp contract(off)
     if (roleA) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { csum.x += r[e].x; csum.y += r[e].y; csum.z += r[e].z; csum.w += r[e].w; }
+      for (int e = 0; e < 8 * TN_NB; ++e) { csum.x += r[e].x; csum.y += r[e].y; csum.z += r[e].z; csum.w += r[e].w; }
     }
     if (X3) {
       unsigned short* hi = reinterpret_cast<unsigned short*>(smem) + (roleA ? 0 : 2) * TN_T * TN_LDM;
       unsigned short* lo = hi + TN_T * TN_LDM;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        tn_bf16x8 h, l;
+      for (int nb = 0; nb < TN_NB; ++nb)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float v = j == 0 ? r[e].x : (j == 1 ? r[e].y : (j == 2 ? r[e].z : r[e].w));
-          const __bf16 vh = (__bf16)v;
-          h[e] = vh;
-          l[e] = (__bf16)(v - (float)vh);
+        for (int j = 0; j < 4; ++j) {
+          tn_bf16x8 h, l;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float4 q = r[8 * nb + e];
+            const float v = j == 0 ? q.x : (j == 1 ? q.y : (j == 2 ? q.z : q.w));
+            const __bf16 vh = (__bf16)v;
+            h[e] = vh;
+            l[e] = (__bf16)(v - (float)vh);
+          }
+          *reinterpret_cast<tn_bf16x8*>(hi + (4 * cg + j) * TN_LDM + 32 * nb + 8 * mg) = h;
+          *reinterpret_cast<tn_bf16x8*>(lo + (4 * cg + j) * TN_LDM + 32 * nb + 8 * mg) = l;
         }
-        *reinterpret_cast<tn_bf16x8*>(hi + (4 * cg + j) * TN_LDM + 8 * mg) = h;
-        *reinterpret_cast<tn_bf16x8*>(lo + (4 * cg + j) * TN_LDM + 8 * mg) = l;
-      }
     } else {
       float* dst = reinterpret_cast<float*>(smem) + (roleA ? 0 : 1) * TN_SLAB * TN_LDF;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) st4(dst + (8 * mg + e) * TN_LDF + 4 * cg, r[e]);
+      for (int e = 0; e < 8 * TN_NB; ++e) st4(dst + (32 * (e >> 3) + 8 * mg + (e & 7)) * TN_LDF + 4 * cg, r[e]);
     }
   };
 
@@ -157,24 +162,27 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
       const unsigned short* Alo = Ahi + TN_T * TN_LDM;
       const unsigned short* Bhi = Alo + TN_T * TN_LDM;
       const unsigned short* Blo = Bhi + TN_T * TN_LDM;
-      tn_bf16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int ra = (wm * 64 + t * 16 + fi) * TN_LDM + 8 * fg;
-        const int rb = (wn * 64 + t * 16 + fi) * TN_LDM + 8 * fg;
-        ah[t] = *reinterpret_cast<const tn_bf16x8*>(Ahi + ra);
-        al[t] = *reinterpret_cast<const tn_bf16x8*>(Alo + ra);
-        bh[t] = *reinterpret_cast<const tn_bf16x8*>(Bhi + rb);
-        bl[t] = *reinterpret_cast<const tn_bf16x8*>(Blo + rb);
-      }
+      for (int nb = 0; nb < TN_NB; ++nb) {
+        tn_bf16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-          acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh[kt], acc[nt][kt], 0, 0, 0);
-          acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl[kt], acc[nt][kt], 0, 0, 0);
-          acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh[kt], acc[nt][kt], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+          const int ra = (wm * 64 + t * 16 + fi) * TN_LDM + 32 * nb + 8 * fg;
+          const int rb = (wn * 64 + t * 16 + fi) * TN_LDM + 32 * nb + 8 * fg;
+          ah[t] = *reinterpret_cast<const tn_bf16x8*>(Ahi + ra);
+          al[t] = *reinterpret_cast<const tn_bf16x8*>(Alo + ra);
+          bh[t] = *reinterpret_cast<const tn_bf16x8*>(Bhi + rb);
+          bl[t] = *reinterpret_cast<const tn_bf16x8*>(Blo + rb);
         }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh[kt], acc[nt][kt], 0, 0, 0);
+            acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl[kt], acc[nt][kt], 0, 0, 0);
+            acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh[kt], acc[nt][kt], 0, 0, 0);
+          }
+      }
     } else {
       const float* As = reinterpret_cast<const float*>(smem);
       const float* Bs = As + TN_SLAB * TN_LDF;

@@ -141,6 +141,41 @@ int launch_glu_bwd(const float* dy, const float* a, float* da, long long M, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Pre-reduction of per-block partials: part [nblk][W] -> out [G][W], out[g] = sum of the rows of group g (contiguous row
+// ranges, fixed order).  The parameter-gradient reducers below then only walk G <= PR_GROUPS rows per output instead of
+// thousands (a thread per output looping over every row chunk of a 500 000-row launch was 5 % of a training step).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int PR_GROUPS = 32;
+__global__ __launch_bounds__(TPB) void prereduce_kernel(const float* __restrict__ part, int nblk, int W, int per_group,
+                                                       float* __restrict__ out) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const int g = blockIdx.y;
+  const int b0 = g * per_group, b1 = min(nblk, b0 + per_group);
+  float a = 0.f;
+  if (col < W)
+    for (int bk = b0 + rl; bk < b1; bk += 4) a += part[(long long)bk * W + col];
+  sh[rl][cl] = a;
+  __syncthreads();
+  if (rl == 0 && col < W) out[(long long)g * W + col] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+}
+// returns the number of rows the caller's reducer has to walk and the buffer holding them
+int prereduce(const float* part, int nblk, int W, float* scratch, const float** rows, hipStream_t s) {
+  if (nblk <= 2 * PR_GROUPS) {
+    *rows = part;
+    return nblk;
+  }
+  const int per_group = (nblk + PR_GROUPS - 1) / PR_GROUPS;
+  const int G = (nblk + per_group - 1) / per_group;
+  hipLaunchKernelGGL(prereduce_kernel, dim3((W + 63) / 64, G), dim3(TPB), 0, s, part, nblk, W, per_group, scratch);
+  *rows = scratch;
+  return G;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
 // GCFN middle backward: depthwise Conv1d(k=3, pad=1) + GLU (network.py:62-65).
 //   c[t] = b + w0 h[t-1] + w1 h[t] + w2 h[t+1] (zero padding per sequence), g = c_v * sigmoid(c_g)
 //   dc_v = dg sig(c_g), dc_g = dg c_v sig (1 - sig);  dh[t] = w0 dc[t+1] + w1 dc[t] + w2 dc[t-1];
@@ -232,7 +267,7 @@ __global__ __launch_bounds__(TPB) void gcfn_mid_reduce_kernel(const float* __res
 
 size_t gcfn_mid_bwd_ws(int n, int T, int C) {
   const int nchunk = (T + GM_TC - 1) / GM_TC;
-  return align_up((size_t)n * nchunk * C * 8 * sizeof(float));
+  return align_up((size_t)n * nchunk * C * 8 * sizeof(float)) + align_up((size_t)PR_GROUPS * C * 8 * sizeof(float));
 }
 int launch_gcfn_mid_bwd(const float* h1, const float* dg, float* dh1, int n, int T, int C, const float* dw_w, const float* dw_b,
                         float* dw_g, float* db_g, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -243,7 +278,10 @@ int launch_gcfn_mid_bwd(const float* h1, const float* dg, float* dh1, int n, int
   float* part = static_cast<float*>(ws);
   hipLaunchKernelGGL(gcfn_mid_bwd_kernel, dim3(n * nchunk, (C + TPB - 1) / TPB), dim3(TPB), 0, s, h1, dg, dh1, T, C, nchunk, dw_w,
                      dw_b, part);
-  hipLaunchKernelGGL(gcfn_mid_reduce_kernel, dim3((C * 8 + TPB - 1) / TPB), dim3(TPB), 0, s, part, n * nchunk, C, dw_g, db_g);
+  float* scratch = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)n * nchunk * C * 8 * sizeof(float)));
+  const float* rows = nullptr;
+  const int nrows = prereduce(part, n * nchunk, C * 8, scratch, &rows, s);
+  hipLaunchKernelGGL(gcfn_mid_reduce_kernel, dim3((C * 8 + TPB - 1) / TPB), dim3(TPB), 0, s, rows, nrows, C, dw_g, db_g);
   SEPR_CHECK_LAUNCH("gcfn_mid_bwd_kernel");
   return SEPR_OK;
 }
@@ -307,7 +345,7 @@ __global__ __launch_bounds__(TPB) void dwconv_wgrad_reduce_kernel(const float* _
 
 size_t dwconv_wgrad_ws(int n, int T, int C, int K) {
   const int nchunk = (T + WG_TC - 1) / WG_TC;
-  return align_up((size_t)n * nchunk * (K + 1) * C * sizeof(float));
+  return align_up((size_t)n * nchunk * (K + 1) * C * sizeof(float)) + align_up((size_t)PR_GROUPS * (K + 1) * C * sizeof(float));
 }
 int launch_dwconv_wgrad(const float* x, const float* dy, int n, int T, int C, int K, float* dw_g, float* db_g, void* ws,
                         size_t ws_bytes, hipStream_t s) {
@@ -318,8 +356,10 @@ int launch_dwconv_wgrad(const float* x, const float* dy, int n, int T, int C, in
   const size_t shm = (size_t)((WG_TC + K - 1) + WG_TC) * WG_CB * sizeof(float);
   float* part = static_cast<float*>(ws);
   hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(n * nchunk, (C + WG_CB - 1) / WG_CB), dim3(TPB), shm, s, x, dy, T, C, K, nchunk, part);
-  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3(((K + 1) * C + TPB - 1) / TPB), dim3(TPB), 0, s, part, n * nchunk, C, K, dw_g,
-                     db_g);
+  float* scratch = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)n * nchunk * (K + 1) * C * sizeof(float)));
+  const float* rows = nullptr;
+  const int nrows = prereduce(part, n * nchunk, (K + 1) * C, scratch, &rows, s);
+  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3(((K + 1) * C + TPB - 1) / TPB), dim3(TPB), 0, s, rows, nrows, C, K, dw_g, db_g);
   SEPR_CHECK_LAUNCH("dwconv_wgrad_kernel");
   return SEPR_OK;
 }
@@ -930,13 +970,14 @@ __global__ __launch_bounds__(TPB) void downconv_bwd_dx_kernel(const float* __res
     st4(dx + row * F + ch, acc);
   }
 }
-// weight / bias partials: block = 256 output frames of one sequence, thread = channel (looping), slots k = 0..K-1, K = bias
+// weight / bias partials: block = DC_TC output frames of one sequence, thread = channel (looping), slots k = 0..K-1, 16 = bias
+constexpr int DC_TC = 32;
 __global__ __launch_bounds__(TPB) void downconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dc, int T, int To,
                                                             int F, int K, int nchunk, float* __restrict__ part) {
   const int seq = blockIdx.x / nchunk, chunk = blockIdx.x - seq * nchunk;
   const int pad = (K - 1) / 2;
-  const int o0 = chunk * 256, o1 = min(To, o0 + 256);
-  for (int ch = threadIdx.x; ch < F; ch += TPB) {
+  const int o0 = chunk * DC_TC, o1 = min(To, o0 + DC_TC);
+  for (int ch = threadIdx.x; ch < F; ch += blockDim.x) {
     float acc[17];
 #pragma unroll
     for (int k = 0; k < 17; ++k) acc[k] = 0.f;
@@ -972,8 +1013,8 @@ __global__ __launch_bounds__(TPB) void downconv_wgrad_reduce_kernel(const float*
 size_t downconv_bwd_ws(int n, int T, int F, int K) {
   const int pad = (K - 1) / 2;
   const int To = (T + 2 * pad - K) / 2 + 1;
-  const int nchunk = (To + 255) / 256;
-  return align_up((size_t)n * nchunk * F * 17 * sizeof(float));
+  const int nchunk = (To + DC_TC - 1) / DC_TC;
+  return align_up((size_t)n * nchunk * F * 17 * sizeof(float)) + align_up((size_t)PR_GROUPS * F * 17 * sizeof(float));
 }
 int launch_downconv_pre(const float* x, float* c, int n, int T, int To, int F, int K, const float* w, const float* b, hipStream_t s) {
   if (n <= 0) return SEPR_OK;
@@ -990,10 +1031,13 @@ int launch_downconv_bwd(const float* x, const float* dc, float* dx, int n, int T
   if (!ws || ws_bytes < downconv_bwd_ws(n, T, F, K)) return SEPR_EWORKSPACE;
   const long long total4 = (long long)n * T * F / 4;
   hipLaunchKernelGGL(downconv_bwd_dx_kernel, dim3(grid_for(total4, TPB, 1 << 16)), dim3(TPB), 0, s, dc, dx, T, To, F, K, w, total4);
-  const int nchunk = (To + 255) / 256;
+  const int nchunk = (To + DC_TC - 1) / DC_TC;
   float* part = static_cast<float*>(ws);
-  hipLaunchKernelGGL(downconv_wgrad_kernel, dim3(n * nchunk), dim3(TPB), 0, s, x, dc, T, To, F, K, nchunk, part);
-  hipLaunchKernelGGL(downconv_wgrad_reduce_kernel, dim3((F * 17 + TPB - 1) / TPB), dim3(TPB), 0, s, part, n * nchunk, F, K, dw_g, db_g);
+  hipLaunchKernelGGL(downconv_wgrad_kernel, dim3(n * nchunk), dim3(F < TPB ? F : TPB), 0, s, x, dc, T, To, F, K, nchunk, part);
+  float* scratch = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)n * nchunk * F * 17 * sizeof(float)));
+  const float* rows = nullptr;
+  const int nrows = prereduce(part, n * nchunk, F * 17, scratch, &rows, s);
+  hipLaunchKernelGGL(downconv_wgrad_reduce_kernel, dim3((F * 17 + TPB - 1) / TPB), dim3(TPB), 0, s, rows, nrows, F, K, dw_g, db_g);
   SEPR_CHECK_LAUNCH("downconv_bwd kernels");
   return SEPR_OK;
 }
@@ -1230,19 +1274,28 @@ __global__ __launch_bounds__(TPB) void finish_norm_rows_kernel(const float* __re
   for (int k = threadIdx.x; k < K; k += TPB) dW_g[(long long)n * K + k] += fmaf(dWh[(long long)n * K + k], g[k], sn * b[k]);
   if (threadIdx.x == 0 && dbias_g) dbias_g[n] += sn;
 }
+// block = 64 input channels k x 4 row lanes: rows n = lane, lane + 4, ... are read as coalesced 256-byte segments
 __global__ __launch_bounds__(TPB) void finish_norm_cols_kernel(const float* __restrict__ dWh, const float* __restrict__ s,
                                                               const float* __restrict__ W, float* __restrict__ dg_g,
                                                               float* __restrict__ db_g, int N, int K) {
-  const int k = blockIdx.x * TPB + threadIdx.x;
-  if (k >= K) return;
+  __shared__ float sh[4][64][2];
+  const int kl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kl;
   float a = 0.f, c = 0.f;
-  for (int n = 0; n < N; ++n) {
-    const float w = W[(long long)n * K + k];
-    a = fmaf(w, dWh[(long long)n * K + k], a);
-    c = fmaf(s[n], w, c);
+  if (k < K) {
+    for (int n = rl; n < N; n += 4) {
+      const float w = W[(long long)n * K + k];
+      a = fmaf(w, dWh[(long long)n * K + k], a);
+      c = fmaf(s[n], w, c);
+    }
   }
-  dg_g[k] += a;
-  db_g[k] += c;
+  sh[rl][kl][0] = a;
+  sh[rl][kl][1] = c;
+  __syncthreads();
+  if (rl == 0 && k < K) {
+    dg_g[k] += (sh[0][kl][0] + sh[1][kl][0]) + (sh[2][kl][0] + sh[3][kl][0]);
+    db_g[k] += (sh[0][kl][1] + sh[1][kl][1]) + (sh[2][kl][1] + sh[3][kl][1]);
+  }
 }
 __global__ __launch_bounds__(64) void finish_ls_kernel(const float* __restrict__ Gr, const float* __restrict__ s, const float* __restrict__ W,
                                                       const float* __restrict__ bias, const float* __restrict__ ls, float* __restrict__ dW_g,
@@ -1266,7 +1319,7 @@ int launch_finish_norm_linear(const float* dWh, const float* s, const float* W, 
                               float* dbias_g, float* dg_g, float* db_g, int N, int K, hipStream_t st) {
   if (!dWh || !s || !W || !g || !b || !dW_g || !dg_g || !db_g || N <= 0 || K <= 0) return SEPR_EINVAL;
   hipLaunchKernelGGL(finish_norm_rows_kernel, dim3(N), dim3(TPB), 0, st, dWh, s, g, b, dW_g, dbias_g, N, K);
-  hipLaunchKernelGGL(finish_norm_cols_kernel, dim3((K + TPB - 1) / TPB), dim3(TPB), 0, st, dWh, s, W, dg_g, db_g, N, K);
+  hipLaunchKernelGGL(finish_norm_cols_kernel, dim3((K + 63) / 64), dim3(TPB), 0, st, dWh, s, W, dg_g, db_g, N, K);
   SEPR_CHECK_LAUNCH("finish_norm_linear kernels");
   return SEPR_OK;
 }

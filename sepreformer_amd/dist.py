@@ -104,21 +104,49 @@ class GradSync:
     The reference trains with single-process ``torch.nn.parallel.data_parallel`` (engine.py:64): every step it
     re-broadcasts all 14.7 M parameters and reduce-adds the replicas' gradients onto GPU 0.  Here every rank owns a full
     replica and its slice of the batch; the training backward leaves ALL parameter gradients in one flat fp32 buffer
-    (``train_pack.GradBuffer``, 58.8 MB for Base), so the exchange is a single RCCL all-reduce over xGMI (one large message
-    instead of 710 small ones; no per-step parameter broadcast) followed by the 1/world scale that turns the sum of
-    per-rank batch-mean losses into the global batch mean.  BatchNorm statistics stay per rank, like the reference's
-    per-replica statistics.  Install with ``model.grad_sync = GradSync()``.
+    (``train_pack.GradBuffer``, 58.8 MB for Base) laid out in parameter order, so the exchange is TWO large RCCL all-reduces
+    over xGMI instead of 710 small ones, and no per-step parameter broadcast:
+
+    * ``begin(flat, offset)`` - called by the backward as soon as the decoder half of the U-Net is done (its parameters,
+      ~60 % of the model, are the tail ``flat[offset:]`` of the buffer): an asynchronous all-reduce that runs on RCCL's
+      stream underneath the encoder half of the backward;
+    * ``__call__(flat)`` - at the end of the backward: all-reduce of the head ``flat[:offset]`` (encoder, shared tables),
+      wait for the first one, then the 1/world scale that turns the sum of per-rank batch-mean losses into the global
+      batch mean.
+
+    xGMI is point-to-point (7 links per GPU), so a ring all-reduce is per-link bound: two ~25-35 MB messages keep every
+    link busy with large transfers, whereas per-tensor reductions would be latency-bound.  BatchNorm statistics stay per
+    rank, like the reference's per-replica statistics.  Install with ``model.grad_sync = GradSync()``.
     """
 
-    def __init__(self, group=None):
-        self.group = group
+    def __init__(self, group=None, overlap: bool = True):
+        self.group, self.overlap = group, overlap
         self.calls = 0
         self.bytes = 0
+        self._pending = None
+
+    def _active(self) -> bool:
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def begin(self, flat: torch.Tensor, offset: int) -> None:
+        if not (self._active() and self.overlap) or offset <= 0 or offset >= flat.numel():
+            return
+        tail = flat[offset:]
+        self._pending = (dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True), offset)
+        self.bytes += tail.numel() * tail.element_size()
 
     def __call__(self, flat: torch.Tensor) -> None:
-        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
+        if not self._active():
             return
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self._pending is not None:
+            work, offset = self._pending
+            self._pending = None
+            head = flat[:offset]
+            dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group)
+            work.wait()
+            self.bytes += head.numel() * head.element_size()
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.bytes += flat.numel() * flat.element_size()
         flat.div_(dist.get_world_size(self.group))
         self.calls += 1
-        self.bytes += flat.numel() * flat.element_size()

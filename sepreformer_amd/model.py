@@ -83,8 +83,13 @@ class _SeparatorFn(torch.autograd.Function):
         if tape is None:
             raise RuntimeError("the HIP training path keeps one tape per forward: backward twice needs a second forward")
         with torch.cuda.device(eng.device):
-            eng.backward(tape, dims, d_wav, list(d_aux), tp, model.dropout_p)
             sync = model.grad_sync
+            early = None
+            if sync is not None and hasattr(sync, "begin"):
+                # parameter order puts the decoder half (fusion convs, decoder stages, heads) at the tail of the buffer
+                tail = gb.offsets["separator.simple_fusion.0.weight"][0]
+                early = lambda: sync.begin(gb.flat, tail)          # noqa: E731
+            eng.backward(tape, dims, d_wav, list(d_aux), tp, model.dropout_p, on_decoder_done=early)
             if sync is not None:
                 sync(gb.flat)
         grads = []

@@ -77,6 +77,7 @@ def main(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_host = time.perf_counter() - t0            # host-side enqueue time of the K steps (no synchronisation inside a step)
     torch.cuda.synchronize(dev)
     sdist.barrier()
     elapsed = time.perf_counter() - t0
@@ -103,6 +104,7 @@ def main(args):
                        "dropout_sites": "all the reference's sites: GCFN x2, CLA, attention probabilities + attention output (EGA and speaker attention)",
                        "optimizer": type(opt).__name__ + (" (fused)" if getattr(opt, "defaults", {}).get("fused") else ""),
                        "clip_norm": 5.0, "parallelism": f"data-parallel x{world}, flat-buffer RCCL all-reduce"},
+            "host_enqueue_ms_per_step": round(1e3 * t_host / max(args.steps, 1), 3),
             "loss": round(float(last["loss"]), 4), "grad_norm": round(float(last["gn"]), 4),
             "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
             "allreduce_bytes_per_step": (sync.bytes // max(sync.calls, 1)) if sync.calls else 0,

@@ -273,8 +273,11 @@ class TrainEngine:
         return wav, aux, tape, (B, T, L_, Lp, Tp)
 
     # ---- backward -----------------------------------------------------------------------------------------------------------
-    def backward(self, tape: list, dims, d_wav: Optional[torch.Tensor], d_aux: List[Optional[torch.Tensor]], tp: TrainPack, p_drop: float):
-        """Replays the tape in reverse.  ``d_wav`` ``[S,B,T']`` / ``d_aux[i]`` gradients of the outputs (``None`` = zero)."""
+    def backward(self, tape: list, dims, d_wav: Optional[torch.Tensor], d_aux: List[Optional[torch.Tensor]], tp: TrainPack, p_drop: float,
+                 on_decoder_done=None):
+        """Replays the tape in reverse.  ``d_wav`` ``[S,B,T']`` / ``d_aux[i]`` gradients of the outputs (``None`` = zero).
+        ``on_decoder_done()`` is called once the expanding half of the U-Net (decoder stages, fusion convs, heads) has been
+        back-propagated: from then on the tail of the gradient buffer is final (``dist.GradSync.begin``)."""
         c = self.cfg
         B, T, L_, Lp, Tp = dims
         S, F, N = c.num_spks, c.feat, c.enc_channels
@@ -311,6 +314,8 @@ class TrainEngine:
                 dcur, dskips[level] = self.fuse_bwd(lo, skip, w, dcur, nS, Ts)
             elif kind == "split":
                 _, xin, cx, w, Tc = rec
+                if on_decoder_done is not None:
+                    on_decoder_done()
                 dx = torch.empty_like(xin)
                 self.split_bwd(xin, cx, w, dcur, dx, False, B, Tc)
                 dcur = dx

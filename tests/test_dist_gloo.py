@@ -114,7 +114,9 @@ def _gradsync_worker(rank, world, port, out_dir):
     g = torch.Generator().manual_seed(100 + rank)
     gb.flat.copy_(torch.randn(gb.numel, generator=g))
     sync = sd.GradSync()
-    sync(gb.flat)
+    tail = gb.offsets["separator.simple_fusion.0.weight"][0]
+    sync.begin(gb.flat, tail)            # decoder half first (asynchronous), as the training backward does
+    sync(gb.flat)                        # then the head, the wait and the 1/world scale
     np.savez(os.path.join(out_dir, f"g{rank}.npz"), w=gb.view("separator.simple_fusion.0.weight").numpy(), calls=sync.calls, nbytes=sync.bytes,
              numel=gb.numel)
     torch.distributed.destroy_process_group()
