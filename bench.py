@@ -116,7 +116,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (default 32; 4 in train mode)")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (default 32; 8 in train mode)")
     ap.add_argument("--variant", default=DEFAULT_VARIANT, help="model variant (models/<variant>/configs.yaml)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer")
     ap.add_argument("--no-cpu-baseline", action="store_true")

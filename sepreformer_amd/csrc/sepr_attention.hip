@@ -181,10 +181,17 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& l) {
   }
 }
 
+// DK = 16 (Base): dk fills half of the K = 32 MFMA step, lane groups 2,3 carry zeros.  DK = 32 (Large): the step is full,
+// O^T has two 16-row tiles (two PV accumulators), the staging moves twice the K / V / band rows per thread.
+template <int DK>
 __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict__ QKV, float* __restrict__ O, int Tp, int F,
                                                         const float* __restrict__ pe, int maxlen, float inv_sqrt_dk) {
-  constexpr int DK = 16, QB = 64, KT = 64;
-  constexpr int KSB = 24;             // K / band row stride in bf16 (16 used + 8 pad: 48 B)
+  static_assert(DK == 16 || DK == 32, "head width");
+  constexpr int QB = 64, KT = 64;
+  constexpr int KSB = DK + 8;         // K / band row stride in bf16 (DK used + 8 pad; DK = 16: the pad is the zero half of K = 32)
+  constexpr int OT = DK / 16;         // 16-row tiles of O^T
+  constexpr int NU = KT * (DK / 4) / 256;                       // K / V float4 per thread per key tile
+  constexpr int NBU = (127 * (DK / 4) + 255) / 256;             // band float4 per thread
   constexpr int VSB = KT + 8;         // V^T row stride in bf16 (144 B)
   constexpr int NBAND = QB + KT - 1;
   constexpr int PSK = 52;             // skew scratch row stride in floats (48 used)
@@ -200,16 +207,16 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
   const float* base = QKV + (long long)seq * Tp * ld + h * DK;
   const int i = i0 + 16 * w + ii;
   const bool active = i < Tp;
-  const bool lowk = g < 2;            // lane groups 2,3 carry the zero half of the K = 32 fragments:
-  const int gk = g & 1;               // they read the (zeroed) 8-element pad at the end of every K / band row
-  const int go = 8 * (g < 2 ? g : 2);
+  const bool lowk = DK == 32 || g < 2;            // DK = 16: lane groups 2,3 carry the zero half of the K = 32 fragments:
+  const int gk = DK == 32 ? g : (g & 1);          // they read the (zeroed) 8-element pad at the end of every K / band row
+  const int go = DK == 32 ? 8 * g : 8 * (g < 2 ? g : 2);
   for (int r = tid; r < KT; r += 256) {
 #pragma unroll
-    for (int e = 16; e < KSB; ++e) Kh[r * KSB + e] = Kl[r * KSB + e] = (__bf16)0.f;
+    for (int e = DK; e < KSB; ++e) Kh[r * KSB + e] = Kl[r * KSB + e] = (__bf16)0.f;
   }
   for (int r = tid; r < NBAND; r += 256) {
 #pragma unroll
-    for (int e = 16; e < KSB; ++e) Bh[r * KSB + e] = Bl[r * KSB + e] = (__bf16)0.f;
+    for (int e = DK; e < KSB; ++e) Bh[r * KSB + e] = Bl[r * KSB + e] = (__bf16)0.f;
   }
 
   // B fragments of this lane's query (scaled), shared by the q.k and the q.band products
@@ -226,24 +233,29 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
       ql[e] = (__bf16)(v - (float)hh);
     }
   }
-  f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};       // O^T[d = 4g + r][query ii]
+  f32x4 o[OT];                                 // O^T[d = 16 t + 4g + r][query ii]
+#pragma unroll
+  for (int t = 0; t < OT; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float mrun = -1e30f, lrun = 0.f;
   float* const psk = Psk + (w * 16 + ii) * PSK;
 
-  // staging registers: one K and one V float4 per thread (64 keys x 16 d) and two band float4 (127 rows x 16 d)
-  const int sjj = tid / (DK / 4), sc4 = tid % (DK / 4);
-  float4 rk, rv, rb[2];
+  // staging registers: NU K and V float4 per thread (64 keys x DK) and NBU band float4 (127 rows x DK)
+  float4 rk[NU], rv[NU], rb[NBU];
   auto fetch = [&](int j0) {          // global -> registers for the key tile starting at j0
-    const int j = j0 + sjj;
-    rk = zero4();
-    rv = zero4();
-    if (j < Tp) {
-      const float* kp = base + (long long)j * ld + F + 4 * sc4;
-      rk = ld4(kp);
-      rv = ld4(kp + F);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int idx = tid + 256 * u;
+      const int j = j0 + idx / (DK / 4), sc4 = idx % (DK / 4);
+      rk[u] = zero4();
+      rv[u] = zero4();
+      if (j < Tp) {
+        const float* kp = base + (long long)j * ld + F + 4 * sc4;
+        rk[u] = ld4(kp);
+        rv[u] = ld4(kp + F);
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NBU; ++u) {
       const int idx = tid + 256 * u;
       const int rr = idx / (DK / 4) < NBAND ? idx / (DK / 4) : NBAND - 1;
       int rel = i0 - j0 - (KT - 1) + rr;                      // i - j for band row rr
@@ -257,17 +269,22 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
     // ---- registers -> LDS: K rows, V transposed and the band of the position table as bf16 hi / lo planes ----------
     {
       bf16x4 hh, ll;
-      split4(rk, hh, ll);
-      *reinterpret_cast<bf16x4*>(Kh + sjj * KSB + 4 * sc4) = hh;
-      *reinterpret_cast<bf16x4*>(Kl + sjj * KSB + 4 * sc4) = ll;
-      split4(rv, hh, ll);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Vh[(4 * sc4 + e) * VSB + sjj] = hh[e];
-        Vl[(4 * sc4 + e) * VSB + sjj] = ll[e];
+      for (int u = 0; u < NU; ++u) {
+        const int idx = tid + 256 * u;
+        const int sjj = idx / (DK / 4), sc4 = idx % (DK / 4);
+        split4(rk[u], hh, ll);
+        *reinterpret_cast<bf16x4*>(Kh + sjj * KSB + 4 * sc4) = hh;
+        *reinterpret_cast<bf16x4*>(Kl + sjj * KSB + 4 * sc4) = ll;
+        split4(rv[u], hh, ll);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          Vh[(4 * sc4 + e) * VSB + sjj] = hh[e];
+          Vl[(4 * sc4 + e) * VSB + sjj] = ll[e];
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < NBU; ++u) {
         const int idx = tid + 256 * u;
         if (idx < NBAND * (DK / 4)) {
           split4(rb[u], hh, ll);
@@ -340,17 +357,18 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
       lrun = lrun * corr + psum;
       mrun = mnew;
       // ---- O^T[d][query] += V^T[d][key slots] . P[key slots][query]; slot e -> key 16 (e / 4) + 4g + e % 4 --------
-      o[0] *= corr; o[1] *= corr; o[2] *= corr; o[3] *= corr;
-      {
-        const __bf16* vh0 = Vh + ii * VSB + 32 * p + 4 * g;
-        const __bf16* vl0 = Vl + ii * VSB + 32 * p + 4 * g;
+#pragma unroll
+      for (int t = 0; t < OT; ++t) {
+        o[t][0] *= corr; o[t][1] *= corr; o[t][2] *= corr; o[t][3] *= corr;
+        const __bf16* vh0 = Vh + (16 * t + ii) * VSB + 32 * p + 4 * g;
+        const __bf16* vl0 = Vl + (16 * t + ii) * VSB + 32 * p + 4 * g;
         const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(vh0), a1 = *reinterpret_cast<const bf16x4*>(vh0 + 16);
         const bf16x4 b0v = *reinterpret_cast<const bf16x4*>(vl0), b1v = *reinterpret_cast<const bf16x4*>(vl0 + 16);
         const bf16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         const bf16x8 vl = {b0v[0], b0v[1], b0v[2], b0v[3], b1v[0], b1v[1], b1v[2], b1v[3]};
-        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o, 0, 0, 0);
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[t], 0, 0, 0);
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[t], 0, 0, 0);
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[t], 0, 0, 0);
       }
     }
   }
@@ -358,7 +376,10 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
   ltot += __shfl_xor(ltot, 32, 64);
   if (active) {
     const float inv = 1.0f / ltot;
-    st4(O + ((long long)seq * Tp + i) * F + h * DK + 4 * g, make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv));
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+      st4(O + ((long long)seq * Tp + i) * F + h * DK + 16 * t + 4 * g,
+          make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv));
   }
 }
 
@@ -370,7 +391,9 @@ int launch_relattn(const float* QKV, float* O, int n, int Tp, int F, int H, cons
   const dim3 grid((Tp + 63) / 64, H, n);
   const float isd = 1.0f / sqrtf((float)dk);
   if (dk == 16 && x3) {
-    hipLaunchKernelGGL(relattn_x3_kernel, grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd);
+    hipLaunchKernelGGL((relattn_x3_kernel<16>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd);
+  } else if (dk == 32 && x3) {
+    hipLaunchKernelGGL((relattn_x3_kernel<32>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd);
   } else if (dk == 16) {
     hipLaunchKernelGGL((relattn_kernel<16>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd);
   } else if (dk == 32) {

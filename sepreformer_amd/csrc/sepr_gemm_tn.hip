@@ -229,23 +229,33 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
   }
 }
 
+// block = 64 output elements x 4 lanes over the slices (fixed order inside a lane, lanes combined in a fixed order)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart, int nsplit,
                                                        int N, int K, float* __restrict__ G, int ldg, int accumulate,
                                                        float* __restrict__ colsum, int colsum_acc) {
+  __shared__ float sh[4][64];
   const long long total = (long long)N * K;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total + N; i += (long long)gridDim.x * 256) {
-    if (i < total) {
-      float s = 0.f;
-      for (int sp = 0; sp < nsplit; ++sp) s += part[(long long)sp * total + i];
-      const int n = (int)(i / K), k = (int)(i - (long long)n * K);
-      float* g = G + (long long)n * ldg + k;
-      *g = accumulate ? *g + s : s;
-    } else if (colsum) {
-      const int n = (int)(i - total);
-      float s = 0.f;
-      for (int sp = 0; sp < nsplit; ++sp) s += cpart[(long long)sp * N + n];
-      colsum[n] = colsum_acc ? colsum[n] + s : s;
-    }
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + el;
+  float s = 0.f;
+  if (i < total) {
+#pragma unroll 4
+    for (int sp = sl; sp < nsplit; sp += 4) s += part[(long long)sp * total + i];
+  } else if (i < total + N && colsum) {
+#pragma unroll 4
+    for (int sp = sl; sp < nsplit; sp += 4) s += cpart[(long long)sp * N + (i - total)];
+  }
+  sh[sl][el] = s;
+  __syncthreads();
+  if (sl != 0) return;
+  s = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
+  if (i < total) {
+    const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+    float* g = G + (long long)n * ldg + k;
+    *g = accumulate ? *g + s : s;
+  } else if (i < total + N && colsum) {
+    const int n = (int)(i - total);
+    colsum[n] = colsum_acc ? colsum[n] + s : s;
   }
 }
 }  // namespace
@@ -274,7 +284,7 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
     hipLaunchKernelGGL((gemm_tn_kernel<false>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
   if (timed) prof_end(slot, 2.0 * (double)a.M * (double)a.N * (double)a.K, s);
   const long long total = (long long)a.N * a.K + a.N;
-  const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  const int rgrid = (int)((total + 63) / 64);
   hipLaunchKernelGGL(tn_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
                      a.colsum, a.colsum_accumulate);
   SEPR_CHECK_LAUNCH("gemm_tn_kernel");

@@ -287,12 +287,14 @@ __global__ __launch_bounds__(AT_THREADS) void relattn_bwd_cols_kernel(const floa
   }
 }
 
-// ---- band partials -> dpe (one thread per (table row r, channel)) ------------------------------------------------------
+// ---- band partials -> dpe: block = 64 (table row r, channel) pairs x 4 lanes over the query tiles --------------------------
 __global__ __launch_bounds__(AT_THREADS) void relattn_band_reduce_kernel(const float* __restrict__ band, int ngroups, int ntiles, int Tp,
                                                                         int DK, int maxlen, float* __restrict__ dpe) {
-  const int e = blockIdx.x * AT_THREADS + threadIdx.x;
-  if (e >= 2 * maxlen * DK) return;
-  const int r = e / DK, d = e - r * DK;
+  __shared__ float sh[4][64];
+  const int el = threadIdx.x & 63, tl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const bool live = e < 2 * maxlen * DK;
+  const int r = live ? e / DK : 0, d = live ? e - r * DK : 0;
   const int nslot = Tp + AT_QT - 1;
   // relative offsets delta = i - j in [-(Tp-1), Tp-1] that map to table row r
   int dlo = r - maxlen, dhi = r - maxlen;
@@ -301,14 +303,19 @@ __global__ __launch_bounds__(AT_THREADS) void relattn_band_reduce_kernel(const f
   if (dlo < -(Tp - 1)) dlo = -(Tp - 1);
   if (dhi > Tp - 1) dhi = Tp - 1;
   float s = 0.f;
-  for (int delta = dlo; delta <= dhi; ++delta) {
-    for (int t = 0; t < ntiles; ++t) {
-      const int slot = delta - (t * AT_QT - Tp + 1);
-      if (slot < 0 || slot >= nslot) continue;
-      for (int g = 0; g < ngroups; ++g) s += band[(((long long)g * ntiles + t) * nslot + slot) * DK + d];
+  if (live) {
+    for (int delta = dlo; delta <= dhi; ++delta) {
+      for (int t = tl; t < ntiles; t += 4) {
+        const int slot = delta - (t * AT_QT - Tp + 1);
+        if (slot < 0 || slot >= nslot) continue;
+#pragma unroll 4
+        for (int g = 0; g < ngroups; ++g) s += band[(((long long)g * ntiles + t) * nslot + slot) * DK + d];
+      }
     }
   }
-  if (dlo <= dhi) dpe[e] += s;
+  sh[tl][el] = s;
+  __syncthreads();
+  if (tl == 0 && live && dlo <= dhi) dpe[e] += (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
 }
 
 size_t fwd_shm(int Tp, int DK) { return (size_t)(AT_QT * Tp + AT_QT * DK + (AT_THREADS / ((DK / 4) * AT_QT)) * AT_QT * DK) * sizeof(float); }
@@ -383,7 +390,7 @@ int launch_relattn_bwd(const float* QKV, const float* P, const float* O, const f
                        dscale, seed, offset);
   }
 #undef SEPR_ROWS
-  hipLaunchKernelGGL(relattn_band_reduce_kernel, dim3((2 * maxlen * DK + AT_THREADS - 1) / AT_THREADS), dim3(AT_THREADS), 0, s, band,
+  hipLaunchKernelGGL(relattn_band_reduce_kernel, dim3((2 * maxlen * DK + 63) / 64), dim3(AT_THREADS), 0, s, band,
                      ngroups, ntiles, Tp, DK, maxlen, dpe_g);
   SEPR_CHECK_LAUNCH("relattn_bwd kernels");
   return SEPR_OK;

@@ -1274,16 +1274,17 @@ __global__ __launch_bounds__(TPB) void finish_norm_rows_kernel(const float* __re
   for (int k = threadIdx.x; k < K; k += TPB) dW_g[(long long)n * K + k] += fmaf(dWh[(long long)n * K + k], g[k], sn * b[k]);
   if (threadIdx.x == 0 && dbias_g) dbias_g[n] += sn;
 }
-// block = 64 input channels k x 4 row lanes: rows n = lane, lane + 4, ... are read as coalesced 256-byte segments
-__global__ __launch_bounds__(TPB) void finish_norm_cols_kernel(const float* __restrict__ dWh, const float* __restrict__ s,
-                                                              const float* __restrict__ W, float* __restrict__ dg_g,
-                                                              float* __restrict__ db_g, int N, int K) {
-  __shared__ float sh[4][64][2];
+// block = 64 input channels k x 16 row lanes: rows n = lane, lane + 16, ... are read as coalesced 256-byte segments
+__global__ __launch_bounds__(1024) void finish_norm_cols_kernel(const float* __restrict__ dWh, const float* __restrict__ s,
+                                                               const float* __restrict__ W, float* __restrict__ dg_g,
+                                                               float* __restrict__ db_g, int N, int K) {
+  __shared__ float sh[16][64][2];
   const int kl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + kl;
   float a = 0.f, c = 0.f;
   if (k < K) {
-    for (int n = rl; n < N; n += 4) {
+#pragma unroll 4
+    for (int n = rl; n < N; n += 16) {
       const float w = W[(long long)n * K + k];
       a = fmaf(w, dWh[(long long)n * K + k], a);
       c = fmaf(s[n], w, c);
@@ -1293,8 +1294,11 @@ __global__ __launch_bounds__(TPB) void finish_norm_cols_kernel(const float* __re
   sh[rl][kl][1] = c;
   __syncthreads();
   if (rl == 0 && k < K) {
-    dg_g[k] += (sh[0][kl][0] + sh[1][kl][0]) + (sh[2][kl][0] + sh[3][kl][0]);
-    db_g[k] += (sh[0][kl][1] + sh[1][kl][1]) + (sh[2][kl][1] + sh[3][kl][1]);
+    float ta = 0.f, tc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ta += sh[r][kl][0]; tc += sh[r][kl][1]; }
+    dg_g[k] += ta;
+    db_g[k] += tc;
   }
 }
 __global__ __launch_bounds__(64) void finish_ls_kernel(const float* __restrict__ Gr, const float* __restrict__ s, const float* __restrict__ W,
@@ -1319,7 +1323,7 @@ int launch_finish_norm_linear(const float* dWh, const float* s, const float* W, 
                               float* dbias_g, float* dg_g, float* db_g, int N, int K, hipStream_t st) {
   if (!dWh || !s || !W || !g || !b || !dW_g || !dg_g || !db_g || N <= 0 || K <= 0) return SEPR_EINVAL;
   hipLaunchKernelGGL(finish_norm_rows_kernel, dim3(N), dim3(TPB), 0, st, dWh, s, g, b, dW_g, dbias_g, N, K);
-  hipLaunchKernelGGL(finish_norm_cols_kernel, dim3((K + 63) / 64), dim3(TPB), 0, st, dWh, s, W, dg_g, db_g, N, K);
+  hipLaunchKernelGGL(finish_norm_cols_kernel, dim3((K + 63) / 64), dim3(1024), 0, st, dWh, s, W, dg_g, db_g, N, K);
   SEPR_CHECK_LAUNCH("finish_norm_linear kernels");
   return SEPR_OK;
 }

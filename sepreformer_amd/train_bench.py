@@ -42,7 +42,7 @@ def main(args):
     model.train()
     sync = sdist.GradSync()
     model.grad_sync = sync
-    B = args.batch or 4
+    B = args.batch or 8
     samples = 32000
     src = torch.from_numpy(synth_sources(B, samples, seed=4321 + rank * B)).to(dev)
     x = src.sum(1).contiguous()

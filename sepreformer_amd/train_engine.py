@@ -37,6 +37,7 @@ class TrainEngine:
         self.lib = L.load()
         self._ws: Optional[torch.Tensor] = None
         self._idx: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._sizes: Dict[tuple, int] = {}      # sepr_train_ctx_bytes / sepr_train_ws_bytes per (kind, op, shape): one C call each, ever
 
     # ---- plumbing -------------------------------------------------------------------------------------------------------
     def _workspace(self, nbytes: int):
@@ -50,12 +51,19 @@ class TrainEngine:
 
     def _ctx(self, op, n, T, Tp=0, H=0):
         c = self.cfg
-        nb = self.lib.sepr_train_ctx_bytes(op, n, T, Tp, c.feat, c.enc_channels, c.num_spks, H or c.heads)
-        return torch.empty(int(nb), dtype=torch.uint8, device=self.device)
+        key = ("c", op, n, T, Tp)
+        nb = self._sizes.get(key)
+        if nb is None:
+            nb = self._sizes[key] = int(self.lib.sepr_train_ctx_bytes(op, n, T, Tp, c.feat, c.enc_channels, c.num_spks, H or c.heads))
+        return torch.empty(nb, dtype=torch.uint8, device=self.device)
 
     def _wsfor(self, op, n, T, Tp=0, K=0):
         c = self.cfg
-        return self._workspace(self.lib.sepr_train_ws_bytes(op, n, T, Tp, c.feat, c.enc_channels, c.num_spks, c.heads, K))
+        key = ("w", op, n, T, Tp, K)
+        nb = self._sizes.get(key)
+        if nb is None:
+            nb = self._sizes[key] = int(self.lib.sepr_train_ws_bytes(op, n, T, Tp, c.feat, c.enc_channels, c.num_spks, c.heads, K))
+        return self._workspace(nb)
 
     def _index(self, src: int, dst: int):
         key = (src, dst)
