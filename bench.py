@@ -222,8 +222,9 @@ def main():
         import numpy as np
         from oracle.sepreformer_oracle import agreement_db, pit_si_snr_db
         g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_base_4s.npz"))
-        out = step()          # (after the timed region: the host-side gate arithmetic idles the GPU for ~0.5 s, which
-                              #  would otherwise put the first timed steps on ramping clocks)
+        # (after the timed region: the host-side gate arithmetic idles the GPU for ~0.5 s, which would otherwise put the first
+        #  timed steps on ramping clocks.  model(x), NOT step(): step() contains the all-reduce and only rank 0 is here)
+        out = model(x)
         main_out = torch.stack([a[0:1] for a in out[0]], 0).cpu()
         parity_db = round(agreement_db(main_out, torch.from_numpy(g["main"])), 1)
         gate = os.path.join(ROOT, "tests", "golden", "pit_gate_base_b32.npz")

@@ -75,8 +75,10 @@ int launch_glu_fwd(const float* a, float* y, long long M, int H, hipStream_t s);
 int launch_glu_bwd(const float* dy, const float* a, float* da, long long M, int H, hipStream_t s);
 // GCFN middle backward: h1 [n,T,2C] (pre-conv hidden: C value channels then C gate channels), dg [n,T,C] ->
 // dh1 [n,T,2C]; depthwise k=3 weight / bias gradients accumulated into dw_g [2C][3] (parameter layout) and db_g [2C].
+// (p > 0: dg is the gradient w.r.t. the DROPPED gated tensor; the mask of generator index offset + element is applied on load)
 int launch_gcfn_mid_bwd(const float* h1, const float* dg, float* dh1, int n, int T, int C, const float* dw_w, const float* dw_b,
-                        float* dw_g, float* db_g, void* ws, size_t ws_bytes, hipStream_t s);
+                        float* dw_g, float* db_g, float p, unsigned long long seed, unsigned long long offset, void* ws, size_t ws_bytes,
+                        hipStream_t s);
 size_t gcfn_mid_bwd_ws(int n, int T, int C);
 // depthwise conv weight gradient, stride 1, 'same' zero padding: dw[c][k] += sum_{seq,t} dy[t][c] * x[t + k - K/2][c];
 // db[c] += sum dy.  x, dy [n,T,C]; dw in parameter layout [C][K]
@@ -104,8 +106,6 @@ int launch_spkmix_train_fwd(const float* QKV, float* O, int B, int S, int T, int
                             unsigned long long offset, hipStream_t s);
 int launch_spkmix_bwd(const float* QKV, const float* dO, float* dQKV, int B, int S, int T, int F, int H, float p, unsigned long long seed,
                       unsigned long long offset, hipStream_t s);
-// y[m][f] = ls[f] * v[m][f]
-int launch_scale_cols(const float* v, const float* ls, float* y, long long M, int F, hipStream_t s);
 // fusion conv backward glue: dcat [n,T,2F] -> dlo [n,T/2,F] (sum of the two frames that read it), dskip [n,T,F];
 // acc_* != 0: add into the destination
 int launch_unfuse(const float* dcat, float* dlo, float* dskip, int n, int T, int F, hipStream_t s);
@@ -124,8 +124,9 @@ int launch_downconv_bwd(const float* x, const float* dc, float* dx, int n, int T
 size_t downconv_bwd_ws(int n, int T, int F, int K);
 // y (+)= a   (gradient accumulation where two consumers read one tensor)
 int launch_add_inplace(float* y, const float* a, long long count, hipStream_t s);
-// y = x + ls[f] * v  /  plain scaled copies used by the dropout-enabled paths
-int launch_res_ls(const float* x, const float* v, const float* ls, float* y, long long M, int F, hipStream_t s);
+// y = (x ? x : 0) + ls[f] * dropout(v)   (p = 0: no dropout): residual + LayerScale tail of the dropout-enabled paths
+int launch_res_ls(const float* x, const float* v, const float* ls, float* y, long long M, int F, float p, unsigned long long seed,
+                  unsigned long long offset, hipStream_t s);
 // inverted dropout with a counter-based generator: y[i] = keep(seed, offset + i) ? x[i] / (1 - p) : 0 (in place allowed)
 int launch_dropout(const float* x, float* y, long long count, float p, unsigned long long seed, unsigned long long offset,
                    hipStream_t s);

@@ -95,8 +95,7 @@ int gcfn_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* 
   if (p > 0.f) {
     SEPR_TRY(launch_dropout(k.g, k.g, 3LL * F * M, p, seed, site_off(0), st));                 // net2[1]
     SEPR_TRY(plain(k.g, 3 * F, out, F, M, F, 3 * F, w->down, nullptr, st));                    // net2[2]
-    SEPR_TRY(launch_dropout(out, out, (long long)F * M, p, seed, site_off(1), st));            // net2[3]
-    SEPR_TRY(launch_res_ls(x, out, w->ls, y, M, F, st));                                       // :66
+    SEPR_TRY(launch_res_ls(x, out, w->ls, y, M, F, p, seed, site_off(1), st));                 // net2[3] dropout, :66
   } else {
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = F; a.K = 3 * F;
@@ -134,9 +133,8 @@ int gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, co
   SEPR_TRY(wgrad(dyq, F, k.g, 3 * F, nullptr, Gr, s2, M, F, 3 * F, 0, x3, tnw, tnb, st));
   SEPR_TRY(launch_finish_linear_ls(Gr, s2, w->w2, w->b2, w->ls, g->w2, g->b2, g->ls, F, 3 * F, st));
   SEPR_TRY(plain(dyq, F, dg, 3 * F, M, 3 * F, F, w->down_t, nullptr, st));
-  if (p > 0.f) SEPR_TRY(launch_dropout(dg, dg, 3LL * F * M, p, seed, site_off(0), st));
-  // GLU + depthwise conv
-  SEPR_TRY(launch_gcfn_mid_bwd(k.h1, dg, dh1, n, T, 3 * F, w->dw_w, w->dw_b, g->dw_w, g->dw_b, midw, midb, st));
+  // GLU + depthwise conv (the dropout mask of the gated tensor is applied while dg is read)
+  SEPR_TRY(launch_gcfn_mid_bwd(k.h1, dg, dh1, n, T, 3 * F, w->dw_w, w->dw_b, g->dw_w, g->dw_b, p, seed, site_off(0), midw, midb, st));
   // net1: LayerNorm-folded projection
   SEPR_TRY(wgrad(dh1, 6 * F, x, F, k.stats, dWh, s1, M, 6 * F, F, 0, x3, tnw, tnb, st));
   SEPR_TRY(launch_finish_norm_linear(dWh, s1, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 6 * F, F, st));
@@ -178,8 +176,7 @@ int cla_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_cla
   SEPR_TRY(launch_bn_gelu_fwd(k.z, k.bn, w->bn_g, w->bn_b, k.d, M, 2 * F, st));               // :183,185 (GELU)
   if (p > 0.f) {
     SEPR_TRY(plain(k.d, 2 * F, out, F, M, F, 2 * F, w->l3, nullptr, st));
-    SEPR_TRY(launch_dropout(out, out, (long long)F * M, p, seed, site_off(0), st));           // linear3[2]
-    SEPR_TRY(launch_res_ls(x, out, w->ls, y, M, F, st));
+    SEPR_TRY(launch_res_ls(x, out, w->ls, y, M, F, p, seed, site_off(0), st));                // linear3[2] dropout, :187
   } else {
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = F; a.K = 2 * F;
@@ -286,8 +283,7 @@ int ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const 
   SEPR_TRY(launch_relattn_train_fwd(k.qkv, k.o, k.P, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), st));   // :106-122
   if (p > 0.f) {
     SEPR_TRY(plain(k.o, F, tmp, F, Mp, F, F, w->attn.out, nullptr, st));                        // :124 linear_out
-    SEPR_TRY(launch_dropout(tmp, tmp, (long long)F * Mp, p, seed, site_off(1), st));            //      dropout
-    SEPR_TRY(launch_scale_cols(tmp, w->attn.ls, k.att, Mp, F, st));                             //      LayerScale
+    SEPR_TRY(launch_res_ls(nullptr, tmp, w->attn.ls, k.att, Mp, F, p, seed, site_off(1), st)); //      dropout, LayerScale
   } else {
     GemmArgs a = gemm_args_zero();
     a.M = (int)Mp; a.N = F; a.K = F;
@@ -363,8 +359,7 @@ int spk_fwd(const float* x, float* y, int nS, int S, int T, int F, int H, const 
   if (p > 0.f) {
     SEPR_TRY(launch_spkmix_train_fwd(k.qkv, k.o, nS / S, S, T, F, H, p, seed, site_off(0), st));
     SEPR_TRY(plain(k.o, F, out, F, M, F, F, w->out, nullptr, st));
-    SEPR_TRY(launch_dropout(out, out, (long long)F * M, p, seed, site_off(1), st));
-    return launch_res_ls(x, out, w->ls, y, M, F, st);
+    return launch_res_ls(x, out, w->ls, y, M, F, p, seed, site_off(1), st);
   }
   SEPR_TRY(launch_spkmix(k.qkv, k.o, nS / S, S, T, F, H, st));
   GemmArgs a = gemm_args_zero();

@@ -189,7 +189,9 @@ constexpr int GM_TC = 64;   // frames per block
 __global__ __launch_bounds__(TPB) void gcfn_mid_bwd_kernel(const float* __restrict__ h1, const float* __restrict__ dg,
                                                           float* __restrict__ dh1, int T, int C, int nchunk,
                                                           const float* __restrict__ w /*[3][2C] tap-major*/,
-                                                          const float* __restrict__ b /*[2C]*/, float* __restrict__ part) {
+                                                          const float* __restrict__ b /*[2C]*/, float* __restrict__ part,
+                                                          unsigned int thr, float dscale, unsigned long long seed,
+                                                          unsigned long long offset) {
   const int c = blockIdx.y * TPB + threadIdx.x;
   if (c >= C) return;
   const int seq = blockIdx.x / nchunk, chunk = blockIdx.x - seq * nchunk;
@@ -217,7 +219,9 @@ __global__ __launch_bounds__(TPB) void gcfn_mid_bwd_kernel(const float* __restri
       const float cv = fmaf(wv2, hv_p, fmaf(wv1, hv_c, fmaf(wv0, hv_m, bv)));
       const float cgt = fmaf(wg2, hg_p, fmaf(wg1, hg_c, fmaf(wg0, hg_m, bg)));
       const float sg = sigmoid_exact(cgt);
-      const float d = ds[(long long)tp * C + c];
+      float d = ds[(long long)tp * C + c];
+      if (thr)   // the forward's dropout on the gated tensor (network.py:55): same generator index = element of [M][C]
+        d = sepr_keep(seed, offset + (unsigned long long)(((long long)seq * T + tp) * C + c), thr) ? d * dscale : 0.f;
       dcv = d * sg;
       dcg = d * cv * sg * (1.f - sg);
       if (own) {
@@ -270,14 +274,15 @@ size_t gcfn_mid_bwd_ws(int n, int T, int C) {
   return align_up((size_t)n * nchunk * C * 8 * sizeof(float)) + align_up((size_t)PR_GROUPS * C * 8 * sizeof(float));
 }
 int launch_gcfn_mid_bwd(const float* h1, const float* dg, float* dh1, int n, int T, int C, const float* dw_w, const float* dw_b,
-                        float* dw_g, float* db_g, void* ws, size_t ws_bytes, hipStream_t s) {
+                        float* dw_g, float* db_g, float p, unsigned long long seed, unsigned long long offset, void* ws, size_t ws_bytes,
+                        hipStream_t s) {
   if (n <= 0 || T <= 0) return SEPR_OK;
   if (!h1 || !dg || !dh1 || !dw_w || !dw_b || !dw_g || !db_g || C <= 0) return SEPR_EINVAL;
   if (!ws || ws_bytes < gcfn_mid_bwd_ws(n, T, C)) return SEPR_EWORKSPACE;
   const int nchunk = (T + GM_TC - 1) / GM_TC;
   float* part = static_cast<float*>(ws);
   hipLaunchKernelGGL(gcfn_mid_bwd_kernel, dim3(n * nchunk, (C + TPB - 1) / TPB), dim3(TPB), 0, s, h1, dg, dh1, T, C, nchunk, dw_w,
-                     dw_b, part);
+                     dw_b, part, p > 0.f ? sepr_drop_threshold(p) : 0u, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, seed, offset);
   float* scratch = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)n * nchunk * C * 8 * sizeof(float)));
   const float* rows = nullptr;
   const int nrows = prereduce(part, n * nchunk, C * 8, scratch, &rows, s);
@@ -1052,13 +1057,24 @@ __global__ __launch_bounds__(TPB) void add_inplace_kernel(float* __restrict__ y,
     st4(y + 4 * i, make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w));
   }
 }
+// y = (x ? x : 0) + ls[f] * drop(v): the residual + LayerScale tail of a block whose output dropout is live (thr > 0)
 __global__ __launch_bounds__(TPB) void res_ls_kernel(const float* __restrict__ x, const float* __restrict__ v, const float* __restrict__ ls,
-                                                    float* __restrict__ y, long long M, int F) {
+                                                    float* __restrict__ y, long long M, int F, unsigned int thr, float dscale,
+                                                    unsigned long long seed, unsigned long long offset) {
   const int f4 = F >> 2;
   const long long total = M * f4;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
     const int c = (int)(i % f4) * 4;
-    const float4 a = ld4(x + 4 * i), b = ld4(v + 4 * i), l = ld4(ls + c);
+    const float4 a = x ? ld4(x + 4 * i) : zero4();
+    float4 b = ld4(v + 4 * i);
+    const float4 l = ld4(ls + c);
+    if (thr) {
+      const unsigned long long e = offset + 4ull * (unsigned long long)i;
+      b.x = sepr_keep(seed, e, thr) ? b.x * dscale : 0.f;
+      b.y = sepr_keep(seed, e + 1, thr) ? b.y * dscale : 0.f;
+      b.z = sepr_keep(seed, e + 2, thr) ? b.z * dscale : 0.f;
+      b.w = sepr_keep(seed, e + 3, thr) ? b.w * dscale : 0.f;
+    }
     st4(y + 4 * i, make_float4(fmaf(b.x, l.x, a.x), fmaf(b.y, l.y, a.y), fmaf(b.z, l.z, a.z), fmaf(b.w, l.w, a.w)));
   }
 }
@@ -1066,16 +1082,6 @@ __global__ __launch_bounds__(TPB) void dropout_kernel(const float* __restrict__ 
                                                      float scale, unsigned long long seed, unsigned long long offset) {
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < count; i += (long long)gridDim.x * TPB)
     y[i] = sepr_keep(seed, offset + (unsigned long long)i, thr) ? x[i] * scale : 0.f;
-}
-__global__ __launch_bounds__(TPB) void scale_cols_kernel(const float* __restrict__ v, const float* __restrict__ ls, float* __restrict__ y,
-                                                        long long M, int F) {
-  const int f4 = F >> 2;
-  const long long total = M * f4;
-  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-    const int c = (int)(i % f4) * 4;
-    const float4 b = ld4(v + 4 * i), l = ld4(ls + c);
-    st4(y + 4 * i, make_float4(b.x * l.x, b.y * l.y, b.z * l.z, b.w * l.w));
-  }
 }
 }  // namespace
 int launch_add_inplace(float* y, const float* a, long long count, hipStream_t s) {
@@ -1085,10 +1091,12 @@ int launch_add_inplace(float* y, const float* a, long long count, hipStream_t s)
   SEPR_CHECK_LAUNCH("add_inplace_kernel");
   return SEPR_OK;
 }
-int launch_res_ls(const float* x, const float* v, const float* ls, float* y, long long M, int F, hipStream_t s) {
+int launch_res_ls(const float* x, const float* v, const float* ls, float* y, long long M, int F, float p, unsigned long long seed,
+                  unsigned long long offset, hipStream_t s) {
   if (M <= 0) return SEPR_OK;
-  if (!x || !v || !ls || !y || F % 4) return SEPR_EINVAL;
-  hipLaunchKernelGGL(res_ls_kernel, dim3(grid_for(M * (F >> 2), TPB, 1 << 16)), dim3(TPB), 0, s, x, v, ls, y, M, F);
+  if (!v || !ls || !y || F % 4 || !(p >= 0.f) || !(p < 1.f)) return SEPR_EINVAL;
+  hipLaunchKernelGGL(res_ls_kernel, dim3(grid_for(M * (F >> 2), TPB, 1 << 16)), dim3(TPB), 0, s, x, v, ls, y, M, F,
+                     p > 0.f ? sepr_drop_threshold(p) : 0u, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, seed, offset);
   SEPR_CHECK_LAUNCH("res_ls_kernel");
   return SEPR_OK;
 }
@@ -1101,14 +1109,6 @@ int launch_dropout(const float* x, float* y, long long count, float p, unsigned 
   SEPR_CHECK_LAUNCH("dropout_kernel");
   return SEPR_OK;
 }
-int launch_scale_cols(const float* v, const float* ls, float* y, long long M, int F, hipStream_t s) {
-  if (M <= 0) return SEPR_OK;
-  if (!v || !ls || !y || F % 4) return SEPR_EINVAL;
-  hipLaunchKernelGGL(scale_cols_kernel, dim3(grid_for(M * (F >> 2), TPB, 1 << 16)), dim3(TPB), 0, s, v, ls, y, M, F);
-  SEPR_CHECK_LAUNCH("scale_cols_kernel");
-  return SEPR_OK;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // waveform ends: ConvTranspose1d decoder (module.py:268-283), masked auxiliary heads (module.py:257-260, network.py:41),
 // Conv1d + GELU encoder (module.py:12-23)

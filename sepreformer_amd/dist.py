@@ -9,6 +9,7 @@ waveforms when one rank must hold them all.
 """
 from __future__ import annotations
 
+import datetime
 import os
 from typing import Callable, List, Optional, Tuple
 
@@ -36,11 +37,13 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # a bounded collective timeout: a rank that died must fail the job, not hang it
+        timeout = datetime.timedelta(seconds=int(os.environ.get("SEPR_DIST_TIMEOUT_S", "300")))
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local
 
 

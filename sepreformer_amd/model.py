@@ -171,8 +171,7 @@ class Model(torch.nn.Module):
 
     def invalidate_packed(self) -> None:
         """Force a re-pack on the next forward.  Needed only after mutations the version counters cannot see
-        (``p.data.copy_()``, ``p.data.mul_()``, re-assigned ``nn.Parameter`` objects)."""
-        self.__dict__.pop("_flat", None)
+        (``p.data.copy_()``, ``p.data.mul_()``; after re-assigning ``nn.Parameter`` objects also drop ``self.__dict__['_flat']``)."""
         self._pack_epoch += 1
 
     def _weights_key(self):
