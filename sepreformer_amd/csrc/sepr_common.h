@@ -42,6 +42,13 @@ __device__ __forceinline__ float sigmoid_f(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
+// GLU on a gate that arrives PRE-SCALED by -log2(e) (the packers fold the factor into the gate's conv taps and bias):
+// value * sigmoid(gate) = value * rcp(1 + exp2(gs)), one multiply less per hidden element than sigmoid_f
+__device__ __forceinline__ float glu_prescaled(float val, float gs) {
+#pragma clang fp contract(off)
+  return val * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gs));
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }

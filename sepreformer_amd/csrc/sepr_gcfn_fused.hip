@@ -36,8 +36,11 @@ struct GcfnFusedArgs {
   float* y;           // [M, F]
   int M, T;           // rows, frames per sequence
   const void* w1p;    // per chunk: [4 tiles: v0 v1 g0 g1][KS][plane][64][8] bf16 (LayerNorm gamma folded), then 4 KB of
-                      // constants [2 tile pairs][10: b1v b1g wv0 wv1 wv2 wg0 wg1 wg2 cbv cbg][16 channels] fp32
-  const void* w2p;    // [NCH][F/16][plane][64][8] bf16, k-slot order (g,e) -> e<4 ? 4g+e : 16+4g+e-4
+                      // constants [2 tile pairs][10: b1v b1g wv0 wv1 wv2 wg0 wg1 wg2 cbv cbg][16 channels] fp32; the gate's
+                      // conv taps and bias (wg*, cbg) are multiplied by -log2(e): see glu_prescaled
+  const void* w2p;    // [NCH][F/16][plane][64][8] bf16, k-slot order (g,e) -> e<4 ? 4g+e : 16+4g+e-4; fragment row 4q+r of
+                      // tile ft is output channel 32*(ft/2) + 8q + 4*(ft%2) + r (a lane's accumulators of a tile pair are 8
+                      // consecutive channels: the same 32 bytes of a frame row it loaded)
   const float* b2;    // [F]
   const float* ls;    // [F]
   float eps;
@@ -46,6 +49,13 @@ struct GcfnFusedArgs {
 
 __device__ __forceinline__ float dpp_ror1(float v) {   // lane i <- lane (i-1) mod 16 of its 16-lane row
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+}
+// shifts instead of rotations: the lane with no source in its 16-lane row (0 for shr, 15 for shl) keeps `old`
+__device__ __forceinline__ float dpp_shr1(float old, float v) {   // lane i <- lane i-1; lane 0 <- old
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_shl1(float old, float v) {   // lane i <- lane i+1; lane 15 <- old
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
 }
 __device__ __forceinline__ float dpp_rol1(float v) {   // lane i <- lane (i+1) mod 16
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x12f, 0xf, 0xf, false));
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
               const float a0g = EDGE ? wg0 * f0[mt] : wg0, a2g = EDGE ? wg2 * f2[mt] : wg2;
               const float val = fmaf(a2v, nv[mt], fmaf(wv1, cv[mt], fmaf(a0v, pv[mt], cbv)));
               const float gat = fmaf(a2g, ng[mt], fmaf(wg1, cg[mt], fmaf(a0g, pg[mt], cbg)));
-              gl[mt][r] = (SEPR_GF_ABL & 16) ? val * gat : val * sigmoid_f(gat);   // 16: no transcendentals
+              gl[mt][r] = (SEPR_GF_ABL & 16) ? val * gat : glu_prescaled(val, gat);   // 16: no transcendentals (gate taps are pre-scaled)
             }
           }
 #pragma unroll
@@ -424,7 +434,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const f32x4 v = acc[ft][mt];
-            st4(base + (MT * fi + mt) * OS + 16 * ft + 4 * fg, make_float4(v[0], v[1], v[2], v[3]));
+            st4(base + (MT * fi + mt) * OS + 32 * (ft >> 1) + 8 * fg + 4 * (ft & 1), make_float4(v[0], v[1], v[2], v[3]));   // w2p row order
           }
       }
       __syncthreads();
@@ -444,6 +454,10 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
   }
 }
 
+
+#ifdef SEPR_WITH_GF5
+#include "sepr_gcfn_fused5.inc"   // the X/Y two-group experiment (library variants gf5*, see that file)
+#endif
 // (A one-workgroup-per-CU, software-pipelined variant of this kernel - "v4", 8 waves, doubled weight buffers, one
 //  barrier per chunk - was measured 10 % slower and removed in round 2; it lives in git history at 7cf5a73.)
 #ifndef SEPR_GF3_MT
@@ -483,17 +497,38 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
       return SEPR_EINVAL;
     }
   } else {
-  constexpr int tile_rows = (SEPR_GF3_XCH && GF3_MT == 2 && SEPR_GF3_UPFIRST) ? GF3_NW * 16 * GF3_MT - 2 : GF3_NW * (16 * GF3_MT - 2);
-  const int ntiles = (a.M + tile_rows - 1) / tile_rows;
-  const int cap = persistent_grid();
-  const int grid = ntiles < cap ? ntiles : cap;
-  if (F == 128) {
-    hipLaunchKernelGGL((gcfn_fused3_kernel<128, GF3_MT, GF3_NW>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
-  } else if (F == 64) {
-    hipLaunchKernelGGL((gcfn_fused3_kernel<64, GF3_MT, GF3_NW>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
-  } else {
-    return SEPR_EINVAL;
-  }
+#ifdef SEPR_WITH_GF5
+    static const int kver = [] {
+      const char* e = getenv("SEPR_GF_KERNEL");
+      return e && e[0] ? atoi(e) : 3;
+    }();
+    if (kver == 5 && GF3_MT == 2) {
+      // one 8-wave workgroup per CU, two groups of 4 waves half a chunk apart; a workgroup walks PAIRS of 126-frame tiles
+      const int ntiles = (a.M + 125) / 126, npairs = (ntiles + 1) / 2;
+      const int cap = persistent_grid() / 2;
+      const int grid = npairs < cap ? npairs : cap;
+      if (F == 128) {
+        hipLaunchKernelGGL((gcfn_fused5_kernel<128>), dim3(grid), dim3(512), 0, stream, a);
+      } else if (F == 64) {
+        hipLaunchKernelGGL((gcfn_fused5_kernel<64>), dim3(grid), dim3(512), 0, stream, a);
+      } else {
+        return SEPR_EINVAL;
+      }
+    } else
+#endif
+    {
+      constexpr int tile_rows = (SEPR_GF3_XCH && GF3_MT == 2 && SEPR_GF3_UPFIRST) ? GF3_NW * 16 * GF3_MT - 2 : GF3_NW * (16 * GF3_MT - 2);
+      const int ntiles = (a.M + tile_rows - 1) / tile_rows;
+      const int cap = persistent_grid();
+      const int grid = ntiles < cap ? ntiles : cap;
+      if (F == 128) {
+        hipLaunchKernelGGL((gcfn_fused3_kernel<128, GF3_MT, GF3_NW>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
+      } else if (F == 64) {
+        hipLaunchKernelGGL((gcfn_fused3_kernel<64, GF3_MT, GF3_NW>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
+      } else {
+        return SEPR_EINVAL;
+      }
+    }
   }
   // algorithmic FLOPs of the block: both projections + the depthwise conv
   if (timed) prof_end(slot, (double)a.M * (2.0 * F * 6 * F + 2.0 * 3 * 6 * F + 2.0 * 3 * F * F), stream);
@@ -502,3 +537,9 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
 }
 
 }  // namespace sepr
+
+#if defined(SEPR_WITH_GF5) && SEPR_GF5_TRACE
+extern "C" int sepr_debug_gf5_trace(unsigned long long* out) {   // [8 waves][512]: stamps of workgroup 0, last launch
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sepr::gf5_trace), sizeof(unsigned long long) * 8 * 512);
+}
+#endif

@@ -146,17 +146,22 @@ def pack_gcfn_fused(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.Tensor, bet
     * ``w1p``: per 32-channel hidden chunk, the up-projection fragments ``[4][F/32][2][64][8]`` bf16 (value tiles 0,1
       then their gate tiles; LayerNorm gamma folded) followed by a 4 KB fp32 constants block
       ``[2 tile pairs][b1v b1g wv0 wv1 wv2 wg0 wg1 wg2 cbv cbg][16 channels]`` (bias with beta folded, conv taps,
-      conv bias), zero padded;
+      conv bias; the gate's taps and conv bias multiplied by -log2(e)), zero padded;
     * ``w2p`` ``[3F/32][F/16][2][64][8]`` bf16: the chunk's K slice of the down-projection with the k-slot order the
-      kernel's registers provide (lane group g, slot e -> hidden channel ``e<4 ? 4g+e : 16+4g+e-4`` of the chunk)."""
+      kernel's registers provide (lane group g, slot e -> hidden channel ``e<4 ? 4g+e : 16+4g+e-4`` of the chunk) and
+      the output rows of each tile pair interleaved (see below)."""
     F = w1.shape[1]
     H3 = 3 * F
     nch = H3 // 32
     dev = w1.device
     w1f = (w1.detach().double() * gamma.detach().double()[None, :]).float()
     b1f = (b1.detach().double() + w1.detach().double() @ beta.detach().double()).float()
-    taps = dw_w.detach().float()[:, 0, :]                                        # [6F, 3]
-    cb = dw_b.detach().float()
+    # the gate half of the depthwise conv (taps and bias) carries the -log2(e) of sigmoid(g) = 1 / (1 + exp2(-log2(e) g)):
+    # the kernels evaluate the GLU as value * rcp(1 + exp2(gate')) (csrc/sepr_common.h glu_prescaled)
+    gscale = torch.ones(2 * H3, dtype=torch.float64, device=dev)
+    gscale[H3:] = -1.4426950408889634
+    taps = (dw_w.detach().double()[:, 0, :] * gscale[:, None]).float()           # [6F, 3]
+    cb = (dw_b.detach().double() * gscale).float()
     chunks = []
     for c in range(nch):
         rows = []
@@ -173,7 +178,13 @@ def pack_gcfn_fused(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.Tensor, bet
             cst[j * 160:(j + 1) * 160] = torch.cat(vals)
         chunks.append(torch.cat([frag, cst.view(torch.uint8)]))
     w1p = torch.stack(chunks, 0).contiguous()
-    w2p = _kslot_frags(w2, nch)
+    # fragment row 4q+r of tile ft <- output channel 32*(ft//2) + 8q + 4*(ft%2) + r: a lane's accumulators of a tile pair are
+    # then 8 consecutive channels of its frame (the kernels' epilogues rely on it)
+    ft = torch.arange(F // 16, device=dev)[:, None, None]
+    q = torch.arange(4, device=dev)[None, :, None]
+    r = torch.arange(4, device=dev)[None, None, :]
+    rows = (32 * (ft // 2) + 8 * q + 4 * (ft % 2) + r).reshape(-1)
+    w2p = _kslot_frags(w2.detach()[rows], nch)
     return w1p, w2p
 
 

@@ -238,7 +238,11 @@ def test_pack_gcfn_fused_layout():
             dwt[v:v + 16] = blk[2:5].t()
             dwt[g_:g_ + 16] = blk[5:8].t()
             dwb[v:v + 16], dwb[g_:g_ + 16] = blk[8], blk[9]
-    assert torch.equal(dwt, sd[p + ".depthwise.weight"][:, 0, :]) and torch.equal(dwb, sd[p + ".depthwise.bias"])
+    # the gate half (rows 3F..6F) of the conv constants is stored multiplied by -log2(e)
+    gs = torch.ones(6 * F, dtype=torch.float64)
+    gs[3 * F:] = -1.4426950408889634
+    assert torch.equal(dwt, (sd[p + ".depthwise.weight"][:, 0, :].double() * gs[:, None]).float())
+    assert torch.equal(dwb, (sd[p + ".depthwise.bias"].double() * gs).float())
     W1 = torch.zeros(6 * F, F, dtype=torch.float64)
     W2 = torch.zeros(F, 3 * F, dtype=torch.float64)
     w1s = (w1p[:, :, :, 0].double() + w1p[:, :, :, 1].double())      # [c, t, ks, lane, 8]
@@ -255,7 +259,8 @@ def test_pack_gcfn_fused_layout():
                 for i in range(16):
                     for e in range(8):
                         n = 4 * g + e if e < 4 else 16 + 4 * g + e - 4
-                        W2[16 * ft + i, 32 * c + n] = w2s[c, ft, g * 16 + i, e]
+                        # fragment row i = 4q + r of tile ft is output channel 32*(ft//2) + 8q + 4*(ft%2) + r
+                        W2[32 * (ft // 2) + 8 * (i // 4) + 4 * (ft % 2) + i % 4, 32 * c + n] = w2s[c, ft, g * 16 + i, e]
     x = torch.randn(2, 21, F, dtype=torch.float64)
     xn = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
     h = xn @ W1.t() + b1f.double()
