@@ -6,6 +6,8 @@
 
 namespace sepr {
 
+int persistent_grid();   // sepr_gemm.hip: 2 workgroups per CU, a multiple of 8
+
 namespace {
 constexpr int TPB = 256;
 
@@ -335,23 +337,26 @@ __global__ __launch_bounds__(TPB) void dwconv_same_kernel(const float* __restric
   }
 }
 
-// Same op for 128-channel slabs, built around what bounds it: 65 FMAs per element is VALU work (2.1 GFMA for
-// 32 x 8000 frames, ~31 us of packed FMAs on 256 CUs; the HBM pass is ~35 us), so
-//  * a lane owns TWO adjacent channels and every multiply-add is a v_pk_fma_f32 (2 FMAs per lane-instruction);
-//  * 8 waves per workgroup (2 per SIMD) instead of 4, each wave = 16 output frames x 128 channels: a tile row is
-//    read from LDS once per wave (80 + 65 ds_read_b64 per 1040 packed FMAs);
-//  * the input tile goes global -> LDS by LDS-DMA (no VGPR round trip, two 512 B rows per wave instruction);
-//  * persistent workgroups (one per CU: tile 96 KB + taps 33 KB of LDS); the taps are staged once per workgroup.
+// Same op, built around what bounds it.  65 FMAs per element is VALU work (44 GFMA per B=32 forward, ~0.8 ms of the chip's
+// packed-FMA rate) and the HBM pass (u in, c out) is ~0.9 ms: the two must OVERLAP, and the LDS-DMA tile load of a workgroup
+// cannot overlap its own arithmetic (single tile buffer).  So:
+//  * 64-channel slabs, 128 output frames per tile: 48 KB tile + 16.6 KB taps = 65 KB of LDS, TWO 4-wave workgroups per CU -
+//    one waits for its tile while the other multiplies (round 1's one 129 KB workgroup per CU serialised the two: 1.9 ms);
+//  * a lane owns TWO adjacent channels and every multiply-add is a v_pk_fma_f32; a wave = 32 frames x 64 channels (lanes 0-31
+//    the first 16 frames, lanes 32-63 the next 16), 16 outputs x 2 channels per lane: a tile row is read from LDS once per
+//    half-wave (80 + 65 ds_read_b64 per 1040 packed FMAs);
+//  * the input tile goes global -> LDS by LDS-DMA (no VGPR round trip, four 256 B rows per wave instruction);
+//  * persistent workgroups walk the tiles slab-major, so the taps are staged once per workgroup and slab.
 // Accumulation order per output is bias, tap 0, ..., tap 64 with fused multiply-adds: the same chain as
 // dwconv_same_kernel, so the two kernels agree bit for bit.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int KW>
-__global__ __launch_bounds__(512) void dwconv_same_pk_kernel(const float* __restrict__ U, float* __restrict__ C, int T, int F,
-                                                            int tiles_per_seq, int ntiles, const float* __restrict__ w,
-                                                            const float* __restrict__ b) {
-  constexpr int HALO = KW / 2, TT = 128, ROWS = TT + KW - 1, CH = 128, OPT = 16, NT = 512;
-  static_assert(ROWS % 16 == 0, "DMA loop: 8 waves x 2 rows per instruction");
+__global__ __launch_bounds__(256, 2) void dwconv_same_pk_kernel(const float* __restrict__ U, float* __restrict__ C, int T, int F,
+                                                               int tiles_per_seq, int ntiles, const float* __restrict__ w,
+                                                               const float* __restrict__ b) {
+  constexpr int HALO = KW / 2, TT = 128, ROWS = TT + KW - 1, CH = 64, OPT = 16, NT = 256, NWV = NT / 64;
+  static_assert(ROWS % (4 * NWV) == 0, "DMA loop: 4 waves x 4 rows per instruction");
   __shared__ __attribute__((aligned(16))) float tile[ROWS * CH];
   __shared__ __attribute__((aligned(16))) float ws[KW * CH];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(512) void dwconv_same_pk_kernel(const float* __rest
   int cur_chunk = -1;
 #pragma unroll 1
   for (int tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
-    // chunk-major tile order: a workgroup's consecutive tiles share the channel slab and its taps
+    // slab-major tile order: a workgroup's consecutive tiles share the channel slab and its taps
     const int chunk = tix / per_chunk, rem = tix % per_chunk;
     const int seq = rem / tiles_per_seq, t0 = (rem % tiles_per_seq) * TT;
     const int c0 = chunk * CH;
@@ -372,11 +377,11 @@ __global__ __launch_bounds__(512) void dwconv_same_pk_kernel(const float* __rest
     }
     const float* src = U + (long long)seq * T * F + c0;
     {  // rows t0-HALO .. t0+TT+HALO-1 -> LDS; out-of-range rows are fetched from a clamped address, zeroed below
-      const int half = lane >> 5, q = lane & 31;
+      const int sub = lane >> 4, q = lane & 15;
 #pragma unroll
-      for (int i = 0; i < ROWS / 16; ++i) {
-        const int r0 = 2 * (i * 8 + wv);
-        int t = t0 - HALO + r0 + half;
+      for (int i = 0; i < ROWS / (4 * NWV); ++i) {
+        const int r0 = 4 * (i * NWV + wv);
+        int t = t0 - HALO + r0 + sub;
         t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
         const float* g = src + (long long)t * F + 4 * q;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -392,14 +397,15 @@ __global__ __launch_bounds__(512) void dwconv_same_pk_kernel(const float* __rest
       }
       __syncthreads();
     }
-    const int rb = wv * OPT;
-    if (t0 + rb < T) {   // wave-uniform
+    const int rb = (2 * wv + (lane >> 5)) * OPT;   // first output frame of this half-wave
+    if (t0 + 2 * wv * OPT < T) {   // wave-uniform (the second half-wave may compute frames past T: never stored)
       f32x2 acc[OPT];
-      const f32x2 bias = *reinterpret_cast<const f32x2*>(b + c0 + 2 * lane);
+      const int cp = 2 * (lane & 31);
+      const f32x2 bias = *reinterpret_cast<const f32x2*>(b + c0 + cp);
 #pragma unroll
       for (int o = 0; o < OPT; ++o) acc[o] = bias;
-      const float* trow = tile + rb * CH + 2 * lane;
-      const float* wrow = ws + 2 * lane;
+      const float* trow = tile + rb * CH + cp;
+      const float* wrow = ws + cp;
       // 16 taps per trip of a real (not unrolled) loop: 256 packed FMAs against 16 new window rows + 16 taps, the
       // 15 rows the next trip re-uses carried in registers.  (One 1040-FMA basic block lets the scheduler hoist
       // all 145 LDS reads to the top and spill; a loop bounds what it can hoist.)
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(512) void dwconv_same_pk_kernel(const float* __rest
         for (int o = 0; o < 15; ++o) acc[o] = __builtin_elementwise_fma(wl, xc[o], acc[o]);
         acc[15] = __builtin_elementwise_fma(wl, xl, acc[15]);
       }
-      float* dst = C + ((long long)seq * T + t0 + rb) * F + c0 + 2 * lane;
+      float* dst = C + ((long long)seq * T + t0 + rb) * F + c0 + cp;
 #pragma unroll
       for (int o = 0; o < OPT; ++o)
         if (t0 + rb + o < T) *reinterpret_cast<f32x2*>(dst + (long long)o * F) = acc[o];
@@ -445,10 +451,11 @@ int launch_dwconv_same(const float* U, float* C, int n, int T, int F, int K, con
   if (K != 65 || F % 64 != 0) return SEPR_EINVAL;
   const int tiles = (T + 127) / 128;
   if (F % 128 == 0 && !legacy_pointwise()) {
-    const long long nt = (long long)tiles * n * (F / 128);
+    const long long nt = (long long)tiles * n * (F / 64);
     if (nt > 0x7fffffffLL) return SEPR_EINVAL;
-    const int grid = (int)(nt < 256 ? nt : 256);   // one 129 KB workgroup per CU
-    hipLaunchKernelGGL((dwconv_same_pk_kernel<65>), dim3(grid), dim3(512), 0, s, U, C, T, F, tiles, (int)nt, w, b);
+    const int cap = persistent_grid();             // two 65 KB workgroups per CU
+    const int grid = (int)(nt < cap ? nt : cap);
+    hipLaunchKernelGGL((dwconv_same_pk_kernel<65>), dim3(grid), dim3(256), 0, s, U, C, T, F, tiles, (int)nt, w, b);
   } else if (F % 128 == 0) {
     hipLaunchKernelGGL((dwconv_same_kernel<65, 128>), dim3(tiles * (F / 128), n), dim3(TPB), 0, s, U, C, T, F, w, b);
   } else {
