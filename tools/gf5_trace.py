@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Phase timeline of the 8-wave GCFN kernel (gcfn_fused5_kernel), workgroup 0, from the s_memtime stamps of the
-`gf5trace` library variant:  make -C sepreformer_amd/csrc ../_native/libsepr_hip_gf5trace.so ;
-SEPR_LIB_VARIANT=gf5trace python tools/gf5_trace.py [n T]
+"""Block timing / phase timeline of the experimental 8-wave GCFN kernel (csrc/sepr_gcfn_fused5.inc).
+  make -C sepreformer_amd/csrc ../_native/libsepr_hip_gf5.so ../_native/libsepr_hip_gf5acc.so
+  SEPR_LIB_VARIANT=gf5 SEPR_GF_KERNEL=5 python tools/gf5_trace.py [n T]      # us per launch (SEPR_GF_KERNEL=3: product kernel)
+  SEPR_LIB_VARIANT=gf5acc SEPR_GF_KERNEL=5 python tools/gf5_trace.py          # + cycles per phase kind (accumulators)
+  SEPR_LIB_VARIANT=gf5trace SEPR_GF_KERNEL=5 python tools/gf5_trace.py        # + s_memtime stamps (perturbs the vmcnt scheme)
 
 Stamp ids: 1 half-step start (U), 2 DMA issued, 3 up-projection issued + seam frames published, 4 after barrier (CD start),
 5 DMA issued, 6 conv + GLU + split done, 7 down-projection issued, (barrier), 8 tile change start, 9 tile change done."""
