@@ -48,7 +48,7 @@ struct GcfnFusedArgs {
 };
 
 __device__ __forceinline__ float dpp_ror1(float v) {   // lane i <- lane (i-1) mod 16 of its 16-lane row
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x121, 0xf, 0xf, true));   // (every lane has a source: no `old`)
 }
 // shifts instead of rotations: the lane with no source in its 16-lane row (0 for shr, 15 for shl) keeps `old`
 __device__ __forceinline__ float dpp_shr1(float old, float v) {   // lane i <- lane i-1; lane 0 <- old
@@ -58,7 +58,7 @@ __device__ __forceinline__ float dpp_shl1(float old, float v) {   // lane i <- l
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
 }
 __device__ __forceinline__ float dpp_rol1(float v) {   // lane i <- lane (i+1) mod 16
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x12f, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x12f, 0xf, 0xf, true));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -346,18 +346,24 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
               cv[mt] = hv[mt][r];
               cg[mt] = hg[mt][r];
             }
+            if (XCH) {
+              // wave seams: lane SHIFTS leave lane 0 / 15 of the 16-lane row without a source - they keep the shift's `old`
+              // operand, the neighbouring wave's frame (one DPP move per neighbour, no select, no rotation fix-up)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              pv[mt] = mt > 0 ? cv[mt - 1] : dpp_ror1(cv[MT - 1]);
-              pg[mt] = mt > 0 ? cg[mt - 1] : dpp_ror1(cg[MT - 1]);
-              nv[mt] = mt + 1 < MT ? cv[mt + 1] : dpp_rol1(cv[0]);
-              ng[mt] = mt + 1 < MT ? cg[mt + 1] : dpp_rol1(cg[0]);
-            }
-            if (XCH) {   // wave seams: the rotation wrapped around; take the neighbouring wave's frame instead
-              pv[0] = fi == 0 ? xpv[r] : pv[0];
-              pg[0] = fi == 0 ? xpg[r] : pg[0];
-              nv[MT - 1] = fi == 15 ? xnv[r] : nv[MT - 1];
-              ng[MT - 1] = fi == 15 ? xng[r] : ng[MT - 1];
+              for (int mt = 0; mt < MT; ++mt) {
+                pv[mt] = mt > 0 ? cv[mt - 1] : dpp_shr1(xpv[r], cv[MT - 1]);
+                pg[mt] = mt > 0 ? cg[mt - 1] : dpp_shr1(xpg[r], cg[MT - 1]);
+                nv[mt] = mt + 1 < MT ? cv[mt + 1] : dpp_shl1(xnv[r], cv[0]);
+                ng[mt] = mt + 1 < MT ? cg[mt + 1] : dpp_shl1(xng[r], cg[0]);
+              }
+            } else {
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) {
+                pv[mt] = mt > 0 ? cv[mt - 1] : dpp_ror1(cv[MT - 1]);
+                pg[mt] = mt > 0 ? cg[mt - 1] : dpp_ror1(cg[MT - 1]);
+                nv[mt] = mt + 1 < MT ? cv[mt + 1] : dpp_rol1(cv[0]);
+                ng[mt] = mt + 1 < MT ? cg[mt + 1] : dpp_rol1(cg[0]);
+              }
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {

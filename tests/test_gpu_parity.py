@@ -384,6 +384,30 @@ def test_gcfn_small_rows_forced_big_kernel():
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_dwconv_k65_matches_first_generation_kernel_bitwise():
+    """The 65-tap depthwise conv of the CLA block (two 65 KB workgroups per CU, 64-channel slabs, LDS-DMA tiles, packed FMAs)
+    against the first-generation kernel (SEPR_LEGACY_POINTWISE=1, read once per process -> own process): same accumulation
+    chain, so the CLA block outputs must be bit-identical.  Shapes: T below the tap count, T = 1 tile, ragged last tiles,
+    several sequences (tile walk crosses sequence and slab boundaries)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch, hashlib; sys.path.insert(0, %r)\n"
+        "from tests.test_gpu_parity import gpu_model, rnd\n"
+        "m, sd = gpu_model('SepReformer_Base_WSJ0', 'bf16x3'); eng = m.engine(); eng.prepare(8, 2400, 2400)\n"
+        "for n, T in ((1, 1), (2, 37), (3, 64), (1, 65), (2, 128), (3, 129), (5, 777), (7, 2001)):\n"
+        "    x = rnd(n, T, m.cfg.feat, seed=T)\n"
+        "    y = eng.cla(x.cuda(), eng.pk.enc_stages[0]['l'][0][0], n, T)\n"
+        "    print(n, T, hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest())\n" % ROOT)
+    outs = []
+    for legacy in ("0", "1"):
+        env = dict(os.environ, SEPR_LEGACY_POINTWISE=legacy)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if len(ln.split()) == 3])
+    assert len(outs[0]) == 8 and outs[0] == outs[1], (outs[0], outs[1])
+
+
 def test_two_replicas_one_device_concurrently():
     """torch.nn.parallel.data_parallel semantics (reference engine.py:64,98,130,167 with several device ids): replicas are
     shallow copies whose parameters are plain attributes, each driven by its own Python thread.  Two replicas on the one
