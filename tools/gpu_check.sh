@@ -12,7 +12,7 @@ lscpu | grep -E "Model name|Socket|Core|Thread|^CPU\(s\)" >> $OUT/device.txt
 echo "== smoke" | tee $OUT/summary.txt
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/summary.txt
 tail -3 $OUT/smoke.log | tee -a $OUT/summary.txt
-for grp in test_linear_core test_blocks "test_gcfn_block_large or test_gcfn_small_rows" "test_e2e_golden or test_intermediate" "test_e2e_pit or test_pit_si_snr" "test_ragged or test_no_padding or test_error or test_weights or test_groupnorm or test_graph or test_two_replicas" test_full_size; do
+for grp in test_linear_core test_blocks "test_gcfn_block_large or test_gcfn_small_rows" "test_e2e_golden or test_intermediate" "test_e2e_pit or test_pit_si_snr" "test_ragged or test_no_padding or test_error or test_weights or test_groupnorm or test_graph or test_two_replicas or test_dwconv" test_full_size; do
   name=$(echo "$grp" | tr ' ' '_' | cut -c1-40)
   timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "$grp" -p no:cacheprovider > "$OUT/pytest_$name.log" 2>&1
   echo "pytest [$grp] rc=$?" | tee -a $OUT/summary.txt
