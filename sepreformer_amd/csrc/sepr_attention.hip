@@ -168,6 +168,10 @@ __global__ __launch_bounds__(256) void relattn_kernel(const float* __restrict__ 
 //     when V^T is read with the matching key-slot order, so PV is 3 MFMAs per 32 keys with no data movement.
 // K, V^T and the band are split into bf16 hi/lo planes once per 64-key tile while they are staged into LDS.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef SEPR_AT_ABL
+#define SEPR_AT_ABL 0   // timing ablations of relattn_x3_kernel (WRONG results): 1 no relative-position product, 2 no exp,
+                       // 4 K / V / band staged once (first key tile only), 8 no PV product, 16 no q.k product
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
   for (int j0 = 0; j0 < Tp; j0 += KT) {
     __syncthreads();   // previous tile fully consumed
     // ---- registers -> LDS: K rows, V transposed and the band of the position table as bf16 hi / lo planes ----------
-    {
+    if (!(SEPR_AT_ABL & 4) || j0 == 0) {
       bf16x4 hh, ll;
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
       }
     }
     __syncthreads();
-    if (j0 + KT < Tp) fetch(j0 + KT);   // the next tile's rows fly under this tile's arithmetic
+    if (j0 + KT < Tp && !(SEPR_AT_ABL & 4)) fetch(j0 + KT);   // the next tile's rows fly under this tile's arithmetic
 
     const int npair = (Tp - j0 >= KT) ? KT / 32 : (Tp - j0 + 31) / 32;
     for (int p = 0; p < npair; ++p) {
@@ -306,15 +310,19 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
         const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + row * KSB + go);
         const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + row * KSB + go);
         f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh, a, 0, 0, 0);
+        if (!(SEPR_AT_ABL & 16)) {
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh, a, 0, 0, 0);
+        } else {
+          a[0] = (float)kh[0] + (float)kl[1];
+        }
         sc[s] = a;
       }
       // ---- relative-position term: P^T[b][query], band row of (query ql, key kl) is bb + b, b = ql - kl + 31 ---------
       const int bb = 16 * w - 32 * p + 32;
 #pragma unroll
-      for (int tb = 0; tb < 3; ++tb) {
+      for (int tb = 0; tb < ((SEPR_AT_ABL & 1) ? 0 : 3); ++tb) {
         const int row = bb + 16 * tb + ii;                    // <= 126 except unused rows of the last tile
         const int rc = row < NBAND ? row : NBAND - 1;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bh + rc * KSB + go);
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
         const int jbase = j0 + 32 * p + 16 * s + 4 * g;
         float bias[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[r] = psk[b0 - r];       // unconditional: the reads issue back to back
+        for (int r = 0; r < 4; ++r) bias[r] = (SEPR_AT_ABL & 1) ? 0.f : psk[b0 - r];       // unconditional: the reads issue back to back
 #pragma unroll
         for (int r = 0; r < 4; ++r) sv[s][r] = (jbase + r < Tp) ? sc[s][r] + bias[r] : -1e30f;
       }
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __expf(sv[s][r] - mnew);
+          const float pv = (SEPR_AT_ABL & 2) ? sv[s][r] - mnew : __expf(sv[s][r] - mnew);
           psum += pv;
           const __bf16 hh = (__bf16)pv;
           ph[4 * s + r] = hh;
@@ -366,6 +374,10 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
         const bf16x4 b0v = *reinterpret_cast<const bf16x4*>(vl0), b1v = *reinterpret_cast<const bf16x4*>(vl0 + 16);
         const bf16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         const bf16x8 vl = {b0v[0], b0v[1], b0v[2], b0v[3], b1v[0], b1v[1], b1v[2], b1v[3]};
+        if (SEPR_AT_ABL & 8) {
+          o[t][0] += (float)vh[0] * (float)ph[0] + (float)vl[1] * (float)pl[1];
+          continue;
+        }
         o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[t], 0, 0, 0);
         o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[t], 0, 0, 0);
         o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[t], 0, 0, 0);
