@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 validation: full inference check (incl. Large), all training tests, training bench + profile, 2-rank shared-GPU bench
+# round-end validation in ONE gpurun call (~6 GPU-minutes): full inference check (incl. Large), all training tests, training bench + profile, 2-rank shared-GPU bench
 set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT
