@@ -27,11 +27,14 @@ def main(args):
     from .model import Model
     from .synth import synth_sources
 
-    rank, world, local = sdist.init_from_env()
+    share = bool(getattr(args, "share_gpu", False))   # DEBUG: all ranks on GPU 0, gloo collectives (exercises the N > 1 code path on one GPU)
+    rank, world, local = sdist.init_from_env("gloo" if share else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the separator path)")
+    if share:
+        local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     lib = L.load()
@@ -103,7 +106,7 @@ def main(args):
                        "batch_per_gpu": B, "samples": samples, "precision": model.precision, "dropout": model.dropout_p,
                        "dropout_sites": "all the reference's sites: GCFN x2, CLA, attention probabilities + attention output (EGA and speaker attention)",
                        "optimizer": type(opt).__name__ + (" (fused)" if getattr(opt, "defaults", {}).get("fused") else ""),
-                       "clip_norm": 5.0, "parallelism": f"data-parallel x{world}, flat-buffer RCCL all-reduce"},
+                       "clip_norm": 5.0, "parallelism": f"data-parallel x{world}, flat-buffer RCCL all-reduce" + (" (DEBUG: all ranks share GPU 0, gloo collective)" if share else "")},
             "host_enqueue_ms_per_step": round(1e3 * t_host / max(args.steps, 1), 3),
             "loss": round(float(last["loss"]), 4), "grad_norm": round(float(last["gn"]), 4),
             "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
