@@ -250,11 +250,12 @@ extern "C" int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int 
   float* att = ar.f32((long long)F * Mp);
   if (!ar.ok()) return SEPR_EWORKSPACE;
   const float* xpool = x;
-  if (fac > 1) {  // adaptive_avg_pool1d                                    (network.py:146)
-    SEPR_TRY(launch_pool(x, xd, n, Tp, fac, F, st));
+  if (fac > 1) {  // adaptive_avg_pool1d + the LayerNorm statistics of the pooled rows  (network.py:146, :99)
+    SEPR_TRY(launch_pool_stats(x, xd, stats_p, n, Tp, fac, F, LN_EPS, st));
     xpool = xd;
+  } else {
+    SEPR_TRY(launch_rowstats(xpool, stats_p, Mp, F, LN_EPS, st));
   }
-  SEPR_TRY(launch_rowstats(xpool, stats_p, Mp, F, LN_EPS, st));
   {  // MHA: LayerNorm -> q,k,v                                             (network.py:99-102)
     GemmArgs a = gemm_args_zero();
     a.M = (int)Mp; a.N = 3 * F; a.K = F;

@@ -16,6 +16,8 @@ int launch_gn_apply(float* X, const float* stats, const float* g, const float* b
 
 // mean over fac consecutive frames: X [n, Tp*fac, F] -> Y [n, Tp, F]
 int launch_pool(const float* X, float* Y, int n, int Tp, int fac, int F, hipStream_t s);
+// ... fused with the LayerNorm statistics [mean, rstd] of the pooled rows (bit-identical to launch_pool + launch_rowstats)
+int launch_pool_stats(const float* X, float* Y, float* stats, int n, int Tp, int fac, int F, float eps, hipStream_t s);
 
 // GCFN middle: depthwise k=3 conv along frames + GLU.  H [n,T,6F] -> G [n,T,3F]
 int launch_dwglu(const float* H, float* G, int n, int T, int F, const float* w, const float* b, hipStream_t s);

@@ -224,6 +224,79 @@ int launch_pool(const float* X, float* Y, int n, int Tp, int fac, int F, hipStre
   return SEPR_OK;
 }
 
+// The same mean, fused with the LayerNorm statistics of the pooled rows (what the q / k / v projection's prologue needs next):
+// 16 lanes per pooled row as in rowstats_kernel, the pooled values stay in registers for both passes.  Summation orders are
+// those of pool_kernel and rowstats_kernel, so outputs and statistics are bit-identical to the two-launch form.
+template <int FAC>   // FAC > 0: the factor at compile time (all of a column's source rows are requested before the first add)
+__global__ __launch_bounds__(TPB) void pool_stats_kernel(const float* __restrict__ X, float* __restrict__ Y, float* __restrict__ stats,
+                                                        long long Mp, int F, int fac, float eps) {
+  const int sub = threadIdx.x & 15;
+  const int nf4 = F >> 2;
+  const float invF = 1.0f / (float)F, inv = 1.0f / (float)fac;
+  for (long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); row < Mp; row += (long long)gridDim.x * 16) {
+    const float* p = X + row * fac * F;
+    float4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = sub + 16 * i;
+      v[i] = zero4();
+      if (c < nf4) {
+        float4 a;
+        if (FAC > 0) {
+          float4 q[FAC > 0 ? FAC : 1];
+#pragma unroll
+          for (int j = 0; j < FAC; ++j) q[j] = ld4(p + (long long)j * F + 4 * c);
+          a = q[0];
+#pragma unroll
+          for (int j = 1; j < FAC; ++j) { a.x += q[j].x; a.y += q[j].y; a.z += q[j].z; a.w += q[j].w; }
+        } else {
+          a = ld4(p + 4 * c);
+          for (int j = 1; j < fac; ++j) {
+            const float4 q = ld4(p + (long long)j * F + 4 * c);
+            a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+          }
+        }
+        v[i] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+        st4(Y + row * F + 4 * c, v[i]);
+      }
+      s += sum4(v[i]);
+    }
+    const float mean = reduce16(s) * invF;
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = sub + 16 * i;
+      if (c < nf4) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, e = v[i].w - mean;
+        d += (a * a + b * b) + (cc * cc + e * e);
+      }
+    }
+    const float var = reduce16(d) * invF;
+    if (sub == 0) {
+      stats[2 * row] = mean;
+      stats[2 * row + 1] = 1.0f / sqrtf(var + eps);
+    }
+  }
+}
+
+int launch_pool_stats(const float* X, float* Y, float* stats, int n, int Tp, int fac, int F, float eps, hipStream_t s) {
+  if (n <= 0 || Tp <= 0) return SEPR_OK;
+  if (F % 4 != 0 || F > 512 || F <= 0 || fac < 1) return SEPR_EINVAL;
+  const long long Mp = (long long)n * Tp;
+  const long long blocks = (Mp + 15) / 16;
+  const int grid = (int)(blocks < (1 << 20) ? blocks : (1 << 20));
+  switch (fac) {
+    case 2: hipLaunchKernelGGL(pool_stats_kernel<2>, dim3(grid), dim3(TPB), 0, s, X, Y, stats, Mp, F, fac, eps); break;
+    case 4: hipLaunchKernelGGL(pool_stats_kernel<4>, dim3(grid), dim3(TPB), 0, s, X, Y, stats, Mp, F, fac, eps); break;
+    case 8: hipLaunchKernelGGL(pool_stats_kernel<8>, dim3(grid), dim3(TPB), 0, s, X, Y, stats, Mp, F, fac, eps); break;
+    case 16: hipLaunchKernelGGL(pool_stats_kernel<16>, dim3(grid), dim3(TPB), 0, s, X, Y, stats, Mp, F, fac, eps); break;
+    default: hipLaunchKernelGGL(pool_stats_kernel<0>, dim3(grid), dim3(TPB), 0, s, X, Y, stats, Mp, F, fac, eps);
+  }
+  SEPR_CHECK_LAUNCH("pool_stats_kernel");
+  return SEPR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // GCFN middle: depthwise Conv1d(6F, k=3, pad=1) along frames + GLU (network.py:52-54,62-65).
 // A thread owns 4 value channels + their 4 gate channels and slides down a strip of frames, so every
