@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SEPR_VERSION 200 /* major*10000 + minor*100 + patch */
+#define SEPR_VERSION 201 /* major*10000 + minor*100 + patch */
 
 #define SEPR_OK 0
 #define SEPR_EINVAL (-1)     /* bad shape / unsupported size / null pointer */
@@ -140,6 +140,12 @@ typedef struct {
   const float* gn_b; /* [F] */
   sepr_x3_w x3_1;
   sepr_x3_w x3_2;
+  /* optional one-kernel form of linear.0 + GLU + linear.2 (bf16x3, F = 128): the [rows, 2FS] gated tensor never reaches
+   * HBM.  fused_w1p: per 32-channel hidden chunk the up-projection fragments + biases (gate rows pre-scaled by -log2 e),
+   * fused_w2p: [FS/128][2FS/32][8][2][64][8] bf16 down-projection slices, one block of 128 output channels after the
+   * other (pack.pack_glumlp_fused).  NULL = the two generic projections. */
+  const void* fused_w1p;
+  const void* fused_w2p;
 } sepr_split_w;
 
 /* Decoder-side fusion conv, modules/module.py:187,214 */
@@ -158,6 +164,9 @@ typedef struct {
   const float* wdec; /* [K,N]   ConvTranspose1d weight [N,1,K] packed tap-major */
   sepr_x3_w x3_1;
   sepr_x3_w x3_2;
+  /* optional one-kernel form of end_conv1x1.0 + GLU + end_conv1x1.2 (bf16x3, F = 128, N % 128 == 0), as in sepr_split_w */
+  const void* fused_w1p;
+  const void* fused_w2p;
 } sepr_out_w;
 
 /* ---- library ---------------------------------------------------------------------------------- */

@@ -15,13 +15,15 @@ void set_hip_error(hipError_t e, const char* where) {
 
 static const float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default (network.py:50,81,133,162)
 
-struct GcfnFusedArgs {
+struct GcfnFusedArgs {   // (layout of sepr_gcfn_fused.hip)
   const float* x; float* y; int M, T;
   const void* w1p; const void* w2p;
   const float* b2; const float* ls; float eps;
   int stagger;
+  int nch, ldy, col_off, in_rows, in_src, out_T, out_S, out_s;   // plain GLU-MLP mode only
 };
 int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream);   // sepr_gcfn_fused.hip
+int launch_glumlp_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream);
 struct SpkFusedArgs {
   const float* x;
   float* y;
@@ -144,7 +146,7 @@ extern "C" int sepr_gcfn_fwd(const float* x, float* y, int n, int T, int F, cons
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
   if (w->fused_w1p && w->fused_w2p && x != y && (F == 64 || F == 128)) {
     // one kernel: LayerNorm + both projections + depthwise conv + GLU + LayerScale + residual
-    GcfnFusedArgs f;
+    GcfnFusedArgs f = {};
     f.x = x; f.y = y; f.M = (int)M; f.T = T;
     f.w1p = w->fused_w1p; f.w2p = w->fused_w2p;
     f.b2 = w->b2; f.ls = w->ls; f.eps = LN_EPS; f.stagger = 0;
@@ -350,6 +352,20 @@ extern "C" int sepr_spksplit_fwd(const float* x, float* y, int B, int S, int T, 
   double* part = ar.f64((size_t)n_out * nchunk * 2);
   float* stats = ar.f32((size_t)n_out * 2);
   if (!ar.ok()) return SEPR_EWORKSPACE;
+  if (w->fused_w1p && w->fused_w2p && F == 128 && x != y) {
+    // one kernel per speaker: Conv1d F->4FS + GLU + the speaker's F rows of Conv1d 2FS->FS, written straight to sequence
+    // b*S+s (module.py:114-116,123); the [rows, 2FS] gated tensor stays in registers
+    const int nch = 2 * F * S / 32;
+    const size_t half_bytes = (size_t)nch * (F / 16) * 2 * 64 * 16;
+    for (int sp = 0; sp < S; ++sp) {
+      GcfnFusedArgs f = {};
+      f.x = x; f.y = y; f.M = (int)M; f.T = T;
+      f.w1p = w->fused_w1p; f.w2p = static_cast<const char*>(w->fused_w2p) + sp * half_bytes;
+      f.b2 = w->b2 + sp * F; f.ls = nullptr; f.eps = 0.f;
+      f.nch = nch; f.ldy = F; f.col_off = 0; f.out_T = T; f.out_S = S; f.out_s = sp;
+      SEPR_TRY(launch_glumlp_fused(f, F, SEPR_SITE_SPLIT, st));
+    }
+  } else {
   {  // Conv1d F->4FS (k=1) + GLU over the channel axis                     (module.py:114-115)
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = 4 * F * S; a.K = F;
@@ -362,6 +378,7 @@ extern "C" int sepr_spksplit_fwd(const float* x, float* y, int B, int S, int T, 
     a.A = z; a.lda = 2 * F * S; a.W = w->w2; a.bias = w->b2; a.Y = y; a.ldc = F;
     a.T = T; a.S = S; a.Fs = F;
     SEPR_TRY(project(PRO_PLAIN, EPI_SPLIT, a, w->x3_2, SEPR_SITE_SPLIT, st));
+  }
   }
   // GroupNorm(1, F) over (F, T) of every (b, s)                            (module.py:124)
   SEPR_TRY(launch_gn_partial(y, part, n_out, count, nchunk, st));
@@ -400,6 +417,20 @@ extern "C" int sepr_outlayer_decoder_fwd(const float* x, int nS, int S, int Tsrc
   // while it reads the rows.  Without idx the row map is the crop of module.py:250.
   const bool unique = idx != nullptr && Tsrc <= L;   // (a down-sampling map keeps the gather in the first projection)
   const long long Mp = unique ? (long long)nS * Tsrc : M;
+  if (w->fused_w1p && w->fused_w2p && F == 128 && N % 128 == 0 && (unique || !idx)) {
+    // one kernel per 128 basis columns: Linear F->4F + GLU + Linear 2F->N; the crop of module.py:250 is the kernel's row map
+    const int nch = 2 * F / 32;
+    const size_t half_bytes = (size_t)nch * (F / 16) * 2 * 64 * 16;
+    for (int h = 0; h < N / 128; ++h) {
+      GcfnFusedArgs f = {};
+      f.x = x; f.y = o2; f.M = (int)Mp; f.T = L;
+      f.w1p = w->fused_w1p; f.w2p = static_cast<const char*>(w->fused_w2p) + h * half_bytes;
+      f.b2 = w->b2 + 128 * h; f.ls = nullptr; f.eps = 0.f;
+      f.nch = nch; f.ldy = N; f.col_off = 128 * h;
+      if (!unique) { f.in_rows = L; f.in_src = Tsrc; }
+      SEPR_TRY(launch_glumlp_fused(f, F, SEPR_SITE_OUT, st));
+    }
+  } else {
   {  // Linear F->4F, GLU                                                   (module.py:250-252, model.py:49)
     GemmArgs a = gemm_args_zero();
     a.M = (int)Mp; a.N = 4 * F; a.K = F;
@@ -413,6 +444,7 @@ extern "C" int sepr_outlayer_decoder_fwd(const float* x, int nS, int S, int Tsrc
     a.M = (int)Mp; a.N = N; a.K = 2 * F;
     a.A = o1; a.lda = 2 * F; a.W = w->w2; a.bias = w->b2; a.Y = o2; a.ldc = N;
     SEPR_TRY(project(PRO_PLAIN, EPI_STORE, a, w->x3_2, SEPR_SITE_OUT, st));
+  }
   }
   // ReLU(.) * encoder_output for the auxiliary heads (module.py:257-260, network.py:41) + ConvTranspose1d (:278-283)
   const int Tout = (L - 1) * stride + K;

@@ -45,6 +45,11 @@ struct GcfnFusedArgs {
   const float* ls;    // [F]
   float eps;
   int stagger;        // s_sleep units (64 clocks each) by which every other co-resident workgroup starts late; 0 = off
+  // MODE 1 (plain GLU-MLP: y = W2 . GLU(W1 x + b1) + b2, no LayerNorm / conv / residual / LayerScale - SpkSplit, OutputLayer):
+  int nch;            // hidden chunks of 32 value + 32 gate channels (GCFN: 3F/32)
+  int ldy, col_off;   // output row stride in floats and first output column (one launch writes F columns of a wider tensor)
+  int in_rows, in_src;          // in_rows > 0: input row of frame m is (m / in_rows) * in_src + m % in_rows (crop of every sequence)
+  int out_T, out_S, out_s;      // out_S > 0: output row of frame m is ((m / out_T) * out_S + out_s) * out_T + m % out_T (speaker split)
 };
 
 __device__ __forceinline__ float dpp_ror1(float v) {   // lane i <- lane (i-1) mod 16 of its 16-lane row
@@ -93,8 +98,9 @@ struct bool_c { static constexpr bool value = V; };
 #ifndef SEPR_GF3_XCH
 #define SEPR_GF3_XCH 1
 #endif
-template <int F, int MT, int NW>
+template <int F, int MT, int NW, int MODE = 0>
 __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
+  constexpr bool PLAIN = MODE == 1;   // frames are independent: no halo, no seam exchange, no conv
   static_assert(MT == 1 || MT == 2, "frame tiles per wave");
   constexpr int RD = SEPR_GF3_RING;      // LDS fragment read-ahead, in MFMA groups
   constexpr bool UF = SEPR_GF3_UPFIRST != 0;
@@ -104,12 +110,13 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
   // two frames at the workgroup's ends are recomputed halo: 126 outputs per 128 frames instead of 120, and - what
   // matters more - 64000 x 2^k rows are then just under 512 x 2^k tiles, i.e. full launch rounds instead of
   // "one round + a 4 % tail" (534 tiles on 512 slots).  Without XCH every wave carries its own two halo frames.
-  constexpr bool XCH = (SEPR_GF3_XCH != 0) && MT == 2 && UF;
-  constexpr int WSTR = XCH ? 16 * MT : 16 * MT - 2;            // frames a wave advances
-  constexpr int GF_TILE = XCH ? NW * 16 * MT - 2 : NW * (16 * MT - 2);   // output frames per workgroup tile
+  constexpr bool XCH = (SEPR_GF3_XCH != 0) && MT == 2 && UF && !PLAIN;
+  constexpr int HALO = PLAIN ? 0 : 1;
+  constexpr int WSTR = (XCH || PLAIN) ? 16 * MT : 16 * MT - 2;            // frames a wave advances
+  constexpr int GF_TILE = XCH ? NW * 16 * MT - 2 : NW * WSTR;   // output frames per workgroup tile
   constexpr int EH = (16 * MT * NW + 63) / 64;   // epilogue passes of up to 64 frames
   constexpr int KS = F / 32;
-  constexpr int NCH = 3 * F / 32;
+  const int NCH = PLAIN ? a.nch : 3 * F / 32;
   constexpr int FT = F / 16;
   constexpr int W1F_U4 = 4 * KS * 2 * 64;
   constexpr int CS_U4 = 256;
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     dma_w1(0);
     dma_w2(0);
     // ---- this wave's 32 frames (lane fi holds frames 2*fi and 2*fi+1): load, LayerNorm, split --------------
-    const int mw0 = tile * GF_TILE + w * WSTR - 1;              // wave frame 0 (tile frame 0 is halo)
+    const int mw0 = tile * GF_TILE + w * WSTR - HALO;           // wave frame 0 (GCFN: tile frame 0 is halo)
     bf16x8 xh[MT][KS], xl[MT][KS];
     float f0[MT], f2[MT];                                        // conv zero-padding flags (sequence start / end)
     bool edge_lane = false;
@@ -191,11 +198,13 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mw0 + MT * fi + mt;
       const bool valid = (m >= 0 && m < a.M);
-      const int trow = valid ? m % a.T : -2;
+      const int trow = (valid && !PLAIN) ? m % a.T : -2;
       f0[mt] = (trow == 0) ? 0.f : 1.f;
       f2[mt] = (trow == a.T - 1) ? 0.f : 1.f;
       edge_lane = edge_lane || trow == 0 || trow == a.T - 1;
-      const float* xp = a.x + (long long)(valid ? m : 0) * F + 8 * fg;
+      long long mi = valid ? m : 0;
+      if (PLAIN && a.in_rows > 0) mi = (long long)(mi / a.in_rows) * a.in_src + mi % a.in_rows;
+      const float* xp = a.x + mi * F + 8 * fg;
       float v[KS][8];
       float s = 0.f;
 #pragma unroll
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
       }
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      const float mean = s * (1.0f / F);
+      const float mean = PLAIN ? 0.f : s * (1.0f / F);
       float d = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
         }
       d += __shfl_xor(d, 16, 64);
       d += __shfl_xor(d, 32, 64);
-      const float rstd = valid ? 1.0f / sqrtf(d * (1.0f / F) + a.eps) : 0.f;   // invalid frames: exactly zero
+      const float rstd = valid ? (PLAIN ? 1.0f : 1.0f / sqrtf(d * (1.0f / F) + a.eps)) : 0.f;   // invalid frames: exactly zero
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         bf16x8 h, l;
@@ -321,6 +330,18 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
           }
           }
           if (!do_conv) continue;
+          if (PLAIN) {   // no conv: GLU straight on the projection (the gate rows of W1 / b1 are pre-scaled by -log2 e)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float g1 = glu_prescaled(hv[mt][r], hg[mt][r]);
+                const __bf16 hh = (__bf16)g1;
+                gh[mt][4 * j + r] = hh;
+                gw[mt][4 * j + r] = (__bf16)(g1 - (float)hh);
+              }
+            continue;
+          }
           // ---- depthwise k=3 conv along frames, GLU ---------------------------------------------------------
           // frame 2*fi+mt: tile 0's previous frame is the left lane's tile-1 value, its next frame the lane's own
           // tile-1 value (and mirrored for tile 1); the rotations wrap onto the two halo frames only.
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     constexpr int RPP = NT / Q;              // rows per pass
     constexpr int NP = (64 + RPP - 1) / RPP;
     const int q4 = tid % Q, rr = tid / Q;
-    const float4 b2 = ld4(a.b2 + 4 * q4), lsv = ld4(a.ls + 4 * q4);
+    const float4 b2 = ld4(a.b2 + 4 * q4), lsv = PLAIN ? zero4() : ld4(a.ls + 4 * q4);
 #pragma unroll 1
     for (int half = 0; half < EH; ++half) {
       if (half > 0) __syncthreads();   // previous pass fully stored (the chunk loop ended on a barrier)
@@ -426,12 +447,12 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
       for (int p = 0; p < NP; ++p) {
         const int row = rr + p * RPP;          // 0..63: WPP waves x 16*MT frames
         const int ww = WPP * half + row / (16 * MT), lr = row % (16 * MT);
-        const int bf = ww * WSTR + lr;                           // frame inside the workgroup tile (0 = halo)
-        const int m = tile * GF_TILE - 1 + bf;
+        const int bf = ww * WSTR + lr;                           // frame inside the workgroup tile (GCFN: 0 = halo)
+        const int m = tile * GF_TILE - HALO + bf;
         const bool ok = row < 64 && ww < NW && m < a.M &&
-                        (XCH ? (bf >= 1 && bf <= GF_TILE) : (lr >= 1 && lr <= 16 * MT - 2));
+                        (PLAIN ? true : (XCH ? (bf >= 1 && bf <= GF_TILE) : (lr >= 1 && lr <= 16 * MT - 2)));
         mrow[p] = ok ? m : -1;
-        xr[p] = ld4(a.x + (long long)(ok ? m : 0) * F + 4 * q4);
+        xr[p] = PLAIN ? zero4() : ld4(a.x + (long long)(ok ? m : 0) * F + 4 * q4);
       }
       if (w / WPP == half) {
         float* base = Os + (w % WPP) * (16 * MT) * OS;
@@ -450,9 +471,15 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
         for (int p = 0; p < NP; ++p) {
           if (mrow[p] >= 0) {
             const float4 o = ld4(Os + (rr + p * RPP) * OS + 4 * q4);
-            st4(a.y + (long long)mrow[p] * F + 4 * q4,
-                make_float4(fmaf(o.x + b2.x, lsv.x, xr[p].x), fmaf(o.y + b2.y, lsv.y, xr[p].y),
-                            fmaf(o.z + b2.z, lsv.z, xr[p].z), fmaf(o.w + b2.w, lsv.w, xr[p].w)));
+            if (PLAIN) {
+              long long mo = mrow[p];
+              if (a.out_S > 0) mo = ((long long)(mo / a.out_T) * a.out_S + a.out_s) * a.out_T + mo % a.out_T;
+              st4(a.y + mo * a.ldy + a.col_off + 4 * q4, make_float4(o.x + b2.x, o.y + b2.y, o.z + b2.z, o.w + b2.w));
+            } else {
+              st4(a.y + (long long)mrow[p] * F + 4 * q4,
+                  make_float4(fmaf(o.x + b2.x, lsv.x, xr[p].x), fmaf(o.y + b2.y, lsv.y, xr[p].y),
+                              fmaf(o.z + b2.z, lsv.z, xr[p].z), fmaf(o.w + b2.w, lsv.w, xr[p].w)));
+            }
           }
         }
       }
@@ -470,6 +497,27 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
 #define SEPR_GF3_MT 2   // v3 frame tiles per wave: 2 -> 4 waves x 30 frames (2 waves per SIMD), 1 -> 6 waves x 14 frames (3 per SIMD)
 #endif
 [[maybe_unused]] constexpr int GF3_MT = SEPR_GF3_MT, GF3_NW = (SEPR_GF3_MT == 1) ? 6 : 4;
+
+// Plain GLU-MLP (MODE 1): one launch computes F = 128 output columns; a wider output takes one launch per 128 columns
+// (the up-projection is recomputed: 1.5x the MFMAs of a single pass, still ~2.5x faster than two generic projections with the
+// [rows, hidden] tensor through HBM).
+int launch_glumlp_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream) {
+  if (a.M <= 0) return SEPR_OK;
+  if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || a.nch <= 0 || a.ldy < F || a.x == a.y || F != 128) return SEPR_EINVAL;
+  long long slot = -1;
+  const bool timed = prof_begin(site, stream, &slot);
+  const int cap = persistent_grid();
+  if (a.M < 12000) {
+    const int ntiles = (a.M + 95) / 96;
+    hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 1>), dim3(ntiles < cap ? ntiles : cap), dim3(384), 0, stream, a);
+  } else {
+    const int ntiles = (a.M + 127) / 128;
+    hipLaunchKernelGGL((gcfn_fused3_kernel<128, 2, 4, 1>), dim3(ntiles < cap ? ntiles : cap), dim3(256), 0, stream, a);
+  }
+  if (timed) prof_end(slot, (double)a.M * (2.0 * F * 64.0 * a.nch + 2.0 * 32.0 * a.nch * F), stream);
+  SEPR_CHECK_LAUNCH("glumlp_fused_kernel");
+  return SEPR_OK;
+}
 
 int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t stream) {
   if (a_in.M <= 0) return SEPR_OK;

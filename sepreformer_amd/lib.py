@@ -52,9 +52,9 @@ class EgaW(C.Structure):
 
 
 DownW = _struct("DownW", ["w", "scale", "shift"])
-SplitW = _struct("SplitW", ["w1", "b1", "w2", "b2", "gn_g", "gn_b"], ["x3_1", "x3_2"])
+SplitW = _struct("SplitW", ["w1", "b1", "w2", "b2", "gn_g", "gn_b"], ["x3_1", "x3_2"], ["fused_w1p", "fused_w2p"])
 FuseW = _struct("FuseW", ["w", "b"], ["x3"])
-OutW = _struct("OutW", ["w1", "b1", "w2", "b2", "wdec"], ["x3_1", "x3_2"])
+OutW = _struct("OutW", ["w1", "b1", "w2", "b2", "wdec"], ["x3_1", "x3_2"], ["fused_w1p", "fused_w2p"])
 
 _i, _f, _sz, _ll = C.c_int, C.c_float, C.c_size_t, C.c_longlong
 _u64, _d = C.c_ulonglong, C.c_double

@@ -59,6 +59,7 @@ class Packed:
         self.fuse_spk = os.environ.get("SEPR_FUSE_SPK", "1") != "0"       # A/B switch for the fused speaker attention
         self.fuse_cla = os.environ.get("SEPR_FUSE_CLA", "1") != "0"       # A/B switch for the fused CLA head / tail
         self.fuse_gate = os.environ.get("SEPR_FUSE_GATE", "1") != "0"     # A/B switch for the fused EGA gate
+        self.fuse_mlp = os.environ.get("SEPR_FUSE_MLP", "1") != "0"       # A/B switch for the fused SpkSplit / OutputLayer GLU-MLP
         self.keep: List[torch.Tensor] = []
 
     def t(self, x: torch.Tensor) -> int:
@@ -78,6 +79,15 @@ class Packed:
         wp = pack_x3(w64.float())
         self.keep.append(wp)
         return L.X3W(wp=wp.data_ptr(), bias=self.t(b64.float()))
+
+    def glumlp_fused(self, w1, b1, w2) -> dict:
+        """Fused Linear -> GLU -> Linear (SpkSplit, OutputLayer) for F = 128 in bf16x3 mode; ``{}`` otherwise."""
+        F, H, N = w1.shape[1], w1.shape[0] // 2, w2.shape[0]
+        if self.precision != "bf16x3" or F != 128 or H % 32 or N % 128 or not self.fuse_mlp:
+            return {}
+        w1p, w2p = pack_glumlp_fused(w1, b1, w2)
+        self.keep += [w1p, w2p]
+        return {"fused_w1p": w1p.data_ptr(), "fused_w2p": w2p.data_ptr()}
 
     def gcfn_fused(self, sd, p: str) -> dict:
         """Fused-GCFN weight forms (bf16x3 mode, F in {64, 128}); empty dict otherwise."""
@@ -185,6 +195,40 @@ def pack_gcfn_fused(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.Tensor, bet
     r = torch.arange(4, device=dev)[None, None, :]
     rows = (32 * (ft // 2) + 8 * q + 4 * (ft % 2) + r).reshape(-1)
     w2p = _kslot_frags(w2.detach()[rows], nch)
+    return w1p, w2p
+
+
+def pack_glumlp_fused(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor):
+    """Weights of the plain GLU-MLP mode of the fused GCFN kernel (``gcfn_fused3_kernel<..., MODE = 1>``):
+    ``y = w2 . GLU(w1 x + b1)`` with ``w1`` ``[2H, F]`` (value rows, then gate rows), ``w2`` ``[N, H]``, N a multiple of 128.
+
+    * ``w1p``: per 32-channel hidden chunk the fragments ``[v0 v1 g0 g1][F/32][2][64][8]`` bf16 + the 4 KB constants block of
+      ``pack_gcfn_fused`` with only the biases filled in; the gate rows and their bias carry the -log2(e) of ``glu_prescaled``;
+    * ``w2p`` ``[N/128][H/32][8][2][64][8]`` bf16: for every block of 128 output channels the K slices in k-slot order with the
+      tile-pair row interleave of ``pack_gcfn_fused`` (one kernel launch per block)."""
+    F, H, N = w1.shape[1], w1.shape[0] // 2, w2.shape[0]
+    nch = H // 32
+    dev = w1.device
+    gscale = torch.ones(2 * H, dtype=torch.float64, device=dev)
+    gscale[H:] = -1.4426950408889634
+    w1f = (w1.detach().double() * gscale[:, None]).float()
+    b1f = (b1.detach().double() * gscale).float()
+    chunks = []
+    for c in range(nch):
+        rows = [w1f[(0 if t < 2 else H) + 32 * c + 16 * (t & 1):][:16] for t in range(4)]
+        frag = _split_frag(torch.cat(rows, 0)).contiguous().view(torch.uint8).reshape(-1)
+        cst = torch.zeros(1024, dtype=torch.float32, device=dev)
+        for j in range(2):
+            v = 32 * c + 16 * j
+            cst[j * 160:j * 160 + 16] = b1f[v:v + 16]
+            cst[j * 160 + 16:j * 160 + 32] = b1f[H + v:H + v + 16]
+        chunks.append(torch.cat([frag, cst.view(torch.uint8)]))
+    w1p = torch.stack(chunks, 0).contiguous()
+    ft = torch.arange(8, device=dev)[:, None, None]
+    q = torch.arange(4, device=dev)[None, :, None]
+    r = torch.arange(4, device=dev)[None, None, :]
+    rows = (32 * (ft // 2) + 8 * q + 4 * (ft % 2) + r).reshape(-1)
+    w2p = torch.stack([_kslot_frags(w2.detach()[128 * h:128 * h + 128][rows], nch) for h in range(N // 128)], 0).contiguous()
     return w1p, w2p
 
 
@@ -336,7 +380,8 @@ def pack_split(pk: Packed, sd, p: str) -> L.SplitW:
         w2=pk.t(sd[p + ".linear.2.weight"][:, :, 0]), b2=pk.t(sd[p + ".linear.2.bias"]),
         gn_g=pk.t(sd[p + ".norm.weight"]), gn_b=pk.t(sd[p + ".norm.bias"]),
         x3_1=pk.x3(sd[p + ".linear.0.weight"][:, :, 0], sd[p + ".linear.0.bias"]),
-        x3_2=pk.x3(sd[p + ".linear.2.weight"][:, :, 0], sd[p + ".linear.2.bias"]))
+        x3_2=pk.x3(sd[p + ".linear.2.weight"][:, :, 0], sd[p + ".linear.2.bias"]),
+        **pk.glumlp_fused(sd[p + ".linear.0.weight"][:, :, 0], sd[p + ".linear.0.bias"], sd[p + ".linear.2.weight"][:, :, 0]))
 
 
 def pack_fuse(pk: Packed, sd, p: str) -> L.FuseW:
@@ -350,7 +395,8 @@ def pack_out(pk: Packed, sd, p: str, dec_weight: torch.Tensor) -> L.OutW:
         w2=pk.t(sd[p + ".end_conv1x1.2.weight"]), b2=pk.t(sd[p + ".end_conv1x1.2.bias"]),
         wdec=pk.t(_tapmajor(dec_weight)),
         x3_1=pk.x3(sd[p + ".end_conv1x1.0.weight"], sd[p + ".end_conv1x1.0.bias"]),
-        x3_2=pk.x3(sd[p + ".end_conv1x1.2.weight"], sd[p + ".end_conv1x1.2.bias"]))
+        x3_2=pk.x3(sd[p + ".end_conv1x1.2.weight"], sd[p + ".end_conv1x1.2.bias"]),
+        **pk.glumlp_fused(sd[p + ".end_conv1x1.0.weight"], sd[p + ".end_conv1x1.0.bias"], sd[p + ".end_conv1x1.2.weight"]))
 
 
 class PackedModel(Packed):

@@ -174,6 +174,52 @@ def test_struct_layouts_match_header():
     assert [f for f, _ in L.EgaW._fields_] == ["attn", "gate_ln_g", "gate_ln_b", "gate_w", "gate_b", "pe_k", "maxlen", "x3_gate", "fused_gate_p"]
 
 
+def test_pack_glumlp_fused_layout():
+    """Fused Linear -> GLU -> Linear packing (SpkSplit / OutputLayer, csrc gcfn_fused3_kernel MODE 1): decode the chunked
+    up-projection fragments (gate rows carry -log2 e), the constants block and the per-128-column down-projection blocks with
+    their k-slot order and tile-pair row interleave; the decoded matrices must reproduce ``w2 . GLU(w1 x + b1)``."""
+    from sepreformer_amd.pack import pack_glumlp_fused
+    g = torch.Generator().manual_seed(3)
+    F, H, N = 128, 96, 256
+    w1, b1 = torch.randn(2 * H, F, generator=g) * 0.1, torch.randn(2 * H, generator=g) * 0.1
+    w2 = torch.randn(N, H, generator=g) * 0.1
+    w1pb, w2p = pack_glumlp_fused(w1, b1, w2)
+    nch, KS = H // 32, F // 32
+    nfrag = 4 * KS * 2 * 64 * 8 * 2
+    assert tuple(w1pb.shape) == (nch, nfrag + 4096) and tuple(w2p.shape) == (N // 128, nch, 8, 2, 64, 8)
+    w1p = w1pb[:, :nfrag].contiguous().view(torch.bfloat16).view(nch, 4, KS, 2, 64, 8)
+    cst = w1pb[:, nfrag:].contiguous().view(torch.float32).view(nch, 1024)
+    W1 = torch.zeros(2 * H, F, dtype=torch.float64)
+    B1 = torch.zeros(2 * H, dtype=torch.float64)
+    w1s = w1p[:, :, :, 0].double() + w1p[:, :, :, 1].double()
+    for c in range(nch):
+        for j in range(2):
+            B1[32 * c + 16 * j:][:16] = cst[c, j * 160:j * 160 + 16].double()
+            B1[H + 32 * c + 16 * j:][:16] = cst[c, j * 160 + 16:j * 160 + 32].double()
+        for t in range(4):
+            base = (0 if t < 2 else H) + 32 * c + 16 * (t & 1)
+            for ks in range(KS):
+                for gq in range(4):
+                    for i in range(16):
+                        W1[base + i, 32 * ks + 8 * gq: 32 * ks + 8 * gq + 8] = w1s[c, t, ks, gq * 16 + i]
+    W2 = torch.zeros(N, H, dtype=torch.float64)
+    w2s = w2p[:, :, :, 0].double() + w2p[:, :, :, 1].double()        # [half, c, ft, lane, 8]
+    for h in range(N // 128):
+        for c in range(nch):
+            for ft in range(8):
+                for gq in range(4):
+                    for i in range(16):
+                        for e in range(8):
+                            n = 4 * gq + e if e < 4 else 16 + 4 * gq + e - 4
+                            W2[128 * h + 32 * (ft // 2) + 8 * (i // 4) + 4 * (ft % 2) + i % 4, 32 * c + n] = w2s[h, c, ft, gq * 16 + i, e]
+    x = torch.randn(5, F, generator=g).double()
+    hcalc = x @ W1.t() + B1
+    y = (hcalc[:, :H] / (1.0 + torch.exp2(hcalc[:, H:]))) @ W2.t()          # value * rcp(1 + exp2(pre-scaled gate))
+    href = x @ w1.double().t() + b1.double()
+    yref = (href[:, :H] * torch.sigmoid(href[:, H:])) @ w2.double().t()
+    assert float((y - yref).abs().max() / yref.abs().max()) < 1e-4
+
+
 def test_pack_x3_layout_and_split():
     """bf16x3 packing: fragment order and hi+lo reconstruction (error <= 2^-16 relative)."""
     from sepreformer_amd.pack import pack_x3
