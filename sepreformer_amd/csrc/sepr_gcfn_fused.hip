@@ -22,6 +22,10 @@
 //   * epilogue: bias, LayerScale, residual; staged through LDS two waves at a time for row-contiguous stores.
 // Two 4-wave workgroups share a CU (48 KB LDS each): one copies its next weight chunk while the other
 // multiplies.
+//
+// The same kernel has a plain mode (template parameter MODE = 1): Linear -> GLU -> Linear without LayerNorm, conv,
+// LayerScale and residual, with a runtime hidden width and input / output row maps - SpkSplitStage's two 1x1 convolutions
+// (modules/module.py:114-116,123) and OutputLayer's two projections (:250-256), one launch per 128 output columns.
 #include "sepr_gemm_epi.h"
 #include <stdlib.h>
 
