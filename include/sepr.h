@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SEPR_VERSION 201 /* major*10000 + minor*100 + patch */
+#define SEPR_VERSION 300 /* major*10000 + minor*100 + patch */
 
 #define SEPR_OK 0
 #define SEPR_EINVAL (-1)     /* bad shape / unsupported size / null pointer */
@@ -290,16 +290,22 @@ int sepr_pit_sisnr_mag_fwd(const float* est, const float* tgt, int S, int B, int
 /*     block's input x alive in between); `ws` is scratch of sepr_train_ws_bytes(op, ...) bytes;                      */
 /*   - parameter gradients are ACCUMULATED (+=) into fp32 buffers laid out exactly like the reference parameters      */
 /*     (e.g. depthwise.weight [C,1,K]); the caller zeroes them once per step; activation gradients are overwritten;   */
-/*   - a projection travels as sepr_lin: exact-f32 form (w: fp32 [N][K] row-major) or bf16x3 form (wp: pack_x3         */
-/*     fragments), never both; b may be NULL.  The host packs, per weight version, the forward form and the            */
+/*   - a projection travels as sepr_lin: exact-f32 form (w: fp32 [N][K] row-major) or packed-bf16 form (wp: pack_x3    */
+/*     fragments, hi and lo planes), never both; b may be NULL.  `planes` selects the arithmetic of the packed form:   */
+/*     0 or 3 = bf16x3 (hi.hi + hi.lo + lo.hi, ~2^-16), 1 = plain bf16 operands (one MFMA per product, fp32           */
+/*     accumulate: the "bf16" training precision of BASELINE configs[4]; activations are rounded to bf16 on the fly,   */
+/*     the lo plane is ignored).  The host packs, per weight version, the forward form and the                         */
 /*     transposed form the input gradient needs, with LayerNorm / GroupNorm affines and LayerScale folded in           */
 /*     (sepreformer_amd/train_pack.py); the raw parameters ride along for the gradient finishers;                      */
 /*   - train-mode BatchNorm uses batch statistics over (sequences x frames) and updates running_mean / running_var     */
 /*     in place (momentum 0.1, unbiased variance), like torch.nn.BatchNorm1d (network.py:167, module.py:69);          */
 /*   - dropout (network.py:55,57,87,121,124,171): inverted dropout from a counter-based generator keyed by             */
 /*     (seed, element index); p_drop = 0 disables it exactly; the backward regenerates the masks from the same seed.  */
+/*     (The fused GCFN pair - sepr_gcfn_train_fwd / sepr_gcfn_bwd with fused_w1p set - draws its two sites from a      */
+/*     cheaper 16-bit-per-element generator, csrc/sepr_train.h sepr_drop_word: p is quantised to p_eff = round(p *     */
+/*     65536) / 65536 and the kept values are scaled by 1 / (1 - p_eff).)                                             */
 /* ================================================================================================================= */
-typedef struct { const float* w; const void* wp; const float* b; } sepr_lin;
+typedef struct { const float* w; const void* wp; const float* b; int planes; } sepr_lin;
 typedef unsigned long long sepr_u64;
 
 /* GCFN, modules/network.py:46-66 */
@@ -312,6 +318,11 @@ typedef struct {
   const float* dw_b; /* [6F] */
   const float* ls;   /* [F] */
   const float* w1; const float* ln_g; const float* ln_b; const float* w2; const float* b2;   /* raw parameters */
+  /* Optional fused form (F in {64, 128}; train_pack.py): the forward is then ONE launch of the fused inference kernel
+   * (sepr_gcfn_fwd's, with both dropout sites and a LayerNorm-statistics side output) that keeps only the per-row
+   * statistics, and the backward recomputes the hidden tensor inside its middle kernel (csrc/sepr_gcfn_bwd_fused.hip).
+   * fused_w1p / fused_w2p exactly as in sepr_gcfn_w.  NULL fused_w1p = the unfused path. */
+  const void* fused_w1p; const void* fused_w2p;
 } sepr_gcfn_tw;
 typedef struct { float* ln_g; float* ln_b; float* w1; float* b1; float* dw_w; float* dw_b; float* w2; float* b2; float* ls; } sepr_gcfn_grad;
 
@@ -378,7 +389,7 @@ typedef struct {
 typedef struct { float* w_enc /* [N,1,K] */; float* gn_g; float* gn_b; float* proj_w; } sepr_front_grad;
 
 enum { SEPR_TOP_GCFN = 0, SEPR_TOP_CLA, SEPR_TOP_EGA, SEPR_TOP_SPKATTN, SEPR_TOP_DOWN, SEPR_TOP_SPLIT, SEPR_TOP_FUSE, SEPR_TOP_OUT,
-       SEPR_TOP_FRONT, SEPR_TOP_COUNT };
+       SEPR_TOP_FRONT, SEPR_TOP_GCFN_FUSED /* sizes of the fused GCFN pair (sepr_gcfn_tw.fused_w1p != NULL) */, SEPR_TOP_COUNT };
 /* n sequences of T frames (Tp: pooled frames for EGA, source frames for OUT, padded frames Lp for FRONT), width F, encoder
  * channels N, S speakers, K = depthwise taps where the op has them (CLA 65, DOWN 5; else ignored). */
 size_t sepr_train_ctx_bytes(int op, int n, int T, int Tp, int F, int N, int S, int H);
@@ -439,7 +450,8 @@ int sepr_front_bwd(const float* wav, const float* enc, const float* dout, float*
                    int Lp, const sepr_front_tw* w, const sepr_front_grad* g, const void* ctx, size_t ctx_bytes, void* ws,
                    size_t ws_bytes, sepr_stream_t stream);
 
-/* G[N][K] (+)= sum_m A[m][n] B[m][k]: the weight-gradient contraction on its own (tests, roofline bench).  x3 != 0: bf16x3. */
+/* G[N][K] (+)= sum_m A[m][n] B[m][k]: the weight-gradient contraction on its own (tests, roofline bench).
+ * x3: 0 = exact f32 MFMA, 1 = bf16x3, 2 = plain bf16 operands. */
 size_t sepr_linear_wgrad_workspace(int M, int N, int K);
 int sepr_linear_wgrad(const float* A, const float* B, float* G, float* colsum, int M, int N, int K, int accumulate, int x3, void* ws,
                       size_t ws_bytes, sepr_stream_t stream);
@@ -459,7 +471,8 @@ size_t sepr_pit_sisnr_mag_bwd_workspace(int S, int B, int T, int frame_len, int 
 enum {
   SEPR_SITE_NONE = 0, SEPR_SITE_GCFN_UP, SEPR_SITE_GCFN_DOWN, SEPR_SITE_CLA, SEPR_SITE_ATTN_PROJ,
   SEPR_SITE_EGA_GATE, SEPR_SITE_SPLIT, SEPR_SITE_FUSE, SEPR_SITE_OUT, SEPR_SITE_PROJECTOR,
-  SEPR_SITE_LINEAR, SEPR_SITE_WGRAD /* gemm_tn (training) */, SEPR_SITE_COUNT
+  SEPR_SITE_LINEAR, SEPR_SITE_WGRAD /* gemm_tn (training) */, SEPR_SITE_GCFN_BWD /* fused GCFN backward middle */,
+  SEPR_SITE_COUNT
 };
 /* Start bracketing every launch of `site` with hipEvents on its own stream (up to max_launches). */
 int sepr_prof_start(int site, int max_launches);

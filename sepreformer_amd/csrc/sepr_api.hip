@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include "sepr_gemm_epi.h"
+#include "sepr_gcfn_fused.h"
 #include "sepr_pointwise.h"
 #include <stdlib.h>
 
@@ -15,15 +16,6 @@ void set_hip_error(hipError_t e, const char* where) {
 
 static const float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default (network.py:50,81,133,162)
 
-struct GcfnFusedArgs {   // (layout of sepr_gcfn_fused.hip)
-  const float* x; float* y; int M, T;
-  const void* w1p; const void* w2p;
-  const float* b2; const float* ls; float eps;
-  int stagger;
-  int nch, ldy, col_off, in_rows, in_src, out_T, out_S, out_s;   // plain GLU-MLP mode only
-};
-int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream);   // sepr_gcfn_fused.hip
-int launch_glumlp_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream);
 struct SpkFusedArgs {
   const float* x;
   float* y;

@@ -1,0 +1,418 @@
+// Fused middle of the GCFN backward (reference modules/network.py:46-66 under torch.autograd).
+//
+// The fused train forward (sepr_gcfn_fused.hip, TRAIN instantiation) keeps nothing of a GCFN block but the LayerNorm
+// statistics of its input rows: neither the [rows, 6F] hidden tensor h1 nor the [rows, 3F] gated tensor ever reach HBM.
+// This kernel is the backward's counterpart.  Per tile of 60 frames x 64 hidden (value, gate) channel pairs it
+//   1. recomputes  h1 = LN(x) . (W1 gamma)^T + b1'                      (MFMA, K = F; the forward's up-projection)
+//   2. computes    dgd = dropout1(dy) . (ls W2)                          (MFMA, K = F; input gradient of net2.2 + LayerScale)
+//   3. from an LDS tile: depthwise k=3 conv, GLU, the gated-tensor dropout, the GLU backward and the conv's transpose:
+//        c = b + w0 h[t-1] + w1 h[t] + w2 h[t+1],  gated = c_v sigmoid(c_g),  g = drop0(gated)      -> g   [rows, 3F]
+//        dc_v = drop0'(dgd) sig,  dc_g = drop0'(dgd) c_v sig (1 - sig)
+//        dh1[t] = w0 dc[t+1] + w1 dc[t] + w2 dc[t-1]                                                -> dh1 [rows, 6F]
+//        dw_k += sum_t dc[t] h[t+k-1],  db += sum_t dc[t]      (per-tile partials, fixed-order reduction afterwards)
+// and - when the output dropout is live - writes dropout1(dy) once for the weight-gradient contraction of net2.2.
+// It replaces the dropout pass over dy, the 3F-wide input-gradient projection and the GLU / conv middle kernel of the
+// unfused backward (and their [rows, 3F] / [rows, 6F] round trips: 9 KB per row at F = 128 instead of 17 KB), and makes
+// the 9F + 2 floats per row the unfused forward had to save unnecessary (1.1 GB per 4 s utterance for Base).
+//
+// Structure: the generic projection core's (sepr_gemm_x3.h) - activations fp32 -> registers -> normalise / mask -> bf16
+// planes in LDS (double buffered), packed weight fragments L2 -> VGPR, wave tile = 64 rows x (16 value + 16 gate + 16
+// gradient columns), four waves side by side - with two accumulation phases and the row-window epilogue above.  Rows
+// m0-2 .. m0+61 are computed per tile (two halo frames on each side: dh1[t] needs dc[t+-1], which needs h1[t+-2]).
+// PLANES = 3: bf16x3 split arithmetic; PLANES = 1: plain bf16 operands (the "bf16" training precision).
+#include "sepr_train.h"
+
+namespace sepr {
+
+typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int GB_BM = 64;            // rows per tile (incl. halo)
+constexpr int GB_OUT = GB_BM - 4;    // rows a tile outputs
+constexpr int GB_BKS = 64;           // K extent of one LDS slab
+constexpr int GB_LDK = GB_BKS + 16;  // bf16 per LDS row (160 B: conflict-free 16-byte fragment reads)
+constexpr int GB_HS = 128 + 4;       // fp32 row stride of the h1 / dc tile (64 value + 64 gate columns)
+constexpr int GB_DS = 64 + 4;        // fp32 row stride of the dgd tile
+constexpr int GB_THREADS = 256;
+
+struct GcfnBwdArgs {
+  const float* x;       // [M][F] block input
+  const float* stats;   // [M][2] (mean, rstd) of the input rows, from the forward
+  const float* dy;      // [M][F] gradient w.r.t. the block output
+  int M, T, F;
+  const void* w1p;      // pack_x3 fragments of W1 * gamma [6F][F]        (sepr_gcfn_tw.up.wp)
+  const float* b1;      // [6F] net1.1.bias + W1 . beta                   (sepr_gcfn_tw.up.b)
+  const void* w2tp;     // pack_x3 fragments of (ls * W2)^T [3F][F]       (sepr_gcfn_tw.down_t.wp)
+  const float* dw_w;    // [3][6F] depthwise taps, tap-major
+  const float* dw_b;    // [6F]
+  float* g;             // out [M][3F] gated tensor after its dropout (the input net2.2 multiplied)
+  float* dh1;           // out [M][6F] gradient w.r.t. the up-projection's output
+  float* dyq;           // out [M][F] dropout1(dy), or null (no output dropout: the contraction reads dy itself)
+  float* part;          // out [MB][3F][8] depthwise weight / bias gradient partials (w0 w1 w2 b of the value, then of the gate)
+  unsigned drop_thr;    // 16-bit keep threshold of both sites (0 = no dropout)
+  float drop_scale;     // 1 / (1 - p_eff)
+  unsigned long long seed;
+  const unsigned long long* salt;
+};
+
+template <int PLANES>
+__global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnBwdArgs a) {
+  constexpr bool ONE = PLANES == 1;
+  constexpr int NP = ONE ? 1 : 2;                              // bf16 planes per LDS buffer
+  constexpr int PLANE_E = GB_BM * GB_LDK;                      // elements of one plane
+  constexpr size_t SLAB_B = sizeof(unsigned short) * 2 * NP * PLANE_E;
+  constexpr size_t TILE_B = sizeof(float) * GB_BM * (GB_HS + GB_DS);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SLAB_B > TILE_B ? SLAB_B : TILE_B];
+  unsigned short* const slab = reinterpret_cast<unsigned short*>(smem);
+  float* const Hs = reinterpret_cast<float*>(smem);            // [64][GB_HS]: h1 (+ b1), later dc   (aliases the slab buffers)
+  float* const Ds = Hs + GB_BM * GB_HS;                        // [64][GB_DS]: dgd, later the reduction scratch
+
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int F = a.F, C3 = 3 * F;
+  const int NB = C3 / 64;
+  const int MB = (a.M + GB_OUT - 1) / GB_OUT;
+  const int ntiles = ((MB + 7) / 8) * 8 * NB;
+  const int nsl = F / GB_BKS, kst = F / 32;
+  const uint4* const W1 = static_cast<const uint4*>(a.w1p);
+  const uint4* const W2 = static_cast<const uint4*>(a.w2tp);
+  const bool drop = a.drop_thr > 0u;
+  DropKey dk0 = {0u, 0u}, dk1 = {0u, 0u};
+  if (drop) {
+    dk0 = sepr_drop_key(a.seed, a.salt, 0u);
+    dk1 = sepr_drop_key(a.seed, a.salt, 1u);
+  }
+  // staging role: one row per 4 threads, 16 consecutive k per thread and slab
+  const int srow = tid >> 2, kq = (tid & 3) * 16;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // same row tile -> same XCD for all its column blocks (block b runs on XCD b % 8): x / dy rows are fetched once per L2
+    const int u = tile >> 3;
+    const int mb = (u / NB) * 8 + (tile & 7), nb = u % NB;
+    if (mb >= MB) continue;
+    const int m0 = mb * GB_OUT;
+    const int ms = m0 - 2 + srow;                              // the row this thread stages
+    const bool svalid = ms >= 0 && ms < a.M;
+    float mean = 0.f, rstd = 0.f;
+    if (svalid) {
+      const float2 st = *reinterpret_cast<const float2*>(a.stats + 2LL * ms);
+      mean = st.x;
+      rstd = st.y;
+    }
+    float4 ra[4];
+    auto load_slab = [&](int q) {                              // q < nsl: x slab q; else dy slab q - nsl
+      const float* src = (q < nsl ? a.x : a.dy) + (long long)(svalid ? ms : 0) * F + (q < nsl ? q : q - nsl) * GB_BKS + kq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ra[j] = ld4(src + 4 * j);
+    };
+    auto store_slab = [&](int q) {
+#pragma clang fp contract(off)
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[4 * j] = ra[j].x; v[4 * j + 1] = ra[j].y; v[4 * j + 2] = ra[j].z; v[4 * j + 3] = ra[j].w; }
+      if (q < nsl) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = svalid ? (v[e] - mean) * rstd : 0.f;
+      } else {
+        const int f0c = (q - nsl) * GB_BKS + kq;                 // first output channel of this thread's 16
+        if (drop) {                                            // network.py:57: the output dropout's mask, keep scale folded in
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            const unsigned d = sepr_drop_word(dk1, (unsigned)ms, (unsigned)((f0c + e) >> 1));
+            v[e] = (d & 0xffffu) >= a.drop_thr ? v[e] * a.drop_scale : 0.f;
+            v[e + 1] = (d >> 16) >= a.drop_thr ? v[e + 1] * a.drop_scale : 0.f;
+          }
+          // one column block writes dropout1(dy) for the weight-gradient contraction of net2.2 (output rows only)
+          if (a.dyq && nb == 0 && srow >= 2 && srow < 2 + GB_OUT && svalid) {
+            float* o = a.dyq + (long long)ms * F + f0c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st4(o + 4 * j, make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]));
+          }
+        }
+        if (!svalid) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] = 0.f;
+        }
+      }
+      unsigned short* hi = slab + ((q & 1) * NP + 0) * PLANE_E + srow * GB_LDK + kq;
+      unsigned short* lo = slab + ((q & 1) * NP + (NP - 1)) * PLANE_E + srow * GB_LDK + kq;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        gb_bf16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const __bf16 xh = (__bf16)v[8 * j + e];
+          h[e] = xh;
+          if (!ONE) l[e] = (__bf16)(v[8 * j + e] - (float)xh);
+        }
+        *reinterpret_cast<gb_bf16x8*>(hi + 8 * j) = h;
+        if (!ONE) *reinterpret_cast<gb_bf16x8*>(lo + 8 * j) = l;
+      }
+    };
+    // weight fragments of one 16-row tile at K step ks: (hi, lo) planes, one coalesced 1 KiB read each
+    auto load_w = [&](const uint4* W, int t16, int ks, uint4 (&w)[2]) {
+      const uint4* p = W + ((long long)(t16 * kst + ks) * 2) * 64 + lane;
+      w[0] = p[0];
+      if (!ONE) w[1] = p[64];
+    };
+
+    f32x4 hv[4], hg[4], dd[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      hv[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      hg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dd[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int tv = 4 * nb + wn, tg = C3 / 16 + 4 * nb + wn;     // this wave's value / gate tile of W1, tv also its W2^T tile
+
+    __syncthreads();   // the previous tile's epilogue is done with the LDS tiles that alias the slab buffers
+    load_slab(0);
+    for (int q = 0; q < 2 * nsl; ++q) {
+      const bool up = q < nsl;
+      const int s = up ? q : q - nsl;
+      uint4 wa[2][2], wb[2][2];                                // [K step of the slab][plane]; a: value (or W2^T), b: gate
+      load_w(up ? W1 : W2, tv, 2 * s, wa[0]);
+      load_w(up ? W1 : W2, tv, 2 * s + 1, wa[1]);
+      if (up) {
+        load_w(W1, tg, 2 * s, wb[0]);
+        load_w(W1, tg, 2 * s + 1, wb[1]);
+      }
+      store_slab(q);
+      __syncthreads();
+      if (q + 1 < 2 * nsl) load_slab(q + 1);                   // in flight under the MFMAs
+      const unsigned short* ph = slab + ((q & 1) * NP + 0) * PLANE_E;
+      const unsigned short* pl = slab + ((q & 1) * NP + (NP - 1)) * PLANE_E;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        gb_bf16x8 xh[4], xl[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int off = (mt * 16 + fi) * GB_LDK + kk * 32 + 8 * fg;
+          xh[mt] = *reinterpret_cast<const gb_bf16x8*>(ph + off);
+          if (!ONE) xl[mt] = *reinterpret_cast<const gb_bf16x8*>(pl + off);
+        }
+        const gb_bf16x8 ah = *reinterpret_cast<const gb_bf16x8*>(&wa[kk][0]);
+        const gb_bf16x8 al = *reinterpret_cast<const gb_bf16x8*>(&wa[kk][ONE ? 0 : 1]);
+        if (up) {
+          const gb_bf16x8 bh = *reinterpret_cast<const gb_bf16x8*>(&wb[kk][0]);
+          const gb_bf16x8 bl = *reinterpret_cast<const gb_bf16x8*>(&wb[kk][ONE ? 0 : 1]);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[mt], hv[mt], 0, 0, 0);
+            hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, xh[mt], hg[mt], 0, 0, 0);
+          }
+          if constexpr (!ONE) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+              hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[mt], hv[mt], 0, 0, 0);
+              hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, xl[mt], hg[mt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+              hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[mt], hv[mt], 0, 0, 0);
+              hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, xh[mt], hg[mt], 0, 0, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) dd[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[mt], dd[mt], 0, 0, 0);
+          if constexpr (!ONE) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) dd[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[mt], dd[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) dd[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[mt], dd[mt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();   // every wave is done with the slab buffers: they become the h1 / dgd tiles
+
+    // ---- stage h1 (+ bias) and dgd: row = frame, a lane holds 4 consecutive channels of one frame per accumulator ----
+    {
+      const int cl = wn * 16 + 4 * fg;
+      const float4 bv = ld4(a.b1 + 64 * nb + cl), bg = ld4(a.b1 + C3 + 64 * nb + cl);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float* hr = Hs + (mt * 16 + fi) * GB_HS;
+        st4(hr + cl, make_float4(hv[mt][0] + bv.x, hv[mt][1] + bv.y, hv[mt][2] + bv.z, hv[mt][3] + bv.w));
+        st4(hr + 64 + cl, make_float4(hg[mt][0] + bg.x, hg[mt][1] + bg.y, hg[mt][2] + bg.z, hg[mt][3] + bg.w));
+        st4(Ds + (mt * 16 + fi) * GB_DS + cl, make_float4(dd[mt][0], dd[mt][1], dd[mt][2], dd[mt][3]));
+      }
+    }
+    __syncthreads();
+
+    // ---- pass A: conv, GLU, dropout, GLU backward for rows 1..62; thread = 4 hidden channel pairs x 4 consecutive rows ----
+    const int q4 = tid & 15, strip = tid >> 4;
+    const int c4 = 4 * q4, hc = 64 * nb + c4;                    // hidden value channel of column 0 (gate: C3 + hc)
+    const int C6 = 2 * C3;
+    const float4 wv0 = ld4(a.dw_w + hc), wv1 = ld4(a.dw_w + C6 + hc), wv2 = ld4(a.dw_w + 2 * C6 + hc);
+    const float4 wg0 = ld4(a.dw_w + C3 + hc), wg1 = ld4(a.dw_w + C6 + C3 + hc), wg2 = ld4(a.dw_w + 2 * C6 + C3 + hc);
+    const float4 cbv = ld4(a.dw_b + hc), cbg = ld4(a.dw_b + C3 + hc);
+    float acc8[4][8];                                          // [column][w0 w1 w2 b of the value, then of the gate]
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc8[e][k] = 0.f;
+    float4 dcv[4], dcg[4];
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * strip + i;
+        const int m = m0 - 2 + r;
+        dcv[i] = zero4();
+        dcg[i] = zero4();
+        if (r < 1 || r > GB_BM - 2 || m < 0 || m >= a.M) continue;
+        const int t = m % a.T;
+        const float f0 = t > 0 ? 1.f : 0.f, f2 = t < a.T - 1 ? 1.f : 0.f;    // zero padding at the sequence ends
+        const float* hr = Hs + r * GB_HS + c4;
+        const float4 hvc = ld4(hr), hgc = ld4(hr + 64);
+        float4 hvm = ld4(hr - GB_HS), hgm = ld4(hr - GB_HS + 64), hvp = ld4(hr + GB_HS), hgp = ld4(hr + GB_HS + 64);
+        hvm.x *= f0; hvm.y *= f0; hvm.z *= f0; hvm.w *= f0;
+        hgm.x *= f0; hgm.y *= f0; hgm.z *= f0; hgm.w *= f0;
+        hvp.x *= f2; hvp.y *= f2; hvp.z *= f2; hvp.w *= f2;
+        hgp.x *= f2; hgp.y *= f2; hgp.z *= f2; hgp.w *= f2;
+        float4 keep = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (drop) {                                            // network.py:55: mask of the gated tensor, element (m, hc + e)
+          const unsigned d0 = sepr_drop_word(dk0, (unsigned)m, (unsigned)(hc >> 1)), d1 = sepr_drop_word(dk0, (unsigned)m, (unsigned)(hc >> 1) + 1u);
+          keep.x = (d0 & 0xffffu) >= a.drop_thr ? a.drop_scale : 0.f;
+          keep.y = (d0 >> 16) >= a.drop_thr ? a.drop_scale : 0.f;
+          keep.z = (d1 & 0xffffu) >= a.drop_thr ? a.drop_scale : 0.f;
+          keep.w = (d1 >> 16) >= a.drop_thr ? a.drop_scale : 0.f;
+        }
+        const float4 dg = ld4(Ds + r * GB_DS + c4);
+        const bool own = r >= 2 && r < 2 + GB_OUT;              // rows this tile outputs (m < M already checked)
+        float4 gd;
+#define SEPR_GB_ELEM(X, E)                                                                            \
+  {                                                                                                   \
+    const float cv = fmaf(wv2.X, hvp.X, fmaf(wv1.X, hvc.X, fmaf(wv0.X, hvm.X, cbv.X)));             \
+    const float cg = fmaf(wg2.X, hgp.X, fmaf(wg1.X, hgc.X, fmaf(wg0.X, hgm.X, cbg.X)));             \
+    const float sg = sigmoid_f(cg);                                                                   \
+    gd.X = cv * sg * keep.X;                                                                          \
+    const float d = dg.X * keep.X;                                                                    \
+    const float dv_ = d * sg, dg_ = d * cv * sg * (1.f - sg);                                        \
+    dcv[i].X = dv_;                                                                                   \
+    dcg[i].X = dg_;                                                                                   \
+    if (own) {                                                                                        \
+      acc8[E][0] = fmaf(dv_, hvm.X, acc8[E][0]); acc8[E][1] = fmaf(dv_, hvc.X, acc8[E][1]);          \
+      acc8[E][2] = fmaf(dv_, hvp.X, acc8[E][2]); acc8[E][3] += dv_;                                  \
+      acc8[E][4] = fmaf(dg_, hgm.X, acc8[E][4]); acc8[E][5] = fmaf(dg_, hgc.X, acc8[E][5]);          \
+      acc8[E][6] = fmaf(dg_, hgp.X, acc8[E][6]); acc8[E][7] += dg_;                                  \
+    }                                                                                                 \
+  }
+        SEPR_GB_ELEM(x, 0)
+        SEPR_GB_ELEM(y, 1)
+        SEPR_GB_ELEM(z, 2)
+        SEPR_GB_ELEM(w, 3)
+#undef SEPR_GB_ELEM
+        if (own) st4(a.g + (long long)m * C3 + hc, gd);
+      }
+      // depthwise gradient partials: sum over the 4 strips of this wave (lanes 16 apart), then over the 4 waves through LDS
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float v = acc8[e][k];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          acc8[e][k] = v;
+        }
+    }
+    __syncthreads();   // all reads of h1 / dgd done: dc overwrites h1 in place, the reduction scratch overwrites dgd
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* hr = Hs + (4 * strip + i) * GB_HS + c4;
+      st4(hr, dcv[i]);
+      st4(hr + 64, dcg[i]);
+    }
+    if (lane < 16) {
+      float* rs = Ds + (wn * 16 + q4) * 32;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        st4(rs + 8 * e, make_float4(acc8[e][0], acc8[e][1], acc8[e][2], acc8[e][3]));
+        st4(rs + 8 * e + 4, make_float4(acc8[e][4], acc8[e][5], acc8[e][6], acc8[e][7]));
+      }
+    }
+    __syncthreads();
+    // ---- pass B: transpose of the conv, rows 2..61 ----
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * strip + i;
+        const int m = m0 - 2 + r;
+        if (r < 2 || r >= 2 + GB_OUT || m >= a.M) continue;
+        const int t = m % a.T;
+        const float f0 = t > 0 ? 1.f : 0.f, f2 = t < a.T - 1 ? 1.f : 0.f;
+        const float* hr = Hs + r * GB_HS + c4;
+        const float4 pv = ld4(hr - GB_HS), pg = ld4(hr - GB_HS + 64), nv = ld4(hr + GB_HS), ng = ld4(hr + GB_HS + 64);
+        // dh[t] = w0 dc[t+1] + w1 dc[t] + w2 dc[t-1]   (frames of OTHER sequences do not contribute: f0 / f2)
+        float4 ov, og;
+        ov.x = fmaf(wv0.x * f2, nv.x, fmaf(wv1.x, dcv[i].x, (wv2.x * f0) * pv.x));
+        ov.y = fmaf(wv0.y * f2, nv.y, fmaf(wv1.y, dcv[i].y, (wv2.y * f0) * pv.y));
+        ov.z = fmaf(wv0.z * f2, nv.z, fmaf(wv1.z, dcv[i].z, (wv2.z * f0) * pv.z));
+        ov.w = fmaf(wv0.w * f2, nv.w, fmaf(wv1.w, dcv[i].w, (wv2.w * f0) * pv.w));
+        og.x = fmaf(wg0.x * f2, ng.x, fmaf(wg1.x, dcg[i].x, (wg2.x * f0) * pg.x));
+        og.y = fmaf(wg0.y * f2, ng.y, fmaf(wg1.y, dcg[i].y, (wg2.y * f0) * pg.y));
+        og.z = fmaf(wg0.z * f2, ng.z, fmaf(wg1.z, dcg[i].z, (wg2.z * f0) * pg.z));
+        og.w = fmaf(wg0.w * f2, ng.w, fmaf(wg1.w, dcg[i].w, (wg2.w * f0) * pg.w));
+        float* o = a.dh1 + (long long)m * C6 + hc;
+        st4(o, ov);
+        st4(o + C3, og);
+      }
+    }
+    // per-tile depthwise partials: part[mb][pair][8], the 64 pairs of this column block are 512 consecutive floats
+    {
+      float* po = a.part + ((long long)mb * C3 + 64 * nb) * 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int o = tid + GB_THREADS * h;                    // (q, slot) = (o / 32, o % 32)
+        po[o] = (Ds[o] + Ds[512 + o]) + (Ds[1024 + o] + Ds[1536 + o]);
+      }
+    }
+  }
+}
+}  // namespace
+
+size_t gcfn_bwd_fused_ws(long long M, int F) {   // partials + the pre-reduction scratch of launch_gcfn_mid_reduce
+  const long long MB = (M + GB_OUT - 1) / GB_OUT;
+  return align_up((size_t)MB * 3 * F * 8 * sizeof(float)) + gcfn_mid_reduce_ws(3 * F);
+}
+
+int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, int n, int T, int F, const sepr_gcfn_tw* w, float* g,
+                          float* dh1, float* dyq, float* dw_g, float* db_g, float p, unsigned long long seed,
+                          const unsigned long long* salt, void* ws, size_t ws_bytes, hipStream_t st) {
+  const long long M = (long long)n * T;
+  if (M <= 0) return SEPR_OK;
+  if (!x || !stats || !dy || !w || !w->up.wp || !w->up.b || !w->down_t.wp || !w->dw_w || !w->dw_b || !g || !dh1 || !dw_g || !db_g ||
+      F % 64 || !(p >= 0.f) || !(p < 1.f))
+    return SEPR_EINVAL;
+  if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
+  if (!ws || ws_bytes < gcfn_bwd_fused_ws(M, F)) return SEPR_EWORKSPACE;
+  GcfnBwdArgs a;
+  a.x = x; a.stats = stats; a.dy = dy; a.M = (int)M; a.T = T; a.F = F;
+  a.w1p = w->up.wp; a.b1 = w->up.b; a.w2tp = w->down_t.wp; a.dw_w = w->dw_w; a.dw_b = w->dw_b;
+  a.g = g; a.dh1 = dh1; a.dyq = p > 0.f ? dyq : nullptr;
+  a.part = static_cast<float*>(ws);
+  a.drop_thr = p > 0.f ? sepr_drop_thr16(p) : 0u;
+  a.drop_scale = p > 0.f ? sepr_drop_scale16(p) : 1.0f;
+  a.seed = seed; a.salt = salt;
+  if (p > 0.f && !dyq) return SEPR_EINVAL;
+  const int MB = (int)((M + GB_OUT - 1) / GB_OUT), NB = 3 * F / 64;
+  const int ntiles = ((MB + 7) / 8) * 8 * NB;
+  const int cap = persistent_grid();
+  const int grid = ntiles < cap ? ntiles : cap;
+  long long slot = -1;
+  const bool timed = prof_begin(SEPR_SITE_GCFN_BWD, st, &slot);
+  if (w->up.planes == 1)
+    hipLaunchKernelGGL((gcfn_bwd_mid_kernel<1>), dim3(grid), dim3(GB_THREADS), 0, st, a);
+  else
+    hipLaunchKernelGGL((gcfn_bwd_mid_kernel<3>), dim3(grid), dim3(GB_THREADS), 0, st, a);
+  // algorithmic FLOPs per row: recomputed up-projection 2 F 6F + input gradient of net2.2 2 F 3F + conv / GLU forward and backward
+  if (timed) prof_end(slot, (double)M * (18.0 * F * F + 60.0 * 3 * F), st);
+  SEPR_CHECK_LAUNCH("gcfn_bwd_mid_kernel");
+  float* scratch = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)MB * 3 * F * 8 * sizeof(float)));
+  return launch_gcfn_mid_reduce(a.part, MB, 3 * F, dw_g, db_g, scratch, st);
+}
+
+}  // namespace sepr

@@ -26,7 +26,8 @@
 // The same kernel has a plain mode (template parameter MODE = 1): Linear -> GLU -> Linear without LayerNorm, conv,
 // LayerScale and residual, with a runtime hidden width and input / output row maps - SpkSplitStage's two 1x1 convolutions
 // (modules/module.py:114-116,123) and OutputLayer's two projections (:250-256), one launch per 128 output columns.
-#include "sepr_gemm_epi.h"
+#include "sepr_gcfn_fused.h"
+#include "sepr_train.h"
 #include <stdlib.h>
 
 namespace sepr {
@@ -35,26 +36,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // frames written per wave = 16*MT - 2 (one recomputed halo frame on each side), per workgroup = NW times that
 
-struct GcfnFusedArgs {
-  const float* x;     // [M, F]
-  float* y;           // [M, F]
-  int M, T;           // rows, frames per sequence
-  const void* w1p;    // per chunk: [4 tiles: v0 v1 g0 g1][KS][plane][64][8] bf16 (LayerNorm gamma folded), then 4 KB of
-                      // constants [2 tile pairs][10: b1v b1g wv0 wv1 wv2 wg0 wg1 wg2 cbv cbg][16 channels] fp32; the gate's
-                      // conv taps and bias (wg*, cbg) are multiplied by -log2(e): see glu_prescaled
-  const void* w2p;    // [NCH][F/16][plane][64][8] bf16, k-slot order (g,e) -> e<4 ? 4g+e : 16+4g+e-4; fragment row 4q+r of
-                      // tile ft is output channel 32*(ft/2) + 8q + 4*(ft%2) + r (a lane's accumulators of a tile pair are 8
-                      // consecutive channels: the same 32 bytes of a frame row it loaded)
-  const float* b2;    // [F]
-  const float* ls;    // [F]
-  float eps;
-  int stagger;        // s_sleep units (64 clocks each) by which every other co-resident workgroup starts late; 0 = off
-  // MODE 1 (plain GLU-MLP: y = W2 . GLU(W1 x + b1) + b2, no LayerNorm / conv / residual / LayerScale - SpkSplit, OutputLayer):
-  int nch;            // hidden chunks of 32 value + 32 gate channels (GCFN: 3F/32)
-  int ldy, col_off;   // output row stride in floats and first output column (one launch writes F columns of a wider tensor)
-  int in_rows, in_src;          // in_rows > 0: input row of frame m is (m / in_rows) * in_src + m % in_rows (crop of every sequence)
-  int out_T, out_S, out_s;      // out_S > 0: output row of frame m is ((m / out_T) * out_S + out_s) * out_T + m % out_T (speaker split)
-};
 
 __device__ __forceinline__ float dpp_ror1(float v) {   // lane i <- lane (i-1) mod 16 of its 16-lane row
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x121, 0xf, 0xf, true));   // (every lane has a source: no `old`)
@@ -102,9 +83,16 @@ struct bool_c { static constexpr bool value = V; };
 #ifndef SEPR_GF3_XCH
 #define SEPR_GF3_XCH 1
 #endif
-template <int F, int MT, int NW, int MODE = 0>
+template <int F, int MT, int NW, int MODE = 0, bool TRAIN = false>
 __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
   constexpr bool PLAIN = MODE == 1;   // frames are independent: no halo, no seam exchange, no conv
+  static_assert(!(TRAIN && PLAIN), "the train instantiation is the GCFN block");
+  const bool drop = TRAIN && a.drop_thr > 0u;
+  DropKey dk0 = {0u, 0u}, dk1 = {0u, 0u};
+  if (drop) {
+    dk0 = sepr_drop_key(a.seed, a.salt, 0u);
+    dk1 = sepr_drop_key(a.seed, a.salt, 1u);
+  }
   static_assert(MT == 1 || MT == 2, "frame tiles per wave");
   constexpr int RD = SEPR_GF3_RING;      // LDS fragment read-ahead, in MFMA groups
   constexpr bool UF = SEPR_GF3_UPFIRST != 0;
@@ -233,6 +221,11 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
       d += __shfl_xor(d, 16, 64);
       d += __shfl_xor(d, 32, 64);
       const float rstd = valid ? (PLAIN ? 1.0f : 1.0f / sqrtf(d * (1.0f / F) + a.eps)) : 0.f;   // invalid frames: exactly zero
+      if (TRAIN) {   // the frames this workgroup OUTPUTS (not its halo) report their statistics: all the backward needs
+        const int lr = MT * fi + mt, bf = w * WSTR + lr;
+        const bool own = XCH ? (bf >= 1 && bf <= GF_TILE) : (lr >= 1 && lr <= 16 * MT - 2);
+        if (a.stats && fg == 0 && valid && own) *reinterpret_cast<float2*>(a.stats + 2LL * m) = make_float2(mean, rstd);
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         bf16x8 h, l;
@@ -399,6 +392,19 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
               gl[mt][r] = (SEPR_GF_ABL & 16) ? val * gat : glu_prescaled(val, gat);   // 16: no transcendentals (gate taps are pre-scaled)
             }
           }
+          if (TRAIN && drop) {   // network.py:55 dropout on the gated tensor: hidden channel 32c + 16j + 4fg + r of frame mw0 + MT*fi + mt
+            const unsigned pr = (unsigned)(16 * c + 8 * j + 2 * fg);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              unsigned row = (unsigned)(mw0 + MT * fi + mt);
+              asm volatile("" : "+v"(row));   // keeps the row term of the hash out of loop-invariant registers (no in-loop spills)
+              const unsigned d0 = sepr_drop_word(dk0, row, pr), d1 = sepr_drop_word(dk0, row, pr + 1u);
+              gl[mt][0] = (d0 & 0xffffu) >= a.drop_thr ? gl[mt][0] : 0.f;
+              gl[mt][1] = (d0 >> 16) >= a.drop_thr ? gl[mt][1] : 0.f;
+              gl[mt][2] = (d1 & 0xffffu) >= a.drop_thr ? gl[mt][2] : 0.f;
+              gl[mt][3] = (d1 >> 16) >= a.drop_thr ? gl[mt][3] : 0.f;
+            }
+          }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -439,7 +445,10 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     constexpr int RPP = NT / Q;              // rows per pass
     constexpr int NP = (64 + RPP - 1) / RPP;
     const int q4 = tid % Q, rr = tid / Q;
-    const float4 b2 = ld4(a.b2 + 4 * q4), lsv = PLAIN ? zero4() : ld4(a.ls + 4 * q4);
+    const float4 b2 = ld4(a.b2 + 4 * q4);
+    float4 lsv = PLAIN ? zero4() : ld4(a.ls + 4 * q4);
+    const float dsc = (TRAIN && drop) ? a.drop_scale : 1.0f;   // keep scale of the gated-tensor dropout: linear, applied to the sum
+    if (TRAIN && drop) { lsv.x *= dsc; lsv.y *= dsc; lsv.z *= dsc; lsv.w *= dsc; }   // ... and of the output dropout
 #pragma unroll 1
     for (int half = 0; half < EH; ++half) {
       if (half > 0) __syncthreads();   // previous pass fully stored (the chunk loop ended on a barrier)
@@ -480,9 +489,17 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
               if (a.out_S > 0) mo = ((long long)(mo / a.out_T) * a.out_S + a.out_s) * a.out_T + mo % a.out_T;
               st4(a.y + mo * a.ldy + a.col_off + 4 * q4, make_float4(o.x + b2.x, o.y + b2.y, o.z + b2.z, o.w + b2.w));
             } else {
+              float4 v = TRAIN ? make_float4(fmaf(o.x, dsc, b2.x), fmaf(o.y, dsc, b2.y), fmaf(o.z, dsc, b2.z), fmaf(o.w, dsc, b2.w))
+                               : make_float4(o.x + b2.x, o.y + b2.y, o.z + b2.z, o.w + b2.w);
+              if (TRAIN && drop) {   // network.py:57 dropout on the block's output (its keep scale rides in lsv)
+                const unsigned d0 = sepr_drop_word(dk1, (unsigned)mrow[p], 2u * q4), d1 = sepr_drop_word(dk1, (unsigned)mrow[p], 2u * q4 + 1u);
+                v.x = (d0 & 0xffffu) >= a.drop_thr ? v.x : 0.f;
+                v.y = (d0 >> 16) >= a.drop_thr ? v.y : 0.f;
+                v.z = (d1 & 0xffffu) >= a.drop_thr ? v.z : 0.f;
+                v.w = (d1 >> 16) >= a.drop_thr ? v.w : 0.f;
+              }
               st4(a.y + (long long)mrow[p] * F + 4 * q4,
-                  make_float4(fmaf(o.x + b2.x, lsv.x, xr[p].x), fmaf(o.y + b2.y, lsv.y, xr[p].y),
-                              fmaf(o.z + b2.z, lsv.z, xr[p].z), fmaf(o.w + b2.w, lsv.w, xr[p].w)));
+                  make_float4(fmaf(v.x, lsv.x, xr[p].x), fmaf(v.y, lsv.y, xr[p].y), fmaf(v.z, lsv.z, xr[p].z), fmaf(v.w, lsv.w, xr[p].w)));
             }
           }
         }
@@ -547,7 +564,11 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
     const int ntiles = (a.M + tile_rows - 1) / tile_rows;
     const int cap = persistent_grid();
     const int grid = ntiles < cap ? ntiles : cap;
-    if (F == 128) {
+    if (a.train) {
+      if (F == 128) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 0, true>), dim3(grid), dim3(384), 0, stream, a);
+      else if (F == 64) hipLaunchKernelGGL((gcfn_fused3_kernel<64, 1, 6, 0, true>), dim3(grid), dim3(384), 0, stream, a);
+      else return SEPR_EINVAL;
+    } else if (F == 128) {
       hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6>), dim3(grid), dim3(384), 0, stream, a);
     } else if (F == 64) {
       hipLaunchKernelGGL((gcfn_fused3_kernel<64, 1, 6>), dim3(grid), dim3(384), 0, stream, a);
@@ -579,7 +600,11 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
       const int ntiles = (a.M + tile_rows - 1) / tile_rows;
       const int cap = persistent_grid();
       const int grid = ntiles < cap ? ntiles : cap;
-      if (F == 128) {
+      if (a.train) {
+        if (F == 128) hipLaunchKernelGGL((gcfn_fused3_kernel<128, GF3_MT, GF3_NW, 0, true>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
+        else if (F == 64) hipLaunchKernelGGL((gcfn_fused3_kernel<64, GF3_MT, GF3_NW, 0, true>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
+        else return SEPR_EINVAL;
+      } else if (F == 128) {
         hipLaunchKernelGGL((gcfn_fused3_kernel<128, GF3_MT, GF3_NW>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
       } else if (F == 64) {
         hipLaunchKernelGGL((gcfn_fused3_kernel<64, GF3_MT, GF3_NW>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);

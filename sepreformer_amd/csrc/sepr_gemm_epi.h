@@ -45,6 +45,7 @@ struct GemmArgs {
   // bf16x3 core only: weights pre-split into bf16 (hi, lo) planes in MFMA-fragment order
   // ([N/16][K/32][plane][lane][8], see pack.py::pack_x3); LayerNorm gamma/beta are folded into Wp / bias.
   const void* Wp;
+  int bf1;   // bf16x3 core: 1 = plain bf16 operands (one MFMA per product; hi planes only), 0 = the split arithmetic
 };
 
 

@@ -53,10 +53,12 @@ inline TnPlan tn_plan(int M, int N, int K) {
   return p;
 }
 
-template <bool X3>
+// MD: 0 = exact f32 MFMA, 1 = bf16x3 split arithmetic, 2 = plain bf16 operands (hi planes only, one MFMA per product)
+template <int MD>
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part,
                                                                float* __restrict__ cpart) {
   // x3: [A_hi, A_lo, B_hi, B_lo][128][72] bf16 = 73 728 B;  f32: [A, B][64][132] fp32 = 67 584 B
+  constexpr bool X3 = MD != 0, ONE = MD == 2;
   __shared__ __attribute__((aligned(16))) unsigned char smem[X3 ? 4 * TN_T * TN_LDM * 2 : 2 * TN_SLAB * TN_LDF * 4];
   __shared__ float csum_s[4][TN_T];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -133,10 +135,10 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
             const float v = j == 0 ? q.x : (j == 1 ? q.y : (j == 2 ? q.z : q.w));
             const __bf16 vh = (__bf16)v;
             h[e] = vh;
-            l[e] = (__bf16)(v - (float)vh);
+            if (!ONE) l[e] = (__bf16)(v - (float)vh);
           }
           *reinterpret_cast<tn_bf16x8*>(hi + (4 * cg + j) * TN_LDM + 32 * nb + 8 * mg) = h;
-          *reinterpret_cast<tn_bf16x8*>(lo + (4 * cg + j) * TN_LDM + 32 * nb + 8 * mg) = l;
+          if (!ONE) *reinterpret_cast<tn_bf16x8*>(lo + (4 * cg + j) * TN_LDM + 32 * nb + 8 * mg) = l;
         }
     } else {
       float* dst = reinterpret_cast<float*>(smem) + (roleA ? 0 : 1) * TN_SLAB * TN_LDF;
@@ -170,17 +172,21 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
           const int ra = (wm * 64 + t * 16 + fi) * TN_LDM + 32 * nb + 8 * fg;
           const int rb = (wn * 64 + t * 16 + fi) * TN_LDM + 32 * nb + 8 * fg;
           ah[t] = *reinterpret_cast<const tn_bf16x8*>(Ahi + ra);
-          al[t] = *reinterpret_cast<const tn_bf16x8*>(Alo + ra);
           bh[t] = *reinterpret_cast<const tn_bf16x8*>(Bhi + rb);
-          bl[t] = *reinterpret_cast<const tn_bf16x8*>(Blo + rb);
+          if (!ONE) {
+            al[t] = *reinterpret_cast<const tn_bf16x8*>(Alo + ra);
+            bl[t] = *reinterpret_cast<const tn_bf16x8*>(Blo + rb);
+          }
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int kt = 0; kt < 4; ++kt) {
             acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh[kt], acc[nt][kt], 0, 0, 0);
-            acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl[kt], acc[nt][kt], 0, 0, 0);
-            acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh[kt], acc[nt][kt], 0, 0, 0);
+            if constexpr (!ONE) {
+              acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl[kt], acc[nt][kt], 0, 0, 0);
+              acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh[kt], acc[nt][kt], 0, 0, 0);
+            }
           }
       }
     } else {
@@ -278,10 +284,12 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   const int grid = p.tn * p.tk * p.nsplit;
   long long slot = -1;
   const bool timed = prof_begin(SEPR_SITE_WGRAD, s, &slot);
-  if (x3)
-    hipLaunchKernelGGL((gemm_tn_kernel<true>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
+  if (x3 == 2)
+    hipLaunchKernelGGL((gemm_tn_kernel<2>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
+  else if (x3)
+    hipLaunchKernelGGL((gemm_tn_kernel<1>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
   else
-    hipLaunchKernelGGL((gemm_tn_kernel<false>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
+    hipLaunchKernelGGL((gemm_tn_kernel<0>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
   if (timed) prof_end(slot, 2.0 * (double)a.M * (double)a.N * (double)a.K, s);
   const long long total = (long long)a.N * a.K + a.N;
   const int rgrid = (int)((total + 63) / 64);

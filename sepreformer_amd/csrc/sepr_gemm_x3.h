@@ -46,6 +46,9 @@ template <int PRO, int EPI, int TAG = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs a) {
   constexpr bool DWGLU = (EPI == EPI_DWGLU);
   constexpr bool GLU = (EPI == EPI_GLU) || DWGLU;
+  // TAG bit 4: plain bf16 operands ("bf16" training precision): activations rounded to bf16 (hi plane only), weights'
+  // hi plane only, ONE MFMA per product instead of three; everything else (staging, tile walk, epilogues) is shared
+  constexpr bool ONE = (TAG & 16) != 0;
   constexpr int ROWS_OUT = DWGLU ? GEMM_DW_ROWS : GEMM_BM;
   // [buffer][plane hi/lo][128 rows][80] bf16 = 81 920 B; the epilogue re-uses it as a [128][132] fp32 tile
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * 2 * X3_PLANE];
@@ -137,10 +140,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
         const float x = (PRO == PRO_NORM) ? (v[e] - mean) * sc : v[e] * sc;
         const __bf16 xh = (__bf16)x;
         h[e] = xh;
-        l[e] = (__bf16)(x - (float)xh);
+        if (!ONE) l[e] = (__bf16)(x - (float)xh);
       }
       *reinterpret_cast<bf16x8*>(hi + 4 * j) = h;
-      *reinterpret_cast<bf16x8*>(lo + 4 * j) = l;
+      if (!ONE) *reinterpret_cast<bf16x8*>(lo + 4 * j) = l;
     }
   };
   // weight fragments of K step ks (global, fragment order: one coalesced 1 KiB load per tile and plane)
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
     for (int nt = 0; nt < 2; ++nt) {
       const uint4* p = Wp + wbase[nt] + (unsigned)ks * 128u + lane;
       wh[nt] = p[0];
-      wl[nt] = p[64];
+      if (!ONE) wl[nt] = p[64];
     }
   };
 
@@ -167,29 +170,31 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
     for (int t = 0; t < 4; ++t) {
       const int off = ((half * 4 + t) * 16 + fi) * X3_LDK + kk * 32 + 8 * fg;
       xh[t] = *reinterpret_cast<const bf16x8*>(ph + off);
-      xl[t] = *reinterpret_cast<const bf16x8*>(pl + off);
+      if (!ONE) xl[t] = *reinterpret_cast<const bf16x8*>(pl + off);
     }
     bf16x8 wfh[2], wfl[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       wfh[nt] = *reinterpret_cast<const bf16x8*>(&wh[nt]);
-      wfl[nt] = *reinterpret_cast<const bf16x8*>(&wl[nt]);
+      if (!ONE) wfl[nt] = *reinterpret_cast<const bf16x8*>(&wl[nt]);
     }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         acc[nt][half * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfh[nt], xh[t], acc[nt][half * 4 + t], 0, 0, 0);
+    if constexpr (!ONE) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        acc[nt][half * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfh[nt], xl[t], acc[nt][half * 4 + t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+          acc[nt][half * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfh[nt], xl[t], acc[nt][half * 4 + t], 0, 0, 0);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        acc[nt][half * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfl[nt], xh[t], acc[nt][half * 4 + t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+          acc[nt][half * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfl[nt], xh[t], acc[nt][half * 4 + t], 0, 0, 0);
+    }
   };
   auto decode = [&](int tile, int& m0, int& nb) -> bool {
     const int q = tile >> 3;

@@ -43,7 +43,16 @@ int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t st
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
   const int key = pro * 16 + epi;
-  if (site == SEPR_SITE_GCFN_UP && key == PRO_NORM * 16 + EPI_DWGLU) {
+  if (a.bf1) {   // plain bf16 operands: the projections of the training path's "bf16" precision
+    switch (key) {
+      case PRO_PLAIN * 16 + EPI_STORE: launch_x3_inst<PRO_PLAIN, EPI_STORE, 16>(a, stream); break;
+      case PRO_PLAIN * 16 + EPI_RES:   launch_x3_inst<PRO_PLAIN, EPI_RES, 16>(a, stream); break;
+      case PRO_PLAIN * 16 + EPI_SPLIT: launch_x3_inst<PRO_PLAIN, EPI_SPLIT, 16>(a, stream); break;
+      case PRO_NORM * 16 + EPI_STORE:  launch_x3_inst<PRO_NORM, EPI_STORE, 16>(a, stream); break;
+      case PRO_CAT2 * 16 + EPI_STORE:  launch_x3_inst<PRO_CAT2, EPI_STORE, 16>(a, stream); break;
+      default: return SEPR_EINVAL;
+    }
+  } else if (site == SEPR_SITE_GCFN_UP && key == PRO_NORM * 16 + EPI_DWGLU) {
     launch_x3_inst<PRO_NORM, EPI_DWGLU, 1>(a, stream);
   } else if (site == SEPR_SITE_GCFN_DOWN && key == PRO_PLAIN * 16 + EPI_RES) {
     launch_x3_inst<PRO_PLAIN, EPI_RES, 2>(a, stream);

@@ -24,6 +24,32 @@ inline unsigned int sepr_drop_threshold(float p) {
   return t >= 4294967295.0 ? 4294967295u : (unsigned int)t;
 }
 
+// ---- cheap generator of the fused GCFN pair (sepr_gcfn_fused.hip train instantiation, sepr_gcfn_bwd_fused.hip) ----------
+// The fused forward evaluates the gated-tensor mask inside its chunk loop, which is VALU-issue co-bound: a 64-bit mix per
+// element (~30 instructions) would double its VALU stream.  Here one 32-bit hash (lowbias32) of (site key, row, channel
+// pair) yields TWO 16-bit draws, ~6 instructions per element; element (row, c) of a site is kept iff its 16-bit draw
+// (low half for even c) >= thr16 = round(p * 65536), so p_eff = thr16 / 65536 and the keep scale is 65536 / (65536 - thr16).
+__device__ __forceinline__ unsigned sepr_hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+struct DropKey { unsigned ka, kb; };
+__device__ __forceinline__ DropKey sepr_drop_key(unsigned long long seed, const unsigned long long* salt, unsigned site) {
+  const unsigned long long z = sepr_mix64(seed ^ (salt ? *salt : 0ull) ^ ((unsigned long long)(site + 1) << 56));
+  DropKey k;
+  k.ka = (unsigned)z;
+  k.kb = (unsigned)(z >> 32);
+  return k;
+}
+__device__ __forceinline__ unsigned sepr_drop_word(DropKey k, unsigned row, unsigned pair) {
+  return sepr_hash32((row * 0x9E3779B1u + k.ka) ^ (pair * 0x85EBCA77u + k.kb));
+}
+inline unsigned sepr_drop_thr16(float p) {
+  const double t = (double)p * 65536.0 + 0.5;
+  return t <= 0.0 ? 0u : (t >= 65535.0 ? 65535u : (unsigned)t);
+}
+inline float sepr_drop_scale16(float p) { return (float)(65536.0 / (65536.0 - (double)sepr_drop_thr16(p))); }
+
 // ---------------------------------------------------------------------------------------------------------------------
 // G[N][K] (+)= sum_m A[m][n] * B'[m][k]      ("TN" contraction over the M = batch x frames rows: every weight gradient)
 //   A  : fp32 rows, leading dimension lda (upstream gradient of the projection's output)
@@ -61,7 +87,7 @@ inline TnArgs tn_args_zero() {
   return a;
 }
 size_t tn_workspace_bytes(int M, int N, int K);
-// x3 != 0: bf16x3 split arithmetic (3 bf16 MFMAs per product), else exact f32 MFMA
+// x3: 1 = bf16x3 split arithmetic (3 bf16 MFMAs per product), 2 = plain bf16 operands (1 MFMA), 0 = exact f32 MFMA
 int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream_t s);
 
 // ---- row-wise / element-wise pieces (sepr_train_pw.hip) -------------------------------------------------------------
@@ -80,6 +106,16 @@ int launch_gcfn_mid_bwd(const float* h1, const float* dg, float* dh1, int n, int
                         float* dw_g, float* db_g, float p, unsigned long long seed, unsigned long long offset, void* ws, size_t ws_bytes,
                         hipStream_t s);
 size_t gcfn_mid_bwd_ws(int n, int T, int C);
+// [nblk][C][8] per-tile partials (w0 w1 w2 b of the value channel, then of the gate) -> dw_g [2C][3] / db_g [2C] (accumulated)
+int launch_gcfn_mid_reduce(const float* part, int nblk, int C, float* dw_g, float* db_g, float* scratch, hipStream_t s);
+size_t gcfn_mid_reduce_ws(int C);
+// Fused middle of the GCFN backward (sepr_gcfn_bwd_fused.hip): recomputes the hidden tensor from x and the saved LayerNorm
+// statistics, x / dy [n*T][F] -> g [n*T][3F] (dropped gated tensor), dh1 [n*T][6F], dyq [n*T][F] (dropout of dy; p > 0 only),
+// depthwise weight / bias gradients accumulated.  Arithmetic follows w->up.planes (bf16x3 or plain bf16).
+int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, int n, int T, int F, const sepr_gcfn_tw* w, float* g,
+                          float* dh1, float* dyq, float* dw_g, float* db_g, float p, unsigned long long seed,
+                          const unsigned long long* salt, void* ws, size_t ws_bytes, hipStream_t st);
+size_t gcfn_bwd_fused_ws(long long M, int F);
 // depthwise conv weight gradient, stride 1, 'same' zero padding: dw[c][k] += sum_{seq,t} dy[t][c] * x[t + k - K/2][c];
 // db[c] += sum dy.  x, dy [n,T,C]; dw in parameter layout [C][K]
 int launch_dwconv_wgrad(const float* x, const float* dy, int n, int T, int C, int K, float* dw_g, float* db_g, void* ws,

@@ -8,6 +8,7 @@
 // (Carve::dry): sepr_train_ctx_bytes / sepr_train_ws_bytes replay the same carving without launching anything.
 #include <string.h>
 
+#include "sepr_gcfn_fused.h"
 #include "sepr_pointwise.h"
 #include "sepr_train.h"
 
@@ -15,6 +16,10 @@ namespace sepr {
 namespace {
 
 const float LN_EPS_T = 1e-5f, BN_EPS_T = 1e-5f, BN_MOM = 0.1f;
+// The sizing entry points (sepr_train_ctx_bytes / sepr_train_ws_bytes) carry no encoder geometry: the training path is
+// sized for - and its waveform-end entry points only accept - the encoder / decoder filter every shipped configuration uses
+// (configs.yaml: kernel_size 16, stride 4).  Any other geometry is a clear SEPR_EINVAL instead of an undersized workspace.
+constexpr int TRAIN_ENC_K = 16, TRAIN_ENC_STRIDE = 4;
 
 struct Carve {
   char* base;
@@ -37,6 +42,7 @@ int lin(int pro, int epi, GemmArgs& a, const sepr_lin& l, int site, hipStream_t 
   a.W = l.w;
   a.Wp = l.wp;
   a.bias = l.b;
+  a.bf1 = (l.wp && l.planes == 1) ? 1 : 0;
   if (l.wp) return launch_gemm_x3(pro, epi, a, site, st);
   if (!l.w) return SEPR_EINVAL;
   return launch_gemm(pro, epi, a, site, st);
@@ -58,14 +64,16 @@ int normed(const float* X, int lda, const float* stats, float* Y, int ldc, long 
 }
 // G[N][K] = sum_m A[m][n] B[m][k] (B optionally normalised with per-row stats), colsum[N]
 int wgrad(const float* A, int lda, const float* B, int ldb, const float* stats, float* G, float* colsum, long long M, int N, int K,
-          int accumulate, bool x3, void* ws, size_t wsb, hipStream_t st) {
+          int accumulate, int x3, void* ws, size_t wsb, hipStream_t st) {
   TnArgs t = tn_args_zero();
   t.M = (int)M; t.N = N; t.K = K;
   t.A = A; t.lda = lda; t.B = B; t.ldb = ldb; t.stats = stats;
   t.G = G; t.ldg = K; t.accumulate = accumulate;
   t.colsum = colsum; t.colsum_accumulate = accumulate;
-  return launch_gemm_tn(t, x3 ? 1 : 0, ws, wsb, st);
+  return launch_gemm_tn(t, x3, ws, wsb, st);
 }
+// arithmetic of the weight-gradient contraction that goes with a projection: 0 exact f32, 1 bf16x3, 2 plain bf16
+int tn_mode(const sepr_lin& l) { return !l.wp ? 0 : (l.planes == 1 ? 2 : 1); }
 bool rows_ok(long long M) { return M > 0 && M <= 0x7fffffffLL / 8; }
 // distinct generator streams per dropout site of one block call
 sepr_u64 site_off(int site) { return (sepr_u64)site << 44; }
@@ -80,6 +88,59 @@ GcfnCtx gcfn_ctx(Carve& c, long long M, int F) {
   k.h1 = c.f32(6LL * F * M);
   k.g = c.f32(3LL * F * M);
   return k;
+}
+// Fused pair (w->fused_w1p set; F in {64, 128}): the forward is ONE launch of the fused inference kernel's TRAIN instantiation
+// and keeps only the LayerNorm statistics; the backward recomputes the hidden tensor in its middle kernel
+// (sepr_gcfn_bwd_fused.hip), then runs the two weight-gradient contractions, their finishers, the F-wide input-gradient
+// projection and the LayerNorm backward of the unfused form.
+bool gcfn_is_fused(const sepr_gcfn_tw* w, int F) { return w && w->fused_w1p && w->fused_w2p && (F == 64 || F == 128); }
+int gcfn_fused_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, Carve& cx, float p, sepr_u64 seed,
+                   hipStream_t st) {
+  const long long M = (long long)n * T;
+  float* stats = cx.f32(2 * M);
+  if (cx.dry) return SEPR_OK;
+  if (!cx.ok()) return SEPR_EWORKSPACE;
+  if (!w->up.wp || !w->down_t.wp) return SEPR_EINVAL;   // the backward's middle kernel runs on the packed-bf16 cores
+  GcfnFusedArgs f = {};
+  f.x = x; f.y = y; f.M = (int)M; f.T = T;
+  f.w1p = w->fused_w1p; f.w2p = w->fused_w2p;
+  f.b2 = w->b2; f.ls = w->ls; f.eps = LN_EPS_T;
+  f.train = 1; f.stats = stats;
+  f.drop_thr = p > 0.f ? sepr_drop_thr16(p) : 0u;
+  f.drop_scale = p > 0.f ? sepr_drop_scale16(p) : 1.0f;
+  f.seed = seed; f.salt = nullptr;
+  return launch_gcfn_fused(f, F, SEPR_SITE_GCFN_UP, st);
+}
+int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, const sepr_gcfn_tw* w, const sepr_gcfn_grad* g,
+                   Carve& cx, Carve& ws, float p, sepr_u64 seed, hipStream_t st) {
+  const long long M = (long long)n * T;
+  float* stats = cx.f32(2 * M);
+  float* gd = ws.f32(3LL * F * M);
+  float* dh1 = ws.f32(6LL * F * M);
+  float* dyp = p > 0.f ? ws.f32((long long)F * M) : nullptr;
+  float* Gr = ws.f32(3LL * F * F);
+  float* s2 = ws.f32(F);
+  float* dWh = ws.f32(6LL * F * F);
+  float* s1 = ws.f32(6 * F);
+  float* dxh = ws.f32((long long)F * M);
+  const size_t tnb = tn_workspace_bytes((int)M, 6 * F, F) > tn_workspace_bytes((int)M, F, 3 * F) ? tn_workspace_bytes((int)M, 6 * F, F)
+                                                                                                   : tn_workspace_bytes((int)M, F, 3 * F);
+  void* tnw = ws.take(tnb);
+  const size_t midb = gcfn_bwd_fused_ws(M, F);
+  void* midw = ws.take(midb);
+  if (ws.dry) return SEPR_OK;
+  if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
+  const int x3 = tn_mode(w->up);
+  SEPR_TRY(launch_gcfn_bwd_fused(x, stats, dy, n, T, F, w, gd, dh1, dyp, g->dw_w, g->dw_b, p, seed, nullptr, midw, midb, st));
+  const float* dyq = p > 0.f ? dyp : dy;
+  // net2.2 + LayerScale
+  SEPR_TRY(wgrad(dyq, F, gd, 3 * F, nullptr, Gr, s2, M, F, 3 * F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_linear_ls(Gr, s2, w->w2, w->b2, w->ls, g->w2, g->b2, g->ls, F, 3 * F, st));
+  // net1 behind the LayerNorm
+  SEPR_TRY(wgrad(dh1, 6 * F, x, F, stats, dWh, s1, M, 6 * F, F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_norm_linear(dWh, s1, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 6 * F, F, st));
+  SEPR_TRY(plain(dh1, 6 * F, dxh, F, M, F, 6 * F, w->up_t, nullptr, st));
+  return launch_ln_bwd(dxh, x, stats, dy, nullptr, 0, 0, 0, dx, M, F, st);
 }
 int gcfn_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, Carve& cx, Carve& ws, float p, sepr_u64 seed,
              hipStream_t st) {
@@ -123,7 +184,7 @@ int gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, co
   void* midw = ws.take(midb);
   if (ws.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
-  const bool x3 = w->up.wp != nullptr;
+  const int x3 = tn_mode(w->up);
   const float* dyq = dy;
   if (p > 0.f) {
     SEPR_TRY(launch_dropout(dy, dyp, (long long)F * M, p, seed, site_off(1), st));
@@ -204,7 +265,7 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
   void* wgw = ws.take(wgb);
   if (ws.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
-  const bool x3 = w->l1.wp != nullptr;
+  const int x3 = tn_mode(w->l1);
   const float* dyq = dy;
   if (p > 0.f) {
     SEPR_TRY(launch_dropout(dy, dyp, (long long)F * M, p, seed, site_off(0), st));
@@ -231,14 +292,14 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
 // =====================================================================================================================
 // d(linear_out * LayerScale): Graw / finish / dO = dy' . (ls * Wo)
 int mha_out_bwd(const float* dyq, const float* o, float* dO, long long M, int F, const sepr_mha_tw* w, const sepr_mha_grad* g, float* Gr,
-                float* s, bool x3, void* tnw, size_t tnb, hipStream_t st) {
+                float* s, int x3, void* tnw, size_t tnb, hipStream_t st) {
   SEPR_TRY(wgrad(dyq, F, o, F, nullptr, Gr, s, M, F, F, 0, x3, tnw, tnb, st));
   SEPR_TRY(launch_finish_linear_ls(Gr, s, w->wo, w->bo, w->ls, g->wo, g->bo, g->ls, F, F, st));
   return plain(dyq, F, dO, F, M, F, F, w->out_t, nullptr, st);
 }
 // d(q/k/v projection behind the LayerNorm): dWh [3F][F] -> three finishers (shared dgamma / dbeta), dxh = dqkv . (Wqkv * gamma)
 int mha_qkv_bwd(const float* dqkv, const float* xin, const float* stats, float* dxh, long long M, int F, const sepr_mha_tw* w,
-                const sepr_mha_grad* g, float* dWh, float* s, bool x3, void* tnw, size_t tnb, hipStream_t st) {
+                const sepr_mha_grad* g, float* dWh, float* s, int x3, void* tnw, size_t tnb, hipStream_t st) {
   SEPR_TRY(wgrad(dqkv, 3 * F, xin, F, stats, dWh, s, M, 3 * F, F, 0, x3, tnw, tnb, st));
   float* gw[3] = {g->wq, g->wk, g->wv};
   float* gb[3] = {g->bq, g->bk, g->bv};
@@ -316,7 +377,7 @@ int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, in
   void* atw = ws.take(atb);
   if (ws.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
-  const bool x3 = w->gate.wp != nullptr;
+  const int x3 = tn_mode(w->gate);
   const float* xp = fac > 1 ? k.xd : x;
   // gate: y = x + sigmoid(zg) * up(att)
   SEPR_TRY(launch_gate_bwd(dy, k.zg, k.att, dzg, datt, n, T, Tp, F, st));
@@ -381,7 +442,7 @@ int spk_bwd(const float* x, const float* dy, float* dx, int nS, int S, int T, in
   void* tnw = ws.take(tnb);
   if (ws.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
-  const bool x3 = w->qkv.wp != nullptr;
+  const int x3 = tn_mode(w->qkv);
   const float* dyq = dy;
   if (p > 0.f) {
     SEPR_TRY(launch_dropout(dy, dyp, (long long)F * M, p, seed, site_off(1), st));
@@ -479,7 +540,7 @@ int split_bwd(const float* x, const float* dy, float* dx, int dx_acc, int B, int
   void* tnw = ws.take(tnb);
   if (ws.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
-  const bool x3 = w->l1.wp != nullptr;
+  const int x3 = tn_mode(w->l1);
   SEPR_TRY(launch_gn_bwd(dy, k.v, k.stats, w->gn_g, dv, g->gn_g, g->gn_b, B * S, T, F, S, gnw, gnb, st));
   SEPR_TRY(wgrad(dv, F * S, k.z, 2 * F * S, nullptr, g->w2, g->b2, M, F * S, 2 * F * S, 1, x3, tnw, tnb, st));
   SEPR_TRY(plain(dv, F * S, dz, 2 * F * S, M, 2 * F * S, F * S, w->l2_t, nullptr, st));
@@ -502,6 +563,7 @@ extern "C" int sepr_gcfn_train_fwd(const float* x, float* y, int n, int T, int F
                                    void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream) {
   if (!x || !y || !w || n <= 0 || T <= 0 || F <= 0 || F % 32 || !rows_ok((long long)n * T) || x == y) return SEPR_EINVAL;
   Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
+  if (gcfn_is_fused(w, F)) return gcfn_fused_fwd(x, y, n, T, F, w, cx, p_drop, seed, SEPR_ST);
   return gcfn_fwd(x, y, n, T, F, w, cx, wk, p_drop, seed, SEPR_ST);
 }
 extern "C" int sepr_gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, const sepr_gcfn_tw* w,
@@ -509,6 +571,7 @@ extern "C" int sepr_gcfn_bwd(const float* x, const float* dy, float* dx, int n, 
                              sepr_u64 seed, sepr_stream_t stream) {
   if (!x || !dy || !dx || !w || !g || n <= 0 || T <= 0 || F <= 0 || F % 32 || !rows_ok((long long)n * T)) return SEPR_EINVAL;
   Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
+  if (gcfn_is_fused(w, F)) return gcfn_fused_bwd(x, dy, dx, n, T, F, w, g, cx, wk, p_drop, seed, SEPR_ST);
   return gcfn_bwd(x, dy, dx, n, T, F, w, g, cx, wk, p_drop, seed, SEPR_ST);
 }
 extern "C" int sepr_cla_train_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_cla_tw* w, void* ctx, size_t ctx_bytes,
@@ -588,7 +651,7 @@ extern "C" size_t sepr_linear_wgrad_workspace(int M, int N, int K) { return tn_w
 extern "C" int sepr_linear_wgrad(const float* A, const float* B, float* G, float* colsum, int M, int N, int K, int accumulate, int x3,
                                  void* ws, size_t ws_bytes, sepr_stream_t stream) {
   if (!A || !B || !G || M <= 0) return SEPR_EINVAL;
-  return wgrad(A, N, B, K, nullptr, G, colsum, M, N, K, accumulate, x3 != 0, ws, ws_bytes, SEPR_ST);
+  return wgrad(A, N, B, K, nullptr, G, colsum, M, N, K, accumulate, x3 < 0 || x3 > 2 ? 1 : x3, ws, ws_bytes, SEPR_ST);
 }
 
 // =====================================================================================================================
@@ -611,7 +674,7 @@ int fuse_bwd(const float* lo, const float* skip, const float* dy, float* dlo, fl
   t.B = lo; t.ldb = F; t.rows_out = T; t.rows_valid = T; t.b_shift = 1; t.seq_stride = (long long)(T / 2) * F;
   t.B2 = skip; t.ldb2 = F; t.ksplit = F;
   t.G = g->w; t.ldg = 2 * F; t.accumulate = 1; t.colsum = g->b; t.colsum_accumulate = 1;
-  SEPR_TRY(launch_gemm_tn(t, w->l.wp != nullptr, tnw, tnb, st));
+  SEPR_TRY(launch_gemm_tn(t, tn_mode(w->l), tnw, tnb, st));
   SEPR_TRY(plain(dy, F, dcat, 2 * F, M, 2 * F, F, w->l_t, nullptr, st));
   return launch_unfuse(dcat, dlo, dskip, n, T, F, st);
 }
@@ -662,7 +725,7 @@ int out_bwd(const float* x, const float* dwav, float* dx, int dx_acc, float* den
   if (ws.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
   if (aux && (!idx_start || !enc || !denc)) return SEPR_EINVAL;
-  const bool x3 = w->l1.wp != nullptr;
+  const int x3 = tn_mode(w->l1);
   SEPR_TRY(launch_permute_sb(dwav, dwp, S, nS / S, Tout, st));
   SEPR_TRY(launch_dec_bwd_dm(dwp, w->wdec, dm, nS, L, N, K, stride, Tout, st));
   const float* m = k.o2;
@@ -744,7 +807,7 @@ int front_bwd(const float* wav, const float* enc, const float* dout, float* denc
     t.B = enc; t.ldb = N; t.rows_out = Lp; t.rows_valid = L; t.seq_stride = (long long)L * N;
     t.stats = stats; t.stat_seq = 1;
     t.G = dWh; t.ldg = N; t.colsum = s;
-    SEPR_TRY(launch_gemm_tn(t, w->proj_t.wp != nullptr, tnw, tnb, st));
+    SEPR_TRY(launch_gemm_tn(t, tn_mode(w->proj_t), tnw, tnb, st));
   }
   SEPR_TRY(launch_finish_norm_linear(dWh, s, w->proj_w, w->gn_g, w->gn_b, g->proj_w, nullptr, g->gn_g, g->gn_b, F, N, st));
   {  // d enc_hat [B*L][N] = dout(valid rows) . (W * gamma)
@@ -781,6 +844,7 @@ extern "C" int sepr_outlayer_decoder_train_fwd(const float* x, int nS, int S, in
                                                void* ws, size_t ws_bytes, sepr_stream_t stream) {
   (void)ws; (void)ws_bytes;
   if (!x || !w || !wav || nS <= 0 || S <= 0 || nS % S || Tsrc <= 0 || L <= 0 || F % 32 || N % 16) return SEPR_EINVAL;
+  if (K != TRAIN_ENC_K || stride != TRAIN_ENC_STRIDE) return SEPR_EINVAL;   // sepr_train_ctx_bytes / ws_bytes size for this geometry
   if (!idx && L > Tsrc) return SEPR_EINVAL;
   if (idx && (Tsrc > L || !enc)) return SEPR_EINVAL;
   Carve cx(ctx, ctx_bytes, false);
@@ -791,6 +855,7 @@ extern "C" int sepr_outlayer_decoder_bwd(const float* x, const float* dwav, floa
                                          int stride, const sepr_out_tw* w, const sepr_out_grad* g, const void* ctx, size_t ctx_bytes,
                                          void* ws, size_t ws_bytes, sepr_stream_t stream) {
   if (!x || !dwav || !dx || !w || !g || nS <= 0 || S <= 0 || nS % S || Tsrc <= 0 || L <= 0 || F % 32 || N % 16) return SEPR_EINVAL;
+  if (K != TRAIN_ENC_K || stride != TRAIN_ENC_STRIDE) return SEPR_EINVAL;
   if (!idx && L > Tsrc) return SEPR_EINVAL;
   if (idx && Tsrc > L) return SEPR_EINVAL;
   Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
@@ -800,6 +865,7 @@ extern "C" int sepr_front_train_fwd(const float* wav, int B, int T, int N, int K
                                     const sepr_front_tw* w, float* enc, float* out, void* ctx, size_t ctx_bytes, void* ws,
                                     size_t ws_bytes, sepr_stream_t stream) {
   if (!wav || !w || !enc || !out || B <= 0 || T < K || stride <= 0 || Lp < (T - K) / stride + 1) return SEPR_EINVAL;
+  if (K != TRAIN_ENC_K || stride != TRAIN_ENC_STRIDE) return SEPR_EINVAL;
   Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
   return front_fwd(wav, B, T, N, K, stride, F, Lp, gn_eps, w, enc, out, cx, wk, SEPR_ST);
 }
@@ -807,6 +873,7 @@ extern "C" int sepr_front_bwd(const float* wav, const float* enc, const float* d
                               int stride, int F, int Lp, const sepr_front_tw* w, const sepr_front_grad* g, const void* ctx,
                               size_t ctx_bytes, void* ws, size_t ws_bytes, sepr_stream_t stream) {
   if (!wav || !enc || !dout || !w || !g || B <= 0 || T < K || stride <= 0) return SEPR_EINVAL;
+  if (K != TRAIN_ENC_K || stride != TRAIN_ENC_STRIDE) return SEPR_EINVAL;
   Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
   return front_bwd(wav, enc, dout, denc_aux, B, T, N, K, stride, F, Lp, w, g, cx, wk, SEPR_ST);
 }
@@ -819,6 +886,10 @@ static void train_sizes(int op, int n, int T, int Tp, int F, int N, int S, int H
     case SEPR_TOP_GCFN:
       gcfn_fwd(nullptr, nullptr, n, T, F, nullptr, cf, wf, p1, 0, nullptr);
       gcfn_bwd(nullptr, nullptr, nullptr, n, T, F, nullptr, nullptr, cb, wb, p1, 0, nullptr);
+      break;
+    case SEPR_TOP_GCFN_FUSED:
+      gcfn_fused_fwd(nullptr, nullptr, n, T, F, nullptr, cf, p1, 0, nullptr);
+      gcfn_fused_bwd(nullptr, nullptr, nullptr, n, T, F, nullptr, nullptr, cb, wb, p1, 0, nullptr);
       break;
     case SEPR_TOP_CLA:
       cla_fwd(nullptr, nullptr, n, T, F, K, nullptr, cf, wf, p1, 0, nullptr);
@@ -849,8 +920,8 @@ static void train_sizes(int op, int n, int T, int Tp, int F, int N, int S, int H
         if (aux && Tp > T) continue;
         if (!aux && T > Tp) continue;
         Carve c1(nullptr, 0, true), c2(nullptr, 0, true), w2(nullptr, 0, true);
-        out_fwd(nullptr, n, S, Tp, T, aux ? &dummy_idx : nullptr, nullptr, F, N, 16, 4, nullptr, nullptr, c1, nullptr);
-        out_bwd(nullptr, nullptr, nullptr, 0, nullptr, n, S, Tp, T, aux ? &dummy_idx : nullptr, nullptr, nullptr, F, N, 16, 4, nullptr,
+        out_fwd(nullptr, n, S, Tp, T, aux ? &dummy_idx : nullptr, nullptr, F, N, TRAIN_ENC_K, TRAIN_ENC_STRIDE, nullptr, nullptr, c1, nullptr);
+        out_bwd(nullptr, nullptr, nullptr, 0, nullptr, n, S, Tp, T, aux ? &dummy_idx : nullptr, nullptr, nullptr, F, N, TRAIN_ENC_K, TRAIN_ENC_STRIDE, nullptr,
                 nullptr, c2, w2, nullptr);
         if (c1.need() > cf.off) cf.off = c1.need();
         if (w2.need() > wb.off) wb.off = w2.need();
@@ -858,8 +929,8 @@ static void train_sizes(int op, int n, int T, int Tp, int F, int N, int S, int H
       break;
     }
     case SEPR_TOP_FRONT: {   // n = B, T = samples, Tp = Lp
-      front_fwd(nullptr, n, T, N, 16, 4, F, Tp, 0.f, nullptr, nullptr, nullptr, cf, wf, nullptr);
-      front_bwd(nullptr, nullptr, nullptr, nullptr, n, T, N, 16, 4, F, Tp, nullptr, nullptr, cb, wb, nullptr);
+      front_fwd(nullptr, n, T, N, TRAIN_ENC_K, TRAIN_ENC_STRIDE, F, Tp, 0.f, nullptr, nullptr, nullptr, cf, wf, nullptr);
+      front_bwd(nullptr, nullptr, nullptr, nullptr, n, T, N, TRAIN_ENC_K, TRAIN_ENC_STRIDE, F, Tp, nullptr, nullptr, cb, wb, nullptr);
       break;
     }
     default: break;

@@ -273,6 +273,17 @@ size_t gcfn_mid_bwd_ws(int n, int T, int C) {
   const int nchunk = (T + GM_TC - 1) / GM_TC;
   return align_up((size_t)n * nchunk * C * 8 * sizeof(float)) + align_up((size_t)PR_GROUPS * C * 8 * sizeof(float));
 }
+// reduction of [nblk][C][8] depthwise partials (the fused backward's tiles, sepr_gcfn_bwd_fused.hip) into the parameter gradients
+size_t gcfn_mid_reduce_ws(int C) { return align_up((size_t)PR_GROUPS * C * 8 * sizeof(float)); }
+int launch_gcfn_mid_reduce(const float* part, int nblk, int C, float* dw_g, float* db_g, float* scratch, hipStream_t s) {
+  if (nblk <= 0) return SEPR_OK;
+  if (!part || !dw_g || !db_g || !scratch || C <= 0) return SEPR_EINVAL;
+  const float* rows = nullptr;
+  const int nrows = prereduce(part, nblk, C * 8, scratch, &rows, s);
+  hipLaunchKernelGGL(gcfn_mid_reduce_kernel, dim3((C * 8 + TPB - 1) / TPB), dim3(TPB), 0, s, rows, nrows, C, dw_g, db_g);
+  SEPR_CHECK_LAUNCH("gcfn_mid_reduce_kernel");
+  return SEPR_OK;
+}
 int launch_gcfn_mid_bwd(const float* h1, const float* dg, float* dh1, int n, int T, int C, const float* dw_w, const float* dw_b,
                         float* dw_g, float* db_g, float p, unsigned long long seed, unsigned long long offset, void* ws, size_t ws_bytes,
                         hipStream_t s) {

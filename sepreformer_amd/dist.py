@@ -26,30 +26,43 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def init_from_env(backend: Optional[str] = None, single_rank_group: bool = False) -> Tuple[int, int, int]:
     """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
-    Returns (rank, world, local_rank); a no-op single-rank answer when WORLD_SIZE is absent or 1."""
+    Returns (rank, world, local_rank).  With WORLD_SIZE absent or 1 no process group is created unless
+    ``single_rank_group`` is set: then a ONE-rank group is initialised (127.0.0.1, a free port), so that the path's
+    collectives (metric all-reduce, gradient all-reduce) really go through RCCL on a 1-GPU box as well."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        # a bounded collective timeout: a rank that died must fail the job, not hang it
-        timeout = datetime.timedelta(seconds=int(os.environ.get("SEPR_DIST_TIMEOUT_S", "300")))
+        # torch's default collective timeouts (600 s nccl / 1800 s gloo) unless SEPR_DIST_TIMEOUT_S bounds them
+        kw = {}
+        if os.environ.get("SEPR_DIST_TIMEOUT_S"):
+            kw["timeout"] = datetime.timedelta(seconds=int(os.environ["SEPR_DIST_TIMEOUT_S"]))
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=timeout)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
 def reduce_metric_sums(values: torch.Tensor) -> torch.Tensor:
     """Sum a small vector of metric accumulators (e.g. [sum SI-SNR, sum SI-SNRi, count]) over ranks."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():                      # a one-rank group still runs the collective (RCCL on a 1-GPU box)
         dist.all_reduce(values, op=dist.ReduceOp.SUM)
     return values
 
@@ -129,9 +142,20 @@ class GradSync:
         self._pending = None
 
     def _active(self) -> bool:
-        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return dist.is_initialized()               # also with ONE rank: the all-reduce then still goes through RCCL
+
+    def abort(self) -> None:
+        """Drop an early all-reduce whose backward did not finish (exception between ``begin`` and ``__call__``)."""
+        if self._pending is not None:
+            work, _ = self._pending
+            self._pending = None
+            try:
+                work.wait()
+            except Exception:      # noqa: BLE001 - the step is already failing; the handle must not leak into the next one
+                pass
 
     def begin(self, flat: torch.Tensor, offset: int) -> None:
+        self.abort()               # a stale handle of a failed step must never be consumed by this one
         if not (self._active() and self.overlap) or offset <= 0 or offset >= flat.numel():
             return
         tail = flat[offset:]
@@ -151,5 +175,6 @@ class GradSync:
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             self.bytes += flat.numel() * flat.element_size()
-        flat.div_(dist.get_world_size(self.group))
+        if dist.get_world_size(self.group) > 1:
+            flat.div_(dist.get_world_size(self.group))
         self.calls += 1

@@ -24,7 +24,7 @@ _ERR = {SEPR_EINVAL: "SEPR_EINVAL (bad shape / unsupported size / null pointer)"
 
 (OP_ENCODER, OP_GCFN, OP_CLA, OP_EGA, OP_SPKATTN, OP_SPKSPLIT, OP_OUTLAYER, OP_PIT) = range(8)
 (SITE_NONE, SITE_GCFN_UP, SITE_GCFN_DOWN, SITE_CLA, SITE_ATTN_PROJ, SITE_EGA_GATE, SITE_SPLIT, SITE_FUSE,
- SITE_OUT, SITE_PROJECTOR, SITE_LINEAR, SITE_WGRAD) = range(12)
+ SITE_OUT, SITE_PROJECTOR, SITE_LINEAR, SITE_WGRAD, SITE_GCFN_BWD) = range(13)
 
 _fp = C.c_void_p  # device pointers travel as plain addresses
 
@@ -62,8 +62,9 @@ _u64, _d = C.c_ulonglong, C.c_double
 
 # ---- training path (include/sepr.h, "Training path") ----------------------------------------------------------------------
 class Lin(C.Structure):
-    """sepr_lin: one projection, exact-f32 form (w) or bf16x3 form (wp); b may be NULL."""
-    _fields_ = [("w", _fp), ("wp", _fp), ("b", _fp)]
+    """sepr_lin: one projection, exact-f32 form (w) or packed-bf16 form (wp); b may be NULL; planes: 0 / 3 = bf16x3 split
+    arithmetic, 1 = plain bf16 operands (the hi plane of the same fragments)."""
+    _fields_ = [("w", _fp), ("wp", _fp), ("b", _fp), ("planes", C.c_int)]
 
 
 def _tstruct(name, spec):
@@ -79,7 +80,8 @@ def _tstruct(name, spec):
     return type(name, (C.Structure,), {"_fields_": fields})
 
 
-GcfnTW = _tstruct("GcfnTW", ["@up", "@up_t", "@down", "@down_t", "dw_w", "dw_b", "ls", "w1", "ln_g", "ln_b", "w2", "b2"])
+GcfnTW = _tstruct("GcfnTW", ["@up", "@up_t", "@down", "@down_t", "dw_w", "dw_b", "ls", "w1", "ln_g", "ln_b", "w2", "b2",
+                              "fused_w1p", "fused_w2p"])
 GcfnGrad = _tstruct("GcfnGrad", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "ls"])
 ClaTW = _tstruct("ClaTW", ["@l1", "@l1_t", "dw_w", "dw_wf", "dw_b", "zeros", "@l2", "@l2_t", "bn_g", "bn_b", "bn_rm", "bn_rv",
                            "@l3", "@l3_t", "ls", "w1", "ln_g", "ln_b", "w3", "b3"])
@@ -107,7 +109,7 @@ OutTW = _tstruct("OutTW", ["@l1", "@l1_t", "@l2", "@l2_t", "wdec"])
 OutGrad = _tstruct("OutGrad", ["w1", "b1", "w2", "b2", "wdec"])
 FrontTW = _tstruct("FrontTW", ["w_enc", "proj_w", "gn_g", "gn_b", "@proj_t", "ones"])
 FrontGrad = _tstruct("FrontGrad", ["w_enc", "gn_g", "gn_b", "proj_w"])
-(TOP_GCFN, TOP_CLA, TOP_EGA, TOP_SPKATTN, TOP_DOWN, TOP_SPLIT, TOP_FUSE, TOP_OUT, TOP_FRONT) = range(9)
+(TOP_GCFN, TOP_CLA, TOP_EGA, TOP_SPKATTN, TOP_DOWN, TOP_SPLIT, TOP_FUSE, TOP_OUT, TOP_FRONT, TOP_GCFN_FUSED) = range(10)
 
 # name -> (restype, argtypes); must list every symbol include/sepr.h declares (tests check this)
 SIGNATURES = {

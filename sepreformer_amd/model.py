@@ -31,8 +31,9 @@ import torch
 
 from .config import SepConfig
 from .engine import SeparatorEngine
-from .pack import PRECISIONS, PackedModel
-from .params import KINDS, build_param_tree
+from .pack import PackedModel
+from .train_pack import PRECISIONS
+from .params import KINDS, build_param_tree, mutation_epoch
 
 
 DEFAULT_PRECISION = "bf16x3"
@@ -69,7 +70,7 @@ class _SeparatorFn(torch.autograd.Function):
             sd = {n: t.detach() for n, t in zip(names, flat)}
             gb = GradBuffer(model.cfg, dev)                  # fresh zeros per step: autograd may keep views of it as .grad
             tp = TrainPack(model.cfg, sd, gb, model.precision)
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if model.dropout_p > 0.0 else 0
+            seed = model._next_dropout_seed() if model.dropout_p > 0.0 else 0
             wav, aux, tape, dims = eng.forward(x.detach().to(torch.float32), tp, model.dropout_p, seed, with_aux=model.compute_aux)
             torch._foreach_add_(tp.bn_counters, 1)           # BatchNorm.num_batches_tracked
         model.invalidate_packed()                            # running statistics changed behind the version counters
@@ -78,10 +79,10 @@ class _SeparatorFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_wav, *d_aux):
+        if ctx.state is None:
+            raise RuntimeError("the HIP training path keeps one tape per forward: backward twice needs a second forward")
         model, eng, tp, gb, tape, dims, n_aux = ctx.state
         ctx.state = None
-        if tape is None:
-            raise RuntimeError("the HIP training path keeps one tape per forward: backward twice needs a second forward")
         with torch.cuda.device(eng.device):
             sync = model.grad_sync
             early = None
@@ -125,7 +126,9 @@ class Model(torch.nn.Module):
         # throughput mode for batches: the batch as N independent pipelines on N streams (engine.forward_split)
         self.pipelines = int(os.environ.get("SEPR_PIPELINES", "1"))
         # projection arithmetic: "fp32" = exact f32 MFMA; "bf16x3" = split-fp32 on the bf16 MFMA (3 MFMAs per
-        # product, ~100 dB agreement with fp32, 5x less matrix time).  Default from SEPR_PRECISION.
+        # product, ~100 dB agreement with fp32, 5x less matrix time); "bf16" = plain bf16 operands with fp32 accumulation
+        # and fp32 master weights - a TRAINING precision (BASELINE configs[4]); eval() forwards of a "bf16" model run in
+        # bf16x3 (plain bf16 operands do not pass the 1e-3 dB SI-SNR gate).  Default from SEPR_PRECISION.
         self.precision = precision or os.environ.get("SEPR_PRECISION", DEFAULT_PRECISION)
         if self.precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {PRECISIONS}")
@@ -133,6 +136,18 @@ class Model(torch.nn.Module):
         # optional callable applied to the flat gradient buffer at the end of backward (dist.GradSync: RCCL all-reduce)
         self.dropout_p = float(self.cfg.dropout)
         self.grad_sync = None
+
+    def _next_dropout_seed(self) -> int:
+        """Per-step dropout seed from a PRIVATE CPU generator (the user's global RNG stream - shuffling, augmentation - is
+        not consumed, as with the reference's device-side dropout), seeded from ``torch.initial_seed()`` and the
+        data-parallel rank so that replicas under one ``torch.manual_seed`` draw different masks."""
+        gen = self.__dict__.get("_drop_gen")
+        if gen is None:
+            rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+            gen = torch.Generator()
+            gen.manual_seed((torch.initial_seed() + 0x9E3779B97F4A7C15 * (rank + 1)) & 0x7FFFFFFFFFFFFFFF)
+            self.__dict__["_drop_gen"] = gen
+        return int(torch.randint(0, 2 ** 62, (1,), generator=gen).item())
 
     # ---- weights -----------------------------------------------------------------------------------
     @classmethod
@@ -145,21 +160,27 @@ class Model(torch.nn.Module):
         self.load_state_dict(synth_state_dict(self.cfg, seed), strict=True)
         return self
 
+    @property
+    def infer_precision(self) -> str:
+        return "bf16x3" if self.precision == "bf16" else self.precision
+
     # ---- packed-weight cache ------------------------------------------------------------------------
     def _flat_tensors(self) -> List[torch.Tensor]:
         """Every tensor of the state_dict, in ``param_rows`` order, resolved by attribute walk - works on the
         replicas ``torch.nn.parallel.replicate`` builds too (their parameters are plain attributes, not
         ``_parameters`` entries, so ``state_dict()`` / ``parameters()`` do not see them)."""
-        flat = None if self._is_replica_module() else self.__dict__.get("_flat")
-        if flat is None:
-            flat = []
-            for name in self._kinds:
-                node = self
-                for part in name.split("."):
-                    node = getattr(node, part)
-                flat.append(node)
-            if not self._is_replica_module():
-                self.__dict__["_flat"] = flat
+        cached = None if self._is_replica_module() else self.__dict__.get("_flat")
+        if cached is not None and cached[0] == mutation_epoch():
+            return cached[1]
+        flat = []
+        for name in self._kinds:
+            node = self
+            for part in name.split("."):
+                node = getattr(node, part)
+            flat.append(node)
+        if not self._is_replica_module():
+            # valid until a tensor attribute of the tree is rebound (params.ParamNode.__setattr__ bumps the epoch)
+            self.__dict__["_flat"] = (mutation_epoch(), flat)
         return flat
 
     def _is_replica_module(self) -> bool:
@@ -171,17 +192,18 @@ class Model(torch.nn.Module):
 
     def invalidate_packed(self) -> None:
         """Force a re-pack on the next forward.  Needed only after mutations the version counters cannot see
-        (``p.data.copy_()``, ``p.data.mul_()``; after re-assigning ``nn.Parameter`` objects also drop ``self.__dict__['_flat']``)."""
+        (``p.data.copy_()``, ``p.data.mul_()``).  Re-bound ``nn.Parameter`` objects and re-assigned ``.data`` are seen."""
         self._pack_epoch += 1
 
     def _weights_key(self):
         """Cheap identity of the current weights: packed copies are caches keyed by it.  In-place updates
         (optimizer steps, ``load_state_dict``, ``p.add_()``) bump a tensor's ``_version`` so the sum changes;
-        ``.to()`` changes the storages (``_apply`` drops the cached list).  ~0.14 ms for Base (1390 tensors)
-        against 2.8 ms for materialising the state_dict; ``.data`` mutations are invisible to it - call
-        ``invalidate_packed()`` after those."""
+        ``.to()``, ``p.data = ...`` and re-bound parameters change a storage address, and every tensor's address is in the
+        key (their sum); re-bound parameter OBJECTS additionally invalidate the cached object list
+        (``params.mutation_epoch``).  ~0.3 ms for Base (1390 tensors) against 2.8 ms for materialising the state_dict;
+        only ``p.data.copy_()``-style writes are invisible to it - call ``invalidate_packed()`` after those."""
         flat = self._flat_tensors()
-        return (flat[0].data_ptr(), flat[-1].data_ptr(), len(flat), sum(t._version for t in flat), self._pack_epoch)
+        return (len(flat), sum(t.data_ptr() for t in flat), sum(t._version for t in flat), self._pack_epoch)
 
     def _packed(self, dev: torch.device) -> PackedModel:
         """Packed weights for ``dev``, shared process-wide: keyed by (device, precision, identity of the ORIGINAL
@@ -189,7 +211,7 @@ class Model(torch.nn.Module):
         (reference engine.py:64,98,130,167 with several device ids) hit the copy packed by an earlier replica on the
         same device instead of re-packing ~750 tensors per call."""
         origin = self._origin[0]() if self._is_replica_module() else self
-        key = (dev.index if dev.index is not None else torch.cuda.current_device(), self.precision,
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), self.infer_precision,
                (origin if origin is not None else self)._weights_key(), self._uid)
         with _PACK_LOCK:
             pk = _PACK_CACHE.get(key)
@@ -198,7 +220,7 @@ class Model(torch.nn.Module):
         names = list(self._kinds)
         sd = {n: t.detach() for n, t in zip(names, self._flat_tensors())}
         with torch.cuda.device(dev):
-            pk = PackedModel(self.cfg, sd, self.precision)
+            pk = PackedModel(self.cfg, sd, self.infer_precision)
         with _PACK_LOCK:
             stale = [k for k in _PACK_CACHE if k[0] == key[0] and k[3] == key[3] and k[1] == key[1] and k != key]
             for k in stale:                              # older weight versions of the same module on this device

@@ -25,7 +25,7 @@ BN_EPS = 1e-5      # torch.nn.BatchNorm1d default
 GN_EPS = 1e-8      # reference modules/module.py:28,117
 
 
-PRECISIONS = ("fp32", "bf16x3")
+PRECISIONS = ("fp32", "bf16x3")          # inference arithmetic (the training path adds "bf16": train_pack.PRECISIONS)
 
 
 def pack_x3(w: torch.Tensor) -> torch.Tensor:
@@ -195,6 +195,59 @@ def pack_gcfn_fused(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.Tensor, bet
     r = torch.arange(4, device=dev)[None, None, :]
     rows = (32 * (ft // 2) + 8 * q + 4 * (ft % 2) + r).reshape(-1)
     w2p = _kslot_frags(w2.detach()[rows], nch)
+    return w1p, w2p
+
+
+def pack_gcfn_fused_batched(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w2: torch.Tensor,
+                            dw_w: torch.Tensor, dw_b: torch.Tensor):
+    """``pack_gcfn_fused`` for a STACK of G blocks in a fixed number of torch ops (the training path re-packs all 56 GCFN
+    blocks after every optimizer step: ``train_pack.py``).  ``w1 [G,6F,F]``, ``b1 [G,6F]``, ``gamma/beta [G,F]``,
+    ``w2 [G,F,3F]``, ``dw_w [G,6F,3]`` (or ``[G,6F,1,3]``), ``dw_b [G,6F]`` -> ``(w1p [G, bytes], w2p [G,3F/32,F/16,2,64,8] bf16)``,
+    byte-identical per block to ``pack_gcfn_fused`` (CPU test)."""
+    G, _, F = w1.shape
+    H3, KS = 3 * F, F // 32
+    nch = H3 // 32
+    dev = w1.device
+    w64 = w1.detach().double()
+    w1f = (w64 * gamma.detach().double()[:, None, :]).float()
+    b1f = (b1.detach().double() + torch.einsum("gnk,gk->gn", w64, beta.detach().double())).float()
+    gscale = torch.ones(2 * H3, dtype=torch.float64, device=dev)
+    gscale[H3:] = -1.4426950408889634
+    taps = (dw_w.detach().double().reshape(G, 2 * H3, 3) * gscale[None, :, None]).float()      # [G,6F,3]
+    cb = (dw_b.detach().double() * gscale[None, :]).float()
+    ar = lambda n: torch.arange(n, device=dev)                                                  # noqa: E731
+    c, t, i = ar(nch)[:, None, None], ar(4)[None, :, None], ar(16)[None, None, :]
+    rows = (torch.where(t < 2, 0, H3) + 32 * c + 16 * (t & 1) + i).reshape(-1)                  # [nch*4*16] chunk, tile, row
+    wsel = w1f[:, rows]                                                                         # [G, nch*64, F]
+    hi = wsel.to(torch.bfloat16)
+    lo = (wsel - hi.to(torch.float32)).to(torch.bfloat16)
+
+    def frag(p):                                                                                # -> [G,nch,tile,KS,g,i,8]
+        return p.view(G, nch, 4, 16, KS, 4, 8).permute(0, 1, 2, 4, 5, 3, 6)
+
+    fr = torch.stack([frag(hi), frag(lo)], dim=4).contiguous().view(torch.uint8).reshape(G, nch, -1)
+    j = ar(2)[None, :, None]
+    v = (32 * ar(nch)[:, None, None] + 16 * j + ar(16)[None, None, :]).reshape(-1)              # [nch*2*16]
+    g_ = H3 + v
+    vals = torch.stack([b1f[:, v], b1f[:, g_], taps[:, v, 0], taps[:, v, 1], taps[:, v, 2], taps[:, g_, 0], taps[:, g_, 1],
+                        taps[:, g_, 2], cb[:, v], cb[:, g_]], dim=1)                            # [G,10,nch*2*16]
+    vals = vals.view(G, 10, nch, 2, 16).permute(0, 2, 3, 1, 4).reshape(G, nch, 320)
+    cst = torch.zeros(G, nch, 1024, dtype=torch.float32, device=dev)
+    cst[:, :, :320] = vals
+    w1p = torch.cat([fr, cst.view(torch.uint8).reshape(G, nch, 4096)], dim=2).reshape(G, -1).contiguous()
+    ft, q, r = ar(F // 16)[:, None, None], ar(4)[None, :, None], ar(4)[None, None, :]
+    orow = (32 * (ft // 2) + 8 * q + 4 * (ft % 2) + r).reshape(-1)
+    gk, e = ar(4)[:, None], ar(8)[None, :]
+    perm = torch.where(e < 4, 4 * gk + e, 16 + 4 * gk + (e - 4)).reshape(-1)                     # [32] slot (g,e) -> channel
+    cols = (32 * ar(nch)[:, None] + perm[None, :]).reshape(-1)
+    w2k = w2.detach().float()[:, orow][:, :, cols].view(G, F, nch, 32).permute(0, 2, 1, 3)      # [G,nch,F,32]
+    h2 = w2k.to(torch.bfloat16)
+    l2 = (w2k - h2.to(torch.float32)).to(torch.bfloat16)
+
+    def frag2(p):                                                                               # -> [G,nch,F/16,g,i,8]
+        return p.reshape(G, nch, F // 16, 16, 4, 8).permute(0, 1, 2, 4, 3, 5)
+
+    w2p = torch.stack([frag2(h2), frag2(l2)], dim=3).reshape(G, nch, F // 16, 2, 64, 8).contiguous()
     return w1p, w2p
 
 

@@ -33,8 +33,31 @@ KINDS = {
 Row = Tuple[str, Tuple[int, ...], str, int]  # name, shape, kind, fan_in
 
 
+# Bumped whenever a tensor ATTRIBUTE of the tree is (re)bound - ``node.weight = nn.Parameter(...)``,
+# ``load_state_dict(..., assign=True)``, parametrizations - i.e. whenever a cached list of the tree's tensor objects may
+# hold stale objects.  (In-place updates and ``.data`` re-assignments keep the objects: Model._weights_key sees those.)
+_MUTATIONS = [0]
+
+
+def mutation_epoch() -> int:
+    return _MUTATIONS[0]
+
+
 class ParamNode(torch.nn.Module):
     """Pure container: holds parameters/buffers/children, has no forward of its own."""
+
+    def __setattr__(self, name, value):
+        if isinstance(value, torch.Tensor) and not self.__dict__.get("_is_replica", False):
+            _MUTATIONS[0] += 1       # (replicas of torch.nn.parallel.replicate rebind plain tensors on throw-away copies)
+        super().__setattr__(name, value)
+
+    def register_parameter(self, name, param):
+        _MUTATIONS[0] += 1
+        super().register_parameter(name, param)
+
+    def register_buffer(self, name, tensor, persistent=True):
+        _MUTATIONS[0] += 1
+        super().register_buffer(name, tensor, persistent=persistent)
 
     def forward(self, *a, **k):  # pragma: no cover - never called
         raise RuntimeError("ParamNode only stores tensors; call Model.forward")

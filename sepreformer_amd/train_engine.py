@@ -80,9 +80,10 @@ class TrainEngine:
         st = torch.cuda.current_stream(self.device).cuda_stream
         y = torch.empty_like(xin)
         if kind == "gcfn":
-            cx = self._ctx(L.TOP_GCFN, n, Tc)
+            op = L.TOP_GCFN_FUSED if (w[0].fused_w1p and F in (64, 128)) else L.TOP_GCFN     # statistics-only context when fused
+            cx = self._ctx(op, n, Tc)
             L.check(lib.sepr_gcfn_train_fwd(xin.data_ptr(), y.data_ptr(), n, Tc, F, C.byref(w[0]), cx.data_ptr(), cx.numel(),
-                                            *self._wsfor(L.TOP_GCFN, n, Tc), p_drop, seed, st), "sepr_gcfn_train_fwd")
+                                            *self._wsfor(op, n, Tc), p_drop, seed, st), "sepr_gcfn_train_fwd")
         elif kind == "cla":
             cx = self._ctx(L.TOP_CLA, n, Tc)
             L.check(lib.sepr_cla_train_fwd(xin.data_ptr(), y.data_ptr(), n, Tc, F, c.cla_kernel, C.byref(w[0]), cx.data_ptr(), cx.numel(),
@@ -107,8 +108,9 @@ class TrainEngine:
         st = torch.cuda.current_stream(self.device).cuda_stream
         dx = torch.empty_like(xin)
         if kind == "gcfn":
+            op = L.TOP_GCFN_FUSED if (w[0].fused_w1p and F in (64, 128)) else L.TOP_GCFN
             L.check(lib.sepr_gcfn_bwd(xin.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, Tc, F, C.byref(w[0]), C.byref(w[1]), cx.data_ptr(),
-                                      cx.numel(), *self._wsfor(L.TOP_GCFN, n, Tc), p_drop, seed, st), "sepr_gcfn_bwd")
+                                      cx.numel(), *self._wsfor(op, n, Tc), p_drop, seed, st), "sepr_gcfn_bwd")
         elif kind == "cla":
             L.check(lib.sepr_cla_bwd(xin.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, Tc, F, c.cla_kernel, C.byref(w[0]), C.byref(w[1]),
                                      cx.data_ptr(), cx.numel(), *self._wsfor(L.TOP_CLA, n, Tc, 0, c.cla_kernel), p_drop, seed, st),

@@ -7,7 +7,11 @@ then just points at its slice.  What is built per projection ``y = norm_affine(x
 
 * forward form: ``W * gamma`` and ``b + W . beta`` (LayerNorm / GroupNorm affine folded in fp64, like ``pack.py``);
 * input-gradient form: the transpose ``(W * gamma)^T``, and for a projection followed by LayerScale ``(ls * W)^T``;
-* exact-f32 mode keeps fp32 ``[N,K]`` matrices, bf16x3 mode the ``pack_x3`` fragments (hi/lo bf16 planes).
+* exact-f32 mode keeps fp32 ``[N,K]`` matrices, bf16x3 mode the ``pack_x3`` fragments (hi/lo bf16 planes); ``bf16`` mode
+  (plain bf16 operands, one MFMA per product, fp32 accumulate and fp32 master weights: the training precision BASELINE
+  configs[4] names) uses the same fragments with ``sepr_lin.planes = 1`` (the kernels then read the hi plane only);
+* GCFN blocks additionally get the fused kernel's weight forms (``pack.pack_gcfn_fused_batched``) when F is 64 or 128: their
+  train forward is then one launch that keeps only the LayerNorm statistics (``include/sepr.h`` sepr_gcfn_tw).
 
 The raw parameters ride along for the gradient finishers, and a ``*Grad`` struct per block points into one flat fp32
 gradient buffer laid out exactly like the parameters (``GradBuffer``).
@@ -16,13 +20,15 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import torch
 
 from . import lib as L
 from .config import SepConfig
 from .params import KINDS, param_rows
 
-PRECISIONS = ("fp32", "bf16x3")
+PRECISIONS = ("fp32", "bf16x3", "bf16")
 
 
 class GradBuffer:
@@ -74,7 +80,8 @@ class _Stack:
         w = w.to(torch.float32).contiguous()
         self.G, self.N, self.K = w.shape
         self.b = None if b is None else b.to(torch.float32).contiguous()
-        if precision == "bf16x3":
+        self.planes = 1 if precision == "bf16" else 0
+        if precision in ("bf16x3", "bf16"):
             self.wp = _pack_x3_batched(w)
             self.w = None
             keep.append(self.wp)
@@ -88,8 +95,8 @@ class _Stack:
     def lin(self, i: int) -> L.Lin:
         bptr = None if self.b is None else self.b.data_ptr() + 4 * i * self.N
         if self.wp is not None:
-            return L.Lin(w=None, wp=self.wp.data_ptr() + 2 * i * 2 * self.N * self.K, b=bptr)
-        return L.Lin(w=self.w.data_ptr() + 4 * i * self.N * self.K, wp=None, b=bptr)
+            return L.Lin(w=None, wp=self.wp.data_ptr() + 2 * i * 2 * self.N * self.K, b=bptr, planes=self.planes)
+        return L.Lin(w=self.w.data_ptr() + 4 * i * self.N * self.K, wp=None, b=bptr, planes=0)
 
 
 def _fold(w: torch.Tensor, b: Optional[torch.Tensor], g: torch.Tensor, beta: torch.Tensor):
@@ -175,10 +182,19 @@ class TrainPack:
         s_up, s_up_t = _Stack(self.keep, w1f, b1f, P), _Stack(self.keep, _t(w1f), None, P)
         s_dn = _Stack(self.keep, g_w2, g_b2, P)
         s_dn_t = _Stack(self.keep, _t(g_w2 * g_ls[:, :, None]), None, P)
+        # fused forward (+ statistics-only context) and recomputing backward: packed-bf16 precisions, F in {64, 128}
+        self.fused_gcfn = (P in ("bf16x3", "bf16") and F in (64, 128) and os.environ.get("SEPR_TRAIN_FUSE_GCFN", "1") != "0")
+        fw1 = fw2 = None
+        if self.fused_gcfn:
+            from .pack import pack_gcfn_fused_batched
+            fw1, fw2 = pack_gcfn_fused_batched(g_w1, g_b1, g_ln_g, g_ln_b, g_w2, st(gcfn_p, ".depthwise.weight", view=(6 * F, 3)), g_db)
+            self.keep += [fw1, fw2]
         self.gcfn = []
         for i, p in enumerate(gcfn_p):
             tw = L.GcfnTW(up=s_up.lin(i), up_t=s_up_t.lin(i), down=s_dn.lin(i), down_t=s_dn_t.lin(i), dw_w=at(g_dw, i), dw_b=at(g_db, i),
-                          ls=at(g_ls, i), w1=at(g_w1, i), ln_g=at(g_ln_g, i), ln_b=at(g_ln_b, i), w2=at(g_w2, i), b2=at(g_b2, i))
+                          ls=at(g_ls, i), w1=at(g_w1, i), ln_g=at(g_ln_g, i), ln_b=at(g_ln_b, i), w2=at(g_w2, i), b2=at(g_b2, i),
+                          fused_w1p=None if fw1 is None else fw1.data_ptr() + i * fw1.shape[1],
+                          fused_w2p=None if fw2 is None else fw2.data_ptr() + i * fw2[0].numel() * 2)
             gr = L.GcfnGrad(ln_g=gp(p + ".net1.0.weight"), ln_b=gp(p + ".net1.0.bias"), w1=gp(p + ".net1.1.weight"), b1=gp(p + ".net1.1.bias"),
                             dw_w=gp(p + ".depthwise.weight"), dw_b=gp(p + ".depthwise.bias"), w2=gp(p + ".net2.2.weight"),
                             b2=gp(p + ".net2.2.bias"), ls=gp(p + ".Layer_scale.layer_scale"))

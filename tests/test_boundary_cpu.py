@@ -509,7 +509,7 @@ def _header_struct_fields(hdr: str, cname: str):
 def test_train_struct_layouts_match_header():
     """ctypes mirrors of the training-path structs (lib.py) against include/sepr.h: same fields, same order, same size."""
     hdr = open(os.path.join(ROOT, "include", "sepr.h")).read()
-    size = {"const float*": 8, "const void*": 8, "float*": 8, "int": 4, "sepr_lin": 24,
+    size = {"const float*": 8, "const void*": 8, "float*": 8, "int": 4, "sepr_lin": 32,
             "sepr_mha_tw": ctypes.sizeof(L.MhaTW), "sepr_mha_grad": ctypes.sizeof(L.MhaGrad)}
     pairs = [("sepr_lin", L.Lin), ("sepr_gcfn_tw", L.GcfnTW), ("sepr_gcfn_grad", L.GcfnGrad), ("sepr_cla_tw", L.ClaTW),
              ("sepr_cla_grad", L.ClaGrad), ("sepr_mha_tw", L.MhaTW), ("sepr_mha_grad", L.MhaGrad), ("sepr_ega_tw", L.EgaTW),
@@ -521,13 +521,13 @@ def test_train_struct_layouts_match_header():
         assert [n for _, n in fields] == [f for f, _ in cls._fields_], cname
         raw = sum(size[k] for k, _ in fields)
         assert ctypes.sizeof(cls) == (raw + 7) // 8 * 8, (cname, ctypes.sizeof(cls), raw)
-    assert ctypes.sizeof(L.Lin) == 24
+    assert ctypes.sizeof(L.Lin) == 32           # three pointers + the planes switch, padded
 
 
 def test_train_sizing_entries_run_without_a_device():
     """sepr_train_ctx_bytes / sepr_train_ws_bytes replay each block's carving in dry mode: no launch, no device needed."""
     lib = L.load()
-    for op in range(9):
+    for op in range(10):
         c = lib.sepr_train_ctx_bytes(op, 4, 1000, 250, 128, 256, 2, 8)
         w = lib.sepr_train_ws_bytes(op, 4, 1000, 250, 128, 256, 2, 8, 65 if op == L.TOP_CLA else 5)
         assert c > 0 and w > 0, op
@@ -536,5 +536,8 @@ def test_train_sizing_entries_run_without_a_device():
     want = n * T * (2 + 6 * F + 3 * F) * 4
     got = lib.sepr_train_ctx_bytes(L.TOP_GCFN, n, T, 0, F, 256, 2, 8)
     assert want <= got <= want + 4096
+    # the fused pair keeps the statistics only (the backward recomputes the hidden tensor)
+    got_f = lib.sepr_train_ctx_bytes(L.TOP_GCFN_FUSED, n, T, 0, F, 256, 2, 8)
+    assert n * T * 2 * 4 <= got_f <= n * T * 2 * 4 + 4096
     assert lib.sepr_train_ctx_bytes(L.TOP_GCFN, 0, T, 0, F, 256, 2, 8) == 0
     assert lib.sepr_gcfn_bwd(None, None, None, 1, 8, 128, None, None, None, 0, None, 0, 0.0, 0, None) == L.SEPR_EINVAL
