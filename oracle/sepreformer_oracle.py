@@ -263,6 +263,9 @@ def separator(sd: SD, cfg, x: Tensor, taps: Optional[dict] = None) -> Tuple[Tens
     return x, outs
 
 
+RELU_MASKS = None   # test hook, see output_layer; None = the reference's ReLU
+
+
 def output_layer(sd: SD, p: str, x: Tensor, enc: Tensor, num_spks: int, masking: bool) -> Tensor:
     """OutputLayer.forward (+Masking with ReLU, concat_opt=None), module.py:249-265, network.py:34-43.
     x: [B*S, F, L_pad], enc: [B, N, L] -> [S, B, N, L]."""
@@ -274,7 +277,12 @@ def output_layer(sd: SD, p: str, x: Tensor, enc: Tensor, num_spks: int, masking:
     B = BS // num_spks
     if masking:
         e = enc.expand(num_spks, B, N, L).transpose(0, 1).contiguous().view(B * num_spks, N, L)  # :258-259
-        x = torch.relu(x) * e                                           # :260, network.py:41
+        if RELU_MASKS is not None:
+            # TEST HOOK (tests/test_train_gpu.py, frozen-gate gradient check): the next 0/1 mask [B*S, N, L] of this iterator
+            # replaces the ReLU's own gate, which makes the loss differentiable in the forward activations
+            x = x * next(RELU_MASKS) * e
+        else:
+            x = torch.relu(x) * e                                       # :260, network.py:41
     return x.view(B, num_spks, N, L).transpose(0, 1)                    # :262-264
 
 

@@ -19,7 +19,18 @@ FP32_MFMA_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS = 157.3, 2500.0
 GFLOP_FWD = {"SepReformer_Base_WSJ0": 182.16, "SepReformer_Large_DM_WHAMR": 684.14}     # per 4 s utterance, forward incl. aux heads
 
 
-def main(args):
+DTYPES = {
+    "bf16x3": ("bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate); fp32 master weights, "
+               "gradients and optimizer state"),
+    "bf16": ("bf16 (plain bf16 operands in every projection, input-gradient projection and weight-gradient contraction: ONE bf16 MFMA per "
+             "product, fp32 accumulate; the fused GCFN forward keeps the bf16x3 kernel); fp32 master weights, gradients and optimizer state"),
+    "fp32": "f32",
+}
+
+
+def run(variant, precision, B, steps, warmup, rank, world, dev, share):
+    """One training measurement on this rank's device; the process group (if any) is already initialised.  Returns the record
+    (rank 0) or None."""
     from . import dist as sdist
     from . import lib as L
     from .config import VARIANTS
@@ -27,25 +38,12 @@ def main(args):
     from .model import Model
     from .synth import synth_sources
 
-    share = bool(getattr(args, "share_gpu", False))   # DEBUG: all ranks on GPU 0, gloo collectives (exercises the N > 1 code path on one GPU)
-    rank, world, local = sdist.init_from_env("gloo" if share else None)
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the separator path)")
-    if share:
-        local = 0
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
     lib = L.load()
-    variant = args.variant
     cfg = VARIANTS[variant]
-    precision = args.precision if args.precision in ("fp32", "bf16x3") else None
     model = Model.from_config(cfg, init_seed=0, precision=precision).load_synthetic_(0).to(dev)
     model.train()
     sync = sdist.GradSync()
     model.grad_sync = sync
-    B = args.batch or 8
     samples = 32000
     src = torch.from_numpy(synth_sources(B, samples, seed=4321 + rank * B)).to(dev)
     x = src.sum(1).contiguous()
@@ -71,14 +69,14 @@ def main(args):
         opt.step()
         last["loss"], last["gn"] = loss.detach(), gn
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
-    L.check(lib.sepr_prof_start(L.SITE_WGRAD, 400 * max(args.steps, 1) + 8), "sepr_prof_start")
+    L.check(lib.sepr_prof_start(L.SITE_WGRAD, 400 * max(steps, 1) + 8), "sepr_prof_start")
     sdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     t_host = time.perf_counter() - t0            # host-side enqueue time of the K steps (no synchronisation inside a step)
     torch.cuda.synchronize(dev)
@@ -87,29 +85,29 @@ def main(args):
     n_l, ms, fl = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
     L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
     elapsed = sdist.max_over_ranks(elapsed, dev)
+    rec = None
     if rank == 0:
-        utt_per_s = world * B * args.steps / elapsed
-        x3 = model.precision == "bf16x3"
-        peak = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
-        mult = 3.0 if x3 else 1.0
+        utt_per_s = world * B * steps / elapsed
+        prec = model.precision
+        peak = FP32_MFMA_PEAK_TFLOPS if prec == "fp32" else BF16_MFMA_PEAK_TFLOPS
+        mult = 3.0 if prec == "bf16x3" else 1.0
         sec = ms.value / 1e3
         algo_tf = fl.value / 1e12 / sec if sec > 0 else 0.0
         gflop = 3.0 * GFLOP_FWD.get(variant, 0.0)                      # forward + input gradients + weight gradients
         rec = {
             "metric": f"training utterances/sec (4 s, 8 kHz, 2-spk) {variant}: forward + PIT SI-SNR losses + backward + clip + AdamW",
-            "value": round(utt_per_s, 3), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate); fp32 master weights, "
-                      "gradients and optimizer state") if x3 else "f32",
-            "data": "synthetic",
+            "value": round(utt_per_s, 3), "unit": "utt/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * elapsed / max(steps, 1), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPES[prec], "data": "synthetic",
             "config": {"workload": f"{variant} training step, batch={B} per GPU, 4 s @ 8 kHz, 2 speakers (BASELINE.json configs[4])",
-                       "batch_per_gpu": B, "samples": samples, "precision": model.precision, "dropout": model.dropout_p,
+                       "batch_per_gpu": B, "samples": samples, "precision": prec, "dropout": model.dropout_p,
                        "dropout_sites": "all the reference's sites: GCFN x2, CLA, attention probabilities + attention output (EGA and speaker attention)",
                        "optimizer": type(opt).__name__ + (" (fused)" if getattr(opt, "defaults", {}).get("fused") else ""),
                        "clip_norm": 5.0, "parallelism": f"data-parallel x{world}, flat-buffer RCCL all-reduce" + (" (DEBUG: all ranks share GPU 0, gloo collective)" if share else "")},
-            "host_enqueue_ms_per_step": round(1e3 * t_host / max(args.steps, 1), 3),
+            "host_enqueue_ms_per_step": round(1e3 * t_host / max(steps, 1), 3),
             "loss": round(float(last["loss"]), 4), "grad_norm": round(float(last["gn"]), 4),
             "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+            "collective_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
             "allreduce_bytes_per_step": (sync.bytes // max(sync.calls, 1)) if sync.calls else 0,
             "model_tflops": round(utt_per_s * gflop / 1e3 / world, 2),
             "model_frac_algorithmic": round(utt_per_s * gflop / 1e3 / world / peak, 4),
@@ -119,6 +117,28 @@ def main(args):
                          "ceiling": round(1.0 / mult, 4), "traffic": None, "launches": int(n_l.value),
                          "avg_launch_ms": round(ms.value / max(n_l.value, 1), 4)},
         }
+    model.grad_sync = None
+    del opt, model
+    torch.cuda.empty_cache()
+    return rec
+
+
+def main(args):
+    from . import dist as sdist
+
+    share = bool(getattr(args, "share_gpu", False))   # DEBUG: all ranks on GPU 0, gloo collectives (exercises the N > 1 code path on one GPU)
+    # a process group also at world size 1: the gradient all-reduce then really runs through RCCL on a 1-GPU box
+    rank, world, local = sdist.init_from_env("gloo" if share else None, single_rank_group=not share)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the separator path)")
+    if share:
+        local = 0
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    rec = run(args.variant, args.precision, args.batch or 8, args.steps, args.warmup, rank, world, dev, share)
+    if rank == 0:
         print(json.dumps(rec), flush=True)
     sdist.barrier()
     if torch.distributed.is_initialized():

@@ -1,6 +1,7 @@
 """N>1 path on CPU: two gloo ranks shard a batch by utterance, separate their slice, gather, and reduce a
 metric.  The compute function here is the oracle (allowed in tests); the sharding / gather / reduce
 logic under test is the product's (sepreformer_amd/dist.py)."""
+import json
 import os
 import socket
 import sys
@@ -94,13 +95,21 @@ def test_bench_self_launches_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT,
                        env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
-    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+    txt = r.stdout + r.stderr
+    ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ngpu >= 2:
         assert r.returncode == 0, r.stderr[-2000:]
+        rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["reduced_metric"]["utterances"] == 64
         return
     assert r.returncode != 0
-    txt = r.stdout + r.stderr
-    assert "WORLD_SIZE" not in txt or "but WORLD_SIZE" not in txt
-    assert "needs an MI355X" in txt or "invalid device ordinal" in txt or "device" in txt.lower(), txt[-2000:]
+    assert "but WORLD_SIZE" not in txt, txt[-2000:]                 # the ranks were started with the torchrun environment
+    if ngpu == 0:
+        # BOTH ranks got past the argument / WORLD_SIZE checks and stopped at the device check, each with the exact message
+        assert txt.count("bench.py needs an MI355X") == 2, txt[-3000:]
+    else:
+        # one visible GPU: rank 0 runs, rank 1 has no device (the shared-GPU debug mode is covered by tests/test_bench_gpu.py)
+        assert "invalid device ordinal" in txt or "device ordinal" in txt.lower() or "hipErrorInvalidDevice" in txt, txt[-3000:]
 
 
 def _gradsync_worker(rank, world, port, out_dir):
