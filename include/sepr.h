@@ -455,6 +455,9 @@ int sepr_front_bwd(const float* wav, const float* enc, const float* dout, float*
 size_t sepr_linear_wgrad_workspace(int M, int N, int K);
 int sepr_linear_wgrad(const float* A, const float* B, float* G, float* colsum, int M, int N, int K, int accumulate, int x3, void* ws,
                       size_t ws_bytes, sepr_stream_t stream);
+/* the same with the normalisation prologue of a projection behind a LayerNorm: B'[m][k] = (B[m][k] - stats[2m]) * stats[2m+1] */
+int sepr_linear_wgrad_norm(const float* A, const float* B, const float* stats, float* G, float* colsum, int M, int N, int K,
+                           int accumulate, int x3, void* ws, size_t ws_bytes, sepr_stream_t stream);
 
 /* PIT_SISNR_time backward (criterions.py:191-217): d(sum_b loss[b] * gl[b]) / d est.  est, tgt, dest [S,B,T]; perm from the forward. */
 int sepr_pit_sisnr_bwd(const float* est, const float* tgt, const int* perm, const float* gl, int S, int B, int T, double eps,

@@ -17,6 +17,7 @@
 //     crop / nearest-upsample / overlapping-frame row maps), so no normalised or gathered copy is ever materialised;
 //   * the column sums of A (bias gradients) ride along in the staging registers.
 #include "sepr_train.h"
+#include <stdlib.h>
 
 namespace sepr {
 
@@ -53,14 +54,21 @@ inline TnPlan tn_plan(int M, int N, int K) {
   return p;
 }
 
-// MD: 0 = exact f32 MFMA, 1 = bf16x3 split arithmetic, 2 = plain bf16 operands (hi planes only, one MFMA per product)
-template <int MD>
+// MD: 0 = exact f32 MFMA, 1 = bf16x3 split arithmetic, 2 = plain bf16 operands (hi planes only, one MFMA per product).
+// GEN: the general B prologue (row maps, index tables, two-source concat, per-sequence statistics, masked A rows) - the fusion
+//      conv, the output heads, the encoder / projector: a handful of launches per step.  !GEN: B is a plain [M][ldb] tensor,
+//      optionally normalised with per-ROW statistics (STATS) - every block's projections, ~290 launches per step.
+// The !GEN loader is straight-line: all 16 row loads of a thread are issued back to back from clamped (always valid)
+// addresses, validity is a select afterwards, and the per-row (mean, rstd) pairs of a slab are fetched ONCE by 64 threads
+// and handed out through LDS instead of 16 x 8-byte loads per staging thread.
+template <int MD, bool GEN, bool STATS>
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part,
                                                                float* __restrict__ cpart) {
   // x3: [A_hi, A_lo, B_hi, B_lo][128][72] bf16 = 73 728 B;  f32: [A, B][64][132] fp32 = 67 584 B
   constexpr bool X3 = MD != 0, ONE = MD == 2;
   __shared__ __attribute__((aligned(16))) unsigned char smem[X3 ? 4 * TN_T * TN_LDM * 2 : 2 * TN_SLAB * TN_LDF * 4];
   __shared__ float csum_s[4][TN_T];
+  __shared__ float2 st_s[TN_SLAB];          // (mean, rstd) of the slab's rows (!GEN && STATS)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int fi = lane & 15, fg = lane >> 4;
@@ -77,49 +85,84 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
   const bool col_ok = col < (roleA ? a.N : a.K);
   float4 r[8 * TN_NB];
   float4 csum = zero4();
+  float2 my_st = make_float2(0.f, 1.f);      // wave 2 only: statistics of row (slab base + lane) for the next slab
 
+  const int row_safe = m_beg < a.M ? m_beg : 0;
+  const int col_c = col_ok ? col : 0;
   auto load_slab = [&](int mb) {
+    if constexpr (!GEN) {
+      const float* base = roleA ? a.A : a.B;                      // wave-uniform
+      const long long ld = roleA ? a.lda : a.ldb;
 #pragma unroll
-    for (int e = 0; e < 8 * TN_NB; ++e) {
-      const int m = mb + 32 * (e >> 3) + 8 * mg + (e & 7);
-      r[e] = zero4();
-      if (m < m_end && col_ok) {
-        if (roleA) {
-          bool valid = true;
-          if (a.mask_a && a.rows_out > 0) valid = (m % a.rows_out) < a.rows_valid;
-          if (valid) r[e] = ld4(a.A + (long long)m * a.lda + col);
+      for (int e = 0; e < 8 * TN_NB; ++e) {
+        const int m = mb + 32 * (e >> 3) + 8 * mg + (e & 7);
+        r[e] = ld4(base + (long long)(m < m_end ? m : row_safe) * ld + col_c);
+      }
+      if (STATS && wid == 2) {
+        const int m = mb + lane;
+        my_st = *reinterpret_cast<const float2*>(a.stats + 2LL * (m < m_end ? m : row_safe));
+        if (m >= m_end) my_st = make_float2(0.f, 0.f);           // rows past the slice: (0 - 0) * 0
+      }
+#pragma unroll
+      for (int e = 0; e < 8 * TN_NB; ++e) {
+        const int m = mb + 32 * (e >> 3) + 8 * mg + (e & 7);
+        if (!(m < m_end && col_ok)) r[e] = zero4();
+      }
+    } else {
+      const bool useB2 = !roleA && a.B2 != nullptr && col_ok && col >= a.ksplit;
+#pragma unroll
+      for (int e = 0; e < 8 * TN_NB; ++e) {
+        const int m0_ = mb + 32 * (e >> 3) + 8 * mg + (e & 7);
+        const bool in = m0_ < m_end && col_ok;
+        const int m = in ? m0_ : row_safe;
+        if (roleA) {                                   // wave-uniform: waves 0,1 stage A, waves 2,3 stage B
+          bool valid = in;
+          if (a.mask_a && a.rows_out > 0) valid = valid && (m % a.rows_out) < a.rows_valid;
+          const float4 v = ld4(a.A + (long long)m * a.lda + col_c);
+          r[e] = valid ? v : zero4();
         } else {
           long long off = (long long)m * a.ldb;
           long long srow = m;
-          bool valid = true;
-          if (a.rows_out > 0) {
+          bool valid = in;
+          if (a.rows_out > 0) {                        // kernel-uniform
             const int seq = m / a.rows_out;
             const int rr = m - seq * a.rows_out;
-            valid = rr < a.rows_valid;
-            const int rs = valid ? ((a.idx ? a.idx[rr] : rr) >> a.b_shift) : 0;
+            const bool rv = rr < a.rows_valid;
+            valid = valid && rv;
+            const int rc = rv ? rr : 0;
+            const int rs = (a.idx ? a.idx[rc] : rc) >> a.b_shift;
             off = (long long)seq * a.seq_stride + (long long)rs * a.ldb;
             srow = seq;
           }
-          if (valid) {
-            float4 v;
-            if (a.B2 && col >= a.ksplit) v = ld4(a.B2 + (long long)m * a.ldb2 + (col - a.ksplit));
-            else v = ld4(a.B + off + col);
-            if (a.stats) {
-              const long long si = a.stat_seq ? srow : m;
-              const float mean = a.stats[2 * si], rstd = a.stats[2 * si + 1];
-              v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd; v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
-            }
-            r[e] = v;
+          const float* src = useB2 ? a.B2 + (long long)m * a.ldb2 + (col_c - a.ksplit) : a.B + off + col_c;
+          float4 v = ld4(src);
+          if (a.stats) {                               // kernel-uniform
+            const long long si = a.stat_seq ? srow : m;
+            const float2 st = *reinterpret_cast<const float2*>(a.stats + 2 * si);
+            v.x = (v.x - st.x) * st.y; v.y = (v.y - st.x) * st.y; v.z = (v.z - st.x) * st.y; v.w = (v.w - st.x) * st.y;
           }
+          r[e] = valid ? v : zero4();
         }
       }
     }
+  };
+  // the statistics a slab's B rows are normalised with travel wave 2 -> LDS -> every staging thread of B (published by the
+  // barrier at the top of the loop; the previous slab's readers are past the barrier in the middle of the loop)
+  auto publish_stats = [&]() {
+    if (!GEN && STATS && wid == 2) st_s[lane] = my_st;
   };
   auto store_slab = [&]() {
 #pragma clang fp contract(off)
     if (roleA) {
 #pragma unroll
       for (int e = 0; e < 8 * TN_NB; ++e) { csum.x += r[e].x; csum.y += r[e].y; csum.z += r[e].z; csum.w += r[e].w; }
+    } else if (!GEN && STATS) {
+#pragma unroll
+      for (int e = 0; e < 8 * TN_NB; ++e) {
+        // (columns past K hold (0 - mean) * rstd garbage: they only ever reach accumulator columns that are never stored)
+        const float2 st = st_s[32 * (e >> 3) + 8 * mg + (e & 7)];
+        r[e].x = (r[e].x - st.x) * st.y; r[e].y = (r[e].y - st.x) * st.y; r[e].z = (r[e].z - st.x) * st.y; r[e].w = (r[e].w - st.x) * st.y;
+      }
     }
     if (X3) {
       unsigned short* hi = reinterpret_cast<unsigned short*>(smem) + (roleA ? 0 : 2) * TN_T * TN_LDM;
@@ -154,6 +197,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (m_beg < m_end) load_slab(m_beg);
+  publish_stats();
   for (int mb = m_beg; mb < m_end; mb += TN_SLAB) {
     __syncthreads();            // every wave is done reading the previous slab
     store_slab();
@@ -207,6 +251,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
             acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv[kt], acc[nt][kt], 0, 0, 0);
       }
     }
+    publish_stats();            // statistics of the slab just requested (no reader of st_s between the two barriers above and the next)
   }
 
   // ---- partial tile -> workspace: part[split][n][k] ----
@@ -284,12 +329,23 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   const int grid = p.tn * p.tk * p.nsplit;
   long long slot = -1;
   const bool timed = prof_begin(SEPR_SITE_WGRAD, s, &slot);
-  if (x3 == 2)
-    hipLaunchKernelGGL((gemm_tn_kernel<2>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
-  else if (x3)
-    hipLaunchKernelGGL((gemm_tn_kernel<1>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
-  else
-    hipLaunchKernelGGL((gemm_tn_kernel<0>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, a.colsum ? cpart : nullptr);
+  const bool gen = a.rows_out > 0 || a.B2 != nullptr || a.idx != nullptr || a.mask_a != 0 || a.stat_seq != 0;
+  float* cp = a.colsum ? cpart : nullptr;
+  // The general loader with statistics runs ONE workgroup per CU (16 KB of dynamic LDS on top of the static 74 KB make a second
+  // one not fit): with two co-resident workgroups its bf16 instantiations returned wrong, run-to-run different values in
+  // the even components of lanes 16-31 / 48-63 of the B staging waves (M >= ~20 000 rows; found by the full-size
+  // determinism test of round 3, reproduced by tools/det_tn.py, root cause not established).  One or two launches per step.
+  const int dyn = (gen && a.stats) ? 16384 : 0;
+#define SEPR_TN_LAUNCH(MD)                                                                                                   \
+  do {                                                                                                                       \
+    if (gen) hipLaunchKernelGGL((gemm_tn_kernel<MD, true, false>), dim3(grid), dim3(TN_THREADS), dyn, s, a, p, part, cp);    \
+    else if (a.stats) hipLaunchKernelGGL((gemm_tn_kernel<MD, false, true>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp); \
+    else hipLaunchKernelGGL((gemm_tn_kernel<MD, false, false>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp);         \
+  } while (0)
+  if (x3 == 2) SEPR_TN_LAUNCH(2);
+  else if (x3) SEPR_TN_LAUNCH(1);
+  else SEPR_TN_LAUNCH(0);
+#undef SEPR_TN_LAUNCH
   if (timed) prof_end(slot, 2.0 * (double)a.M * (double)a.N * (double)a.K, s);
   const long long total = (long long)a.N * a.K + a.N;
   const int rgrid = (int)((total + 63) / 64);

@@ -654,6 +654,12 @@ extern "C" int sepr_linear_wgrad(const float* A, const float* B, float* G, float
   return wgrad(A, N, B, K, nullptr, G, colsum, M, N, K, accumulate, x3 < 0 || x3 > 2 ? 1 : x3, ws, ws_bytes, SEPR_ST);
 }
 
+extern "C" int sepr_linear_wgrad_norm(const float* A, const float* B, const float* stats, float* G, float* colsum, int M, int N, int K,
+                                      int accumulate, int x3, void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  if (!A || !B || !stats || !G || M <= 0) return SEPR_EINVAL;
+  return wgrad(A, N, B, K, stats, G, colsum, M, N, K, accumulate, x3 < 0 || x3 > 2 ? 1 : x3, ws, ws_bytes, SEPR_ST);
+}
+
 // =====================================================================================================================
 // fusion conv, OutputLayer + decoder, encoder + projector, sizing
 // =====================================================================================================================

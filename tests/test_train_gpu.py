@@ -168,6 +168,35 @@ def test_wgrad_core(M, N, K, x3):
     soft.done()
 
 
+@pytest.mark.parametrize("x3", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(64000, 768, 128), (20000, 256, 128), (300000, 128, 128), (777, 384, 128)])
+def test_wgrad_norm_full_size(M, N, K, x3):
+    """The contraction behind a LayerNorm (normalisation prologue from per-row statistics) at the launch sizes of a 4 s batch:
+    two workgroups per CU, dozens of row slices.  Round 3 found the first version of this path returning wrong (1e-2 relative),
+    run-to-run different values in its bf16 instantiations exactly there - no test went beyond 8000 rows.  Checked against fp64
+    and for bitwise repeatability."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(M)
+    a, b = torch.randn(M, N, generator=g), torch.randn(M, K, generator=g) * 2 + 0.5
+    mean, rstd = b.mean(1), 1.0 / torch.sqrt(b.var(1, unbiased=False) + 1e-5)
+    want = (a.double().t() @ ((b.double() - mean.double()[:, None]) * rstd.double()[:, None])).float()
+    ad, bd, sd_ = a.cuda(), b.cuda(), torch.stack([mean, rstd], 1).contiguous().cuda()
+    ws = torch.empty(int(lib.sepr_linear_wgrad_workspace(M, N, K)) + 256, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for _ in range(3):
+        G = torch.empty(N, K, device="cuda")
+        cs = torch.empty(N, device="cuda")
+        L.check(lib.sepr_linear_wgrad_norm(ad.data_ptr(), bd.data_ptr(), sd_.data_ptr(), G.data_ptr(), cs.data_ptr(), M, N, K, 0, x3,
+                                           ws.data_ptr(), ws.numel(), st), "wgrad_norm")
+        outs.append((G, cs))
+    soft = Soft(f"wgrad_norm.{M}x{N}x{K}.{['f32', 'x3', 'bf16'][x3]}")
+    soft.agree("G", outs[0][0], want, [110.0, 85.0, 40.0][x3])
+    soft.agree("colsum", outs[0][1], a.double().sum(0).float(), 110.0)
+    assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
+    soft.done()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # every block: train-mode forward and backward against autograd over the oracle's restatement of the same module
 # ---------------------------------------------------------------------------------------------------------------------
