@@ -146,6 +146,7 @@ def parse_args():
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: all ranks use GPU 0 and the gloo backend (exercises the N > 1 path end to end on a 1-GPU box; "
                          "the throughput it prints is NOT a scaling number)")
+    ap.add_argument("--no-train-graphs", action="store_true", help="train mode: launch every kernel from the host instead of replaying captured hipGraphs")
     ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default=None,
                     help="projection arithmetic (default: the package default / SEPR_PRECISION)")
     return ap.parse_args()

@@ -323,6 +323,7 @@ typedef struct {
    * statistics, and the backward recomputes the hidden tensor inside its middle kernel (csrc/sepr_gcfn_bwd_fused.hip).
    * fused_w1p / fused_w2p exactly as in sepr_gcfn_w.  NULL fused_w1p = the unfused path. */
   const void* fused_w1p; const void* fused_w2p;
+  const sepr_u64* seed_salt;   /* optional device word XOR-ed into `seed` by every dropout kernel of the call (hipGraph replay) */
 } sepr_gcfn_tw;
 typedef struct { float* ln_g; float* ln_b; float* w1; float* b1; float* dw_w; float* dw_b; float* w2; float* b2; float* ls; } sepr_gcfn_grad;
 
@@ -338,6 +339,7 @@ typedef struct {
   sepr_lin l3, l3_t;   /* [F,2F] linear3.1; [2F,F] (layer_scale * linear3.1.weight)^T */
   const float* ls;
   const float* w1; const float* ln_g; const float* ln_b; const float* w3; const float* b3;   /* raw parameters */
+  const sepr_u64* seed_salt;   /* as in sepr_gcfn_tw */
 } sepr_cla_tw;
 typedef struct { float* ln_g; float* ln_b; float* w1; float* b1; float* dw_w; float* dw_b; float* w2; float* b2; float* bn_g; float* bn_b;
                  float* w3; float* b3; float* ls; } sepr_cla_grad;
@@ -348,6 +350,7 @@ typedef struct {
   sepr_lin out, out_t;  /* [F,F] linear_out; (layer_scale * linear_out.weight)^T */
   const float* ls;
   const float* wqkv; const float* ln_g; const float* ln_b; const float* wo; const float* bo;   /* raw (wqkv stacked [3F,F]) */
+  const sepr_u64* seed_salt;   /* as in the GCFN struct; for EGA the attention struct carries it for the whole block */
 } sepr_mha_tw;
 typedef struct { float* ln_g; float* ln_b; float* wq; float* bq; float* wk; float* bk; float* wv; float* bv; float* wo; float* bo; float* ls; } sepr_mha_grad;
 

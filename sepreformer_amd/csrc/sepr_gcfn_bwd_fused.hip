@@ -55,7 +55,11 @@ struct GcfnBwdArgs {
   const unsigned long long* salt;
 };
 
-template <int PLANES>
+// NSL = F / 64 slabs per operand.  All 2 * NSL activation slabs of a tile (x, then dy) are requested TOGETHER, one tile ahead:
+// the loads of tile t+1 are issued when tile t's accumulators have been staged and fly under its whole row-window epilogue.
+// (First version: one slab in flight at a time, requested during the previous slab's ~800-cycle MFMA phase - every slab paid
+//  an exposed L2 / HBM latency and a 64-row tile took 16 us.)
+template <int PLANES, int NSL>
 __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnBwdArgs a) {
   constexpr bool ONE = PLANES == 1;
   constexpr int NP = ONE ? 1 : 2;                              // bf16 planes per LDS buffer
@@ -73,7 +77,8 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnB
   const int NB = C3 / 64;
   const int MB = (a.M + GB_OUT - 1) / GB_OUT;
   const int ntiles = ((MB + 7) / 8) * 8 * NB;
-  const int nsl = F / GB_BKS, kst = F / 32;
+  constexpr int nsl = NSL;
+  const int kst = F / 32;
   const uint4* const W1 = static_cast<const uint4*>(a.w1p);
   const uint4* const W2 = static_cast<const uint4*>(a.w2tp);
   const bool drop = a.drop_thr > 0u;
@@ -85,31 +90,42 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnB
   // staging role: one row per 4 threads, 16 consecutive k per thread and slab
   const int srow = tid >> 2, kq = (tid & 3) * 16;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // same row tile -> same XCD for all its column blocks (block b runs on XCD b % 8): x / dy rows are fetched once per L2
+  // tile walk: same row tile -> same XCD for all its column blocks (block b runs on XCD b % 8): x / dy rows are fetched once per L2
+  auto decode = [&](int tile, int& mb, int& nb) -> bool {
     const int u = tile >> 3;
-    const int mb = (u / NB) * 8 + (tile & 7), nb = u % NB;
-    if (mb >= MB) continue;
+    mb = (u / NB) * 8 + (tile & 7);
+    nb = u % NB;
+    return mb < MB;
+  };
+  float4 ra[2 * NSL][4];                                       // this tile's slabs (x: 0..NSL-1, dy: NSL..2NSL-1), 16 k per thread each
+  float2 rst = make_float2(0.f, 0.f);                          // (mean, rstd) of the staged row
+  auto load_tile = [&](int mb_) {
+    const int msn = mb_ * GB_OUT - 2 + srow;
+    const long long row = (msn >= 0 && msn < a.M) ? msn : 0;
+    const float* px = a.x + row * F + kq;
+    const float* pd = a.dy + row * F + kq;
+#pragma unroll
+    for (int q = 0; q < NSL; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ra[q][j] = ld4(px + q * GB_BKS + 4 * j);
+        ra[NSL + q][j] = ld4(pd + q * GB_BKS + 4 * j);
+      }
+    rst = *reinterpret_cast<const float2*>(a.stats + 2 * row);
+  };
+  int tile = blockIdx.x, mb = 0, nb = 0;
+  while (tile < ntiles && !decode(tile, mb, nb)) tile += gridDim.x;
+  if (tile < ntiles) load_tile(mb);
+  while (tile < ntiles) {
     const int m0 = mb * GB_OUT;
     const int ms = m0 - 2 + srow;                              // the row this thread stages
     const bool svalid = ms >= 0 && ms < a.M;
-    float mean = 0.f, rstd = 0.f;
-    if (svalid) {
-      const float2 st = *reinterpret_cast<const float2*>(a.stats + 2LL * ms);
-      mean = st.x;
-      rstd = st.y;
-    }
-    float4 ra[4];
-    auto load_slab = [&](int q) {                              // q < nsl: x slab q; else dy slab q - nsl
-      const float* src = (q < nsl ? a.x : a.dy) + (long long)(svalid ? ms : 0) * F + (q < nsl ? q : q - nsl) * GB_BKS + kq;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ra[j] = ld4(src + 4 * j);
-    };
+    const float mean = rst.x, rstd = rst.y;
     auto store_slab = [&](int q) {
 #pragma clang fp contract(off)
       float v[16];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { v[4 * j] = ra[j].x; v[4 * j + 1] = ra[j].y; v[4 * j + 2] = ra[j].z; v[4 * j + 3] = ra[j].w; }
+      for (int j = 0; j < 4; ++j) { v[4 * j] = ra[q][j].x; v[4 * j + 1] = ra[q][j].y; v[4 * j + 2] = ra[q][j].z; v[4 * j + 3] = ra[q][j].w; }
       if (q < nsl) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = svalid ? (v[e] - mean) * rstd : 0.f;
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnB
     const int tv = 4 * nb + wn, tg = C3 / 16 + 4 * nb + wn;     // this wave's value / gate tile of W1, tv also its W2^T tile
 
     __syncthreads();   // the previous tile's epilogue is done with the LDS tiles that alias the slab buffers
-    load_slab(0);
+#pragma unroll
     for (int q = 0; q < 2 * nsl; ++q) {
       const bool up = q < nsl;
       const int s = up ? q : q - nsl;
@@ -179,7 +195,6 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnB
       }
       store_slab(q);
       __syncthreads();
-      if (q + 1 < 2 * nsl) load_slab(q + 1);                   // in flight under the MFMAs
       const unsigned short* ph = slab + ((q & 1) * NP + 0) * PLANE_E;
       const unsigned short* pl = slab + ((q & 1) * NP + (NP - 1)) * PLANE_E;
 #pragma unroll
@@ -239,6 +254,10 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnB
         st4(Ds + (mt * 16 + fi) * GB_DS + cl, make_float4(dd[mt][0], dd[mt][1], dd[mt][2], dd[mt][3]));
       }
     }
+    // the next tile of this workgroup: all its activation slabs go in flight now, under the epilogue below
+    int nxt = tile + gridDim.x, mb_n = 0, nb_n = 0;
+    while (nxt < ntiles && !decode(nxt, mb_n, nb_n)) nxt += gridDim.x;
+    if (nxt < ntiles) load_tile(mb_n);
     __syncthreads();
 
     // ---- pass A: conv, GLU, dropout, GLU backward for rows 1..62; thread = 4 hidden channel pairs x 4 consecutive rows ----
@@ -370,6 +389,9 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnB
         po[o] = (Ds[o] + Ds[512 + o]) + (Ds[1024 + o] + Ds[1536 + o]);
       }
     }
+    tile = nxt;
+    mb = mb_n;
+    nb = nb_n;
   }
 }
 }  // namespace
@@ -385,7 +407,7 @@ int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, i
   const long long M = (long long)n * T;
   if (M <= 0) return SEPR_OK;
   if (!x || !stats || !dy || !w || !w->up.wp || !w->up.b || !w->down_t.wp || !w->dw_w || !w->dw_b || !g || !dh1 || !dw_g || !db_g ||
-      F % 64 || !(p >= 0.f) || !(p < 1.f))
+      (F != 64 && F != 128) || !(p >= 0.f) || !(p < 1.f))
     return SEPR_EINVAL;
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
   if (!ws || ws_bytes < gcfn_bwd_fused_ws(M, F)) return SEPR_EWORKSPACE;
@@ -404,10 +426,16 @@ int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, i
   const int grid = ntiles < cap ? ntiles : cap;
   long long slot = -1;
   const bool timed = prof_begin(SEPR_SITE_GCFN_BWD, st, &slot);
-  if (w->up.planes == 1)
-    hipLaunchKernelGGL((gcfn_bwd_mid_kernel<1>), dim3(grid), dim3(GB_THREADS), 0, st, a);
-  else
-    hipLaunchKernelGGL((gcfn_bwd_mid_kernel<3>), dim3(grid), dim3(GB_THREADS), 0, st, a);
+  const bool one = w->up.planes == 1;
+  if (F == 128) {
+    if (one) hipLaunchKernelGGL((gcfn_bwd_mid_kernel<1, 2>), dim3(grid), dim3(GB_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((gcfn_bwd_mid_kernel<3, 2>), dim3(grid), dim3(GB_THREADS), 0, st, a);
+  } else if (F == 64) {
+    if (one) hipLaunchKernelGGL((gcfn_bwd_mid_kernel<1, 1>), dim3(grid), dim3(GB_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((gcfn_bwd_mid_kernel<3, 1>), dim3(grid), dim3(GB_THREADS), 0, st, a);
+  } else {
+    return SEPR_EINVAL;   // (the fused pair exists for F = 64 / 128: sepr_gcfn_fused.hip)
+  }
   // algorithmic FLOPs per row: recomputed up-projection 2 F 6F + input gradient of net2.2 2 F 3F + conv / GLU forward and backward
   if (timed) prof_end(slot, (double)M * (18.0 * F * F + 60.0 * 3 * F), st);
   SEPR_CHECK_LAUNCH("gcfn_bwd_mid_kernel");

@@ -19,6 +19,19 @@ __device__ __forceinline__ unsigned long long sepr_mix64(unsigned long long z) {
 __device__ __forceinline__ bool sepr_keep(unsigned long long seed, unsigned long long index, unsigned int thr) {
   return (unsigned int)(sepr_mix64(seed ^ sepr_mix64(index)) >> 32) >= thr;
 }
+// Optional per-step salt of every dropout site: a device-resident 64-bit word XOR-ed into the by-value seed at kernel start.
+// It is what lets a captured hipGraph of a training step draw fresh masks on every replay (the by-value seeds are frozen into
+// the graph; the host rewrites the word before each replay).  The block entry points set it from their weight struct
+// (sepr_*_tw.seed_salt, may be NULL) for the duration of the call - thread-local, so concurrent callers do not interfere.
+const unsigned long long* drop_salt();
+struct DropSaltScope {
+  const unsigned long long* prev;
+  explicit DropSaltScope(const unsigned long long* s);
+  ~DropSaltScope();
+};
+__device__ __forceinline__ unsigned long long sepr_salted(unsigned long long seed, const unsigned long long* salt) {
+  return salt ? (seed ^ *salt) : seed;
+}
 inline unsigned int sepr_drop_threshold(float p) {
   const double t = (double)p * 4294967296.0;
   return t >= 4294967295.0 ? 4294967295u : (unsigned int)t;

@@ -108,7 +108,7 @@ int gcfn_fused_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcf
   f.train = 1; f.stats = stats;
   f.drop_thr = p > 0.f ? sepr_drop_thr16(p) : 0u;
   f.drop_scale = p > 0.f ? sepr_drop_scale16(p) : 1.0f;
-  f.seed = seed; f.salt = nullptr;
+  f.seed = seed; f.salt = drop_salt();
   return launch_gcfn_fused(f, F, SEPR_SITE_GCFN_UP, st);
 }
 int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, const sepr_gcfn_tw* w, const sepr_gcfn_grad* g,
@@ -131,7 +131,7 @@ int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int
   if (ws.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
   const int x3 = tn_mode(w->up);
-  SEPR_TRY(launch_gcfn_bwd_fused(x, stats, dy, n, T, F, w, gd, dh1, dyp, g->dw_w, g->dw_b, p, seed, nullptr, midw, midb, st));
+  SEPR_TRY(launch_gcfn_bwd_fused(x, stats, dy, n, T, F, w, gd, dh1, dyp, g->dw_w, g->dw_b, p, seed, drop_salt(), midw, midb, st));
   const float* dyq = p > 0.f ? dyp : dy;
   // net2.2 + LayerScale
   SEPR_TRY(wgrad(dyq, F, gd, 3 * F, nullptr, Gr, s2, M, F, 3 * F, 0, x3, tnw, tnb, st));
@@ -562,6 +562,7 @@ using namespace sepr;
 extern "C" int sepr_gcfn_train_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, void* ctx, size_t ctx_bytes,
                                    void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream) {
   if (!x || !y || !w || n <= 0 || T <= 0 || F <= 0 || F % 32 || !rows_ok((long long)n * T) || x == y) return SEPR_EINVAL;
+  DropSaltScope salt_scope(w->seed_salt);
   Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
   if (gcfn_is_fused(w, F)) return gcfn_fused_fwd(x, y, n, T, F, w, cx, p_drop, seed, SEPR_ST);
   return gcfn_fwd(x, y, n, T, F, w, cx, wk, p_drop, seed, SEPR_ST);
@@ -570,6 +571,7 @@ extern "C" int sepr_gcfn_bwd(const float* x, const float* dy, float* dx, int n, 
                              const sepr_gcfn_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop,
                              sepr_u64 seed, sepr_stream_t stream) {
   if (!x || !dy || !dx || !w || !g || n <= 0 || T <= 0 || F <= 0 || F % 32 || !rows_ok((long long)n * T)) return SEPR_EINVAL;
+  DropSaltScope salt_scope(w->seed_salt);
   Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
   if (gcfn_is_fused(w, F)) return gcfn_fused_bwd(x, dy, dx, n, T, F, w, g, cx, wk, p_drop, seed, SEPR_ST);
   return gcfn_bwd(x, dy, dx, n, T, F, w, g, cx, wk, p_drop, seed, SEPR_ST);
@@ -577,6 +579,7 @@ extern "C" int sepr_gcfn_bwd(const float* x, const float* dy, float* dx, int n, 
 extern "C" int sepr_cla_train_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_cla_tw* w, void* ctx, size_t ctx_bytes,
                                   void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream) {
   if (!x || !y || !w || n <= 0 || T <= 0 || F <= 0 || F % 64 || !rows_ok((long long)n * T) || x == y) return SEPR_EINVAL;
+  DropSaltScope salt_scope(w->seed_salt);
   Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
   return cla_fwd(x, y, n, T, F, K, w, cx, wk, p_drop, seed, SEPR_ST);
 }
@@ -584,6 +587,7 @@ extern "C" int sepr_cla_bwd(const float* x, const float* dy, float* dx, int n, i
                             const sepr_cla_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop,
                             sepr_u64 seed, sepr_stream_t stream) {
   if (!x || !dy || !dx || !w || !g || n <= 0 || T <= 0 || F <= 0 || F % 64 || !rows_ok((long long)n * T)) return SEPR_EINVAL;
+  DropSaltScope salt_scope(w->seed_salt);
   Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
   return cla_bwd(x, dy, dx, n, T, F, K, w, g, cx, wk, p_drop, seed, SEPR_ST);
 }
@@ -592,6 +596,7 @@ extern "C" int sepr_ega_train_fwd(const float* x, float* y, int n, int T, int Tp
   if (!x || !y || !w || x == y || n <= 0 || T <= 0 || Tp <= 0 || T % Tp || F <= 0 || F % 32 || H <= 0 || F % H ||
       !rows_ok((long long)n * T))
     return SEPR_EINVAL;
+  DropSaltScope salt_scope(w->attn.seed_salt);
   Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
   return ega_fwd(x, y, n, T, Tp, F, H, w, cx, wk, p_drop, seed, SEPR_ST);
 }
@@ -601,6 +606,7 @@ extern "C" int sepr_ega_bwd(const float* x, const float* dy, float* dx, int n, i
   if (!x || !dy || !dx || !w || !g || n <= 0 || T <= 0 || Tp <= 0 || T % Tp || F <= 0 || F % 32 || H <= 0 || F % H ||
       !rows_ok((long long)n * T))
     return SEPR_EINVAL;
+  DropSaltScope salt_scope(w->attn.seed_salt);
   Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
   return ega_bwd(x, dy, dx, n, T, Tp, F, H, w, g, cx, wk, p_drop, seed, SEPR_ST);
 }
@@ -608,6 +614,7 @@ extern "C" int sepr_spkattn_train_fwd(const float* x, float* y, int nS, int S, i
                                       size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop, sepr_u64 seed, sepr_stream_t stream) {
   if (!x || !y || !w || nS <= 0 || S <= 0 || nS % S || T <= 0 || F <= 0 || F % 32 || H <= 0 || F % H || !rows_ok((long long)nS * T))
     return SEPR_EINVAL;
+  DropSaltScope salt_scope(w->seed_salt);
   Carve cx(ctx, ctx_bytes, false), wk(ws, ws_bytes, false);
   return spk_fwd(x, y, nS, S, T, F, H, w, cx, wk, p_drop, seed, SEPR_ST);
 }
@@ -617,6 +624,7 @@ extern "C" int sepr_spkattn_bwd(const float* x, const float* dy, float* dx, int 
   if (!x || !dy || !dx || !w || !g || nS <= 0 || S <= 0 || nS % S || T <= 0 || F <= 0 || F % 32 || H <= 0 || F % H ||
       !rows_ok((long long)nS * T))
     return SEPR_EINVAL;
+  DropSaltScope salt_scope(w->seed_salt);
   Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
   return spk_bwd(x, dy, dx, nS, S, T, F, H, w, g, cx, wk, p_drop, seed, SEPR_ST);
 }

@@ -31,7 +31,9 @@ template <int DK>
 __global__ __launch_bounds__(AT_THREADS) void relattn_train_fwd_kernel(const float* __restrict__ QKV, float* __restrict__ O,
                                                                       float* __restrict__ P, int Tp, int F, int H,
                                                                       const float* __restrict__ pe, int maxlen, float isd, unsigned int thr,
-                                                                      float dscale, unsigned long long seed, unsigned long long offset) {
+                                                                      float dscale, unsigned long long seed, unsigned long long offset,
+                                                                      const unsigned long long* __restrict__ salt) {
+  seed = sepr_salted(seed, salt);
   extern __shared__ float sm[];
   float* sc = sm;                        // [AT_QT][Tp]
   float* qs = sm + AT_QT * Tp;           // [AT_QT][DK]
@@ -98,6 +100,9 @@ __global__ __launch_bounds__(AT_THREADS) void relattn_train_fwd_kernel(const flo
     constexpr int NPART = AT_THREADS / (D4 * AT_QT);
     float4 acc = zero4();
     const unsigned long long rowoff = offset + ((unsigned long long)nh * Tp + (i0 + row)) * Tp;
+    // (unrolled by 8: the V rows of 8 iterations are requested together - one global-load latency per 8 keys instead of per key;
+    //  with one load in flight this loop was ~60 dependent L2 round trips per workgroup, the bulk of the kernel's time)
+#pragma unroll 8
     for (int j = part; j < Tp; j += NPART) {
       float p = sc[row * Tp + j];
       if (thr) p = sepr_keep(seed, rowoff + j, thr) ? p * dscale : 0.f;      // network.py:121 (dropout on the probabilities)
@@ -125,7 +130,9 @@ __global__ __launch_bounds__(AT_THREADS) void relattn_bwd_rows_kernel(const floa
                                                                      float* __restrict__ dQKV, float* __restrict__ dS,
                                                                      float* __restrict__ band, int NH, int Tp, int F, int H,
                                                                      const float* __restrict__ pe, int maxlen, float isd, unsigned int thr,
-                                                                     float dscale, unsigned long long seed, unsigned long long offset) {
+                                                                     float dscale, unsigned long long seed, unsigned long long offset,
+                                                                     const unsigned long long* __restrict__ salt) {
+  seed = sepr_salted(seed, salt);
   extern __shared__ float sm[];
   float* sc = sm;                        // [AT_QT][Tp]   P, then dS
   float* qs = sm + AT_QT * Tp;           // [AT_QT][DK]
@@ -192,6 +199,7 @@ __global__ __launch_bounds__(AT_THREADS) void relattn_bwd_rows_kernel(const floa
     {  // dq_i = sum_j dS[i][j] (k_j + pe[r(i,j)])
       const int d4 = tid % D4, row = (tid / D4) % AT_QT, part = tid / (D4 * AT_QT);
       float4 acc = zero4();
+#pragma unroll 8
       for (int j = part; j < Tp; j += NPART) {
         const float s = sc[row * Tp + j];
         const float4 kv = ld4(base + (long long)j * 3 * F + F + 4 * d4);
@@ -248,7 +256,9 @@ template <int DK>
 __global__ __launch_bounds__(AT_THREADS) void relattn_bwd_cols_kernel(const float* __restrict__ QKV, const float* __restrict__ P,
                                                                      const float* __restrict__ dS, const float* __restrict__ dO,
                                                                      float* __restrict__ dQKV, int Tp, int F, int H, unsigned int thr,
-                                                                     float dscale, unsigned long long seed, unsigned long long offset) {
+                                                                     float dscale, unsigned long long seed, unsigned long long offset,
+                                                                     const unsigned long long* __restrict__ salt) {
+  seed = sepr_salted(seed, salt);
   constexpr int D4 = DK / 4;
   constexpr int NPART = AT_THREADS / (D4 * AT_QT);
   __shared__ float redk[NPART][AT_QT][DK], redv[NPART][AT_QT][DK];
@@ -260,6 +270,7 @@ __global__ __launch_bounds__(AT_THREADS) void relattn_bwd_cols_kernel(const floa
   const int j = j0 + col;
   float4 ak = zero4(), av = zero4();
   if (j < Tp) {
+#pragma unroll 8
     for (int i = part; i < Tp; i += NPART) {
       const long long e = ((long long)nh * Tp + i) * Tp + j;
       float p = P[e];
@@ -343,10 +354,10 @@ int launch_relattn_train_fwd(const float* QKV, float* O, float* P, int n, int Tp
   const dim3 grid(n * H, (Tp + AT_QT - 1) / AT_QT);
   if (DK == 16) {
     hipLaunchKernelGGL((relattn_train_fwd_kernel<16>), grid, dim3(AT_THREADS), fwd_shm(Tp, 16), s, QKV, O, P, Tp, F, H, pe_k, maxlen, isd, thr,
-                       dscale, seed, offset);
+                       dscale, seed, offset, drop_salt());
   } else if (DK == 32) {
     hipLaunchKernelGGL((relattn_train_fwd_kernel<32>), grid, dim3(AT_THREADS), fwd_shm(Tp, 32), s, QKV, O, P, Tp, F, H, pe_k, maxlen, isd, thr,
-                       dscale, seed, offset);
+                       dscale, seed, offset, drop_salt());
   } else {
     return SEPR_EINVAL;
   }
@@ -375,19 +386,19 @@ int launch_relattn_bwd(const float* QKV, const float* P, const float* O, const f
   const float isd = 1.0f / sqrtf((float)DK);
 #define SEPR_ROWS(DD, NO)                                                                                                         \
   hipLaunchKernelGGL((relattn_bwd_rows_kernel<DD, NO>), dim3(ngroups, ntiles), dim3(AT_THREADS), bwd_shm(Tp, DD), s, QKV, P, O, dO, \
-                     dQKV, dS, band, NH, Tp, F, H, pe_k, maxlen, isd, thr, dscale, seed, offset)
+                     dQKV, dS, band, NH, Tp, F, H, pe_k, maxlen, isd, thr, dscale, seed, offset, drop_salt())
   if (DK == 16) {
     if (nown <= 8) SEPR_ROWS(16, 8);
     else if (nown <= 16) SEPR_ROWS(16, 16);
     else SEPR_ROWS(16, 32);
     hipLaunchKernelGGL((relattn_bwd_cols_kernel<16>), dim3(NH, ntiles), dim3(AT_THREADS), 0, s, QKV, P, dS, dO, dQKV, Tp, F, H, thr,
-                       dscale, seed, offset);
+                       dscale, seed, offset, drop_salt());
   } else {
     if (nown <= 8) SEPR_ROWS(32, 8);
     else if (nown <= 16) SEPR_ROWS(32, 16);
     else SEPR_ROWS(32, 32);
     hipLaunchKernelGGL((relattn_bwd_cols_kernel<32>), dim3(NH, ntiles), dim3(AT_THREADS), 0, s, QKV, P, dS, dO, dQKV, Tp, F, H, thr,
-                       dscale, seed, offset);
+                       dscale, seed, offset, drop_salt());
   }
 #undef SEPR_ROWS
   hipLaunchKernelGGL(relattn_band_reduce_kernel, dim3((2 * maxlen * DK + 63) / 64), dim3(AT_THREADS), 0, s, band,

@@ -9,6 +9,12 @@
 
 namespace sepr {
 
+static thread_local const unsigned long long* tl_drop_salt = nullptr;
+const unsigned long long* drop_salt() { return tl_drop_salt; }
+DropSaltScope::DropSaltScope(const unsigned long long* s) : prev(tl_drop_salt) { tl_drop_salt = s; }
+DropSaltScope::~DropSaltScope() { tl_drop_salt = prev; }
+
+
 namespace {
 constexpr int TPB = 256;
 
@@ -191,7 +197,8 @@ __global__ __launch_bounds__(TPB) void gcfn_mid_bwd_kernel(const float* __restri
                                                           const float* __restrict__ w /*[3][2C] tap-major*/,
                                                           const float* __restrict__ b /*[2C]*/, float* __restrict__ part,
                                                           unsigned int thr, float dscale, unsigned long long seed,
-                                                          unsigned long long offset) {
+                                                          unsigned long long offset, const unsigned long long* __restrict__ salt) {
+  seed = sepr_salted(seed, salt);
   const int c = blockIdx.y * TPB + threadIdx.x;
   if (c >= C) return;
   const int seq = blockIdx.x / nchunk, chunk = blockIdx.x - seq * nchunk;
@@ -293,7 +300,7 @@ int launch_gcfn_mid_bwd(const float* h1, const float* dg, float* dh1, int n, int
   const int nchunk = (T + GM_TC - 1) / GM_TC;
   float* part = static_cast<float*>(ws);
   hipLaunchKernelGGL(gcfn_mid_bwd_kernel, dim3(n * nchunk, (C + TPB - 1) / TPB), dim3(TPB), 0, s, h1, dg, dh1, T, C, nchunk, dw_w,
-                     dw_b, part, p > 0.f ? sepr_drop_threshold(p) : 0u, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, seed, offset);
+                     dw_b, part, p > 0.f ? sepr_drop_threshold(p) : 0u, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, seed, offset, drop_salt());
   float* scratch = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)n * nchunk * C * 8 * sizeof(float)));
   const float* rows = nullptr;
   const int nrows = prereduce(part, n * nchunk, C * 8, scratch, &rows, s);
@@ -632,7 +639,9 @@ namespace {
 template <int S, int DK, bool FWD>
 __global__ __launch_bounds__(TPB) void spkmix_bwd_kernel(const float* __restrict__ QKV, const float* __restrict__ dO,
                                                         float* __restrict__ dQKV, long long frames, int T, int F, int H, float isd,
-                                                        unsigned int thr, float dscale, unsigned long long seed, unsigned long long offset) {
+                                                        unsigned int thr, float dscale, unsigned long long seed, unsigned long long offset,
+                                                        const unsigned long long* __restrict__ salt) {
+  seed = sepr_salted(seed, salt);
   const long long total = frames * H;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
     const long long fr = i / H;
@@ -738,8 +747,8 @@ static int spkmix_train_launch(bool fwd, const float* QKV, const float* dO, floa
   const dim3 g(grid_for(frames * H, TPB, 1 << 16)), t(TPB);
 #define SEPR_SPKB(SS, DD)                                                                                                               \
   do {                                                                                                                                  \
-    if (fwd) hipLaunchKernelGGL((spkmix_bwd_kernel<SS, DD, true>), g, t, 0, s, QKV, dO, out, frames, T, F, H, isd, thr, dscale, seed, offset); \
-    else hipLaunchKernelGGL((spkmix_bwd_kernel<SS, DD, false>), g, t, 0, s, QKV, dO, out, frames, T, F, H, isd, thr, dscale, seed, offset);    \
+    if (fwd) hipLaunchKernelGGL((spkmix_bwd_kernel<SS, DD, true>), g, t, 0, s, QKV, dO, out, frames, T, F, H, isd, thr, dscale, seed, offset, drop_salt()); \
+    else hipLaunchKernelGGL((spkmix_bwd_kernel<SS, DD, false>), g, t, 0, s, QKV, dO, out, frames, T, F, H, isd, thr, dscale, seed, offset, drop_salt());    \
   } while (0)
   if (S == 2 && dk == 16) SEPR_SPKB(2, 16);
   else if (S == 2 && dk == 32) SEPR_SPKB(2, 32);
@@ -1071,7 +1080,9 @@ __global__ __launch_bounds__(TPB) void add_inplace_kernel(float* __restrict__ y,
 // y = (x ? x : 0) + ls[f] * drop(v): the residual + LayerScale tail of a block whose output dropout is live (thr > 0)
 __global__ __launch_bounds__(TPB) void res_ls_kernel(const float* __restrict__ x, const float* __restrict__ v, const float* __restrict__ ls,
                                                     float* __restrict__ y, long long M, int F, unsigned int thr, float dscale,
-                                                    unsigned long long seed, unsigned long long offset) {
+                                                    unsigned long long seed, unsigned long long offset,
+                                                    const unsigned long long* __restrict__ salt) {
+  seed = sepr_salted(seed, salt);
   const int f4 = F >> 2;
   const long long total = M * f4;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
@@ -1090,7 +1101,9 @@ __global__ __launch_bounds__(TPB) void res_ls_kernel(const float* __restrict__ x
   }
 }
 __global__ __launch_bounds__(TPB) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long count, unsigned int thr,
-                                                     float scale, unsigned long long seed, unsigned long long offset) {
+                                                     float scale, unsigned long long seed, unsigned long long offset,
+                                                     const unsigned long long* __restrict__ salt) {
+  seed = sepr_salted(seed, salt);
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < count; i += (long long)gridDim.x * TPB)
     y[i] = sepr_keep(seed, offset + (unsigned long long)i, thr) ? x[i] * scale : 0.f;
 }
@@ -1107,7 +1120,7 @@ int launch_res_ls(const float* x, const float* v, const float* ls, float* y, lon
   if (M <= 0) return SEPR_OK;
   if (!v || !ls || !y || F % 4 || !(p >= 0.f) || !(p < 1.f)) return SEPR_EINVAL;
   hipLaunchKernelGGL(res_ls_kernel, dim3(grid_for(M * (F >> 2), TPB, 1 << 16)), dim3(TPB), 0, s, x, v, ls, y, M, F,
-                     p > 0.f ? sepr_drop_threshold(p) : 0u, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, seed, offset);
+                     p > 0.f ? sepr_drop_threshold(p) : 0u, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, seed, offset, drop_salt());
   SEPR_CHECK_LAUNCH("res_ls_kernel");
   return SEPR_OK;
 }
@@ -1116,7 +1129,7 @@ int launch_dropout(const float* x, float* y, long long count, float p, unsigned 
   if (count <= 0) return SEPR_OK;
   if (!x || !y || !(p >= 0.f) || !(p < 1.f)) return SEPR_EINVAL;
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(count, TPB, 1 << 16)), dim3(TPB), 0, s, x, y, count, sepr_drop_threshold(p),
-                     1.0f / (1.0f - p), seed, offset);
+                     1.0f / (1.0f - p), seed, offset, drop_salt());
   SEPR_CHECK_LAUNCH("dropout_kernel");
   return SEPR_OK;
 }

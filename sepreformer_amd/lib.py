@@ -81,12 +81,12 @@ def _tstruct(name, spec):
 
 
 GcfnTW = _tstruct("GcfnTW", ["@up", "@up_t", "@down", "@down_t", "dw_w", "dw_b", "ls", "w1", "ln_g", "ln_b", "w2", "b2",
-                              "fused_w1p", "fused_w2p"])
+                              "fused_w1p", "fused_w2p", "seed_salt"])
 GcfnGrad = _tstruct("GcfnGrad", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "ls"])
 ClaTW = _tstruct("ClaTW", ["@l1", "@l1_t", "dw_w", "dw_wf", "dw_b", "zeros", "@l2", "@l2_t", "bn_g", "bn_b", "bn_rm", "bn_rv",
-                           "@l3", "@l3_t", "ls", "w1", "ln_g", "ln_b", "w3", "b3"])
+                           "@l3", "@l3_t", "ls", "w1", "ln_g", "ln_b", "w3", "b3", "seed_salt"])
 ClaGrad = _tstruct("ClaGrad", ["ln_g", "ln_b", "w1", "b1", "dw_w", "dw_b", "w2", "b2", "bn_g", "bn_b", "w3", "b3", "ls"])
-MhaTW = _tstruct("MhaTW", ["@qkv", "@qkv_t", "@out", "@out_t", "ls", "wqkv", "ln_g", "ln_b", "wo", "bo"])
+MhaTW = _tstruct("MhaTW", ["@qkv", "@qkv_t", "@out", "@out_t", "ls", "wqkv", "ln_g", "ln_b", "wo", "bo", "seed_salt"])
 MhaGrad = _tstruct("MhaGrad", ["ln_g", "ln_b", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ls"])
 
 

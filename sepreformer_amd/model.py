@@ -50,6 +50,90 @@ def _evict_packed(uid: int) -> None:
             del _PACK_CACHE[k]
 
 
+class _TrainGraph:
+    """One captured training step for one (batch, samples) shape: the per-step weight re-pack AND the ~2 500 launches of the
+    train-mode forward are one hipGraph, the ~2 700 launches of the backward another.  A step is then two graph replays plus
+    the (eager) criteria and optimizer: host time per step drops from ~100 ms of Python / ctypes / launch calls to a few ms.
+
+    Static state: the input buffer, the outputs, every saved-for-backward context (allocated inside the capture, so it lives in
+    the graphs' private pool), the flat gradient buffer, the output-gradient buffers.  Dropout: the by-value seeds are frozen
+    into the graph; the per-step seed goes into the device word ``TrainPack.salt`` that every dropout kernel XORs in
+    (``include/sepr.h`` seed_salt).  BatchNorm running statistics and ``num_batches_tracked`` are updated by the replay itself.
+    The graph reads the parameters where they live (optimizer steps are in place); anything that moves them (``.to()``,
+    re-bound parameters) changes ``Model._graph_key`` and triggers a re-capture."""
+
+    CAPTURE_SEED = 0x5EED5EED5EED
+
+    def __init__(self, model: "Model", x: torch.Tensor):
+        from .train_engine import TrainEngine
+        from .train_pack import GradBuffer, TrainPack
+        dev = x.device
+        self.model_ref = weakref.ref(model)
+        cfg = model.cfg
+        eng = model.__dict__.get("_train_engine")
+        if eng is None or eng.device != dev:
+            eng = TrainEngine(cfg, dev)
+            model.__dict__["_train_engine"] = eng
+        self.eng = eng
+        self.p = float(model.dropout_p)
+        self.with_aux = bool(model.compute_aux)
+        names = list(model._kinds)
+        flat = model._flat_tensors()
+        sd = {n: t.detach() for n, t in zip(names, flat)}
+        self.x = x.detach().to(torch.float32).contiguous().clone()
+        # ---- warm-up (eager): fills the engine's size / index caches and grows its workspace to this shape, so that the capture
+        #      contains launches only.  It is a real train-mode forward: BatchNorm state is restored afterwards.
+        keep = {n: t.detach().clone() for n, t, kind in zip(names, flat, model._kinds.values()) if KINDS[kind]}
+        gb0 = GradBuffer(cfg, dev)
+        tp0 = TrainPack(cfg, sd, gb0, model.precision)
+        wav, aux, tape, dims = eng.forward(self.x, tp0, self.p, self.CAPTURE_SEED, with_aux=self.with_aux)
+        eng.backward(tape, dims, torch.zeros_like(wav), [torch.zeros_like(a) for a in aux], tp0, self.p)
+        for n, t in keep.items():
+            sd[n].copy_(t)
+        del tp0, gb0, wav, aux, tape
+        torch.cuda.synchronize(dev)
+        # ---- capture
+        self.gb = GradBuffer(cfg, dev)
+        self.g_fwd, self.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(self.g_fwd, pool=pool):
+            self.tp = TrainPack(cfg, sd, self.gb, model.precision)
+            self.wav, self.aux, self.tape, self.dims = eng.forward(self.x, self.tp, self.p, self.CAPTURE_SEED, with_aux=self.with_aux)
+            torch._foreach_add_(self.tp.bn_counters, 1)          # BatchNorm.num_batches_tracked
+        self.d_wav = torch.zeros_like(self.wav)
+        self.d_aux = [torch.zeros_like(a) for a in self.aux]
+        with torch.cuda.graph(self.g_bwd, pool=pool):
+            self.gb.flat.zero_()
+            eng.backward(self.tape, self.dims, self.d_wav, self.d_aux, self.tp, self.p)
+        # the capture itself executed nothing: BatchNorm state is still the pre-warm-up one
+        self.replays = 0
+
+    def forward(self, x: torch.Tensor, seed: int):
+        self.x.copy_(x)
+        self.tp.salt.fill_(seed & 0x7FFFFFFFFFFFFFFF)
+        self.g_fwd.replay()
+        self.replays += 1
+        # fresh tensor objects over the static buffers (autograd attaches a node to what a Function returns)
+        return (self.wav.detach(), *[a.detach() for a in self.aux])
+
+    def backward(self, d_wav, d_aux):
+        if d_wav is None:
+            self.d_wav.zero_()
+        else:
+            self.d_wav.copy_(d_wav)
+        for buf, g in zip(self.d_aux, list(d_aux) + [None] * (len(self.d_aux) - len(d_aux))):
+            if g is None:
+                buf.zero_()
+            elif g.shape == buf.shape:
+                buf.copy_(g)
+            else:                                                  # Model.forward crops the aux outputs (model.py:51)
+                buf.zero_()
+                buf[..., : g.shape[-1]].copy_(g)
+        self.g_bwd.replay()
+        # one copy out of the static buffer: the parameters' .grad must not alias memory the next replay rewrites
+        return self.gb.flat.clone()
+
+
 class _SeparatorFn(torch.autograd.Function):
     """Whole-model forward / backward through the HIP training path.  Inputs: the module, the mixture, then every
     parameter (so autograd routes the returned gradients into ``.grad``); outputs: main waveforms ``[S,B,T']`` and the R
@@ -60,6 +144,14 @@ class _SeparatorFn(torch.autograd.Function):
         from .train_engine import TrainEngine
         from .train_pack import GradBuffer, TrainPack
         dev = x.device
+        if model.train_graphs:
+            with torch.cuda.device(dev):
+                tg = model._train_graph(x)
+                seed = model._next_dropout_seed() if model.dropout_p > 0.0 else 0
+                outs = tg.forward(x.detach().to(torch.float32), seed)
+            model.invalidate_packed()
+            ctx.state = ("graph", model, tg)
+            return outs
         with torch.cuda.device(dev):
             eng = model.__dict__.get("_train_engine")
             if eng is None or eng.device != dev:
@@ -81,6 +173,23 @@ class _SeparatorFn(torch.autograd.Function):
     def backward(ctx, d_wav, *d_aux):
         if ctx.state is None:
             raise RuntimeError("the HIP training path keeps one tape per forward: backward twice needs a second forward")
+        if ctx.state[0] == "graph":
+            _, model, tg = ctx.state
+            ctx.state = None
+            with torch.cuda.device(tg.x.device):
+                flat = tg.backward(d_wav, d_aux)
+                if model.grad_sync is not None:
+                    model.grad_sync(flat)                         # (no early bucket: the backward is one graph)
+            grads = []
+            for name, kind in model._kinds.items():
+                if KINDS[kind]:
+                    continue
+                off, shape = tg.gb.offsets[name]
+                n = 1
+                for d in shape:
+                    n *= d
+                grads.append(flat[off:off + n].view(shape))
+            return (None, None, *grads)
         model, eng, tp, gb, tape, dims, n_aux = ctx.state
         ctx.state = None
         with torch.cuda.device(eng.device):
@@ -136,6 +245,24 @@ class Model(torch.nn.Module):
         # optional callable applied to the flat gradient buffer at the end of backward (dist.GradSync: RCCL all-reduce)
         self.dropout_p = float(self.cfg.dropout)
         self.grad_sync = None
+        # train mode: replay the step from captured hipGraphs (one capture per input shape; _TrainGraph).  Opt-in: the captured
+        # step keeps its activations resident between steps and re-captures when the shape changes.
+        self.train_graphs = os.environ.get("SEPR_TRAIN_GRAPHS", "0") == "1"
+
+    def _graph_key(self, x: torch.Tensor):
+        flat = self._flat_tensors()
+        return (tuple(x.shape), x.device.index, self.precision, float(self.dropout_p), bool(self.compute_aux), len(flat),
+                sum(t.data_ptr() for t in flat), mutation_epoch())
+
+    def _train_graph(self, x: torch.Tensor) -> "_TrainGraph":
+        graphs = self.__dict__.setdefault("_train_graphs", {})
+        key = self._graph_key(x)
+        tg = graphs.get(key)
+        if tg is None:
+            for k in [k for k in graphs if k[0] == key[0] or len(graphs) >= 2]:      # same shape with stale weights / precision; cap
+                del graphs[k]
+            tg = graphs[key] = _TrainGraph(self, x)
+        return tg
 
     def _next_dropout_seed(self) -> int:
         """Per-step dropout seed from a PRIVATE CPU generator (the user's global RNG stream - shuffling, augmentation - is

@@ -28,7 +28,7 @@ DTYPES = {
 }
 
 
-def run(variant, precision, B, steps, warmup, rank, world, dev, share):
+def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=True):
     """One training measurement on this rank's device; the process group (if any) is already initialised.  Returns the record
     (rank 0) or None."""
     from . import dist as sdist
@@ -42,6 +42,7 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share):
     cfg = VARIANTS[variant]
     model = Model.from_config(cfg, init_seed=0, precision=precision).load_synthetic_(0).to(dev)
     model.train()
+    model.train_graphs = bool(graphs)          # the step replays from captured hipGraphs (model._TrainGraph); --no-train-graphs: eager
     sync = sdist.GradSync()
     model.grad_sync = sync
     samples = 32000
@@ -69,10 +70,11 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share):
         opt.step()
         last["loss"], last["gn"] = loss.detach(), gn
 
-    for _ in range(warmup):
+    for _ in range(max(warmup, 1) if graphs else warmup):     # (graph mode: the first step captures)
         step()
     torch.cuda.synchronize(dev)
-    L.check(lib.sepr_prof_start(L.SITE_WGRAD, 400 * max(steps, 1) + 8), "sepr_prof_start")
+    if not graphs:
+        L.check(lib.sepr_prof_start(L.SITE_WGRAD, 400 * max(steps, 1) + 8), "sepr_prof_start")
     sdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -83,6 +85,14 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share):
     sdist.barrier()
     elapsed = time.perf_counter() - t0
     n_l, ms, fl = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
+    if graphs:
+        # a replayed graph has no per-launch events: the dominant kernel's launch durations come from ONE extra eager step
+        # of the same model outside the timed region (same kernels, same shapes)
+        model.train_graphs = False
+        L.check(lib.sepr_prof_start(L.SITE_WGRAD, 400 + 8), "sepr_prof_start")
+        step()
+        torch.cuda.synchronize(dev)
+        model.train_graphs = True
     L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
     elapsed = sdist.max_over_ranks(elapsed, dev)
     rec = None
@@ -102,6 +112,8 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share):
             "config": {"workload": f"{variant} training step, batch={B} per GPU, 4 s @ 8 kHz, 2 speakers (BASELINE.json configs[4])",
                        "batch_per_gpu": B, "samples": samples, "precision": prec, "dropout": model.dropout_p,
                        "dropout_sites": "all the reference's sites: GCFN x2, CLA, attention probabilities + attention output (EGA and speaker attention)",
+                       "step_launch": ("two hipGraph replays per step (weight re-pack + forward; backward) + eager criteria / clip / optimizer"
+                                       if graphs else "eager (every kernel launched from the host)"),
                        "optimizer": type(opt).__name__ + (" (fused)" if getattr(opt, "defaults", {}).get("fused") else ""),
                        "clip_norm": 5.0, "parallelism": f"data-parallel x{world}, flat-buffer RCCL all-reduce" + (" (DEBUG: all ranks share GPU 0, gloo collective)" if share else "")},
             "host_enqueue_ms_per_step": round(1e3 * t_host / max(steps, 1), 3),
@@ -137,7 +149,8 @@ def main(args):
         local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    rec = run(args.variant, args.precision, args.batch or 8, args.steps, args.warmup, rank, world, dev, share)
+    graphs = not getattr(args, "no_train_graphs", False) and os.environ.get("SEPR_TRAIN_GRAPHS", "1") != "0"
+    rec = run(args.variant, args.precision, args.batch or 8, args.steps, args.warmup, rank, world, dev, share, graphs)
     if rank == 0:
         print(json.dumps(rec), flush=True)
     sdist.barrier()

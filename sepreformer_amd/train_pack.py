@@ -124,6 +124,9 @@ class TrainPack:
         dev = next(iter(sd.values())).device
         F, S, N = cfg.feat, cfg.num_spks, cfg.enc_channels
         R = cfg.num_stages
+        # device word XOR-ed into every dropout seed of the step (include/sepr.h seed_salt): zero in eager mode (the by-value
+        # seeds change every step), rewritten before each replay of a captured step (model.py, SEPR_TRAIN_GRAPHS)
+        self.salt = torch.zeros(1, dtype=torch.int64, device=dev)
         self.zeros = torch.zeros(max(2 * F, N, 8 * F), dtype=torch.float32, device=dev)
         self.ones = torch.ones(max(2 * F, N), dtype=torch.float32, device=dev)
 
@@ -194,7 +197,7 @@ class TrainPack:
             tw = L.GcfnTW(up=s_up.lin(i), up_t=s_up_t.lin(i), down=s_dn.lin(i), down_t=s_dn_t.lin(i), dw_w=at(g_dw, i), dw_b=at(g_db, i),
                           ls=at(g_ls, i), w1=at(g_w1, i), ln_g=at(g_ln_g, i), ln_b=at(g_ln_b, i), w2=at(g_w2, i), b2=at(g_b2, i),
                           fused_w1p=None if fw1 is None else fw1.data_ptr() + i * fw1.shape[1],
-                          fused_w2p=None if fw2 is None else fw2.data_ptr() + i * fw2[0].numel() * 2)
+                          fused_w2p=None if fw2 is None else fw2.data_ptr() + i * fw2[0].numel() * 2, seed_salt=self.salt.data_ptr())
             gr = L.GcfnGrad(ln_g=gp(p + ".net1.0.weight"), ln_b=gp(p + ".net1.0.bias"), w1=gp(p + ".net1.1.weight"), b1=gp(p + ".net1.1.bias"),
                             dw_w=gp(p + ".depthwise.weight"), dw_b=gp(p + ".depthwise.bias"), w2=gp(p + ".net2.2.weight"),
                             b2=gp(p + ".net2.2.bias"), ls=gp(p + ".Layer_scale.layer_scale"))
@@ -213,7 +216,7 @@ class TrainPack:
             res = []
             for i, p in enumerate(names):
                 tw = L.MhaTW(qkv=s_qkv.lin(i), qkv_t=s_qkv_t.lin(i), out=s_out.lin(i), out_t=s_out_t.lin(i), ls=at(ls, i),
-                             wqkv=at(wqkv, i), ln_g=at(ln_g, i), ln_b=at(ln_b, i), wo=at(wo, i), bo=at(bo, i))
+                             wqkv=at(wqkv, i), ln_g=at(ln_g, i), ln_b=at(ln_b, i), wo=at(wo, i), bo=at(bo, i), seed_salt=self.salt.data_ptr())
                 gr = L.MhaGrad(ln_g=gp(p + ".layer_norm.weight"), ln_b=gp(p + ".layer_norm.bias"),
                                wq=gp(p + ".linear_q.weight"), bq=gp(p + ".linear_q.bias"), wk=gp(p + ".linear_k.weight"),
                                bk=gp(p + ".linear_k.bias"), wv=gp(p + ".linear_v.weight"), bv=gp(p + ".linear_v.bias"),
@@ -259,7 +262,7 @@ class TrainPack:
                          l2=s_l2.lin(i), l2_t=s_l2_t.lin(i), bn_g=at(c_bn_g, i), bn_b=at(c_bn_b, i),
                          bn_rm=sd[p + ".BN.running_mean"].data_ptr(), bn_rv=sd[p + ".BN.running_var"].data_ptr(),
                          l3=s_l3.lin(i), l3_t=s_l3_t.lin(i), ls=at(c_ls, i), w1=at(c_w1, i), ln_g=at(c_ln_g, i), ln_b=at(c_ln_b, i),
-                         w3=at(c_w3, i), b3=at(c_b3, i))
+                         w3=at(c_w3, i), b3=at(c_b3, i), seed_salt=self.salt.data_ptr())
             gr = L.ClaGrad(ln_g=gp(p + ".layer_norm.weight"), ln_b=gp(p + ".layer_norm.bias"), w1=gp(p + ".linear1.weight"),
                            b1=gp(p + ".linear1.bias"), dw_w=gp(p + ".dw_conv_1d.weight"), dw_b=gp(p + ".dw_conv_1d.bias"),
                            w2=gp(p + ".linear2.weight"), b2=gp(p + ".linear2.bias"), bn_g=gp(p + ".BN.weight"), bn_b=gp(p + ".BN.bias"),

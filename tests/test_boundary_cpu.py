@@ -499,7 +499,7 @@ def _header_struct_fields(hdr: str, cname: str):
         stmt = " ".join(stmt.split())
         if not stmt:
             continue
-        m = re.match(r"(const float\*|const void\*|float\*|int|sepr_lin|sepr_mha_tw|sepr_mha_grad)\s*(.*)", stmt)
+        m = re.match(r"(const float\*|const void\*|const sepr_u64\*|float\*|int|sepr_lin|sepr_mha_tw|sepr_mha_grad)\s*(.*)", stmt)
         assert m, (cname, stmt)
         for decl in m.group(2).split(","):
             out.append((m.group(1), decl.strip()))
@@ -509,7 +509,7 @@ def _header_struct_fields(hdr: str, cname: str):
 def test_train_struct_layouts_match_header():
     """ctypes mirrors of the training-path structs (lib.py) against include/sepr.h: same fields, same order, same size."""
     hdr = open(os.path.join(ROOT, "include", "sepr.h")).read()
-    size = {"const float*": 8, "const void*": 8, "float*": 8, "int": 4, "sepr_lin": 32,
+    size = {"const float*": 8, "const void*": 8, "const sepr_u64*": 8, "float*": 8, "int": 4, "sepr_lin": 32,
             "sepr_mha_tw": ctypes.sizeof(L.MhaTW), "sepr_mha_grad": ctypes.sizeof(L.MhaGrad)}
     pairs = [("sepr_lin", L.Lin), ("sepr_gcfn_tw", L.GcfnTW), ("sepr_gcfn_grad", L.GcfnGrad), ("sepr_cla_tw", L.ClaTW),
              ("sepr_cla_grad", L.ClaGrad), ("sepr_mha_tw", L.MhaTW), ("sepr_mha_grad", L.MhaGrad), ("sepr_ega_tw", L.EgaTW),

@@ -781,6 +781,63 @@ def test_train_step_full_size_properties():
     soft.done()
 
 
+def test_train_graph_replay_matches_eager():
+    """The captured training step (model.train_graphs: weight re-pack + forward as one hipGraph, backward as another) against
+    the eager step.  Dropout off: same kernels in the same order, so loss, every gradient and the updated BatchNorm state are
+    BITWISE those of the eager step, also on the second and third replay with the weights changed in between by the optimizer.
+    Dropout on: every replay draws fresh masks (the per-step seed travels through the device-side salt), and two models built
+    from the same seed follow the same trajectory."""
+    from sepreformer_amd.criterion import PIT_SISNR_mag, PIT_SISNR_time
+    from sepreformer_amd.model import Model
+    dev = torch.device("cuda:0")
+    B, T = 2, 4000
+    srcn = synth_sources(B, T, seed=31)
+    src = [torch.from_numpy(srcn[:, s].copy()).to(dev) for s in range(2)]
+    x = (src[0] + src[1]).contiguous()
+    sizes = torch.full((B,), T)
+
+    def trajectory(graphs, p_drop, steps, seed=7):
+        torch.manual_seed(seed)
+        cfg = dataclasses.replace(VARIANTS["SepReformer_Base_WSJ0"], dropout=p_drop)
+        m = Model.from_config(cfg, init_seed=0, precision="bf16x3").load_synthetic_(0).to(dev)
+        m.train()
+        m.train_graphs = graphs
+        opt = torch.optim.AdamW(m.parameters(), lr=1.0e-4)
+        ct, cm = PIT_SISNR_time(dev, 2, True), PIT_SISNR_mag(dev, 512, 128, "hann", cfg.num_stages, 2, True, False)
+        out = []
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            audio, aux = m(x)
+            lm = [cm(estims=a, idx=i, input_sizes=sizes, target_attr=src) for i, a in enumerate(aux)]
+            loss = (0.6 * ct(estims=audio, input_sizes=sizes, target_attr=src) + 0.4 * sum(lm) / len(lm)) / 2
+            loss.backward()
+            out.append((float(loss), torch.cat([p_.grad.reshape(-1) for p_ in m.parameters()]).clone()))
+            opt.step()
+        return m, out
+
+    me, eager = trajectory(False, 0.0, 3)
+    mg, graph = trajectory(True, 0.0, 3)
+    for i, ((le, ge), (lg, gg)) in enumerate(zip(eager, graph)):
+        assert le == lg, (i, le, lg)
+        assert torch.equal(ge, gg), i
+    for (k, a), (_, b) in zip(me.state_dict().items(), mg.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert len(mg.__dict__["_train_graphs"]) == 1 and next(iter(mg.__dict__["_train_graphs"].values())).replays == 3
+    # dropout: fresh masks per replay, reproducible from the seed
+    _, d1 = trajectory(True, 0.3, 2, seed=11)
+    _, d2 = trajectory(True, 0.3, 2, seed=11)
+    assert d1[0][0] == d2[0][0] and d1[1][0] == d2[1][0] and torch.equal(d1[1][1], d2[1][1])
+    m3, _ = trajectory(True, 0.3, 1, seed=11)
+    tg = next(iter(m3.__dict__["_train_graphs"].values()))
+    la = []
+    for _ in range(2):                                          # the SAME weights and input twice: only the masks differ
+        audio, aux = m3(x)
+        la.append(float(torch.stack(audio).abs().sum()))
+        torch.stack(audio).sum().backward()
+    assert la[0] != la[1], la
+    assert tg.replays == 3
+
+
 def test_train_step_tiny_bf16():
     """precision="bf16" (plain bf16 operands in every projection / contraction of the step, fp32 accumulate, fp32 master
     weights and gradients): the tiny configuration's whole step against the oracle.  Outputs / loss / gradients are those of
