@@ -377,10 +377,26 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
     return rec
 
 
+def protect_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a five-line version banner from C
+    when a communicator is created), so file descriptor 1 is pointed at stderr for the rest of the process and the JSON line
+    goes to a private duplicate of the original stdout."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(rec):
+        os.write(real, (json.dumps(rec) + "\n").encode())
+
+    return emit
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+    emit = protect_stdout()
+    args._emit = emit
     if args.mode == "train":
         from sepreformer_amd import train_bench
         return train_bench.main(args)
@@ -430,7 +446,7 @@ def main():
             rec["train"] = {}
             for prec in ("bf16x3", "bf16"):
                 try:
-                    tr = train_bench.run(DEFAULT_VARIANT, prec, 8, 2, 1, rank, world, dev, False)
+                    tr = train_bench.run(DEFAULT_VARIANT, prec, 16, 2, 1, rank, world, dev, False)
                     rec["train"][prec] = {k: tr[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config",
                                                               "host_enqueue_ms_per_step", "loss", "grad_norm", "collective_backend",
                                                               "allreduce_bytes_per_step", "model_tflops", "model_frac_algorithmic",
@@ -442,7 +458,7 @@ def main():
             threads = int(os.environ.get("SEPR_CPU_THREADS", str(physical_cores())))
             rec["cpu_baseline"] = cpu_baseline(VARIANTS[variant], threads)
             rec["speedup_vs_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
-        print(json.dumps(rec), flush=True)
+        emit(rec)
     sdist.barrier()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

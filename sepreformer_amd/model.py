@@ -94,10 +94,11 @@ class _TrainGraph:
         torch.cuda.synchronize(dev)
         # ---- capture
         self.gb = GradBuffer(cfg, dev)
+        self.salt = torch.zeros(1, dtype=torch.int64, device=dev)     # outside the capture: replays must not reset it
         self.g_fwd, self.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         pool = torch.cuda.graph_pool_handle()
         with torch.cuda.graph(self.g_fwd, pool=pool):
-            self.tp = TrainPack(cfg, sd, self.gb, model.precision)
+            self.tp = TrainPack(cfg, sd, self.gb, model.precision, salt=self.salt)
             self.wav, self.aux, self.tape, self.dims = eng.forward(self.x, self.tp, self.p, self.CAPTURE_SEED, with_aux=self.with_aux)
             torch._foreach_add_(self.tp.bn_counters, 1)          # BatchNorm.num_batches_tracked
         self.d_wav = torch.zeros_like(self.wav)
@@ -110,7 +111,7 @@ class _TrainGraph:
 
     def forward(self, x: torch.Tensor, seed: int):
         self.x.copy_(x)
-        self.tp.salt.fill_(seed & 0x7FFFFFFFFFFFFFFF)
+        self.salt.fill_(seed & 0x7FFFFFFFFFFFFFFF)
         self.g_fwd.replay()
         self.replays += 1
         # fresh tensor objects over the static buffers (autograd attaches a node to what a Function returns)

@@ -152,7 +152,11 @@ def main(args):
     graphs = not getattr(args, "no_train_graphs", False) and os.environ.get("SEPR_TRAIN_GRAPHS", "1") != "0"
     rec = run(args.variant, args.precision, args.batch or 8, args.steps, args.warmup, rank, world, dev, share, graphs)
     if rank == 0:
-        print(json.dumps(rec), flush=True)
+        emit = getattr(args, "_emit", None)
+        if emit is not None:
+            emit(rec)
+        else:
+            print(json.dumps(rec), flush=True)
     sdist.barrier()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

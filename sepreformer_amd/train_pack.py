@@ -116,7 +116,8 @@ def _t(w: torch.Tensor) -> torch.Tensor:
 class TrainPack:
     """All blocks of one model in training form, addressed the way ``train_engine`` walks them."""
 
-    def __init__(self, cfg: SepConfig, sd: Dict[str, torch.Tensor], grads: GradBuffer, precision: str = "bf16x3"):
+    def __init__(self, cfg: SepConfig, sd: Dict[str, torch.Tensor], grads: GradBuffer, precision: str = "bf16x3",
+                 salt: Optional[torch.Tensor] = None):
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {PRECISIONS}")
         self.cfg, self.precision, self.keep = cfg, precision, []
@@ -126,7 +127,8 @@ class TrainPack:
         R = cfg.num_stages
         # device word XOR-ed into every dropout seed of the step (include/sepr.h seed_salt): zero in eager mode (the by-value
         # seeds change every step), rewritten before each replay of a captured step (model.py, SEPR_TRAIN_GRAPHS)
-        self.salt = torch.zeros(1, dtype=torch.int64, device=dev)
+        # (a captured step passes its own word in: one created here would be re-zeroed by every replay of the capture)
+        self.salt = salt if salt is not None else torch.zeros(1, dtype=torch.int64, device=dev)
         self.zeros = torch.zeros(max(2 * F, N, 8 * F), dtype=torch.float32, device=dev)
         self.ones = torch.ones(max(2 * F, N), dtype=torch.float32, device=dev)
 
