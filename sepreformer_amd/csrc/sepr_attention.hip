@@ -17,6 +17,7 @@
 //     consecutive band rows (the skewed index i-j does not map onto an MFMA fragment);
 //   * exact online softmax (fp32, rescale every sub-tile), masked keys contribute exp(-1e30 - m) = 0.
 #include "sepr_pointwise.h"
+#include "sepr_train.h"
 
 namespace sepr {
 
@@ -187,10 +188,18 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& l) {
 
 // DK = 16 (Base): dk fills half of the K = 32 MFMA step, lane groups 2,3 carry zeros.  DK = 32 (Large): the step is full,
 // O^T has two 16-row tiles (two PV accumulators), the staging moves twice the K / V / band rows per thread.
-template <int DK>
+// TRAIN (sepr_train_attn_x3.hip's forward): additionally writes lse[(seq*H + h)*Tp + i] = log sum_j exp(score_ij) - all the
+// backward keeps of the probabilities - and applies inverted dropout to the probabilities that multiply V (network.py:121;
+// the softmax denominator sums the undropped ones); mask of element (row = (seq*H + h)*Tp + i, key j) = 16-bit half j & 1 of
+// sepr_drop_word(dkey, row, j >> 1) >= thr (sepr_train.h).
+template <int DK, bool TRAIN = false>
 __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict__ QKV, float* __restrict__ O, int Tp, int F,
-                                                        const float* __restrict__ pe, int maxlen, float inv_sqrt_dk) {
+                                                        const float* __restrict__ pe, int maxlen, float inv_sqrt_dk,
+                                                        float* __restrict__ lse = nullptr, unsigned thr = 0u, float dscale = 1.0f,
+                                                        unsigned long long seed = 0ull, const unsigned long long* __restrict__ salt = nullptr) {
   static_assert(DK == 16 || DK == 32, "head width");
+  DropKey dkey = {0u, 0u};
+  if (TRAIN && thr) dkey = sepr_drop_key(seed, salt, 2u);
   constexpr int QB = 64, KT = 64;
   constexpr int KSB = DK + 8;         // K / band row stride in bf16 (DK used + 8 pad; DK = 16: the pad is the zero half of K = 32)
   constexpr int OT = DK / 16;         // 16-row tiles of O^T
@@ -362,6 +371,19 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
           ph[4 * s + r] = hh;
           pl[4 * s + r] = (__bf16)(pv - (float)hh);
         }
+      if (TRAIN && thr) {   // dropped probabilities for the PV product only; keys 16 s + 4g + {0,1} / {2,3} are the element pairs
+        const unsigned row = (unsigned)((seq * gridDim.y + h) * Tp + i);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const unsigned jp = (unsigned)(j0 + 32 * p + 16 * s + 4 * g) >> 1;
+          const unsigned d0 = sepr_drop_word(dkey, row, jp), d1 = sepr_drop_word(dkey, row, jp + 1u);
+          const bool k0 = (d0 & 0xffffu) >= thr, k1 = (d0 >> 16) >= thr, k2 = (d1 & 0xffffu) >= thr, k3 = (d1 >> 16) >= thr;
+          if (!k0) { ph[4 * s] = (__bf16)0.f; pl[4 * s] = (__bf16)0.f; }
+          if (!k1) { ph[4 * s + 1] = (__bf16)0.f; pl[4 * s + 1] = (__bf16)0.f; }
+          if (!k2) { ph[4 * s + 2] = (__bf16)0.f; pl[4 * s + 2] = (__bf16)0.f; }
+          if (!k3) { ph[4 * s + 3] = (__bf16)0.f; pl[4 * s + 3] = (__bf16)0.f; }
+        }
+      }
       lrun = lrun * corr + psum;
       mrun = mnew;
       // ---- O^T[d][query] += V^T[d][key slots] . P[key slots][query]; slot e -> key 16 (e / 4) + 4g + e % 4 --------
@@ -387,12 +409,30 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
   float ltot = lrun + __shfl_xor(lrun, 16, 64);
   ltot += __shfl_xor(ltot, 32, 64);
   if (active) {
-    const float inv = 1.0f / ltot;
+    const float inv = (TRAIN ? dscale : 1.0f) / ltot;
 #pragma unroll
     for (int t = 0; t < OT; ++t)
       st4(O + ((long long)seq * Tp + i) * F + h * DK + 16 * t + 4 * g,
           make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv));
+    if (TRAIN && lse && g == 0) lse[((long long)seq * gridDim.y + h) * Tp + i] = mrun + logf(ltot);
   }
+}
+
+// train forward on the bf16x3 kernel: O, lse [n*H*Tp]; p > 0: dropout of the probabilities (16-bit generator, site 2)
+int launch_relattn_x3_train_fwd(const float* QKV, float* O, float* lse, int n, int Tp, int F, int H, const float* pe_k, int maxlen,
+                                float p, unsigned long long seed, const unsigned long long* salt, hipStream_t s) {
+  if (n <= 0 || Tp <= 0) return SEPR_OK;
+  if (H <= 0 || F % H != 0 || maxlen <= 0 || !pe_k || !lse || n > 65535 || !(p >= 0.f) || !(p < 1.f)) return SEPR_EINVAL;
+  const int dk = F / H;
+  const dim3 grid((Tp + 63) / 64, H, n);
+  const float isd = 1.0f / sqrtf((float)dk);
+  const unsigned thr = p > 0.f ? sepr_drop_thr16(p) : 0u;
+  const float dscale = p > 0.f ? sepr_drop_scale16(p) : 1.0f;
+  if (dk == 16) hipLaunchKernelGGL((relattn_x3_kernel<16, true>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, lse, thr, dscale, seed, salt);
+  else if (dk == 32) hipLaunchKernelGGL((relattn_x3_kernel<32, true>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, lse, thr, dscale, seed, salt);
+  else return SEPR_EINVAL;
+  SEPR_CHECK_LAUNCH("relattn_x3_kernel<train>");
+  return SEPR_OK;
 }
 
 int launch_relattn(const float* QKV, float* O, int n, int Tp, int F, int H, const float* pe_k, int maxlen, int x3,

@@ -219,4 +219,14 @@ int launch_relattn_bwd(const float* QKV, const float* P, const float* O, const f
                        int F, int H, const float* pe_k, int maxlen, float p, unsigned long long seed, unsigned long long offset, void* ws,
                        size_t ws_bytes, hipStream_t s);
 
+// ---- EGA attention on the bf16 MFMA, flash style (sepr_attention.hip TRAIN instantiation + sepr_train_attn_x3.hip) ------------
+// forward: QKV [n,Tp,3F] -> O [n,Tp,F], lse [n*H,Tp] (all the backward keeps of the probabilities)
+int launch_relattn_x3_train_fwd(const float* QKV, float* O, float* lse, int n, int Tp, int F, int H, const float* pe_k, int maxlen,
+                                float p, unsigned long long seed, const unsigned long long* salt, hipStream_t s);
+size_t relattn_x3_bwd_ws(int n, int Tp, int F, int H);
+// dO [n,Tp,F] -> dQKV [n,Tp,3F]; dpe [2*maxlen][dk] accumulated
+int launch_relattn_x3_bwd(const float* QKV, const float* lse, const float* O, const float* dO, float* dQKV, float* dpe_g, int n, int Tp,
+                          int F, int H, const float* pe_k, int maxlen, float p, unsigned long long seed, const unsigned long long* salt,
+                          void* ws, size_t ws_bytes, hipStream_t s);
+
 }  // namespace sepr

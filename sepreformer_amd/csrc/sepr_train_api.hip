@@ -6,6 +6,7 @@
 //
 // Layout of a block's context and scratch is defined ONCE, by the block's own implementation running in "dry" mode
 // (Carve::dry): sepr_train_ctx_bytes / sepr_train_ws_bytes replay the same carving without launching anything.
+#include <stdlib.h>
 #include <string.h>
 
 #include "sepr_gcfn_fused.h"
@@ -312,25 +313,37 @@ int mha_qkv_bwd(const float* dqkv, const float* xin, const float* stats, float* 
 // =====================================================================================================================
 // EGA  (network.py:126-155)
 // =====================================================================================================================
+// The attention of the packed-bf16 precisions runs flash-style on the bf16 MFMA (sepr_attention.hip TRAIN instantiation,
+// sepr_train_attn_x3.hip): its context keeps one log-sum-exp per query row where the exact-f32 VALU kernels keep the [Tp, Tp]
+// probabilities (k.P below is then [n*H, Tp]).  SEPR_TRAIN_ATTN_VALU=1 forces the VALU kernels (A/B, tests).
+bool ega_mfma(const sepr_ega_tw* w, int F, int H) {
+  static const bool force_valu = [] {
+    const char* e = getenv("SEPR_TRAIN_ATTN_VALU");
+    return e && e[0] == '1';
+  }();
+  const int dk = H > 0 ? F / H : 0;
+  return w && w->attn.qkv.wp && !force_valu && (dk == 16 || dk == 32);
+}
 struct EgaCtx { float *stats, *stats_p, *xd, *qkv, *P, *o, *att, *zg; };
-EgaCtx ega_ctx(Carve& cx, int n, int T, int Tp, int F, int H) {
+EgaCtx ega_ctx(Carve& cx, int n, int T, int Tp, int F, int H, bool mfma = false) {
   const long long M = (long long)n * T, Mp = (long long)n * Tp;
   EgaCtx k;
   k.stats = cx.f32(2 * M);
   k.stats_p = cx.f32(2 * Mp);
   k.xd = cx.f32((long long)F * Mp);
   k.qkv = cx.f32(3LL * F * Mp);
-  k.P = cx.f32((long long)n * H * Tp * Tp);
+  k.P = cx.f32(mfma ? (long long)n * H * Tp : (long long)n * H * Tp * Tp);
   k.o = cx.f32((long long)F * Mp);
   k.att = cx.f32((long long)F * Mp);
   k.zg = cx.f32((long long)F * M);
   return k;
 }
 int ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const sepr_ega_tw* w, Carve& cx, Carve& ws, float p,
-            sepr_u64 seed, hipStream_t st) {
+            sepr_u64 seed, hipStream_t st, int mfma_dry = -1) {
   const long long M = (long long)n * T, Mp = (long long)n * Tp;
   const int fac = T / Tp;
-  EgaCtx k = ega_ctx(cx, n, T, Tp, F, H);
+  const bool mfma = mfma_dry >= 0 ? mfma_dry != 0 : ega_mfma(w, F, H);
+  EgaCtx k = ega_ctx(cx, n, T, Tp, F, H, mfma);
   float* tmp = p > 0.f ? ws.f32((long long)F * Mp) : nullptr;
   if (cx.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
@@ -341,7 +354,8 @@ int ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const 
   }
   SEPR_TRY(launch_rowstats(xp, k.stats_p, Mp, F, LN_EPS_T, st));
   SEPR_TRY(normed(xp, F, k.stats_p, k.qkv, 3 * F, Mp, 3 * F, F, w->attn.qkv, st));             // :99-102
-  SEPR_TRY(launch_relattn_train_fwd(k.qkv, k.o, k.P, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), st));   // :106-122
+  if (mfma) SEPR_TRY(launch_relattn_x3_train_fwd(k.qkv, k.o, k.P, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, drop_salt(), st));
+  else SEPR_TRY(launch_relattn_train_fwd(k.qkv, k.o, k.P, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), st));   // :106-122
   if (p > 0.f) {
     SEPR_TRY(plain(k.o, F, tmp, F, Mp, F, F, w->attn.out, nullptr, st));                        // :124 linear_out
     SEPR_TRY(launch_res_ls(nullptr, tmp, w->attn.ls, k.att, Mp, F, p, seed, site_off(1), st)); //      dropout, LayerScale
@@ -357,10 +371,11 @@ int ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const 
   return SEPR_OK;
 }
 int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, int F, int H, const sepr_ega_tw* w, const sepr_ega_grad* g,
-            Carve& cx, Carve& ws, float p, sepr_u64 seed, hipStream_t st) {
+            Carve& cx, Carve& ws, float p, sepr_u64 seed, hipStream_t st, int mfma_dry = -1) {
   const long long M = (long long)n * T, Mp = (long long)n * Tp;
   const int fac = T / Tp;
-  EgaCtx k = ega_ctx(cx, n, T, Tp, F, H);
+  const bool mfma = mfma_dry >= 0 ? mfma_dry != 0 : ega_mfma(w, F, H);
+  EgaCtx k = ega_ctx(cx, n, T, Tp, F, H, mfma);
   float* dzg = ws.f32((long long)F * M);
   float* datt = ws.f32((long long)F * Mp);
   float* dO = ws.f32((long long)F * Mp);
@@ -373,7 +388,7 @@ int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, in
   size_t tnb = tn_workspace_bytes((int)M, F, F);
   if (tn_workspace_bytes((int)Mp, 3 * F, F) > tnb) tnb = tn_workspace_bytes((int)Mp, 3 * F, F);
   void* tnw = ws.take(tnb);
-  const size_t atb = relattn_train_ws(n, Tp, F, H);
+  const size_t atb = mfma ? relattn_x3_bwd_ws(n, Tp, F, H) : relattn_train_ws(n, Tp, F, H);
   void* atw = ws.take(atb);
   if (ws.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
@@ -384,7 +399,8 @@ int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, in
   if (p > 0.f) SEPR_TRY(launch_dropout(datt, datt, (long long)F * Mp, p, seed, site_off(1), st));   // attention-output dropout mask
   // attention branch first (its input gradient is added while the gate branch's LayerNorm backward writes dx)
   SEPR_TRY(mha_out_bwd(datt, k.o, dO, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, st));
-  SEPR_TRY(launch_relattn_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), atw, atb, st));
+  if (mfma) SEPR_TRY(launch_relattn_x3_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, drop_salt(), atw, atb, st));
+  else SEPR_TRY(launch_relattn_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), atw, atb, st));
   SEPR_TRY(mha_qkv_bwd(dqkv, xp, k.stats_p, dxh_p, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, st));
   SEPR_TRY(launch_ln_bwd(dxh_p, xp, k.stats_p, nullptr, nullptr, 0, 0, 0, dxd, Mp, F, st));
   // gate projection behind its own LayerNorm
@@ -910,8 +926,12 @@ static void train_sizes(int op, int n, int T, int Tp, int F, int N, int S, int H
       cla_bwd(nullptr, nullptr, nullptr, n, T, F, K, nullptr, nullptr, cb, wb, p1, 0, nullptr);
       break;
     case SEPR_TOP_EGA:
-      ega_fwd(nullptr, nullptr, n, T, Tp, F, H, nullptr, cf, wf, p1, 0, nullptr);
-      ega_bwd(nullptr, nullptr, nullptr, n, T, Tp, F, H, nullptr, nullptr, cb, wb, p1, 0, nullptr);
+      ega_fwd(nullptr, nullptr, n, T, Tp, F, H, nullptr, cf, wf, p1, 0, nullptr, 0);
+      ega_bwd(nullptr, nullptr, nullptr, n, T, Tp, F, H, nullptr, nullptr, cb, wb, p1, 0, nullptr, 0);
+      break;
+    case SEPR_TOP_EGA_X3:
+      ega_fwd(nullptr, nullptr, n, T, Tp, F, H, nullptr, cf, wf, p1, 0, nullptr, 1);
+      ega_bwd(nullptr, nullptr, nullptr, n, T, Tp, F, H, nullptr, nullptr, cb, wb, p1, 0, nullptr, 1);
       break;
     case SEPR_TOP_SPKATTN:
       spk_fwd(nullptr, nullptr, n, S, T, F, H, nullptr, cf, wf, p1, 0, nullptr);

@@ -14,6 +14,7 @@ auxiliary head) get their second contribution through the ``*_accumulate`` switc
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -72,6 +73,13 @@ class TrainEngine:
             self._idx[key] = (torch.from_numpy(idx).to(self.device), torch.from_numpy(inverse_index_start(idx, src)).to(self.device))
         return self._idx[key]
 
+    def _ega_op(self, tw) -> int:
+        """Sizing op of an EGA block: the packed-bf16 precisions run the attention flash-style on the bf16 MFMA (context = one
+        log-sum-exp per query row instead of the [Tp, Tp] probabilities); mirrors ``ega_mfma`` of csrc/sepr_train_api.hip."""
+        dk = self.cfg.feat // self.cfg.heads
+        mfma = bool(tw.attn.qkv.wp) and dk in (16, 32) and os.environ.get("SEPR_TRAIN_ATTN_VALU", "0") != "1"
+        return L.TOP_EGA_X3 if mfma else L.TOP_EGA
+
     # ---- single blocks (also what the unit tests drive) --------------------------------------------------------------------
     def block_fwd(self, kind: str, xin: torch.Tensor, w, n: int, Tc: int, Tp: int = 0, p_drop: float = 0.0, seed: int = 0):
         """One residual block (``gcfn`` / ``cla`` / ``ega`` / ``spk``) in train mode -> (output, tape record)."""
@@ -89,9 +97,10 @@ class TrainEngine:
             L.check(lib.sepr_cla_train_fwd(xin.data_ptr(), y.data_ptr(), n, Tc, F, c.cla_kernel, C.byref(w[0]), cx.data_ptr(), cx.numel(),
                                            *self._wsfor(L.TOP_CLA, n, Tc, 0, c.cla_kernel), p_drop, seed, st), "sepr_cla_train_fwd")
         elif kind == "ega":
-            cx = self._ctx(L.TOP_EGA, n, Tc, Tp)
+            op = self._ega_op(w[0])
+            cx = self._ctx(op, n, Tc, Tp)
             L.check(lib.sepr_ega_train_fwd(xin.data_ptr(), y.data_ptr(), n, Tc, Tp, F, H, C.byref(w[0]), cx.data_ptr(), cx.numel(),
-                                           *self._wsfor(L.TOP_EGA, n, Tc, Tp), p_drop, seed, st), "sepr_ega_train_fwd")
+                                           *self._wsfor(op, n, Tc, Tp), p_drop, seed, st), "sepr_ega_train_fwd")
         elif kind == "spk":
             cx = self._ctx(L.TOP_SPKATTN, n, Tc)
             L.check(lib.sepr_spkattn_train_fwd(xin.data_ptr(), y.data_ptr(), n, S, Tc, F, H, C.byref(w[0]), cx.data_ptr(), cx.numel(),
@@ -117,7 +126,7 @@ class TrainEngine:
                     "sepr_cla_bwd")
         elif kind == "ega":
             L.check(lib.sepr_ega_bwd(xin.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, Tc, Tp, F, H, C.byref(w[0]), C.byref(w[1]),
-                                     cx.data_ptr(), cx.numel(), *self._wsfor(L.TOP_EGA, n, Tc, Tp), p_drop, seed, st), "sepr_ega_bwd")
+                                     cx.data_ptr(), cx.numel(), *self._wsfor(self._ega_op(w[0]), n, Tc, Tp), p_drop, seed, st), "sepr_ega_bwd")
         else:
             L.check(lib.sepr_spkattn_bwd(xin.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, S, Tc, F, H, C.byref(w[0]), C.byref(w[1]),
                                          cx.data_ptr(), cx.numel(), *self._wsfor(L.TOP_SPKATTN, n, Tc), p_drop, seed, st), "sepr_spkattn_bwd")

@@ -527,7 +527,7 @@ def test_train_struct_layouts_match_header():
 def test_train_sizing_entries_run_without_a_device():
     """sepr_train_ctx_bytes / sepr_train_ws_bytes replay each block's carving in dry mode: no launch, no device needed."""
     lib = L.load()
-    for op in range(10):
+    for op in range(11):
         c = lib.sepr_train_ctx_bytes(op, 4, 1000, 250, 128, 256, 2, 8)
         w = lib.sepr_train_ws_bytes(op, 4, 1000, 250, 128, 256, 2, 8, 65 if op == L.TOP_CLA else 5)
         assert c > 0 and w > 0, op
