@@ -531,32 +531,45 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) 
 // table gradient: band[grp][rel + Tp - 1][d] = sum over the group's (sequence, head) pairs and queries of
 // dS[nh][i][i - rel] * q[nh][i][d]   (rel = i - j in (-Tp, Tp)); consecutive threads = consecutive rel = consecutive j
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int AXB_GROUP = 8;
+constexpr int AXB_GROUP = 4;
+// One block = 64 consecutive relative offsets x 4 query partitions (one partition per wave).  Every lane of a wave walks the
+// SAME queries i (so the q rows are wave-uniform: scalar loads) and reads dS[i][i - rel] when that key exists; consecutive
+// lanes = consecutive rel = consecutive (descending) keys: 256-byte coalesced reads of every dS row, each element once.
 template <int DK>
 __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restrict__ QKV, const float* __restrict__ dS, float* __restrict__ band,
                                                           int NH, int Tp, int F, int H) {
-  constexpr int D4 = DK / 4;
-  const int tid = threadIdx.x;
-  const int rl = tid / D4, d4 = tid % D4;                     // 256 / D4 relative offsets per block
-  const int rel = blockIdx.x * (256 / D4) + rl - (Tp - 1);
+  __shared__ float red[4][64][DK + 1];
+  const int rl = threadIdx.x & 63;
+  const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rel = blockIdx.x * 64 + rl - (Tp - 1);
   const int grp = blockIdx.y;
-  float4 acc = zero4();
-  if (rel < Tp) {
-    const int ilo = rel > 0 ? rel : 0, ihi = rel < 0 ? Tp + rel : Tp;     // queries with 0 <= i - rel < Tp
-    for (int gi = 0; gi < AXB_GROUP; ++gi) {
-      const int nh = grp * AXB_GROUP + gi;
-      if (nh >= NH) break;
-      const int n = nh / H, h = nh - n * H;
-      const float* qb = QKV + (long long)n * Tp * 3 * F + h * DK + 4 * d4;
-      const float* sb = dS + (long long)nh * Tp * Tp - rel;
-#pragma unroll 8
-      for (int i = ilo; i < ihi; ++i) {
-        const float s = sb[(long long)i * Tp + i];
-        const float4 q = ld4(qb + (long long)i * 3 * F);
-        acc.x = fmaf(s, q.x, acc.x); acc.y = fmaf(s, q.y, acc.y); acc.z = fmaf(s, q.z, acc.z); acc.w = fmaf(s, q.w, acc.w);
-      }
+  float acc[DK];
+#pragma unroll
+  for (int d = 0; d < DK; ++d) acc[d] = 0.f;
+  for (int gi = 0; gi < AXB_GROUP; ++gi) {
+    const int nh = grp * AXB_GROUP + gi;
+    if (nh >= NH) break;
+    const int n = nh / H, h = nh - n * H;
+    const float* qb = QKV + (long long)n * Tp * 3 * F + h * DK;
+    const float* sb = dS + (long long)nh * Tp * Tp;
+#pragma unroll 4
+    for (int i = part; i < Tp; i += 4) {
+      const int j = i - rel;
+      const float s = (j >= 0 && j < Tp) ? sb[(long long)i * Tp + j] : 0.f;
+      const float* q = qb + (long long)i * 3 * F;
+#pragma unroll
+      for (int d = 0; d < DK; ++d) acc[d] = fmaf(s, q[d], acc[d]);
     }
-    st4(band + ((long long)grp * (2 * Tp - 1) + rel + Tp - 1) * DK + 4 * d4, acc);
+  }
+#pragma unroll
+  for (int d = 0; d < DK; ++d) red[part][rl][d] = acc[d];
+  __syncthreads();
+  // 64 offsets x DK channels summed over the 4 partitions in a fixed order
+  for (int e = threadIdx.x; e < 64 * DK; e += 256) {
+    const int r2 = e / DK, d = e - r2 * DK;
+    const int rel2 = blockIdx.x * 64 + r2 - (Tp - 1);
+    if (rel2 < Tp)
+      band[((long long)grp * (2 * Tp - 1) + rel2 + Tp - 1) * DK + d] = (red[0][r2][d] + red[1][r2][d]) + (red[2][r2][d] + red[3][r2][d]);
   }
 }
 // dpe[r][d] += sum over groups and over the relative offsets that clamp to table row r
@@ -611,8 +624,7 @@ int launch_relattn_x3_bwd(const float* QKV, const float* lse, const float* O, co
   a.dscale = p > 0.f ? sepr_drop_scale16(p) : 1.0f;
   a.seed = seed; a.salt = salt;
   const dim3 grid((Tp + 63) / 64, H, n);
-  const int rels_per_block = 256 / (DK / 4);
-  const dim3 bgrid((2 * Tp - 1 + rels_per_block - 1) / rels_per_block, ngroups);
+  const dim3 bgrid((2 * Tp - 1 + 63) / 64, ngroups);
   if (DK == 16) {
     hipLaunchKernelGGL((relattn_bwd_q_x3_kernel<16>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL((relattn_bwd_kv_x3_kernel<16>), grid, dim3(256), 0, s, a);
