@@ -25,6 +25,15 @@
 namespace sepr {
 
 typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gb_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gb_store4(void* base, long long idx, const float4 v, const bool as16) {
+  if (as16) {
+    gb_bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *reinterpret_cast<gb_bf16x4*>(static_cast<__bf16*>(base) + idx) = h;
+  } else {
+    st4(static_cast<float*>(base) + idx, v);
+  }
+}
 
 namespace {
 constexpr int GB_BM = 64;            // rows per tile (incl. halo)
@@ -45,8 +54,11 @@ struct GcfnBwdArgs {
   const void* w2tp;     // pack_x3 fragments of (ls * W2)^T [3F][F]       (sepr_gcfn_tw.down_t.wp)
   const float* dw_w;    // [3][6F] depthwise taps, tap-major
   const float* dw_b;    // [6F]
-  float* g;             // out [M][3F] gated tensor after its dropout (the input net2.2 multiplied)
-  float* dh1;           // out [M][6F] gradient w.r.t. the up-projection's output
+  void* g;              // out [M][3F] gated tensor after its dropout (the input net2.2 multiplied); fp32, or bf16 when out16
+  void* dh1;            // out [M][6F] gradient w.r.t. the up-projection's output; fp32 or bf16
+  int out16;            // 1: g / dh1 are stored as bf16 - the plain-bf16 precision rounds them to bf16 as MFMA operands of the two
+                        // weight-gradient contractions and of the input-gradient projection anyway, so the stored form loses nothing
+                        // and halves 4.6 of the block's ~9 KB of HBM traffic per row
   float* dyq;           // out [M][F] dropout1(dy), or null (no output dropout: the contraction reads dy itself)
   float* part;          // out [MB][3F][8] depthwise weight / bias gradient partials (w0 w1 w2 b of the value, then of the gate)
   unsigned drop_thr;    // 16-bit keep threshold of both sites (0 = no dropout)
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnB
         SEPR_GB_ELEM(z, 2)
         SEPR_GB_ELEM(w, 3)
 #undef SEPR_GB_ELEM
-        if (own) st4(a.g + (long long)m * C3 + hc, gd);
+        if (own) gb_store4(a.g, (long long)m * C3 + hc, gd, a.out16 != 0);
       }
       // depthwise gradient partials: sum over the 4 strips of this wave (lanes 16 apart), then over the 4 waves through LDS
 #pragma unroll
@@ -375,9 +387,8 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnB
         og.y = fmaf(wg0.y * f2, ng.y, fmaf(wg1.y, dcg[i].y, (wg2.y * f0) * pg.y));
         og.z = fmaf(wg0.z * f2, ng.z, fmaf(wg1.z, dcg[i].z, (wg2.z * f0) * pg.z));
         og.w = fmaf(wg0.w * f2, ng.w, fmaf(wg1.w, dcg[i].w, (wg2.w * f0) * pg.w));
-        float* o = a.dh1 + (long long)m * C6 + hc;
-        st4(o, ov);
-        st4(o + C3, og);
+        gb_store4(a.dh1, (long long)m * C6 + hc, ov, a.out16 != 0);
+        gb_store4(a.dh1, (long long)m * C6 + C3 + hc, og, a.out16 != 0);
       }
     }
     // per-tile depthwise partials: part[mb][pair][8], the 64 pairs of this column block are 512 consecutive floats
@@ -401,8 +412,8 @@ size_t gcfn_bwd_fused_ws(long long M, int F) {   // partials + the pre-reduction
   return align_up((size_t)MB * 3 * F * 8 * sizeof(float)) + gcfn_mid_reduce_ws(3 * F);
 }
 
-int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, int n, int T, int F, const sepr_gcfn_tw* w, float* g,
-                          float* dh1, float* dyq, float* dw_g, float* db_g, float p, unsigned long long seed,
+int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, int n, int T, int F, const sepr_gcfn_tw* w, void* g,
+                          void* dh1, int out16, float* dyq, float* dw_g, float* db_g, float p, unsigned long long seed,
                           const unsigned long long* salt, void* ws, size_t ws_bytes, hipStream_t st) {
   const long long M = (long long)n * T;
   if (M <= 0) return SEPR_OK;
@@ -414,7 +425,7 @@ int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, i
   GcfnBwdArgs a;
   a.x = x; a.stats = stats; a.dy = dy; a.M = (int)M; a.T = T; a.F = F;
   a.w1p = w->up.wp; a.b1 = w->up.b; a.w2tp = w->down_t.wp; a.dw_w = w->dw_w; a.dw_b = w->dw_b;
-  a.g = g; a.dh1 = dh1; a.dyq = p > 0.f ? dyq : nullptr;
+  a.g = g; a.dh1 = dh1; a.out16 = out16; a.dyq = p > 0.f ? dyq : nullptr;
   a.part = static_cast<float*>(ws);
   a.drop_thr = p > 0.f ? sepr_drop_thr16(p) : 0u;
   a.drop_scale = p > 0.f ? sepr_drop_scale16(p) : 1.0f;

@@ -46,6 +46,7 @@ struct GemmArgs {
   // ([N/16][K/32][plane][lane][8], see pack.py::pack_x3); LayerNorm gamma/beta are folded into Wp / bias.
   const void* Wp;
   int bf1;   // bf16x3 core: 1 = plain bf16 operands (one MFMA per product; hi planes only), 0 = the split arithmetic
+  int a16;   // bf1 only, PRO_PLAIN / EPI_STORE: A is a bf16 tensor (lda in elements)
 };
 
 

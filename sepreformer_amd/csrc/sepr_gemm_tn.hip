@@ -93,10 +93,21 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
     if constexpr (!GEN) {
       const float* base = roleA ? a.A : a.B;                      // wave-uniform
       const long long ld = roleA ? a.lda : a.ldb;
+      if (roleA ? a.a16 != 0 : a.b16 != 0) {                      // wave-uniform: a bf16 operand (8 bytes per 4 columns)
+        const unsigned short* b16 = reinterpret_cast<const unsigned short*>(base);
 #pragma unroll
-      for (int e = 0; e < 8 * TN_NB; ++e) {
-        const int m = mb + 32 * (e >> 3) + 8 * mg + (e & 7);
-        r[e] = ld4(base + (long long)(m < m_end ? m : row_safe) * ld + col_c);
+        for (int e = 0; e < 8 * TN_NB; ++e) {
+          const int m = mb + 32 * (e >> 3) + 8 * mg + (e & 7);
+          const uint2 u = *reinterpret_cast<const uint2*>(b16 + (long long)(m < m_end ? m : row_safe) * ld + col_c);
+          r[e] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                             __uint_as_float(u.y & 0xffff0000u));
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8 * TN_NB; ++e) {
+          const int m = mb + 32 * (e >> 3) + 8 * mg + (e & 7);
+          r[e] = ld4(base + (long long)(m < m_end ? m : row_safe) * ld + col_c);
+        }
       }
       if (STATS && wid == 2) {
         const int m = mb + lane;
@@ -330,6 +341,7 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   long long slot = -1;
   const bool timed = prof_begin(SEPR_SITE_WGRAD, s, &slot);
   const bool gen = a.rows_out > 0 || a.B2 != nullptr || a.idx != nullptr || a.mask_a != 0 || a.stat_seq != 0;
+  if (gen && (a.a16 || a.b16)) return SEPR_EINVAL;
   float* cp = a.colsum ? cpart : nullptr;
   // The general loader with statistics runs ONE workgroup per CU (16 KB of dynamic LDS on top of the static 74 KB make a second
   // one not fit): with two co-resident workgroups its bf16 instantiations returned wrong, run-to-run different values in

@@ -49,6 +49,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
   // TAG bit 4: plain bf16 operands ("bf16" training precision): activations rounded to bf16 (hi plane only), weights'
   // hi plane only, ONE MFMA per product instead of three; everything else (staging, tile walk, epilogues) is shared
   constexpr bool ONE = (TAG & 16) != 0;
+  // TAG bit 5: the A operand is a bf16 tensor (lda in elements; PRO_PLAIN, no row map): the plain-bf16 training precision keeps
+  // the [rows, 6F] input-gradient operand of the GCFN in bf16 (sepr_gcfn_bwd_fused.hip)
+  constexpr bool A16 = (TAG & 32) != 0;
   constexpr int ROWS_OUT = DWGLU ? GEMM_DW_ROWS : GEMM_BM;
   // [buffer][plane hi/lo][128 rows][80] bf16 = 81 920 B; the epilogue re-uses it as a [128][132] fp32 tile
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * 2 * X3_PLANE];
@@ -121,6 +124,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
     if (s > 0 || blockIdx.x != (unsigned)a.M) return;   // timing ablation
 #endif
     const int k = s * X3_BKS + kh;
+    if constexpr (A16) {
+      const unsigned short* src16 = reinterpret_cast<const unsigned short*>(a.A) + pa + k;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const uint4 u = *reinterpret_cast<const uint4*>(src16 + 4 * j);      // 8 bf16
+        ra[j] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                            __uint_as_float(u.y & 0xffff0000u));
+        ra[j + 1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                                __uint_as_float(u.w & 0xffff0000u));
+      }
+      return;
+    }
     const float* src = a.A + pa + k;
     if (PRO == PRO_CAT2 && k >= a.ksplit) src = a.A2 + pa2 + (k - a.ksplit);
 #pragma unroll

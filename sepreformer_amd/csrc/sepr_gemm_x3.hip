@@ -43,7 +43,10 @@ int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t st
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
   const int key = pro * 16 + epi;
-  if (a.bf1) {   // plain bf16 operands: the projections of the training path's "bf16" precision
+  if (a.bf1 && a.a16) {
+    if (key != PRO_PLAIN * 16 + EPI_STORE || a.rows_out > 0 || (a.lda % 8) != 0) return SEPR_EINVAL;
+    launch_x3_inst<PRO_PLAIN, EPI_STORE, 16 | 32>(a, stream);
+  } else if (a.bf1) {   // plain bf16 operands: the projections of the training path's "bf16" precision
     switch (key) {
       case PRO_PLAIN * 16 + EPI_STORE: launch_x3_inst<PRO_PLAIN, EPI_STORE, 16>(a, stream); break;
       case PRO_PLAIN * 16 + EPI_RES:   launch_x3_inst<PRO_PLAIN, EPI_RES, 16>(a, stream); break;

@@ -88,6 +88,7 @@ struct TnArgs {
   int mask_a;           // 1: rows of A that the row map declares invalid (r >= rows_valid) count as zero too (colsum)
   const float* stats;   // normalisation: (mean, rstd) per row (stat_seq == 0) or per sequence (stat_seq == 1); null = none
   int stat_seq;
+  int a16, b16;         // plain loader only: A / B are bf16 tensors (lda / ldb in elements), widened exactly while staged
   float* G;
   int ldg;
   int accumulate;       // 1: G += result, 0: G = result
@@ -125,8 +126,8 @@ size_t gcfn_mid_reduce_ws(int C);
 // Fused middle of the GCFN backward (sepr_gcfn_bwd_fused.hip): recomputes the hidden tensor from x and the saved LayerNorm
 // statistics, x / dy [n*T][F] -> g [n*T][3F] (dropped gated tensor), dh1 [n*T][6F], dyq [n*T][F] (dropout of dy; p > 0 only),
 // depthwise weight / bias gradients accumulated.  Arithmetic follows w->up.planes (bf16x3 or plain bf16).
-int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, int n, int T, int F, const sepr_gcfn_tw* w, float* g,
-                          float* dh1, float* dyq, float* dw_g, float* db_g, float p, unsigned long long seed,
+int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, int n, int T, int F, const sepr_gcfn_tw* w, void* g,
+                          void* dh1, int out16 /* g, dh1 stored as bf16 */, float* dyq, float* dw_g, float* db_g, float p, unsigned long long seed,
                           const unsigned long long* salt, void* ws, size_t ws_bytes, hipStream_t st);
 size_t gcfn_bwd_fused_ws(long long M, int F);
 // depthwise conv weight gradient, stride 1, 'same' zero padding: dw[c][k] += sum_{seq,t} dy[t][c] * x[t + k - K/2][c];

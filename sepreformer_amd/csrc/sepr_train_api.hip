@@ -116,8 +116,10 @@ int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int
                    Carve& cx, Carve& ws, float p, sepr_u64 seed, hipStream_t st) {
   const long long M = (long long)n * T;
   float* stats = cx.f32(2 * M);
-  float* gd = ws.f32(3LL * F * M);
-  float* dh1 = ws.f32(6LL * F * M);
+  // plain-bf16 precision: the two big intermediates are STORED as bf16 (their consumers round them to bf16 anyway)
+  const bool o16 = ws.dry ? false : (w->up.planes == 1);
+  void* gd = ws.take((size_t)3 * F * M * sizeof(float));       // (sized for fp32 in both cases: one workspace plan)
+  void* dh1 = ws.take((size_t)6 * F * M * sizeof(float));
   float* dyp = p > 0.f ? ws.f32((long long)F * M) : nullptr;
   float* Gr = ws.f32(3LL * F * F);
   float* s2 = ws.f32(F);
@@ -132,15 +134,32 @@ int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int
   if (ws.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
   const int x3 = tn_mode(w->up);
-  SEPR_TRY(launch_gcfn_bwd_fused(x, stats, dy, n, T, F, w, gd, dh1, dyp, g->dw_w, g->dw_b, p, seed, drop_salt(), midw, midb, st));
+  SEPR_TRY(launch_gcfn_bwd_fused(x, stats, dy, n, T, F, w, gd, dh1, o16 ? 1 : 0, dyp, g->dw_w, g->dw_b, p, seed, drop_salt(), midw, midb, st));
   const float* dyq = p > 0.f ? dyp : dy;
   // net2.2 + LayerScale
-  SEPR_TRY(wgrad(dyq, F, gd, 3 * F, nullptr, Gr, s2, M, F, 3 * F, 0, x3, tnw, tnb, st));
+  {
+    TnArgs t = tn_args_zero();
+    t.M = (int)M; t.N = F; t.K = 3 * F;
+    t.A = dyq; t.lda = F; t.B = static_cast<const float*>(gd); t.ldb = 3 * F; t.b16 = o16 ? 1 : 0;
+    t.G = Gr; t.ldg = 3 * F; t.colsum = s2;
+    SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
+  }
   SEPR_TRY(launch_finish_linear_ls(Gr, s2, w->w2, w->b2, w->ls, g->w2, g->b2, g->ls, F, 3 * F, st));
   // net1 behind the LayerNorm
-  SEPR_TRY(wgrad(dh1, 6 * F, x, F, stats, dWh, s1, M, 6 * F, F, 0, x3, tnw, tnb, st));
+  {
+    TnArgs t = tn_args_zero();
+    t.M = (int)M; t.N = 6 * F; t.K = F;
+    t.A = static_cast<const float*>(dh1); t.lda = 6 * F; t.a16 = o16 ? 1 : 0; t.B = x; t.ldb = F; t.stats = stats;
+    t.G = dWh; t.ldg = F; t.colsum = s1;
+    SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
+  }
   SEPR_TRY(launch_finish_norm_linear(dWh, s1, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 6 * F, F, st));
-  SEPR_TRY(plain(dh1, 6 * F, dxh, F, M, F, 6 * F, w->up_t, nullptr, st));
+  {
+    GemmArgs ga = gemm_args_zero();
+    ga.M = (int)M; ga.N = F; ga.K = 6 * F;
+    ga.A = static_cast<const float*>(dh1); ga.lda = 6 * F; ga.Y = dxh; ga.ldc = F; ga.a16 = o16 ? 1 : 0;
+    SEPR_TRY(lin(PRO_PLAIN, EPI_STORE, ga, w->up_t, SEPR_SITE_NONE, st));
+  }
   return launch_ln_bwd(dxh, x, stats, dy, nullptr, 0, 0, 0, dx, M, F, st);
 }
 int gcfn_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, Carve& cx, Carve& ws, float p, sepr_u64 seed,
