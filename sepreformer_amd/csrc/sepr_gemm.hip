@@ -74,6 +74,7 @@ int launch_gemm(int pro, int epi, const GemmArgs& a, int site, hipStream_t strea
   }
   if ((epi == EPI_GLU || epi == EPI_DWGLU) && !a.bias) return SEPR_EINVAL;
   if (epi == EPI_DWGLU && (!a.dw_w || !a.dw_b || a.T <= 0 || ((a.N / 2) % 4) != 0)) return SEPR_EINVAL;
+  if (epi == EPI_LNBWD && (a.N > GEMM_BN || !a.aux || !a.stats || (a.aux2 && (a.T <= 0 || a.Tp <= 0 || a.fac <= 0)))) return SEPR_EINVAL;
 
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
@@ -91,6 +92,7 @@ int launch_gemm(int pro, int epi, const GemmArgs& a, int site, hipStream_t strea
     case PRO_PLAIN * 16 + EPI_RES:   launch_inst<PRO_PLAIN, EPI_RES>(a, stream); break;
     case PRO_PLAIN * 16 + EPI_SPLIT: launch_inst<PRO_PLAIN, EPI_SPLIT>(a, stream); break;
     case PRO_PLAIN * 16 + EPI_MASK:  launch_inst<PRO_PLAIN, EPI_MASK>(a, stream); break;
+    case PRO_PLAIN * 16 + EPI_LNBWD: launch_inst<PRO_PLAIN, EPI_LNBWD>(a, stream); break;
     case PRO_NORM * 16 + EPI_STORE:  launch_inst<PRO_NORM, EPI_STORE>(a, stream); break;
     case PRO_NORM * 16 + EPI_GLU:    launch_inst<PRO_NORM, EPI_GLU>(a, stream); break;
     case PRO_NORM * 16 + EPI_GATE:   launch_inst<PRO_NORM, EPI_GATE>(a, stream); break;

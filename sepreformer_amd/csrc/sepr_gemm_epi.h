@@ -6,7 +6,7 @@
 namespace sepr {
 
 enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_CAT2 = 2 };
-enum { EPI_STORE = 0, EPI_GLU = 1, EPI_GELU = 2, EPI_RES = 3, EPI_GATE = 4, EPI_SPLIT = 5, EPI_MASK = 6, EPI_DWGLU = 7 };
+enum { EPI_STORE = 0, EPI_GLU = 1, EPI_GELU = 2, EPI_RES = 3, EPI_GATE = 4, EPI_SPLIT = 5, EPI_MASK = 6, EPI_DWGLU = 7, EPI_LNBWD = 8 };
 
 struct GemmArgs {
   int M, N, K;
@@ -46,7 +46,12 @@ struct GemmArgs {
   // ([N/16][K/32][plane][lane][8], see pack.py::pack_x3); LayerNorm gamma/beta are folded into Wp / bias.
   const void* Wp;
   int bf1;   // bf16x3 core: 1 = plain bf16 operands (one MFMA per product; hi planes only), 0 = the split arithmetic
-  int a16;   // bf1 only, PRO_PLAIN / EPI_STORE: A is a bf16 tensor (lda in elements)
+  int a16;   // bf1 only, PRO_PLAIN / EPI_STORE / EPI_LNBWD: A is a bf16 tensor (lda in elements)
+  // EPI_LNBWD (training: the input-gradient projection behind a LayerNorm, N <= 128 = one column tile): the tile holds whole rows
+  // of dxh = d(loss)/d(normalised input), so the LayerNorm backward runs in the epilogue:
+  //   Y[m] = (R ? R[m] : 0) + rstd_m (dxh - mean_f dxh - xh mean_f (dxh xh)) + (aux2 ? aux2[(m / T) Tp + (m % T) / fac] / fac : 0)
+  // with xh = (aux[m] - mean_m) rstd_m, (mean, rstd) = stats[2m..]; aux = the LayerNorm's input x, aux2 = a pooled gradient (EGA)
+  const float* aux2;
 };
 
 
@@ -132,6 +137,55 @@ __device__ __forceinline__ void epilogue_from_lds(const GemmArgs& a, const float
           make_float4(v.x * sigmoid_f(g.x), v.y * sigmoid_f(g.y), v.z * sigmoid_f(g.z), v.w * sigmoid_f(g.w)));
       pv = cv; pg = cg; cv = nv; cg = ng;
       t = (t + 1 == a.T) ? 0 : t + 1;
+    }
+  } else if (EPI == EPI_LNBWD) {
+    const int q4 = tid & 31, rg = tid >> 5;       // 32 float4 columns x 8 strips of 16 rows; a row = the 32 lanes of a half wave
+    const int ncol = 4 * q4;
+    const bool cok = ncol < a.N;
+    const int cc = cok ? ncol : 0;
+    const float invN = 1.0f / (float)a.N, invfac = a.fac > 0 ? 1.0f / (float)a.fac : 0.f;
+#pragma unroll
+    for (int ib = 0; ib < 16; ib += 8) {
+      if (m0 + rg * 16 + ib >= a.M) break;        // uniform over the half wave that shares the shuffles below
+      float4 xs[8], rs[8], ps[8];
+      float2 st[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int mr = m0 + rg * 16 + ib + i;
+        const long long m = mr < a.M ? mr : a.M - 1;
+        xs[i] = ld4(a.aux + m * a.ldc + cc);
+        st[i] = *reinterpret_cast<const float2*>(a.stats + 2 * m);
+        rs[i] = a.R ? ld4(a.R + m * a.ldc + cc) : zero4();
+        ps[i] = zero4();
+        if (a.aux2) {
+          const long long seq = m / a.T;
+          ps[i] = ld4(a.aux2 + (seq * a.Tp + (m - seq * a.T) / a.fac) * a.ldc + cc);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = rg * 16 + ib + i;
+        const int m = m0 + r;
+        float4 v = cok ? ld4(Hs + r * HS + ncol) : zero4();
+        const float mean = st[i].x, rstd = st[i].y;
+        float4 xh = make_float4((xs[i].x - mean) * rstd, (xs[i].y - mean) * rstd, (xs[i].z - mean) * rstd, (xs[i].w - mean) * rstd);
+        if (!cok) xh = zero4();
+        float s1 = (v.x + v.y) + (v.z + v.w);
+        float s2 = (v.x * xh.x + v.y * xh.y) + (v.z * xh.z + v.w * xh.w);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          s1 += __shfl_xor(s1, o, 32);
+          s2 += __shfl_xor(s2, o, 32);
+        }
+        const float m1 = s1 * invN, m2 = s2 * invN;
+        if (m < a.M && cok) {
+          float4 o4 = make_float4(rstd * (v.x - m1 - xh.x * m2), rstd * (v.y - m1 - xh.y * m2), rstd * (v.z - m1 - xh.z * m2),
+                                  rstd * (v.w - m1 - xh.w * m2));
+          o4.x += rs[i].x; o4.y += rs[i].y; o4.z += rs[i].z; o4.w += rs[i].w;
+          if (a.aux2) { o4.x = fmaf(ps[i].x, invfac, o4.x); o4.y = fmaf(ps[i].y, invfac, o4.y); o4.z = fmaf(ps[i].z, invfac, o4.z); o4.w = fmaf(ps[i].w, invfac, o4.w); }
+          st4(a.Y + (long long)m * a.ldc + ncol, o4);
+        }
+      }
     }
   } else if (EPI == EPI_GLU) {
     const int q4 = tid & 15, rg = tid >> 4;       // 16 float4 columns (64 outputs) x 16 strips of 8 rows

@@ -43,14 +43,17 @@ int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t st
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
   const int key = pro * 16 + epi;
+  if (epi == EPI_LNBWD && (a.N > GEMM_BN || !a.aux || !a.stats || (a.aux2 && (a.T <= 0 || a.Tp <= 0 || a.fac <= 0)))) return SEPR_EINVAL;
   if (a.bf1 && a.a16) {
-    if (key != PRO_PLAIN * 16 + EPI_STORE || a.rows_out > 0 || (a.lda % 8) != 0) return SEPR_EINVAL;
-    launch_x3_inst<PRO_PLAIN, EPI_STORE, 16 | 32>(a, stream);
+    if ((key != PRO_PLAIN * 16 + EPI_STORE && key != PRO_PLAIN * 16 + EPI_LNBWD) || a.rows_out > 0 || (a.lda % 8) != 0) return SEPR_EINVAL;
+    if (epi == EPI_LNBWD) launch_x3_inst<PRO_PLAIN, EPI_LNBWD, 16 | 32>(a, stream);
+    else launch_x3_inst<PRO_PLAIN, EPI_STORE, 16 | 32>(a, stream);
   } else if (a.bf1) {   // plain bf16 operands: the projections of the training path's "bf16" precision
     switch (key) {
       case PRO_PLAIN * 16 + EPI_STORE: launch_x3_inst<PRO_PLAIN, EPI_STORE, 16>(a, stream); break;
       case PRO_PLAIN * 16 + EPI_RES:   launch_x3_inst<PRO_PLAIN, EPI_RES, 16>(a, stream); break;
       case PRO_PLAIN * 16 + EPI_SPLIT: launch_x3_inst<PRO_PLAIN, EPI_SPLIT, 16>(a, stream); break;
+      case PRO_PLAIN * 16 + EPI_LNBWD: launch_x3_inst<PRO_PLAIN, EPI_LNBWD, 16>(a, stream); break;
       case PRO_NORM * 16 + EPI_STORE:  launch_x3_inst<PRO_NORM, EPI_STORE, 16>(a, stream); break;
       case PRO_CAT2 * 16 + EPI_STORE:  launch_x3_inst<PRO_CAT2, EPI_STORE, 16>(a, stream); break;
       default: return SEPR_EINVAL;
@@ -67,6 +70,7 @@ int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t st
     case PRO_PLAIN * 16 + EPI_RES:   launch_x3_inst<PRO_PLAIN, EPI_RES>(a, stream); break;
     case PRO_PLAIN * 16 + EPI_SPLIT: launch_x3_inst<PRO_PLAIN, EPI_SPLIT>(a, stream); break;
     case PRO_PLAIN * 16 + EPI_MASK:  launch_x3_inst<PRO_PLAIN, EPI_MASK>(a, stream); break;
+    case PRO_PLAIN * 16 + EPI_LNBWD: launch_x3_inst<PRO_PLAIN, EPI_LNBWD>(a, stream); break;
     case PRO_NORM * 16 + EPI_STORE:  launch_x3_inst<PRO_NORM, EPI_STORE>(a, stream); break;
     case PRO_NORM * 16 + EPI_GLU:    launch_x3_inst<PRO_NORM, EPI_GLU>(a, stream); break;
     case PRO_NORM * 16 + EPI_GATE:   launch_x3_inst<PRO_NORM, EPI_GATE>(a, stream); break;

@@ -63,6 +63,24 @@ int normed(const float* X, int lda, const float* stats, float* Y, int ldc, long 
   a.A = X; a.lda = lda; a.stats = stats; a.Y = Y; a.ldc = ldc;
   return lin(PRO_NORM, EPI_STORE, a, l, SEPR_SITE_NONE, st);
 }
+// dx = (dres ? dres : 0) + LayerNorm'(dA . W^T) (+ pooled gradient): the input-gradient projection behind a LayerNorm with the
+// LayerNorm backward in its epilogue (EPI_LNBWD: an F-wide output is one column tile, so a tile holds whole rows) - one launch and
+// no [M, F] round trip where there were a projection and launch_ln_bwd.  F > 128 (Large) keeps the two-launch form.
+int dgrad_ln(const float* dA, int lda, int K, const sepr_lin& l, int a16, const float* x, const float* stats, const float* dres,
+             const float* padd, int T, int Tp, int fac, float* dx, float* scratch, long long M, int F, hipStream_t st) {
+  if (F <= GEMM_BN) {
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = F; a.K = K;
+    a.A = dA; a.lda = lda; a.a16 = a16; a.Y = dx; a.ldc = F;
+    a.aux = x; a.stats = stats; a.R = dres; a.aux2 = padd; a.T = T; a.Tp = Tp; a.fac = fac;
+    return lin(PRO_PLAIN, EPI_LNBWD, a, l, SEPR_SITE_NONE, st);
+  }
+  GemmArgs a = gemm_args_zero();
+  a.M = (int)M; a.N = F; a.K = K;
+  a.A = dA; a.lda = lda; a.a16 = a16; a.Y = scratch; a.ldc = F;
+  SEPR_TRY(lin(PRO_PLAIN, EPI_STORE, a, l, SEPR_SITE_NONE, st));
+  return launch_ln_bwd(scratch, x, stats, dres, padd, T, Tp, fac, dx, M, F, st);
+}
 // G[N][K] = sum_m A[m][n] B[m][k] (B optionally normalised with per-row stats), colsum[N]
 int wgrad(const float* A, int lda, const float* B, int ldb, const float* stats, float* G, float* colsum, long long M, int N, int K,
           int accumulate, int x3, void* ws, size_t wsb, hipStream_t st) {
@@ -154,13 +172,7 @@ int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int
     SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
   }
   SEPR_TRY(launch_finish_norm_linear(dWh, s1, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 6 * F, F, st));
-  {
-    GemmArgs ga = gemm_args_zero();
-    ga.M = (int)M; ga.N = F; ga.K = 6 * F;
-    ga.A = static_cast<const float*>(dh1); ga.lda = 6 * F; ga.Y = dxh; ga.ldc = F; ga.a16 = o16 ? 1 : 0;
-    SEPR_TRY(lin(PRO_PLAIN, EPI_STORE, ga, w->up_t, SEPR_SITE_NONE, st));
-  }
-  return launch_ln_bwd(dxh, x, stats, dy, nullptr, 0, 0, 0, dx, M, F, st);
+  return dgrad_ln(static_cast<const float*>(dh1), 6 * F, 6 * F, w->up_t, o16 ? 1 : 0, x, stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
 int gcfn_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, Carve& cx, Carve& ws, float p, sepr_u64 seed,
              hipStream_t st) {
@@ -219,9 +231,7 @@ int gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, co
   // net1: LayerNorm-folded projection
   SEPR_TRY(wgrad(dh1, 6 * F, x, F, k.stats, dWh, s1, M, 6 * F, F, 0, x3, tnw, tnb, st));
   SEPR_TRY(launch_finish_norm_linear(dWh, s1, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 6 * F, F, st));
-  SEPR_TRY(plain(dh1, 6 * F, dxh, F, M, F, 6 * F, w->up_t, nullptr, st));
-  SEPR_TRY(launch_ln_bwd(dxh, x, k.stats, dy, nullptr, 0, 0, 0, dx, M, F, st));
-  return SEPR_OK;
+  return dgrad_ln(dh1, 6 * F, 6 * F, w->up_t, 0, x, k.stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
 
 // =====================================================================================================================
@@ -302,9 +312,7 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
   SEPR_TRY(launch_glu_bwd(du, k.a, dd, M, F, st));                                             // dd := da [M][2F]
   SEPR_TRY(wgrad(dd, 2 * F, x, F, k.stats, Gr, s, M, 2 * F, F, 0, x3, tnw, tnb, st));
   SEPR_TRY(launch_finish_norm_linear(Gr, s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, st));
-  SEPR_TRY(plain(dd, 2 * F, dxh, F, M, F, 2 * F, w->l1_t, nullptr, st));
-  SEPR_TRY(launch_ln_bwd(dxh, x, k.stats, dy, nullptr, 0, 0, 0, dx, M, F, st));
-  return SEPR_OK;
+  return dgrad_ln(dd, 2 * F, 2 * F, w->l1_t, 0, x, k.stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
 
 // =====================================================================================================================
@@ -319,14 +327,15 @@ int mha_out_bwd(const float* dyq, const float* o, float* dO, long long M, int F,
 }
 // d(q/k/v projection behind the LayerNorm): dWh [3F][F] -> three finishers (shared dgamma / dbeta), dxh = dqkv . (Wqkv * gamma)
 int mha_qkv_bwd(const float* dqkv, const float* xin, const float* stats, float* dxh, long long M, int F, const sepr_mha_tw* w,
-                const sepr_mha_grad* g, float* dWh, float* s, int x3, void* tnw, size_t tnb, hipStream_t st) {
+                const sepr_mha_grad* g, float* dWh, float* s, int x3, void* tnw, size_t tnb, const float* dres, float* dx, hipStream_t st) {
   SEPR_TRY(wgrad(dqkv, 3 * F, xin, F, stats, dWh, s, M, 3 * F, F, 0, x3, tnw, tnb, st));
   float* gw[3] = {g->wq, g->wk, g->wv};
   float* gb[3] = {g->bq, g->bk, g->bv};
   for (int i = 0; i < 3; ++i)
     SEPR_TRY(launch_finish_norm_linear(dWh + (long long)i * F * F, s + i * F, w->wqkv + (long long)i * F * F, w->ln_g, w->ln_b, gw[i],
                                        gb[i], g->ln_g, g->ln_b, F, F, st));
-  return plain(dqkv, 3 * F, dxh, F, M, F, 3 * F, w->qkv_t, nullptr, st);
+  // dx = dres + LayerNorm'(dqkv . (Wqkv gamma))   (dxh: scratch of the two-launch form for F > 128)
+  return dgrad_ln(dqkv, 3 * F, 3 * F, w->qkv_t, 0, xin, stats, dres, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
 
 // =====================================================================================================================
@@ -420,16 +429,13 @@ int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, in
   SEPR_TRY(mha_out_bwd(datt, k.o, dO, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, st));
   if (mfma) SEPR_TRY(launch_relattn_x3_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, drop_salt(), atw, atb, st));
   else SEPR_TRY(launch_relattn_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), atw, atb, st));
-  SEPR_TRY(mha_qkv_bwd(dqkv, xp, k.stats_p, dxh_p, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, st));
-  SEPR_TRY(launch_ln_bwd(dxh_p, xp, k.stats_p, nullptr, nullptr, 0, 0, 0, dxd, Mp, F, st));
+  SEPR_TRY(mha_qkv_bwd(dqkv, xp, k.stats_p, dxh_p, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, nullptr, dxd, st));
   // gate projection behind its own LayerNorm
   SEPR_TRY(wgrad(dzg, F, x, F, k.stats, dWh, s, M, F, F, 0, x3, tnw, tnb, st));
   SEPR_TRY(launch_finish_norm_linear(dWh, s, w->gate_w, w->gate_ln_g, w->gate_ln_b, g->gate_w, g->gate_b, g->gate_ln_g, g->gate_ln_b, F, F,
                                      st));
-  SEPR_TRY(plain(dzg, F, dxh, F, M, F, F, w->gate_t, nullptr, st));
-  // dx = dy + LN'(dxh) + avg-pool backward of dxd
-  SEPR_TRY(launch_ln_bwd(dxh, x, k.stats, dy, dxd, T, Tp, fac, dx, M, F, st));
-  return SEPR_OK;
+  // dx = dy + LN'(dzg . (Wgate gamma)) + avg-pool backward of dxd
+  return dgrad_ln(dzg, F, F, w->gate_t, 0, x, k.stats, dy, dxd, T, Tp, fac, dx, dxh, M, F, st);
 }
 
 // =====================================================================================================================
@@ -485,8 +491,7 @@ int spk_bwd(const float* x, const float* dy, float* dx, int nS, int S, int T, in
   }
   SEPR_TRY(mha_out_bwd(dyq, k.o, dO, M, F, w, g, dWh, s, x3, tnw, tnb, st));
   SEPR_TRY(launch_spkmix_bwd(k.qkv, dO, dqkv, nS / S, S, T, F, H, p, seed, site_off(0), st));
-  SEPR_TRY(mha_qkv_bwd(dqkv, x, k.stats, dxh, M, F, w, g, dWh, s, x3, tnw, tnb, st));
-  return launch_ln_bwd(dxh, x, k.stats, dy, nullptr, 0, 0, 0, dx, M, F, st);
+  return mha_qkv_bwd(dqkv, x, k.stats, dxh, M, F, w, g, dWh, s, x3, tnw, tnb, dy, dx, st);
 }
 
 // =====================================================================================================================
