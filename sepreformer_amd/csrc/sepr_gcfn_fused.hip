@@ -83,6 +83,12 @@ struct bool_c { static constexpr bool value = V; };
 #ifndef SEPR_GF3_XCH
 #define SEPR_GF3_XCH 1
 #endif
+#ifndef SEPR_GF3_RESX
+#define SEPR_GF3_RESX 0   // EXPERIMENT (round-3 review item 6): 1 = the residual x is rebuilt from the bf16 hi + lo planes the wave
+                          // already holds ((hi + lo) / rstd + mean, 2^-17 relative) instead of being re-read from HBM in the
+                          // epilogue: removes 512 of the 1.7 KB per frame the kernel moves; costs end-to-end agreement (measured:
+                          // profiles/r03_v2_gcfn_resx_experiment.txt).  Off in the product build.
+#endif
 template <int F, int MT, int NW, int MODE = 0, bool TRAIN = false>
 __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
   constexpr bool PLAIN = MODE == 1;   // frames are independent: no halo, no seam exchange, no conv
@@ -184,6 +190,9 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     // ---- this wave's 32 frames (lane fi holds frames 2*fi and 2*fi+1): load, LayerNorm, split --------------
     const int mw0 = tile * GF_TILE + w * WSTR - HALO;           // wave frame 0 (GCFN: tile frame 0 is halo)
     bf16x8 xh[MT][KS], xl[MT][KS];
+#if SEPR_GF3_RESX
+    float mu_[MT], sg_[MT];
+#endif
     float f0[MT], f2[MT];                                        // conv zero-padding flags (sequence start / end)
     bool edge_lane = false;
 #pragma unroll
@@ -221,6 +230,10 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
       d += __shfl_xor(d, 16, 64);
       d += __shfl_xor(d, 32, 64);
       const float rstd = valid ? (PLAIN ? 1.0f : 1.0f / sqrtf(d * (1.0f / F) + a.eps)) : 0.f;   // invalid frames: exactly zero
+#if SEPR_GF3_RESX
+      mu_[mt] = mean;
+      sg_[mt] = PLAIN ? 1.0f : sqrtf(d * (1.0f / F) + a.eps);
+#endif
       if (TRAIN) {   // the frames this workgroup OUTPUTS (not its halo) report their statistics: all the backward needs
         const int lr = MT * fi + mt, bf = w * WSTR + lr;
         const bool own = XCH ? (bf >= 1 && bf <= GF_TILE) : (lr >= 1 && lr <= 16 * MT - 2);
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
         const bool ok = row < 64 && ww < NW && m < a.M &&
                         (PLAIN ? true : (XCH ? (bf >= 1 && bf <= GF_TILE) : (lr >= 1 && lr <= 16 * MT - 2)));
         mrow[p] = ok ? m : -1;
-        xr[p] = PLAIN ? zero4() : ld4(a.x + (long long)(ok ? m : 0) * F + 4 * q4);
+        xr[p] = (PLAIN || (SEPR_GF3_RESX && !TRAIN)) ? zero4() : ld4(a.x + (long long)(ok ? m : 0) * F + 4 * q4);
       }
       if (w / WPP == half) {
         float* base = Os + (w % WPP) * (16 * MT) * OS;
@@ -473,7 +486,20 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
         for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 v = acc[ft][mt];
+            f32x4 v = acc[ft][mt];
+#if SEPR_GF3_RESX
+            if (!PLAIN && !TRAIN) {   // the FINAL y = x_rec + ls (acc + b2) is staged; the store pass below only copies
+              const int c0 = 32 * (ft >> 1) + 8 * fg + 4 * (ft & 1);
+              const float4 l4 = ld4(a.ls + c0), b4 = ld4(a.b2 + c0);
+              const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, bb4[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int e = 4 * (ft & 1) + r;
+                const float xn = (float)xh[mt][ft >> 1][e] + (float)xl[mt][ft >> 1][e];
+                v[r] = fmaf(v[r] + bb4[r], ll[r], fmaf(xn, sg_[mt], mu_[mt]));
+              }
+            }
+#endif
             st4(base + (MT * fi + mt) * OS + 32 * (ft >> 1) + 8 * fg + 4 * (ft & 1), make_float4(v[0], v[1], v[2], v[3]));   // w2p row order
           }
       }
@@ -488,6 +514,8 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
               long long mo = mrow[p];
               if (a.out_S > 0) mo = ((long long)(mo / a.out_T) * a.out_S + a.out_s) * a.out_T + mo % a.out_T;
               st4(a.y + mo * a.ldy + a.col_off + 4 * q4, make_float4(o.x + b2.x, o.y + b2.y, o.z + b2.z, o.w + b2.w));
+            } else if (SEPR_GF3_RESX && !TRAIN) {
+              st4(a.y + (long long)mrow[p] * F + 4 * q4, o);
             } else {
               float4 v = TRAIN ? make_float4(fmaf(o.x, dsc, b2.x), fmaf(o.y, dsc, b2.y), fmaf(o.z, dsc, b2.z), fmaf(o.w, dsc, b2.w))
                                : make_float4(o.x + b2.x, o.y + b2.y, o.z + b2.z, o.w + b2.w);
