@@ -485,6 +485,9 @@ enum {
 int sepr_prof_start(int site, int max_launches);
 /* Synchronise the recorded events; returns launches, summed kernel ms and summed algorithmic FLOPs. */
 int sepr_prof_stop(long long* launches, double* total_ms, double* flops);
+/* Algorithmic HBM bytes of the launches of the session sepr_prof_stop last closed (sites that report them: the weight-gradient
+ * contraction and the fused GCFN backward; 0 otherwise). */
+double sepr_prof_last_bytes(void);
 
 #ifdef __cplusplus
 }

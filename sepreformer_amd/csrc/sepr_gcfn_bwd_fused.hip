@@ -448,7 +448,10 @@ int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, i
     return SEPR_EINVAL;   // (the fused pair exists for F = 64 / 128: sepr_gcfn_fused.hip)
   }
   // algorithmic FLOPs per row: recomputed up-projection 2 F 6F + input gradient of net2.2 2 F 3F + conv / GLU forward and backward
-  if (timed) prof_end(slot, (double)M * (18.0 * F * F + 60.0 * 3 * F), st);
+  if (timed) {
+    prof_end(slot, (double)M * (18.0 * F * F + 60.0 * 3 * F), st);
+    prof_bytes((double)M * (8.0 * F + 8.0 + (out16 ? 2.0 : 4.0) * 9.0 * F + (p > 0.f ? 4.0 * F : 0.0)));   // x, dy, stats in; g, dh1 (, dyq) out
+  }
   SEPR_CHECK_LAUNCH("gcfn_bwd_mid_kernel");
   float* scratch = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)MB * 3 * F * 8 * sizeof(float)));
   return launch_gcfn_mid_reduce(a.part, MB, 3 * F, dw_g, db_g, scratch, st);

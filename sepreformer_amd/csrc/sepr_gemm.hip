@@ -15,6 +15,7 @@ struct Prof {
   std::vector<hipEvent_t> ev;  // 2 per launch
   long long launches = 0;
   double flops = 0.0;
+  double bytes = 0.0, last_bytes = 0.0;   // algorithmic HBM bytes of the timed launches (sites that report them)
 };
 Prof g_prof;
 }  // namespace
@@ -31,6 +32,10 @@ void prof_end(long long slot, double flops, hipStream_t stream) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   (void)hipEventRecord(g_prof.ev[2 * slot + 1], stream);
   g_prof.flops += flops;
+}
+void prof_bytes(double bytes) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.bytes += bytes;
 }
 
 // co-resident workgroups: 2 per CU (LDS-limited), as a multiple of 8 so a workgroup keeps its XCD
@@ -117,8 +122,14 @@ extern "C" int sepr_prof_start(int site, int max_launches) {
   g_prof.cap = max_launches;
   g_prof.launches = 0;
   g_prof.flops = 0.0;
+  g_prof.bytes = 0.0;
   g_prof.site = site;
   return SEPR_OK;
+}
+
+extern "C" double sepr_prof_last_bytes(void) {
+  std::lock_guard<std::mutex> lk(sepr::g_prof.mu);
+  return sepr::g_prof.last_bytes;
 }
 
 extern "C" int sepr_prof_stop(long long* launches, double* total_ms, double* flops) {
@@ -135,6 +146,7 @@ extern "C" int sepr_prof_stop(long long* launches, double* total_ms, double* flo
   if (launches) *launches = g_prof.launches;
   if (total_ms) *total_ms = ms;
   if (flops) *flops = g_prof.flops;
+  g_prof.last_bytes = g_prof.bytes;
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
   g_prof.ev.clear();
   g_prof.cap = 0;

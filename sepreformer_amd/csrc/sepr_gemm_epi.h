@@ -81,6 +81,7 @@ int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t st
 // profiling hooks shared by both launchers (sepr_gemm.hip)
 bool prof_begin(int site, hipStream_t stream, long long* slot);
 void prof_end(long long slot, double flops, hipStream_t stream);
+void prof_bytes(double bytes);   // algorithmic HBM bytes of the launch just timed (optional)
 int persistent_grid();
 
 // ---------------------------------------------------------------------------------------------------------

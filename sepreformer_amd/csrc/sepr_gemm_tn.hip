@@ -358,7 +358,11 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   else if (x3) SEPR_TN_LAUNCH(1);
   else SEPR_TN_LAUNCH(0);
 #undef SEPR_TN_LAUNCH
-  if (timed) prof_end(slot, 2.0 * (double)a.M * (double)a.N * (double)a.K, s);
+  if (timed) {
+    prof_end(slot, 2.0 * (double)a.M * (double)a.N * (double)a.K, s);
+    // both operands once (bf16 sources: 2 bytes per element) + the statistics: what a contraction over M rows has to read
+    prof_bytes((double)a.M * ((double)a.N * (a.a16 ? 2.0 : 4.0) + (double)a.K * (a.b16 ? 2.0 : 4.0) + (a.stats ? 8.0 : 0.0)));
+  }
   const long long total = (long long)a.N * a.K + a.N;
   const int rgrid = (int)((total + 63) / 64);
   hipLaunchKernelGGL(tn_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,

@@ -311,17 +311,20 @@ int launch_gcfn_mid_bwd(const float* h1, const float* dg, float* dh1, int n, int
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Depthwise 'same' conv weight gradient (CLA dw_conv_1d, network.py:165,179): dw[c][k] = sum dy[t][c] x[t + k - K/2][c].
-// Block = (sequence, 64-frame chunk, 64 channels); x chunk (+halo) and dy chunk staged in LDS; thread (c, tap lane)
-// accumulates taps k = lane, lane + 4, ... over the chunk.  Partials [block][K + 1][C] -> reduce.
+// Block = (sequence, 64-frame chunk, 64 channels); x chunk (+halo) and dy chunk staged in LDS; lane = channel, wave = tap group.
+// A wave owns 16 consecutive taps per pass (taps 64 P + 16 w ...): their 16 accumulators and a 16-deep sliding window of x live in
+// registers, so a frame costs two LDS reads (dy[r], x[r + k0 + 15]) for 16 FMAs.  The K % 64 left-over taps (one for K = 65) go
+// round-robin over the waves with a plain two-read loop; the bias column is the sum of dy (wave 0).  Partials [block][K + 1][C].
+// (First version: every FMA read both operands from LDS - 2.1 MB of LDS reads per block, 150 us per launch on average.)
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int WG_TC = 64, WG_CB = 64, WG_KMAX = 129;   // (64 + 128 + 64) x 64 x 4 B = 64 KB of LDS at most
+constexpr int WG_TC = 64, WG_CB = 64, WG_KMAX = 129;   // (64 + 128 + 16 + 64) x 64 x 4 B = 68 KB of LDS at most
 
 __global__ __launch_bounds__(TPB) void dwconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int T, int C,
                                                           int K, int nchunk, float* __restrict__ part) {
   extern __shared__ float sm[];
   const int pad = K / 2;
-  const int rows_x = WG_TC + K - 1;
+  const int rows_x = WG_TC + K - 1 + 16;   // + 16 zero rows: the window of the last full tap group reads one group ahead
   float* xs = sm;                       // [rows_x][64]
   float* ds = sm + rows_x * WG_CB;      // [WG_TC][64]
   const int seq = blockIdx.x / nchunk, chunk = blockIdx.x - seq * nchunk;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(TPB) void dwconv_wgrad_kernel(const float* __restri
   for (int i = threadIdx.x; i < rows_x * WG_CB; i += TPB) {
     const int r = i >> 6, cc = i & 63;
     const int t = t0 - pad + r;
-    xs[i] = (t >= 0 && t < T && c0 + cc < C) ? xq[(long long)t * C + c0 + cc] : 0.f;
+    xs[i] = (r < WG_TC + K - 1 && t >= 0 && t < T && c0 + cc < C) ? xq[(long long)t * C + c0 + cc] : 0.f;
   }
   for (int i = threadIdx.x; i < WG_TC * WG_CB; i += TPB) {
     const int r = i >> 6, cc = i & 63;
@@ -342,7 +345,30 @@ __global__ __launch_bounds__(TPB) void dwconv_wgrad_kernel(const float* __restri
   }
   __syncthreads();
   float* p = part + (long long)blockIdx.x * (K + 1) * C;
-  for (int k = kl; k <= K; k += 4) {    // k == K: the bias column
+  const bool cok = c0 + cl < C;
+  const int npass = K / 64;
+  for (int ps = 0; ps < npass; ++ps) {
+    const int k0 = 64 * ps + 16 * kl;
+    float acc[16], win[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      acc[j] = 0.f;
+      win[j] = xs[(k0 + j) * WG_CB + cl];                 // x[r + k0 + j] at r = 0
+    }
+    for (int r0 = 0; r0 < WG_TC; r0 += 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {                      // frame r = r0 + i: win[(i + j) & 15] holds x[r + k0 + j]
+        const float d = ds[(r0 + i) * WG_CB + cl];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = fmaf(d, win[(i + j) & 15], acc[j]);
+        win[i] = xs[(r0 + i + 16 + k0) * WG_CB + cl];     // slot of x[r + k0] becomes x[r + 1 + k0 + 15]
+      }
+    }
+    if (cok)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) p[(long long)(k0 + j) * C + c0 + cl] = acc[j];
+  }
+  for (int k = 64 * npass + kl; k <= K; k += 4) {          // left-over taps; k == K: the bias column
     float acc = 0.f;
     if (k < K) {
 #pragma unroll 8
@@ -351,7 +377,7 @@ __global__ __launch_bounds__(TPB) void dwconv_wgrad_kernel(const float* __restri
 #pragma unroll 8
       for (int r = 0; r < WG_TC; ++r) acc += ds[r * WG_CB + cl];
     }
-    if (c0 + cl < C) p[(long long)k * C + c0 + cl] = acc;
+    if (cok) p[(long long)k * C + c0 + cl] = acc;
   }
 }
 __global__ __launch_bounds__(TPB) void dwconv_wgrad_reduce_kernel(const float* __restrict__ part, int nblk, int C, int K,
@@ -376,8 +402,12 @@ int launch_dwconv_wgrad(const float* x, const float* dy, int n, int T, int C, in
   if (!x || !dy || !dw_g || !db_g || C <= 0 || K <= 0 || (K & 1) == 0 || K > WG_KMAX) return SEPR_EINVAL;
   if (!ws || ws_bytes < dwconv_wgrad_ws(n, T, C, K)) return SEPR_EWORKSPACE;
   const int nchunk = (T + WG_TC - 1) / WG_TC;
-  const size_t shm = (size_t)((WG_TC + K - 1) + WG_TC) * WG_CB * sizeof(float);
+  const size_t shm = (size_t)((WG_TC + K - 1 + 16) + WG_TC) * WG_CB * sizeof(float);
   float* part = static_cast<float*>(ws);
+  if (shm > 64 * 1024) {   // K > 113: above the default dynamic-LDS limit
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (attr != hipSuccess) return SEPR_EINVAL;
+  }
   hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(n * nchunk, (C + WG_CB - 1) / WG_CB), dim3(TPB), shm, s, x, dy, T, C, K, nchunk, part);
   float* scratch = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)n * nchunk * (K + 1) * C * sizeof(float)));
   const float* rows = nullptr;
@@ -450,16 +480,39 @@ __global__ __launch_bounds__(TPB) void colred_kernel(const float* __restrict__ z
   }
 }
 
+// Combine of the per-chunk fp64 partials: a workgroup owns 16 columns, 16 threads per column walk the chunks (thread j takes chunks
+// j, j + 16, ...), then a fixed-order sum of the 16 lanes' sums - the order depends on nblk only, so the result is run-to-run identical.
+// (First version: one thread per column walking all M / 512 chunks serially - 40 us at 128 k rows, as long as the reduction itself.)
+__device__ __forceinline__ void colpart_sum(const double* __restrict__ part, int nblk, int C, int c, double& o1, double& o2) {
+  __shared__ double shp[16][16][2];
+  const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int bk = j; bk < nblk; bk += 16) {
+      const double2 v = *reinterpret_cast<const double2*>(part + ((long long)bk * C + c) * 2);
+      s1 += v.x;
+      s2 += v.y;
+    }
+  shp[j][cl][0] = s1;
+  shp[j][cl][1] = s2;
+  __syncthreads();
+  o1 = 0.0;
+  o2 = 0.0;
+  if (j == 0)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o1 += shp[r][cl][0];
+      o2 += shp[r][cl][1];
+    }
+}
+
 __global__ __launch_bounds__(TPB) void colstats_final_kernel(const double* __restrict__ part, int nblk, long long M, int C, float eps,
                                                             float momentum, float* __restrict__ stats, float* __restrict__ run_mean,
                                                             float* __restrict__ run_var) {
-  const int c = blockIdx.x * TPB + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int bk = 0; bk < nblk; ++bk) {
-    s += part[((long long)bk * C + c) * 2];
-    ss += part[((long long)bk * C + c) * 2 + 1];
-  }
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  double s, ss;
+  colpart_sum(part, nblk, C, c, s, ss);
+  if (c >= C || (threadIdx.x >> 4) != 0) return;
   const double mean = s / (double)M;
   double var = ss / (double)M - mean * mean;
   var = var > 0.0 ? var : 0.0;
@@ -474,13 +527,10 @@ __global__ __launch_bounds__(TPB) void colstats_final_kernel(const double* __res
 
 __global__ __launch_bounds__(TPB) void colred_final2_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ sums,
                                                            float* __restrict__ dg_g, float* __restrict__ db_g) {
-  const int c = blockIdx.x * TPB + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int bk = 0; bk < nblk; ++bk) {
-    s1 += part[((long long)bk * C + c) * 2];
-    s2 += part[((long long)bk * C + c) * 2 + 1];
-  }
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  double s1, s2;
+  colpart_sum(part, nblk, C, c, s1, s2);
+  if (c >= C || (threadIdx.x >> 4) != 0) return;
   sums[c] = (float)s1;
   sums[C + c] = (float)s2;
   if (db_g) db_g[c] += (float)s1;
@@ -541,7 +591,7 @@ int launch_colstats(const float* z, long long M, int C, float eps, float momentu
   double* part = static_cast<double*>(ws);
   hipLaunchKernelGGL((colred_kernel<0>), dim3(nblk, (C + 63) / 64), dim3(TPB), 0, s, z, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, M, C, part);
-  hipLaunchKernelGGL(colstats_final_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, s, part, nblk, M, C, eps, momentum, stats, run_mean,
+  hipLaunchKernelGGL(colstats_final_kernel, dim3((C + 15) / 16), dim3(TPB), 0, s, part, nblk, M, C, eps, momentum, stats, run_mean,
                      run_var);
   SEPR_CHECK_LAUNCH("colstats kernels");
   return SEPR_OK;
@@ -562,7 +612,7 @@ int launch_bn_gelu_bwd(const float* dy, const float* z, const float* stats, cons
   double* part = static_cast<double*>(ws);
   float* sums = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)nblk * C * 2 * sizeof(double)));
   hipLaunchKernelGGL((colred_kernel<1>), dim3(nblk, (C + 63) / 64), dim3(TPB), 0, s, z, dy, stats, g, b, M, C, part);
-  hipLaunchKernelGGL(colred_final2_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, s, part, nblk, C, sums, dg_g, db_g);
+  hipLaunchKernelGGL(colred_final2_kernel, dim3((C + 15) / 16), dim3(TPB), 0, s, part, nblk, C, sums, dg_g, db_g);
   hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel, dim3(grid_for(M * (C >> 2), TPB, 1 << 16)), dim3(TPB), 0, s, dy, z, stats, g, b, sums, dz,
                      M, C);
   SEPR_CHECK_LAUNCH("bn_gelu_bwd kernels");
@@ -903,16 +953,30 @@ __global__ __launch_bounds__(TPB) void gn_bwd_apply_kernel(const float* __restri
     }
   }
 }
+// 16 channels per workgroup, 16 threads per channel over the partial rows (thread j: rows j, j + 16, ...), fixed-order combine
 __global__ __launch_bounds__(TPB) void gn_bwd_param_kernel(const float* __restrict__ ch_part, int nblk, int F, float* __restrict__ dg_g,
                                                           float* __restrict__ db_g) {
-  const int c = blockIdx.x * TPB + threadIdx.x;
-  if (c >= F) return;
+  __shared__ float shp[16][16][2];
+  const int cl = threadIdx.x & 15, jl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   const int q = c >> 2, j = c & 3;
   const int f4 = F >> 2;
   float s1 = 0.f, s2 = 0.f;
-  for (int bk = 0; bk < nblk; ++bk) {
-    s1 += ch_part[((long long)bk * f4 + q) * 8 + j];
-    s2 += ch_part[((long long)bk * f4 + q) * 8 + 4 + j];
+  if (c < F)
+    for (int bk = jl; bk < nblk; bk += 16) {
+      s1 += ch_part[((long long)bk * f4 + q) * 8 + j];
+      s2 += ch_part[((long long)bk * f4 + q) * 8 + 4 + j];
+    }
+  shp[jl][cl][0] = s1;
+  shp[jl][cl][1] = s2;
+  __syncthreads();
+  if (jl != 0 || c >= F) return;
+  s1 = 0.f;
+  s2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    s1 += shp[r][cl][0];
+    s2 += shp[r][cl][1];
   }
   dg_g[c] += s1;
   db_g[c] += s2;
@@ -945,7 +1009,7 @@ int launch_gn_bwd(const float* dy, const float* v, const float* stats, const flo
   const long long total4 = (long long)n * T * F / 4;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total4, TPB, 1 << 16)), dim3(TPB), 0, s, dy, v, stats, g, sc_part, nchunk, dv, T, F,
                      S, total4);
-  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, ch_part, n * nchunk, F, dg_g, db_g);
+  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((F + 15) / 16), dim3(TPB), 0, s, ch_part, n * nchunk, F, dg_g, db_g);
   SEPR_CHECK_LAUNCH("gn_bwd kernels");
   return SEPR_OK;
 }
@@ -1165,6 +1229,29 @@ __global__ __launch_bounds__(TPB) void dec_bwd_dm_kernel(const float* __restrict
     st4(dm + row * N + c, acc);
   }
 }
+// Same sum with the K taps of a thread's four columns held in registers: a thread keeps its column group and walks rows, so the
+// weights are read once per thread instead of once per output (the loop above re-reads 16 float4 of weights per float4 of output)
+template <int KK>
+__global__ __launch_bounds__(TPB) void dec_bwd_dm_fixed_kernel(const float* __restrict__ dwp, const float* __restrict__ wdec,
+                                                              float* __restrict__ dm, int L, int N, int stride, int Tout, long long rows) {
+  const int n4 = N >> 2, rpb = TPB / n4;
+  const int c = (threadIdx.x % n4) * 4, rl = threadIdx.x / n4;
+  float4 w[KK];
+#pragma unroll
+  for (int k = 0; k < KK; ++k) w[k] = ld4(wdec + k * N + c);
+  for (long long row = (long long)blockIdx.x * rpb + rl; row < rows; row += (long long)gridDim.x * rpb) {
+    const long long seq = row / L;
+    const int l = (int)(row - seq * L);
+    const float* f = dwp + seq * Tout + (long long)stride * l;
+    float4 acc = zero4();
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+      const float d = f[k];
+      acc.x = fmaf(d, w[k].x, acc.x); acc.y = fmaf(d, w[k].y, acc.y); acc.z = fmaf(d, w[k].z, acc.z); acc.w = fmaf(d, w[k].w, acc.w);
+    }
+    st4(dm + row * N + c, acc);
+  }
+}
 __global__ __launch_bounds__(TPB) void aux_m_kernel(const float* __restrict__ o2, const float* __restrict__ enc, const int* __restrict__ idx,
                                                    float* __restrict__ m, int S, int Tsrc, int L, int N, long long total4) {
   const int n4 = N >> 2;
@@ -1249,7 +1336,14 @@ int launch_permute_sb(const float* dwav, float* dwp, int S, int B, int Tout, hip
 int launch_dec_bwd_dm(const float* dwp, const float* wdec, float* dm, int nS, int L, int N, int K, int stride, int Tout, hipStream_t s) {
   if (!dwp || !wdec || !dm || nS <= 0 || L <= 0 || N % 4 || (L - 1) * stride + K > Tout) return SEPR_EINVAL;
   const long long total4 = (long long)nS * L * N / 4;
-  hipLaunchKernelGGL(dec_bwd_dm_kernel, dim3(grid_for(total4, TPB, 1 << 16)), dim3(TPB), 0, s, dwp, wdec, dm, L, N, K, stride, Tout, total4);
+  const int n4 = N >> 2;
+  if (K == 16 && n4 <= TPB && TPB % n4 == 0) {
+    const long long rows = total4 / n4;
+    hipLaunchKernelGGL((dec_bwd_dm_fixed_kernel<16>), dim3(grid_for(rows, TPB / n4, 2048)), dim3(TPB), 0, s, dwp, wdec, dm, L, N, stride, Tout,
+                       rows);
+  } else {
+    hipLaunchKernelGGL(dec_bwd_dm_kernel, dim3(grid_for(total4, TPB, 1 << 16)), dim3(TPB), 0, s, dwp, wdec, dm, L, N, K, stride, Tout, total4);
+  }
   SEPR_CHECK_LAUNCH("dec_bwd_dm_kernel");
   return SEPR_OK;
 }

@@ -162,6 +162,7 @@ SIGNATURES = {
     "sepr_pit_sisnr_mag_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _i, _i, _d, _fp, _fp, _sz, _fp]),
     "sepr_prof_start": (_i, [_i, _i]),
     "sepr_prof_stop": (_i, [C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sepr_prof_last_bytes": (C.c_double, []),
 }
 
 _lib: Optional[C.CDLL] = None

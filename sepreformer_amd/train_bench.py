@@ -16,6 +16,19 @@ import time
 import torch
 
 FP32_MFMA_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS = 157.3, 2500.0
+HBM_PEAK_GBS = 8000.0
+TRAFFIC_SOURCE = "static: profiles/pmc_gemm_tn.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the contraction launches of one eager step, tools/pmc_traffic.sh); not re-measured in this run"
+
+
+def _static_traffic(prec, launches):
+    """HBM bytes per launch from the committed PMC collection (average over the 299 contractions of a batch-16 step)."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_gemm_tn.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return rec.get(prec, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 GFLOP_FWD = {"SepReformer_Base_WSJ0": 182.16, "SepReformer_Large_DM_WHAMR": 684.14}     # per 4 s utterance, forward incl. aux heads
 
 
@@ -94,6 +107,7 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
         torch.cuda.synchronize(dev)
         model.train_graphs = True
     L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
+    algo_bytes = float(lib.sepr_prof_last_bytes())
     elapsed = sdist.max_over_ranks(elapsed, dev)
     rec = None
     if rank == 0:
@@ -123,11 +137,17 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
             "allreduce_bytes_per_step": (sync.bytes // max(sync.calls, 1)) if sync.calls else 0,
             "model_tflops": round(utt_per_s * gflop / 1e3 / world, 2),
             "model_frac_algorithmic": round(utt_per_s * gflop / 1e3 / world / peak, 4),
-            "roofline": {"kernel": "gemm_tn_kernel (weight-gradient contraction G[N][K] = sum_m dY[m][n] X[m][k], all projections)",
-                         "bound": "mfma", "achieved": round(algo_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(algo_tf / peak, 4),
-                         "frac_algorithmic": round(algo_tf / peak, 4), "mfma_pipe_frac": round(mult * algo_tf / peak, 4),
-                         "ceiling": round(1.0 / mult, 4), "traffic": None, "launches": int(n_l.value),
-                         "avg_launch_ms": round(ms.value / max(n_l.value, 1), 4)},
+            # The contraction over M = batch x frames rows reads both operands once for a [N,K] result with N, K <= 1024: at
+            # 2 N K / (4 (N + K)) = 50-130 FLOP per byte it sits under the ridge of the bf16 MFMA (312 FLOP/B) - HBM is its roofline.
+            # achieved = algorithmic bytes of the timed launches / their hipEvent durations; the matrix-pipe view rides along.
+            "roofline": {"kernel": "gemm_tn_kernel (weight-gradient contraction G[N][K] = sum_m dY[m][n] X[m][k], all 299 projections of a step)",
+                         "bound": "hbm", "achieved": round(algo_bytes / 1e9 / sec, 1) if sec > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(algo_bytes / 1e9 / sec / HBM_PEAK_GBS, 4) if sec > 0 else 0.0,
+                         "algorithmic_tflops": round(algo_tf, 2), "mfma_pipe_frac": round(mult * algo_tf / peak, 4),
+                         "traffic": _static_traffic(prec, n_l.value), "traffic_source": TRAFFIC_SOURCE,
+                         "algorithmic_bytes_per_launch": round(algo_bytes / max(n_l.value, 1)), "launches": int(n_l.value),
+                         "avg_launch_ms": round(ms.value / max(n_l.value, 1), 4),
+                         "measured_on": "one eager step after the timed region (a replayed hipGraph has no per-launch events)" if graphs else "the timed steps"},
         }
     model.grad_sync = None
     del opt, model
