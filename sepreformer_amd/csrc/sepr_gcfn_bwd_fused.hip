@@ -70,7 +70,9 @@ struct GcfnBwdArgs {
 // NSL = F / 64 slabs per operand.  All 2 * NSL activation slabs of a tile (x, then dy) are requested TOGETHER, one tile ahead:
 // the loads of tile t+1 are issued when tile t's accumulators have been staged and fly under its whole row-window epilogue.
 // (First version: one slab in flight at a time, requested during the previous slab's ~800-cycle MFMA phase - every slab paid
-//  an exposed L2 / HBM latency and a 64-row tile took 16 us.)
+//  an exposed L2 / HBM latency and a 64-row tile took 16 us.  Also measured, round 3: giving up the tile-ahead prefetch for a third
+//  workgroup per CU - 168 VGPRs, 46 dwords spilled once per tile - is SLOWER, 337 us against 283 us per launch at batch 16: the tile
+//  is not latency-bound but the sum of ~1 650 VALU instructions, ~250 LDS instructions and 144 MFMAs per wave between 9 barriers.)
 template <int PLANES, int NSL>
 __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnBwdArgs a) {
   constexpr bool ONE = PLANES == 1;

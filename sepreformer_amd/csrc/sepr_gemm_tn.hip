@@ -19,6 +19,9 @@
 #include "sepr_train.h"
 #include <stdlib.h>
 
+#ifndef SEPR_TN_ABL
+#define SEPR_TN_ABL 0   // timing ablations (wrong results): 1 no MFMAs, 2 no conversion / LDS staging, 4 no global loads
+#endif
 namespace sepr {
 
 typedef __bf16 tn_bf16x8 __attribute__((ext_vector_type(8)));
@@ -72,7 +75,12 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int fi = lane & 15, fg = lane >> 4;
-  const int tile = blockIdx.x % (p.tn * p.tk), split = blockIdx.x / (p.tn * p.tk);
+  // XCD-aware walk: hardware block b runs on XCD b % 8, and each XCD has its own L2.  The tiles of one row slice share an operand
+  // (B for the tn tiles of a k column, A for the tk tiles of an n row), so they get CONSECUTIVE virtual ids on ONE XCD - the shared
+  // slab is fetched from HBM once per slice instead of once per tile (PMC, round 3: 1.67 x the algorithmic bytes before).
+  const int gq = gridDim.x >> 3, gr = gridDim.x & 7, bx = blockIdx.x & 7;
+  const int vb = bx * gq + (bx < gr ? bx : gr) + (blockIdx.x >> 3);
+  const int tile = vb % (p.tn * p.tk), split = vb / (p.tn * p.tk);
   const int n0 = (tile / p.tk) * TN_T, k0 = (tile % p.tk) * TN_T;
   const int m_beg = split * p.rows_per_split;
   const int m_end = min(a.M, m_beg + p.rows_per_split);
@@ -90,6 +98,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
   const int row_safe = m_beg < a.M ? m_beg : 0;
   const int col_c = col_ok ? col : 0;
   auto load_slab = [&](int mb) {
+    if (SEPR_TN_ABL & 4) return;
     if constexpr (!GEN) {
       const float* base = roleA ? a.A : a.B;                      // wave-uniform
       const long long ld = roleA ? a.lda : a.ldb;
@@ -164,6 +173,11 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
   };
   auto store_slab = [&]() {
 #pragma clang fp contract(off)
+    if (SEPR_TN_ABL & 2) {
+#pragma unroll
+      for (int e = 0; e < 8 * TN_NB; ++e) asm volatile("" ::"v"(r[e].x), "v"(r[e].y), "v"(r[e].z), "v"(r[e].w));
+      return;
+    }
     if (roleA) {
 #pragma unroll
       for (int e = 0; e < 8 * TN_NB; ++e) { csum.x += r[e].x; csum.y += r[e].y; csum.z += r[e].z; csum.w += r[e].w; }
@@ -237,6 +251,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int kt = 0; kt < 4; ++kt) {
+            if (SEPR_TN_ABL & 1) { acc[nt][kt][0] += (float)ah[nt][0] + (float)bh[kt][0]; continue; }
             acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh[kt], acc[nt][kt], 0, 0, 0);
             if constexpr (!ONE) {
               acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl[kt], acc[nt][kt], 0, 0, 0);

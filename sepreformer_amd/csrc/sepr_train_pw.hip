@@ -312,8 +312,8 @@ int launch_gcfn_mid_bwd(const float* h1, const float* dg, float* dh1, int n, int
 // ---------------------------------------------------------------------------------------------------------------------
 // Depthwise 'same' conv weight gradient (CLA dw_conv_1d, network.py:165,179): dw[c][k] = sum dy[t][c] x[t + k - K/2][c].
 // Block = (sequence, 64-frame chunk, 64 channels); x chunk (+halo) and dy chunk staged in LDS; lane = channel, wave = tap group.
-// A wave owns 16 consecutive taps per pass (taps 64 P + 16 w ...): their 16 accumulators and a 16-deep sliding window of x live in
-// registers, so a frame costs two LDS reads (dy[r], x[r + k0 + 15]) for 16 FMAs.  The K % 64 left-over taps (one for K = 65) go
+// A wave owns 16 consecutive taps per pass (taps 64 P + 16 w ...): their 16 accumulators and a sliding window of x live in
+// registers, so a frame costs two LDS reads (dy[r], one new x) for 16 FMAs (8 packed).  The K % 64 left-over taps (one for K = 65) go
 // round-robin over the waves with a plain two-read loop; the bias column is the sum of dy (wave 0).  Partials [block][K + 1][C].
 // (First version: every FMA read both operands from LDS - 2.1 MB of LDS reads per block, 150 us per launch on average.)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -322,7 +322,7 @@ constexpr int WG_TC = 64, WG_CB = 64, WG_KMAX = 129;   // (64 + 128 + 16 + 64) x
 
 __global__ __launch_bounds__(TPB) void dwconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int T, int C,
                                                           int K, int nchunk, float* __restrict__ part) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int pad = K / 2;
   const int rows_x = WG_TC + K - 1 + 16;   // + 16 zero rows: the window of the last full tap group reads one group ahead
   float* xs = sm;                       // [rows_x][64]
@@ -333,40 +333,57 @@ __global__ __launch_bounds__(TPB) void dwconv_wgrad_kernel(const float* __restri
   const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
   const float* xq = x + (long long)seq * T * C;
   const float* dq = dy + (long long)seq * T * C;
-  for (int i = threadIdx.x; i < rows_x * WG_CB; i += TPB) {
-    const int r = i >> 6, cc = i & 63;
+  for (int i = threadIdx.x; i < rows_x * (WG_CB / 4); i += TPB) {   // C % 4 == 0: a float4 is inside or outside the channel range
+    const int r = i >> 4, cc = (i & 15) * 4;
     const int t = t0 - pad + r;
-    xs[i] = (r < WG_TC + K - 1 && t >= 0 && t < T && c0 + cc < C) ? xq[(long long)t * C + c0 + cc] : 0.f;
+    const bool in = r < WG_TC + K - 1 && t >= 0 && t < T && c0 + cc < C;
+    st4(xs + r * WG_CB + cc, in ? ld4(xq + (long long)t * C + c0 + cc) : zero4());
   }
-  for (int i = threadIdx.x; i < WG_TC * WG_CB; i += TPB) {
-    const int r = i >> 6, cc = i & 63;
+  for (int i = threadIdx.x; i < WG_TC * (WG_CB / 4); i += TPB) {
+    const int r = i >> 4, cc = (i & 15) * 4;
     const int t = t0 + r;
-    ds[i] = (t < T && c0 + cc < C) ? dq[(long long)t * C + c0 + cc] : 0.f;
+    st4(ds + r * WG_CB + cc, (t < T && c0 + cc < C) ? ld4(dq + (long long)t * C + c0 + cc) : zero4());
   }
   __syncthreads();
   float* p = part + (long long)blockIdx.x * (K + 1) * C;
   const bool cok = c0 + cl < C;
   const int npass = K / 64;
+  typedef float f2 __attribute__((ext_vector_type(2)));
   for (int ps = 0; ps < npass; ++ps) {
     const int k0 = 64 * ps + 16 * kl;
-    float acc[16], win[16];
+    const float* xk = xs + k0 * WG_CB + cl;               // xk[q * 64] = x~[q]: the x value tap k0 + j meets at frame q - j
+    // Packed FMAs want (tap 2m, tap 2m + 1) operand PAIRS in adjacent registers, and the window slides by one value per frame, so
+    // two rings of pairs are kept: E[p] = (x~[2p], x~[2p+1]) serves even frames, O[p] = (x~[2p+1], x~[2p+2]) odd frames.
+    // (A single 16-value ring compiled to 3 register moves per packed FMA - slower than the two-reads-per-FMA version.)
+    f2 acc[8], E[8], O[8];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      acc[j] = 0.f;
-      win[j] = xs[(k0 + j) * WG_CB + cl];                 // x[r + k0 + j] at r = 0
+    for (int m = 0; m < 8; ++m) {
+      acc[m] = (f2){0.f, 0.f};
+      E[m] = (f2){xk[(2 * m) * WG_CB], xk[(2 * m + 1) * WG_CB]};
+      O[m] = (f2){xk[(2 * m + 1) * WG_CB], xk[(2 * m + 2) * WG_CB]};
     }
-    for (int r0 = 0; r0 < WG_TC; r0 += 16) {
+#pragma unroll 1
+    for (int u0 = 0; u0 < WG_TC / 2; u0 += 8) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {                      // frame r = r0 + i: win[(i + j) & 15] holds x[r + k0 + j]
-        const float d = ds[(r0 + i) * WG_CB + cl];
+      for (int uu = 0; uu < 8; ++uu) {                    // frames 2u, 2u + 1; slot uu holds E[u], O[u]
+        const int u = u0 + uu;
+        const float d0 = ds[(2 * u) * WG_CB + cl], d1 = ds[(2 * u + 1) * WG_CB + cl];
+        const f2 dd0 = (f2){d0, d0}, dd1 = (f2){d1, d1};
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = fmaf(d, win[(i + j) & 15], acc[j]);
-        win[i] = xs[(r0 + i + 16 + k0) * WG_CB + cl];     // slot of x[r + k0] becomes x[r + 1 + k0 + 15]
+        for (int m = 0; m < 8; ++m) acc[m] = __builtin_elementwise_fma(dd0, E[(uu + m) & 7], acc[m]);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = __builtin_elementwise_fma(dd1, O[(uu + m) & 7], acc[m]);
+        const float n1 = xk[(2 * u + 17) * WG_CB], n2 = xk[(2 * u + 18) * WG_CB];
+        E[uu] = (f2){O[(uu + 7) & 7].y, n1};              // E[u + 8] = (x~[2u+16], x~[2u+17])
+        O[uu] = (f2){n1, n2};                             // O[u + 8]
       }
     }
     if (cok)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) p[(long long)(k0 + j) * C + c0 + cl] = acc[j];
+      for (int m = 0; m < 8; ++m) {
+        p[(long long)(k0 + 2 * m) * C + c0 + cl] = acc[m].x;
+        p[(long long)(k0 + 2 * m + 1) * C + c0 + cl] = acc[m].y;
+      }
   }
   for (int k = 64 * npass + kl; k <= K; k += 4) {          // left-over taps; k == K: the bias column
     float acc = 0.f;
@@ -399,7 +416,7 @@ size_t dwconv_wgrad_ws(int n, int T, int C, int K) {
 int launch_dwconv_wgrad(const float* x, const float* dy, int n, int T, int C, int K, float* dw_g, float* db_g, void* ws,
                         size_t ws_bytes, hipStream_t s) {
   if (n <= 0 || T <= 0) return SEPR_OK;
-  if (!x || !dy || !dw_g || !db_g || C <= 0 || K <= 0 || (K & 1) == 0 || K > WG_KMAX) return SEPR_EINVAL;
+  if (!x || !dy || !dw_g || !db_g || C <= 0 || (C % 4) || K <= 0 || (K & 1) == 0 || K > WG_KMAX) return SEPR_EINVAL;
   if (!ws || ws_bytes < dwconv_wgrad_ws(n, T, C, K)) return SEPR_EWORKSPACE;
   const int nchunk = (T + WG_TC - 1) / WG_TC;
   const size_t shm = (size_t)((WG_TC + K - 1 + 16) + WG_TC) * WG_CB * sizeof(float);

@@ -8,7 +8,7 @@ from sepreformer_amd import lib as L
 
 lib = L.load()
 dev = torch.device("cuda:0")
-shapes = [(32000, 768, 128), (32000, 128, 384), (32000, 384, 128), (32000, 128, 128), (64000, 768, 128), (64000, 128, 384),
+shapes = [(128000, 768, 128), (128000, 128, 384), (32000, 768, 128), (32000, 128, 384), (32000, 384, 128), (32000, 128, 128), (64000, 768, 128), (64000, 128, 384),
           (16000, 768, 128), (8000, 768, 128), (4000, 384, 128), (2000, 128, 128)]
 for M, N, K in shapes:
     A = torch.randn(M, N, device=dev)
@@ -19,8 +19,15 @@ for M, N, K in shapes:
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
 
+    stats = torch.stack([torch.zeros(M, device=dev), torch.ones(M, device=dev)], 1).contiguous()
+    NORM = os.environ.get("WGRAD_NORM", "0") == "1"      # the LayerNorm-prologue instantiation (sepr_linear_wgrad_norm)
+    X3 = int(os.environ.get("WGRAD_X3", "1"))
+
     def run():
-        rc = lib.sepr_linear_wgrad(A.data_ptr(), B.data_ptr(), G.data_ptr(), cs.data_ptr(), M, N, K, 0, 1, ws.data_ptr(), wsb, st)
+        if NORM:
+            rc = lib.sepr_linear_wgrad_norm(A.data_ptr(), B.data_ptr(), stats.data_ptr(), G.data_ptr(), cs.data_ptr(), M, N, K, 0, X3, ws.data_ptr(), wsb, st)
+        else:
+            rc = lib.sepr_linear_wgrad(A.data_ptr(), B.data_ptr(), G.data_ptr(), cs.data_ptr(), M, N, K, 0, X3, ws.data_ptr(), wsb, st)
         assert rc == 0, rc
     for _ in range(3):
         run()
