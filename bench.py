@@ -147,6 +147,8 @@ def parse_args():
                     help="debug: all ranks use GPU 0 and the gloo backend (exercises the N > 1 path end to end on a 1-GPU box; "
                          "the throughput it prints is NOT a scaling number)")
     ap.add_argument("--no-train-graphs", action="store_true", help="train mode: launch every kernel from the host instead of replaying captured hipGraphs")
+    ap.add_argument("--pmc", choices=["auto", "on", "off"], default="auto",
+                    help="HBM traffic of the dominant kernel from rocprofv3 PMC passes of a short sub-run (auto: in the default 1-GPU run)")
     ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default=None,
                     help="projection arithmetic (default: the package default / SEPR_PRECISION)")
     return ap.parse_args()
@@ -163,6 +165,56 @@ def self_launch(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+PMC_KERNEL_RE = "gcfn_fused3_kernel<[0-9]+, [0-9], [0-9], 0, false>"     # the GCFN instantiations of the fused kernel (not the plain GLU-MLP mode)
+
+
+def measure_pmc_traffic(budget_s=150.0):
+    """HBM bytes per launch of the fused GCFN kernel, measured NOW: ``rocprofv3 --pmc FETCH_SIZE`` and ``--pmc WRITE_SIZE`` in separate
+    passes (kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short sub-run of this script at the same batch.  Returns
+    (record, None) or (None, reason).  FETCH_SIZE x2: the guide's gfx950 correction for 16 B/lane streaming reads; counters are KiB."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    sums, launches, algo = {}, 0, None
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"sepr_pmc_{ctr}_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--kernel-include-regex", PMC_KERNEL_RE, "--output-format", "csv", "-d", d, "-o", "t", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-alt-precision", "--pmc", "off"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        try:
+            out = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=budget_s, text=True)
+        except (subprocess.TimeoutExpired, OSError) as e:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"{ctr} pass: {type(e).__name__}"
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if out.returncode != 0 or not files:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"{ctr} pass: rc {out.returncode}, {len(files)} counter files"
+        with open(files[0]) as f:
+            rows = [r for r in csv.DictReader(f) if r.get("Counter_Name") == ctr]
+        shutil.rmtree(d, ignore_errors=True)
+        if not rows:
+            return None, f"{ctr} pass: no rows for {PMC_KERNEL_RE}"
+        sums[ctr], launches = sum(float(r["Counter_Value"]) for r in rows), len(rows)
+        for line in out.stdout.splitlines():
+            if line.startswith("{"):
+                try:
+                    algo = json.loads(line)["roofline"].get("algorithmic_bytes_per_launch")
+                except (ValueError, KeyError):
+                    pass
+    fetch = 2.0 * 1024.0 * sums["FETCH_SIZE"] / launches
+    write = 1024.0 * sums["WRITE_SIZE"] / launches
+    return {"hbm_bytes_per_launch": round(fetch + write), "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
+            "launches": launches, "algorithmic_bytes_per_launch": algo,
+            "traffic_over_algorithmic": round((fetch + write) / algo, 3) if algo else None}, None
 
 
 GOLDEN_4S = {"SepReformer_Base_WSJ0": "e2e_base_4s.npz", "SepReformer_Large_DM_WHAMR": "e2e_large_whamr_4s.npz"}
@@ -454,6 +506,22 @@ def main():
                 except Exception as e:          # noqa: BLE001
                     rec["train"][prec] = {"error": f"{type(e).__name__}: {e}"[:300]}
             rec["sub_records_s"] = round(time.perf_counter() - t_sub, 1)
+        if world == 1 and (args.pmc == "on" or (args.pmc == "auto" and default_run)) and rec["roofline"].get("algorithmic_bytes_per_launch"):
+            # traffic re-measured in THIS run (two short PMC sub-runs at the same batch: every launch they count has the timed launches' size)
+            t_pmc = time.perf_counter()
+            torch.cuda.synchronize(dev)
+            pm, why = measure_pmc_traffic()
+            if pm and pm.get("traffic_over_algorithmic"):
+                rec["roofline"]["traffic"] = round(pm["traffic_over_algorithmic"] * rec["roofline"]["algorithmic_bytes_per_launch"])
+                rec["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) over "
+                                                      f"{pm['launches']} launches of a 1-step sub-run at the same batch; FETCH_SIZE x2 (gfx950 correction of "
+                                                      "MI355X_MICROARCH.md), KiB units; fetch "
+                                                      f"{pm['fetch_bytes_per_launch']} + write {pm['write_bytes_per_launch']} B per launch there = "
+                                                      f"{pm['traffic_over_algorithmic']} x the algorithmic bytes")
+                rec["roofline"]["traffic_over_algorithmic"] = pm["traffic_over_algorithmic"]
+            else:
+                rec["roofline"]["traffic_source"] = (rec["roofline"].get("traffic_source") or "") + f" (live PMC passes failed: {why})"
+            rec["pmc_s"] = round(time.perf_counter() - t_pmc, 1)
         if world == 1 and not args.no_cpu_baseline:
             threads = int(os.environ.get("SEPR_CPU_THREADS", str(physical_cores())))
             rec["cpu_baseline"] = cpu_baseline(VARIANTS[variant], threads)

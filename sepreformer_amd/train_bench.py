@@ -87,7 +87,7 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
         step()
     torch.cuda.synchronize(dev)
     if not graphs:
-        L.check(lib.sepr_prof_start(L.SITE_WGRAD, 400 * max(steps, 1) + 8), "sepr_prof_start")
+        L.check(lib.sepr_prof_start(L.SITE_WGRAD, 400 * (max(steps, 1) + 1) + 8), "sepr_prof_start")
     sdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -97,6 +97,12 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
     torch.cuda.synchronize(dev)
     sdist.barrier()
     elapsed = time.perf_counter() - t0
+    # host cost of a step on its own: one more step enqueued to an IDLE device, outside the timed region (inside it the host runs
+    # ahead of the device and the wall time of its loop includes waiting for queue slots - 16 ms at 2 steps, 54 ms at 4)
+    te0 = time.perf_counter()
+    step()
+    t_enq = time.perf_counter() - te0
+    torch.cuda.synchronize(dev)
     n_l, ms, fl = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
     if graphs:
         # a replayed graph has no per-launch events: the dominant kernel's launch durations come from ONE extra eager step
@@ -130,7 +136,8 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
                                        if graphs else "eager (every kernel launched from the host)"),
                        "optimizer": type(opt).__name__ + (" (fused)" if getattr(opt, "defaults", {}).get("fused") else ""),
                        "clip_norm": 5.0, "parallelism": f"data-parallel x{world}, flat-buffer RCCL all-reduce" + (" (DEBUG: all ranks share GPU 0, gloo collective)" if share else "")},
-            "host_enqueue_ms_per_step": round(1e3 * t_host / max(steps, 1), 3),
+            "host_enqueue_ms_per_step": round(1e3 * t_enq, 3),
+            "host_loop_ms_per_step": round(1e3 * t_host / max(steps, 1), 3),
             "loss": round(float(last["loss"]), 4), "grad_norm": round(float(last["gn"]), 4),
             "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
             "collective_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,

@@ -44,3 +44,16 @@ def test_bench_single_gpu_runs_its_collectives_through_rccl():
     assert rec["reduced_metric"]["utterances"] == 4
     rec = _bench("--mode", "train", "--batch", "2", "--steps", "1", "--warmup", "1")
     assert rec["collective_backend"] == "nccl" and rec["allreduce_bytes_per_step"] > 50_000_000
+
+
+def test_bench_measures_hbm_traffic_live():
+    """--pmc on: the roofline's ``traffic`` comes from rocprofv3 FETCH_SIZE / WRITE_SIZE passes of THIS invocation (separate passes,
+    kernel-trace only), not from a committed file; the fused GCFN kernel moves more than its algorithmic bytes and less than 3 x."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    rec = _bench("--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-alt-precision", "--pmc", "on", timeout=600)
+    roof = rec["roofline"]
+    assert roof["traffic_source"].startswith("measured in this run"), roof["traffic_source"]
+    assert 1.0 < roof["traffic_over_algorithmic"] < 3.0, roof
+    assert roof["traffic"] == round(roof["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"])
