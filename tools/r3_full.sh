@@ -19,4 +19,4 @@ for k, t in r.get("train", {}).items(): print("train", k, {q: t.get(q) for q in 
 print("sub_records_s", r.get("sub_records_s")); c = r.get("cpu_baseline", {}); print("cpu:", c.get("value"), c.get("cores"), c.get("oracle_over_ref_walltime"))
 PY
 tail -3 $OUT/bench_default.err | cut -c1-300
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_criterion.py tests/test_infer.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -3 | cut -c1-400
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_criterion.py tests/test_infer.py -m gpu -q -x -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -3 | cut -c1-400

@@ -32,3 +32,4 @@ l = r.get("large", {}); print("large:", {k: l.get(k) for k in ("value", "ms_per_
 for k, t in r.get("train", {}).items(): print("train", k, {q: t.get(q) for q in ("value", "ms_per_step", "host_enqueue_ms_per_step", "loss", "collective_backend", "error")})
 print("sub_records_s", r.get("sub_records_s"), "cpu", (r.get("cpu_baseline") or {}).get("value"))
 PY
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_criterion.py tests/test_infer.py -m gpu -q -x -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -3 | cut -c1-400
