@@ -200,7 +200,7 @@ def test_wgrad_norm_full_size(M, N, K, x3):
 # ---------------------------------------------------------------------------------------------------------------------
 # every block: train-mode forward and backward against autograd over the oracle's restatement of the same module
 # ---------------------------------------------------------------------------------------------------------------------
-BLOCK_VARIANTS = ["tiny", "SepReformer_Base_WSJ0"]
+BLOCK_VARIANTS = ["tiny", "SepReformer_Base_WSJ0", "SepReformer_Large_DM_WHAMR"]   # F = 16 / 128 / 256 (dk = 32, generic GCFN pair)
 
 
 @pytest.mark.parametrize("precision", PRECISIONS_T)
@@ -596,6 +596,34 @@ def test_train_step_base_matches_oracle(precision, aux_loss):
             continue
         downstream = k.startswith(("separator.dec_stages.3.", "out_layer.", "audio_decoder."))
         agree_grad(soft, "grad." + k, k, p_.grad, sdl[k].grad, gscale, MIN_DB if downstream else relaxed)
+    soft.done()
+
+
+def test_train_step_large_matches_oracle():
+    """Large_DM_WHAMR (F = 256, dk = 32: the generic GCFN pair, the dk = 32 MFMA attention backward), 0.5 s, one utterance, the smooth
+    main-output loss: loss and every gradient tensor against the oracle at the 80 dB bar in the default bf16x3 arithmetic."""
+    B, T = 1, 4000
+    srcn = synth_sources(B, T, seed=37)
+    src = [torch.from_numpy(srcn[:, s].copy()) for s in range(2)]
+    x = src[0] + src[1]
+    variant = "SepReformer_Large_DM_WHAMR"
+    cfg, m, audio, aux, loss, l_time, l_mag = _train_step(variant, "bf16x3", x, src, False)
+    sdl = tor.leaf_state(synth_state_dict(cfg, 0))
+    o_audio, o_aux = tor.model_forward_train(sdl, cfg, x)
+    o_loss = co.pit_sisnr_time(o_audio, src)[0] / cfg.num_spks
+    o_loss.backward()
+    soft = Soft("train_step.large.bf16x3.main")
+    soft.agree("main", torch.stack(list(audio), 0), torch.stack([a.detach() for a in o_audio], 0))
+    assert abs(float(loss) - float(o_loss)) < 5e-3, (float(loss), float(o_loss))
+    gscale = max(float(v.grad.abs().max()) for v in sdl.values() if v.requires_grad and v.grad is not None)
+    n = 0
+    for k, p_ in m.named_parameters():
+        if sdl[k].grad is None:                       # auxiliary-head parameters under the main-only loss
+            assert p_.grad is None or float(p_.grad.abs().max()) == 0.0, k
+            continue
+        agree_grad(soft, "grad." + k, k, p_.grad, sdl[k].grad, gscale, MIN_DB)
+        n += 1
+    assert n > 500, n
     soft.done()
 
 
