@@ -599,20 +599,21 @@ def test_train_step_base_matches_oracle(precision, aux_loss):
     soft.done()
 
 
-def test_train_step_large_matches_oracle():
-    """Large_DM_WHAMR (F = 256, dk = 32: the generic GCFN pair, the dk = 32 MFMA attention backward), 0.5 s, one utterance, the smooth
-    main-output loss: loss and every gradient tensor against the oracle at the 80 dB bar in the default bf16x3 arithmetic."""
+@pytest.mark.parametrize("variant", ["SepReformer_Large_DM_WHAMR", "SepReformer_Large_DM_WHAM"])
+def test_train_step_large_matches_oracle(variant):
+    """Large (F = 256, dk = 32: the generic GCFN pair, the dk = 32 MFMA attention backward; _WHAM: one speaker split per level
+    instead of the shared one), 0.5 s, one utterance, the smooth main-output loss: loss and every gradient tensor against the
+    oracle at the 80 dB bar in the default bf16x3 arithmetic."""
     B, T = 1, 4000
     srcn = synth_sources(B, T, seed=37)
     src = [torch.from_numpy(srcn[:, s].copy()) for s in range(2)]
     x = src[0] + src[1]
-    variant = "SepReformer_Large_DM_WHAMR"
     cfg, m, audio, aux, loss, l_time, l_mag = _train_step(variant, "bf16x3", x, src, False)
     sdl = tor.leaf_state(synth_state_dict(cfg, 0))
     o_audio, o_aux = tor.model_forward_train(sdl, cfg, x)
     o_loss = co.pit_sisnr_time(o_audio, src)[0] / cfg.num_spks
     o_loss.backward()
-    soft = Soft("train_step.large.bf16x3.main")
+    soft = Soft(f"train_step.{variant}.bf16x3.main")
     soft.agree("main", torch.stack(list(audio), 0), torch.stack([a.detach() for a in o_audio], 0))
     assert abs(float(loss) - float(o_loss)) < 5e-3, (float(loss), float(o_loss))
     gscale = max(float(v.grad.abs().max()) for v in sdl.values() if v.requires_grad and v.grad is not None)
