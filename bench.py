@@ -146,6 +146,9 @@ def parse_args():
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: all ranks use GPU 0 and the gloo backend (exercises the N > 1 path end to end on a 1-GPU box; "
                          "the throughput it prints is NOT a scaling number)")
+    ap.add_argument("--train-graphs", choices=["step", "split", "off"], default=None,
+                    help="train mode: step (default) = the whole step as hipGraph replays, split = separator forward / backward graphs with eager "
+                         "criteria / clip / optimizer, off = eager")
     ap.add_argument("--no-train-graphs", action="store_true", help="train mode: launch every kernel from the host instead of replaying captured hipGraphs")
     ap.add_argument("--pmc", choices=["auto", "on", "off"], default="auto",
                     help="HBM traffic of the dominant kernel from rocprofv3 PMC passes of a short sub-run (auto: in the default 1-GPU run)")
@@ -494,15 +497,21 @@ def main():
                                                      "model_mfma_frac", "roofline")}
             except Exception as e:              # noqa: BLE001
                 rec["large"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            from sepreformer_amd import train_bench
+            # the training lines run in their own processes: a fault of the training path cannot take the headline line with it
             rec["train"] = {}
+            keys = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "capture_fallback", "host_enqueue_ms_per_step",
+                    "host_loop_ms_per_step", "loss", "grad_norm", "collective_backend", "allreduce_bytes_per_step", "model_tflops",
+                    "model_frac_algorithmic", "roofline")
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
             for prec in ("bf16x3", "bf16"):
                 try:
-                    tr = train_bench.run(DEFAULT_VARIANT, prec, 16, 2, 1, rank, world, dev, False)
-                    rec["train"][prec] = {k: tr[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config",
-                                                              "host_enqueue_ms_per_step", "loss", "grad_norm", "collective_backend",
-                                                              "allreduce_bytes_per_step", "model_tflops", "model_frac_algorithmic",
-                                                              "roofline")}
+                    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "train", "--batch", "16", "--steps", "2", "--warmup", "1",
+                                          "--precision", prec], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+                    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+                    if out.returncode != 0 or not lines:
+                        raise RuntimeError(f"rc {out.returncode}: {out.stderr[-200:]}")
+                    tr = json.loads(lines[-1])
+                    rec["train"][prec] = {k: tr.get(k) for k in keys}
                 except Exception as e:          # noqa: BLE001
                     rec["train"][prec] = {"error": f"{type(e).__name__}: {e}"[:300]}
             rec["sub_records_s"] = round(time.perf_counter() - t_sub, 1)

@@ -97,13 +97,13 @@ class _TrainGraph:
         self.salt = torch.zeros(1, dtype=torch.int64, device=dev)     # outside the capture: replays must not reset it
         self.g_fwd, self.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(self.g_fwd, pool=pool):
+        with torch.cuda.graph(self.g_fwd, pool=pool, capture_error_mode="thread_local"):    # (see train_step.CAPTURE_MODE)
             self.tp = TrainPack(cfg, sd, self.gb, model.precision, salt=self.salt)
             self.wav, self.aux, self.tape, self.dims = eng.forward(self.x, self.tp, self.p, self.CAPTURE_SEED, with_aux=self.with_aux)
             torch._foreach_add_(self.tp.bn_counters, 1)          # BatchNorm.num_batches_tracked
         self.d_wav = torch.zeros_like(self.wav)
         self.d_aux = [torch.zeros_like(a) for a in self.aux]
-        with torch.cuda.graph(self.g_bwd, pool=pool):
+        with torch.cuda.graph(self.g_bwd, pool=pool, capture_error_mode="thread_local"):
             self.gb.flat.zero_()
             eng.backward(self.tape, self.dims, self.d_wav, self.d_aux, self.tp, self.p)
         # the capture itself executed nothing: BatchNorm state is still the pre-warm-up one
@@ -162,7 +162,8 @@ class _SeparatorFn(torch.autograd.Function):
             flat = model._flat_tensors()
             sd = {n: t.detach() for n, t in zip(names, flat)}
             gb = GradBuffer(model.cfg, dev)                  # fresh zeros per step: autograd may keep views of it as .grad
-            tp = TrainPack(model.cfg, sd, gb, model.precision)
+            salt = model.dropout_salt if (model.dropout_salt is not None and model.dropout_salt.device == dev) else None
+            tp = TrainPack(model.cfg, sd, gb, model.precision, salt=salt)
             seed = model._next_dropout_seed() if model.dropout_p > 0.0 else 0
             wav, aux, tape, dims = eng.forward(x.detach().to(torch.float32), tp, model.dropout_p, seed, with_aux=model.compute_aux)
             torch._foreach_add_(tp.bn_counters, 1)           # BatchNorm.num_batches_tracked
@@ -203,6 +204,7 @@ class _SeparatorFn(torch.autograd.Function):
             eng.backward(tape, dims, d_wav, list(d_aux), tp, model.dropout_p, on_decoder_done=early)
             if sync is not None:
                 sync(gb.flat)
+            model.__dict__["_grad_flat"] = gb.flat                 # the buffer the returned gradients are views of (train_step.py)
         grads = []
         for name, kind in model._kinds.items():
             if KINDS[kind]:
@@ -249,6 +251,9 @@ class Model(torch.nn.Module):
         # train mode: replay the step from captured hipGraphs (one capture per input shape; _TrainGraph).  Opt-in: the captured
         # step keeps its activations resident between steps and re-captures when the shape changes.
         self.train_graphs = os.environ.get("SEPR_TRAIN_GRAPHS", "0") == "1"
+        # device word XOR-ed into every dropout seed of the EAGER train path (int64[1] or None): what lets a caller capture
+        # whole steps into a hipGraph (train_step.CapturedTrainStep) and still draw fresh masks per replay
+        self.dropout_salt = None
 
     def _graph_key(self, x: torch.Tensor):
         flat = self._flat_tensors()

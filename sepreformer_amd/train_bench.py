@@ -55,7 +55,11 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
     cfg = VARIANTS[variant]
     model = Model.from_config(cfg, init_seed=0, precision=precision).load_synthetic_(0).to(dev)
     model.train()
-    model.train_graphs = bool(graphs)          # the step replays from captured hipGraphs (model._TrainGraph); --no-train-graphs: eager
+    # launch mode of the step: "step" = the WHOLE step as hipGraph replays (train_step.CapturedTrainStep: forward + criteria + backward;
+    # RCCL all-reduce; clip + optimizer), "split" = the separator's forward / backward as graphs with eager criteria / clip / optimizer
+    # (model._TrainGraph), "off" = every kernel launched from the host.  True selects "step" with "split" as the fallback.
+    mode = {True: "step", False: "off", None: "off"}.get(graphs, graphs)
+    model.train_graphs = mode == "split"
     sync = sdist.GradSync()
     model.grad_sync = sync
     samples = 32000
@@ -67,25 +71,47 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
     crit_m = PIT_SISNR_mag(dev, 512, 128, "hann", cfg.num_stages, cfg.num_spks, True, False)
     params = list(model.parameters())
     try:
-        opt = torch.optim.AdamW(params, lr=1.0e-4, weight_decay=1.0e-2, fused=True)
+        opt = torch.optim.AdamW(params, lr=1.0e-4, weight_decay=1.0e-2, fused=True, capturable=(mode == "step"))
     except (TypeError, RuntimeError):
-        opt = torch.optim.AdamW(params, lr=1.0e-4, weight_decay=1.0e-2)
+        opt = torch.optim.AdamW(params, lr=1.0e-4, weight_decay=1.0e-2, capturable=(mode == "step"))
     last = {}
 
-    def step():
+    def loss_fn(audio, aux, *tg):
+        tg = list(tg)
+        l_time = crit_t(estims=audio, input_sizes=sizes, target_attr=tg)
+        l_mag = [crit_m(estims=a, idx=i, input_sizes=sizes, target_attr=tg) for i, a in enumerate(aux)]
+        return ((1 - 0.4) * l_time + 0.4 * sum(l_mag) / len(l_mag)) / cfg.num_spks             # engine.py:72-74
+
+    def host_step():
         opt.zero_grad(set_to_none=True)
         audio, aux = model(x)
-        l_time = crit_t(estims=audio, input_sizes=sizes, target_attr=targets)
-        l_mag = [crit_m(estims=a, idx=i, input_sizes=sizes, target_attr=targets) for i, a in enumerate(aux)]
-        loss = ((1 - 0.4) * l_time + 0.4 * sum(l_mag) / len(l_mag)) / cfg.num_spks           # engine.py:72-74
+        loss = loss_fn(audio, aux, *targets)
         loss.backward()
         gn = torch.nn.utils.clip_grad_norm_(params, 5.0)                                      # engine.py:76
         opt.step()
         last["loss"], last["gn"] = loss.detach(), gn
 
-    for _ in range(max(warmup, 1) if graphs else warmup):     # (graph mode: the first step captures)
-        step()
+    captured, capture_error = None, None
+    if mode == "step":
+        try:
+            from .train_step import CapturedTrainStep
+            captured = CapturedTrainStep(model, loss_fn, opt, x, targets, max_norm=5.0, warmup=max(warmup, 1))
+        except Exception as e:                      # noqa: BLE001 - a box that cannot capture the whole step still gets measured
+            capture_error = f"{type(e).__name__}: {e}"[:300]
+            mode = "split"
+            model.train_graphs = True
+
+    def step():
+        if captured is not None:
+            last["loss"], last["gn"] = captured(x, targets)
+        else:
+            host_step()
+
+    if captured is None:
+        for _ in range(max(warmup, 1) if mode == "split" else warmup):     # (split mode: the first step captures)
+            step()
     torch.cuda.synchronize(dev)
+    graphs = mode != "off"
     if not graphs:
         L.check(lib.sepr_prof_start(L.SITE_WGRAD, 400 * (max(steps, 1) + 1) + 8), "sepr_prof_start")
     sdist.barrier()
@@ -109,9 +135,9 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
         # of the same model outside the timed region (same kernels, same shapes)
         model.train_graphs = False
         L.check(lib.sepr_prof_start(L.SITE_WGRAD, 400 + 8), "sepr_prof_start")
-        step()
+        host_step()
         torch.cuda.synchronize(dev)
-        model.train_graphs = True
+        model.train_graphs = mode == "split"
     L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
     algo_bytes = float(lib.sepr_prof_last_bytes())
     elapsed = sdist.max_over_ranks(elapsed, dev)
@@ -132,10 +158,13 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
             "config": {"workload": f"{variant} training step, batch={B} per GPU, 4 s @ 8 kHz, 2 speakers (BASELINE.json configs[4])",
                        "batch_per_gpu": B, "samples": samples, "precision": prec, "dropout": model.dropout_p,
                        "dropout_sites": "all the reference's sites: GCFN x2, CLA, attention probabilities + attention output (EGA and speaker attention)",
-                       "step_launch": ("two hipGraph replays per step (weight re-pack + forward; backward) + eager criteria / clip / optimizer"
-                                       if graphs else "eager (every kernel launched from the host)"),
+                       "step_launch": {"step": "two hipGraph replays per step: weight re-pack + forward + criteria + backward | RCCL all-reduce (eager) | "
+                                               "clip + optimizer (train_step.CapturedTrainStep)",
+                                       "split": "two hipGraph replays per step (weight re-pack + forward; backward) + eager criteria / clip / optimizer",
+                                       "off": "eager (every kernel launched from the host)"}[mode],
                        "optimizer": type(opt).__name__ + (" (fused)" if getattr(opt, "defaults", {}).get("fused") else ""),
                        "clip_norm": 5.0, "parallelism": f"data-parallel x{world}, flat-buffer RCCL all-reduce" + (" (DEBUG: all ranks share GPU 0, gloo collective)" if share else "")},
+            "capture_fallback": capture_error,
             "host_enqueue_ms_per_step": round(1e3 * t_enq, 3),
             "host_loop_ms_per_step": round(1e3 * t_host / max(steps, 1), 3),
             "loss": round(float(last["loss"]), 4), "grad_norm": round(float(last["gn"]), 4),
@@ -176,7 +205,9 @@ def main(args):
         local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    graphs = not getattr(args, "no_train_graphs", False) and os.environ.get("SEPR_TRAIN_GRAPHS", "1") != "0"
+    graphs = getattr(args, "train_graphs", None) or "step"
+    if getattr(args, "no_train_graphs", False) or os.environ.get("SEPR_TRAIN_GRAPHS", "1") == "0":
+        graphs = "off"
     rec = run(args.variant, args.precision, args.batch or 8, args.steps, args.warmup, rank, world, dev, share, graphs)
     if rank == 0:
         emit = getattr(args, "_emit", None)

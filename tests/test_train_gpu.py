@@ -867,6 +867,74 @@ def test_train_graph_replay_matches_eager():
     assert tg.replays == 3
 
 
+def test_captured_whole_step_matches_eager():
+    """train_step.CapturedTrainStep (forward + criteria + backward in one hipGraph, clip + AdamW in a second) against the same
+    step launched from the host.  Dropout off: the captured kernels are the eager ones in the same order, so after the same number
+    of optimizer steps every parameter, every BatchNorm buffer and the loss are BITWISE equal.  Dropout on: the device-side salt
+    gives every replay its own masks (checked with a zero learning rate: same weights, same input, different loss), and the
+    trajectory is reproducible from the seed."""
+    from sepreformer_amd.criterion import PIT_SISNR_mag, PIT_SISNR_time
+    from sepreformer_amd.model import Model
+    from sepreformer_amd.train_step import CapturedTrainStep
+    dev = torch.device("cuda:0")
+    B, T = 2, 4000
+    srcn = synth_sources(B, T, seed=31)
+    src = [torch.from_numpy(srcn[:, s].copy()).to(dev) for s in range(2)]
+    x = (src[0] + src[1]).contiguous()
+    sizes = torch.full((B,), T)
+
+    def build(p_drop, lr, seed):
+        torch.manual_seed(seed)
+        cfg = dataclasses.replace(VARIANTS["SepReformer_Base_WSJ0"], dropout=p_drop)
+        m = Model.from_config(cfg, init_seed=0, precision="bf16x3").load_synthetic_(0).to(dev)
+        m.train()
+        opt = torch.optim.AdamW(m.parameters(), lr=lr, weight_decay=0.0 if lr == 0.0 else 1.0e-2, capturable=True)
+        ct, cm = PIT_SISNR_time(dev, 2, True), PIT_SISNR_mag(dev, 512, 128, "hann", cfg.num_stages, 2, True, False)
+
+        def loss_fn(audio, aux, *tg):
+            tg = list(tg)
+            lm = [cm(estims=a, idx=i, input_sizes=sizes, target_attr=tg) for i, a in enumerate(aux)]
+            return (0.6 * ct(estims=audio, input_sizes=sizes, target_attr=tg) + 0.4 * sum(lm) / len(lm)) / 2
+        return m, opt, loss_fn
+
+    def eager(steps):
+        m, opt, loss_fn = build(0.0, 1.0e-4, 7)
+        params = list(m.parameters())
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            audio, aux = m(x)
+            loss = loss_fn(audio, aux, *src)
+            loss.backward()
+            gn = torch.nn.utils.clip_grad_norm_(params, 5.0)
+            opt.step()
+        return m, float(loss), float(gn)
+
+    me, le, ge = eager(4)
+    mc, opt, loss_fn = build(0.0, 1.0e-4, 7)
+    step = CapturedTrainStep(mc, loss_fn, opt, x, src, max_norm=5.0, warmup=1)      # 1 eager step + 3 replays = 4 optimizer steps
+    for _ in range(3):
+        lc, gc = step(x, src)
+    assert step.calls == 3 and float(lc) == le and float(gc) == ge, (float(lc), le, float(gc), ge)
+    for (k, a), (_, b) in zip(me.state_dict().items(), mc.state_dict().items()):
+        assert torch.equal(a, b), k
+    # the evaluation path sees the weights the replays wrote (the packed forms are invalidated by every call)
+    mc.eval(); me.eval()
+    with torch.no_grad():
+        a_c, _ = mc(x)
+        a_e, _ = me(x)
+    assert torch.equal(torch.stack(list(a_c)), torch.stack(list(a_e)))
+    # dropout: a zero learning rate keeps the weights, so only the masks can change the loss between replays
+    md, optd, lfd = build(0.3, 0.0, 11)
+    sd_ = CapturedTrainStep(md, lfd, optd, x, src, max_norm=5.0, warmup=1)
+    l1 = float(sd_(x, src)[0])
+    salt1 = int(sd_.salt.item())
+    l2 = float(sd_(x, src)[0])
+    assert l1 != l2 and int(sd_.salt.item()) != salt1, (l1, l2)
+    md2, optd2, lfd2 = build(0.3, 0.0, 11)
+    sd2 = CapturedTrainStep(md2, lfd2, optd2, x, src, max_norm=5.0, warmup=1)
+    assert float(sd2(x, src)[0]) == l1 and float(sd2(x, src)[0]) == l2
+
+
 def test_train_step_tiny_bf16():
     """precision="bf16" (plain bf16 operands in every projection / contraction of the step, fp32 accumulate, fp32 master
     weights and gradients): the tiny configuration's whole step against the oracle.  Outputs / loss / gradients are those of
