@@ -541,3 +541,17 @@ def test_train_sizing_entries_run_without_a_device():
     assert n * T * 2 * 4 <= got_f <= n * T * 2 * 4 + 4096
     assert lib.sepr_train_ctx_bytes(L.TOP_GCFN, 0, T, 0, F, 256, 2, 8) == 0
     assert lib.sepr_gcfn_bwd(None, None, None, 1, 8, 128, None, None, None, 0, None, 0, 0.0, 0, None) == L.SEPR_EINVAL
+
+
+def test_captured_train_step_refuses_what_it_cannot_capture():
+    """train_step.CapturedTrainStep: no CPU path (the product fails loudly without the device), and an optimizer whose step counter
+    lives on the host cannot be replayed from a graph - both are refused before anything runs."""
+    import torch
+    from sepreformer_amd.model import Model
+    from sepreformer_amd.train_step import CapturedTrainStep
+    m = Model.from_config(VARIANTS["tiny"], init_seed=0)
+    x = torch.zeros(1, 2000)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        CapturedTrainStep(m, lambda a, b, *t: a[0].sum(), opt, x, [x, x])
+    assert m.dropout_salt is None and m.train_graphs in (False, True)
