@@ -503,17 +503,17 @@ def main():
                     "host_loop_ms_per_step", "loss", "grad_norm", "collective_backend", "allreduce_bytes_per_step", "model_tflops",
                     "model_frac_algorithmic", "roofline")
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-            for prec in ("bf16x3", "bf16"):
+            for name, prec, tb in (("bf16x3", "bf16x3", 16), ("bf16", "bf16", 16), ("bf16_b32", "bf16", 32)):
                 try:
-                    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "train", "--batch", "16", "--steps", "2", "--warmup", "1",
+                    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "train", "--batch", str(tb), "--steps", "2", "--warmup", "1",
                                           "--precision", prec], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
                     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
                     if out.returncode != 0 or not lines:
                         raise RuntimeError(f"rc {out.returncode}: {out.stderr[-200:]}")
                     tr = json.loads(lines[-1])
-                    rec["train"][prec] = {k: tr.get(k) for k in keys}
+                    rec["train"][name] = {k: tr.get(k) for k in keys}
                 except Exception as e:          # noqa: BLE001
-                    rec["train"][prec] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    rec["train"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
             rec["sub_records_s"] = round(time.perf_counter() - t_sub, 1)
         if world == 1 and (args.pmc == "on" or (args.pmc == "auto" and default_run)) and rec["roofline"].get("algorithmic_bytes_per_launch"):
             # traffic re-measured in THIS run (two short PMC sub-runs at the same batch: every launch they count has the timed launches' size)
