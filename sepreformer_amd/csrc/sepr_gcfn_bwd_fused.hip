@@ -39,7 +39,10 @@ namespace {
 constexpr int GB_BM = 64;            // rows per tile (incl. halo)
 constexpr int GB_OUT = GB_BM - 4;    // rows a tile outputs
 constexpr int GB_BKS = 64;           // K extent of one LDS slab
-constexpr int GB_LDK = GB_BKS + 16;  // bf16 per LDS row (160 B: conflict-free 16-byte fragment reads)
+#ifndef SEPR_GB_LDK_PAD
+#define SEPR_GB_LDK_PAD 16
+#endif
+constexpr int GB_LDK = GB_BKS + SEPR_GB_LDK_PAD;  // bf16 per LDS row (160 B; 144 B with pad 8)
 constexpr int GB_HS = 128 + 4;       // fp32 row stride of the h1 / dc tile (64 value + 64 gate columns)
 constexpr int GB_DS = 64 + 4;        // fp32 row stride of the dgd tile
 constexpr int GB_THREADS = 256;

@@ -88,7 +88,13 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
   // ---- staging role: threads 0..127 stage A, 128..255 stage B; each 8 rows x 4 columns per slab ----
   const bool roleA = tid < 128;
   const int t7 = tid & 127;
-  const int cg = t7 & 31, mg = t7 >> 5;
+#ifndef SEPR_TN_LANEMAP
+#define SEPR_TN_LANEMAP 0
+#endif
+  // lane -> (column group cg, row group mg).  LANEMAP 1 (packed-bf16 planes only): the row group is the FAST lane index, so the 8 lanes
+  // the LDS serves together store 4 row groups x 2 column groups = 8 distinct 16-byte bank windows (with cg fast, the 576-byte lane
+  // stride of the transposing store reaches only 16 of the 32 banks: PMC 65 % conflict cycles, profiles/r03_v5_pmc_train_kernels.txt)
+  const int cg = (SEPR_TN_LANEMAP && MD != 0) ? (t7 >> 2) : (t7 & 31), mg = (SEPR_TN_LANEMAP && MD != 0) ? (t7 & 3) : (t7 >> 5);
   const int col = (roleA ? n0 : k0) + 4 * cg;
   const bool col_ok = col < (roleA ? a.N : a.K);
   float4 r[8 * TN_NB];

@@ -39,7 +39,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define SEPR_ABL_NOMMA 0
 #endif
 constexpr int X3_BKS = 64;                  // K extent of one LDS slab
-constexpr int X3_LDK = X3_BKS + 16;         // bf16 elements per LDS row (160 B)
+#ifndef SEPR_X3_LDK_PAD
+#define SEPR_X3_LDK_PAD 16   // 16: 160-byte rows (rounds 1-3); 8: 144-byte rows
+#endif
+constexpr int X3_LDK = X3_BKS + SEPR_X3_LDK_PAD;   // bf16 elements per LDS row
 constexpr int X3_PLANE = GEMM_BM * X3_LDK;  // elements of one plane of one buffer
 
 template <int PRO, int EPI, int TAG = 0>
