@@ -189,7 +189,7 @@ def measure_pmc_traffic(budget_s=150.0):
         d = tempfile.mkdtemp(prefix=f"sepr_pmc_{ctr}_", dir="/tmp")
         cmd = [exe, "--pmc", ctr, "--kernel-trace", "--kernel-include-regex", PMC_KERNEL_RE, "--output-format", "csv", "-d", d, "-o", "t", "--",
                sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-alt-precision", "--pmc", "off"]
-        env = dict(os.environ, TMPDIR="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp", SEPR_PIPELINES="1")      # one pipeline: every counted launch has the full-batch size
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
         try:
@@ -259,12 +259,18 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
             metric_acc.copy_(sdist.reduce_metric_sums(acc))
         return out
 
+    # Throughput mode: the batch as two half-batch pipelines on two streams (engine.forward_split: the pipelines fill each other's
+    # launch tails; bit-identical results, +2.5-3.7 % at batch 32 in round 3).  Two concurrent launches share the device, so the
+    # per-launch event durations of the roofline are taken from a second, single-pipeline region right after the timed one.
+    pl = int(os.environ.get("SEPR_PIPELINES", "2")) if (B >= 16 and not args.share_gpu) else 1
+    model.pipelines = pl
     for _ in range(warmup):
         out = step()
     torch.cuda.synchronize(dev)
 
     launches_per_step = 56 * 4                  # GCFN launches per forward (56) x sub-batch pipelines; sizes the event pool
-    L.check(lib.sepr_prof_start(L.SITE_GCFN_UP, launches_per_step * max(steps, 1) + 8), "sepr_prof_start")
+    if pl == 1:
+        L.check(lib.sepr_prof_start(L.SITE_GCFN_UP, launches_per_step * max(steps, 1) + 8), "sepr_prof_start")
     sdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -274,7 +280,25 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
     sdist.barrier()
     elapsed = time.perf_counter() - t0
     n_l, ms, fl = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
-    L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
+    single = None
+    if pl == 1:
+        L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
+    else:
+        model.pipelines = 1
+        step()
+        torch.cuda.synchronize(dev)
+        L.check(lib.sepr_prof_start(L.SITE_GCFN_UP, launches_per_step * max(steps, 1) + 8), "sepr_prof_start")
+        sdist.barrier()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        sdist.barrier()
+        e1 = sdist.max_over_ranks(time.perf_counter() - t1, dev)
+        L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
+        single = {"value": round(world * B * steps / e1, 3), "unit": "utt/s", "ms_per_step": round(1e3 * e1 / max(steps, 1), 3), "steps": steps}
+        model.pipelines = pl
     elapsed = sdist.max_over_ranks(elapsed, dev)
     rccl_ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
@@ -350,7 +374,11 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
             "frac_of_ceiling": round(algo_tf / peak / ceiling, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "launches": int(n_l.value), "avg_launch_ms": round(ms.value / n_launch, 4),
-            "algorithmic_gflop_per_launch": round(fl.value / 1e9 / n_launch, 3)}
+            "algorithmic_gflop_per_launch": round(fl.value / 1e9 / n_launch, 3),
+            "measured_on": ("the timed steps" if pl == 1 else
+                            f"{steps} steps of the same workload run as ONE pipeline right after the timed region (two concurrent pipelines share the "
+                            "device: per-launch durations inside the timed region would not describe one kernel); rocprofv3 summary: the same "
+                            "command with SEPR_PIPELINES=1")}
     if algo_bytes_launch:
         gbs = rows * 8.0 * F / 1e9 / sec if sec > 0 else 0.0
         roof.update({"algorithmic_bytes_per_launch": round(algo_bytes_launch), "hbm_gbs": round(gbs, 1),
@@ -365,6 +393,7 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
         "config": {"workload": f"{variant} inference, batch={B} per GPU, 4 s @ 8 kHz, 2 speakers"
                                + (f" (BASELINE.json configs[{cfg_idx}])" if cfg_idx else ""),
                    "batch_per_gpu": B, "samples": SAMPLES, "aux_heads": not args.no_aux, "precision": precision,
+                   "pipelines": pl,
                    "weights": "synthetic seed 0 (O(1) LayerScale)",
                    "parallelism": f"utterance-sharded x{world}" + (" (DEBUG: all ranks share GPU 0, gloo collective)" if args.share_gpu else ""),
                    "step": "Model.forward (main + aux heads)" + ("" if args.no_metric else
@@ -383,6 +412,8 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
         "model_mfma_frac": round(utt_per_s * gflop / 1e3 / world * mult / peak, 4),
         "roofline": roof,
     }
+    if single is not None:
+        rec["single_pipeline"] = single
     if not full:
         del model
         torch.cuda.empty_cache()
