@@ -512,6 +512,30 @@ def test_full_size_batch_properties(precision):
     agree(f"full.{precision}.vs_golden.b0", wav[:, 0:1], torch.from_numpy(g["main"]))
 
 
+@pytest.mark.parametrize("B,T,parts", [(32, 32000, 2), (17, 8000, 2), (24, 4000, 3)])
+def test_batch_pipelines_are_bit_identical(B, T, parts):
+    """model.pipelines > 1 (engine.forward_split: the batch as independent sub-batches on their own streams, what bench.py's timed
+    region uses): utterances are independent in eval mode and no kernel's arithmetic depends on the batch composition, so the main
+    AND the auxiliary outputs equal the single-pipeline ones BITWISE - also for batches that do not split evenly."""
+    m, _ = gpu_model("SepReformer_Base_WSJ0", "bf16x3")
+    xd = synth_mixture(B, T, seed=77).cuda()
+    assert m.pipelines == 1
+    audio1, aux1 = m(xd)
+    audio1 = [a.clone() for a in audio1]
+    aux1 = [[a.clone() for a in lvl] for lvl in aux1]
+    m.pipelines = parts
+    try:
+        audio2, aux2 = m(xd)
+        audio3, _ = m(xd)                                   # and again (the peers' arenas are reused)
+    finally:
+        m.pipelines = 1
+    for a, b, c in zip(audio1, audio2, audio3):
+        assert a.shape == b.shape and torch.equal(a, b) and torch.equal(a, c)
+    for l1, l2 in zip(aux1, aux2):
+        for a, b in zip(l1, l2):
+            assert torch.equal(a, b)
+
+
 # ---------------------------------------------------------------------------------------------------
 # edge cases and error behaviour
 # ---------------------------------------------------------------------------------------------------
