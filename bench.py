@@ -550,7 +550,10 @@ def main():
             # traffic re-measured in THIS run (two short PMC sub-runs at the same batch: every launch they count has the timed launches' size)
             t_pmc = time.perf_counter()
             torch.cuda.synchronize(dev)
-            pm, why = measure_pmc_traffic()
+            try:
+                pm, why = measure_pmc_traffic()
+            except Exception as e:              # noqa: BLE001 - the side measurement must never cost the line
+                pm, why = None, f"{type(e).__name__}: {e}"[:200]
             if pm and pm.get("traffic_over_algorithmic"):
                 rec["roofline"]["traffic"] = round(pm["traffic_over_algorithmic"] * rec["roofline"]["algorithmic_bytes_per_launch"])
                 rec["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) over "
