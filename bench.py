@@ -567,8 +567,11 @@ def main():
             rec["pmc_s"] = round(time.perf_counter() - t_pmc, 1)
         if world == 1 and not args.no_cpu_baseline:
             threads = int(os.environ.get("SEPR_CPU_THREADS", str(physical_cores())))
-            rec["cpu_baseline"] = cpu_baseline(VARIANTS[variant], threads)
-            rec["speedup_vs_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
+            try:
+                rec["cpu_baseline"] = cpu_baseline(VARIANTS[variant], threads)
+                rec["speedup_vs_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
+            except Exception as e:              # noqa: BLE001 - the line is still worth printing without it
+                rec["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         emit(rec)
     sdist.barrier()
     if torch.distributed.is_initialized():
