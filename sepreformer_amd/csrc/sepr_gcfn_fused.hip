@@ -537,9 +537,8 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
 }
 
 
-#ifdef SEPR_WITH_GF5
-#include "sepr_gcfn_fused5.inc"   // the X/Y two-group experiment (library variants gf5*, see that file)
-#endif
+// (The X/Y two-group experiment "v5" - one 8-wave workgroup per CU, MFMA stream and VALU stream in sibling waves - was
+//  measured not faster in round 2 and removed in round 4; it lives in git history at a01c6d4, sepr_gcfn_fused5.inc.)
 // (A one-workgroup-per-CU, software-pipelined variant of this kernel - "v4", 8 waves, doubled weight buffers, one
 //  barrier per chunk - was measured 10 % slower and removed in round 2; it lives in git history at 7cf5a73.)
 #ifndef SEPR_GF3_MT
@@ -604,25 +603,6 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
       return SEPR_EINVAL;
     }
   } else {
-#ifdef SEPR_WITH_GF5
-    static const int kver = [] {
-      const char* e = getenv("SEPR_GF_KERNEL");
-      return e && e[0] ? atoi(e) : 3;
-    }();
-    if (kver == 5 && GF3_MT == 2) {
-      // one 8-wave workgroup per CU, two groups of 4 waves half a chunk apart; a workgroup walks PAIRS of 126-frame tiles
-      const int ntiles = (a.M + 125) / 126, npairs = (ntiles + 1) / 2;
-      const int cap = persistent_grid() / 2;
-      const int grid = npairs < cap ? npairs : cap;
-      if (F == 128) {
-        hipLaunchKernelGGL((gcfn_fused5_kernel<128>), dim3(grid), dim3(512), 0, stream, a);
-      } else if (F == 64) {
-        hipLaunchKernelGGL((gcfn_fused5_kernel<64>), dim3(grid), dim3(512), 0, stream, a);
-      } else {
-        return SEPR_EINVAL;
-      }
-    } else
-#endif
     {
       constexpr int tile_rows = (SEPR_GF3_XCH && GF3_MT == 2 && SEPR_GF3_UPFIRST) ? GF3_NW * 16 * GF3_MT - 2 : GF3_NW * (16 * GF3_MT - 2);
       const int ntiles = (a.M + tile_rows - 1) / tile_rows;
@@ -648,9 +628,3 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
 }
 
 }  // namespace sepr
-
-#if defined(SEPR_WITH_GF5) && SEPR_GF5_TRACE
-extern "C" int sepr_debug_gf5_trace(unsigned long long* out) {   // [8 waves][512]: stamps of workgroup 0, last launch
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sepr::gf5_trace), sizeof(unsigned long long) * 8 * 512);
-}
-#endif

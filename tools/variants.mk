@@ -1,0 +1,35 @@
+# A/B and timing-ablation builds of the library (NOT product code).  Run from sepreformer_amd/csrc:
+#   make -f ../../tools/variants.mk ../_native/libsepr_hip_<tag>.so      then      SEPR_LIB_VARIANT=<tag> python ...
+# Each variant is a one-shot whole-library build with extra -D switches (see the SEPR_* macros at the top of each .hip file).
+include Makefile
+# projection core: persistence / stagger, load / store / weight / MFMA ablations, LDS pads
+VARIANT_np = -DSEPR_GEMM_PERSIST=0 -DSEPR_GEMM_STAGGER=0
+VARIANT_ns = -DSEPR_GEMM_STAGGER=0
+VARIANT_ablst = -DSEPR_ABL_NOSTORE=1
+VARIANT_ablld = -DSEPR_ABL_NOLOAD=1
+VARIANT_ablw = -DSEPR_ABL_NOW=1
+VARIANT_ablmma = -DSEPR_ABL_NOMMA=1
+VARIANT_ablall = -DSEPR_ABL_NOLOAD=1 -DSEPR_ABL_NOSTORE=1 -DSEPR_ABL_NOW=1
+VARIANT_x3p8 = -DSEPR_X3_LDK_PAD=8
+VARIANT_gbp8 = -DSEPR_GB_LDK_PAD=8
+# fused GCFN: 6 x 14-frame waves everywhere
+VARIANT_gfmt1 = -DSEPR_GF3_MT=1
+# EGA attention timing ablations (bit mask, profiles/r02_v5_attention_ablation.txt)
+VARIANT_at1 = -DSEPR_AT_ABL=1
+VARIANT_at2 = -DSEPR_AT_ABL=2
+VARIANT_at4 = -DSEPR_AT_ABL=4
+VARIANT_at8 = -DSEPR_AT_ABL=8
+VARIANT_at16 = -DSEPR_AT_ABL=16
+VARIANT_at31 = -DSEPR_AT_ABL=31
+# weight-gradient contraction ablations (profiles/r03_v3_gemm_tn_ablation.txt)
+VARIANT_tnmap = -DSEPR_TN_LANEMAP=1
+VARIANT_tn1 = -DSEPR_TN_ABL=1
+VARIANT_tn2 = -DSEPR_TN_ABL=2
+VARIANT_tn3 = -DSEPR_TN_ABL=3
+VARIANT_tn4 = -DSEPR_TN_ABL=4
+VARIANT_tn7 = -DSEPR_TN_ABL=7
+ablations: $(OUTDIR)/libsepr_hip_ablst.so $(OUTDIR)/libsepr_hip_ablld.so $(OUTDIR)/libsepr_hip_ablw.so $(OUTDIR)/libsepr_hip_ablmma.so $(OUTDIR)/libsepr_hip_ablall.so
+$(OUTDIR)/libsepr_hip_%.so: $(SRCS) $(HDRS)
+	@mkdir -p $(OUTDIR)
+	$(HIPCC) $(CXXFLAGS) $(VARIANT_$*) -shared $(SRCS) -o $@
+VARIANT_resx = -DSEPR_GF3_RESX=1
