@@ -220,6 +220,8 @@ def measure_pmc_traffic(budget_s=90.0):
             "traffic_over_algorithmic": round((fetch + write) / algo, 3) if algo else None}, None
 
 
+PARITY_MIN_DB = 80.0        # agreement with the golden waveform (SURVEY.md section 8d gate i)
+PIT_GATE_DB = 1e-3          # |PIT SI-SNR(hip) - PIT SI-SNR(reference)| per utterance (north_star; gate ii)
 GOLDEN_4S = {"SepReformer_Base_WSJ0": "e2e_base_4s.npz", "SepReformer_Large_DM_WHAMR": "e2e_large_whamr_4s.npz"}
 
 
@@ -262,8 +264,12 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
     # Throughput mode: the batch as two half-batch pipelines on two streams (engine.forward_split: the pipelines fill each other's
     # launch tails; bit-identical results, +2.5-3.7 % at batch 32 in round 3).  Two concurrent launches share the device, so the
     # per-launch event durations of the roofline are taken from a second, single-pipeline region right after the timed one.
-    pl = int(os.environ.get("SEPR_PIPELINES", "2")) if (B >= 16 and not args.share_gpu) else 1
-    model.pipelines = pl
+    # Round 4: that IS the product default now (Model.pipelines = 0 = auto: two pipelines from 16 utterances up), so the timed region
+    # runs the public call in its default mode.
+    if args.share_gpu:
+        model.pipelines = 1
+    pl_setting = model.pipelines
+    pl = model.effective_pipelines(B)
     for _ in range(warmup):
         out = step()
     torch.cuda.synchronize(dev)
@@ -298,7 +304,7 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
         e1 = sdist.max_over_ranks(time.perf_counter() - t1, dev)
         L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
         single = {"value": round(world * B * steps / e1, 3), "unit": "utt/s", "ms_per_step": round(1e3 * e1 / max(steps, 1), 3), "steps": steps}
-        model.pipelines = pl
+        model.pipelines = pl_setting
     elapsed = sdist.max_over_ranks(elapsed, dev)
     rccl_ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
@@ -393,13 +399,15 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
         "config": {"workload": f"{variant} inference, batch={B} per GPU, 4 s @ 8 kHz, 2 speakers"
                                + (f" (BASELINE.json configs[{cfg_idx}])" if cfg_idx else ""),
                    "batch_per_gpu": B, "samples": SAMPLES, "aux_heads": not args.no_aux, "precision": precision,
-                   "pipelines": pl,
+                   "pipelines": pl, "pipelines_source": "Model default (auto: 2 from 16 utterances up)" if pl_setting == 0 else "SEPR_PIPELINES / --share-gpu",
                    "weights": "synthetic seed 0 (O(1) LayerScale)",
                    "parallelism": f"utterance-sharded x{world}" + (" (DEBUG: all ranks share GPU 0, gloo collective)" if args.share_gpu else ""),
                    "step": "Model.forward (main + aux heads)" + ("" if args.no_metric else
                            " + device PIT SI-SNR/SI-SNRi of the batch + 3-scalar all-reduce")},
         "parity_db_vs_golden": parity_db,
         "pit_si_snr_max_abs_delta_db": None if pit_delta is None else float(f"{pit_delta:.3e}"),
+        # the gates of SURVEY.md section 8d, enforced: a failed gate makes the process exit non-zero (main())
+        "parity_ok": None if parity_db is None else bool(parity_db >= PARITY_MIN_DB and pit_delta is not None and pit_delta <= PIT_GATE_DB),
         "rccl_ranks": rccl_ranks, "collective_backend": backend,
         "reduced_metric": None if args.no_metric else {
             "utterances": int(acc[2].item()), "mean_pit_si_snr_db": round(float(acc[0] / acc[2]) / cfg.num_spks, 4),
@@ -433,6 +441,7 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
                                 "ms_per_step": round(1e3 * alt_s, 3),
                                 "parity_db_vs_golden": round(agreement_db(torch.stack([a[0:1] for a in out_alt[0]], 0).cpu(),
                                                                           torch.from_numpy(g["main"])), 1)}
+        rec["alt_precision"]["parity_ok"] = bool(rec["alt_precision"]["parity_db_vs_golden"] >= PARITY_MIN_DB)
         model.precision = precision
     if world == 1 and not args.no_alt_precision:
         # single-utterance latency: B=1 x 4 s through the PUBLIC call, model(x)
@@ -461,6 +470,22 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
     del model
     torch.cuda.empty_cache()
     return rec
+
+
+def gate_failures(rec) -> list:
+    """Every parity gate carried by the line (headline, alt precision, sub-records); a non-empty list makes bench.py exit 3
+    AFTER printing the line, so that the driver's return code reflects a wrong answer."""
+    bad = []
+    if rec.get("parity_ok") is False:
+        bad.append(f"headline: {rec.get('parity_db_vs_golden')} dB vs golden (>= {PARITY_MIN_DB}), PIT delta {rec.get('pit_si_snr_max_abs_delta_db')} dB (<= {PIT_GATE_DB})")
+    if (rec.get("alt_precision") or {}).get("parity_ok") is False:
+        bad.append(f"alt_precision: {rec['alt_precision'].get('parity_db_vs_golden')} dB vs golden")
+    if (rec.get("large") or {}).get("parity_ok") is False:
+        bad.append(f"large: {rec['large'].get('parity_db_vs_golden')} dB, PIT delta {rec['large'].get('pit_si_snr_max_abs_delta_db')} dB")
+    for name, tr in (rec.get("train") or {}).items():
+        if isinstance(tr, dict) and tr.get("parity_ok") is False:
+            bad.append(f"train.{name}: {tr.get('parity_note')}")
+    return bad
 
 
 def protect_stdout():
@@ -524,7 +549,7 @@ def main():
             try:
                 sub = measure_infer(args, "SepReformer_Large_DM_WHAMR", 2, 1, rank, world, dev, lib, full=False)
                 rec["large"] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "parity_db_vs_golden",
-                                                     "pit_si_snr_max_abs_delta_db", "model_tflops", "model_frac_algorithmic",
+                                                     "pit_si_snr_max_abs_delta_db", "parity_ok", "model_tflops", "model_frac_algorithmic",
                                                      "model_mfma_frac", "roofline")}
             except Exception as e:              # noqa: BLE001
                 rec["large"] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -540,7 +565,14 @@ def main():
                                           "--precision", prec], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
                     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
                     if out.returncode != 0 or not lines:
-                        raise RuntimeError(f"rc {out.returncode}: {out.stderr[-200:]}")
+                        try:                    # the whole stderr of a failed sub-run is worth keeping (gpurun_out/ travels back)
+                            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                            with open(os.path.join(ROOT, "gpurun_out", f"bench_train_{name}.stderr"), "w") as f:
+                                f.write(out.stderr)
+                        except OSError:
+                            pass
+                        head = [ln for ln in out.stderr.splitlines() if "Error" in ln or "error" in ln or "terminate" in ln][:3]
+                        raise RuntimeError(f"rc {out.returncode}: {' | '.join(head)[:400]} ... {out.stderr[-200:]}")
                     tr = json.loads(lines[-1])
                     rec["train"][name] = {k: tr.get(k) for k in keys}
                 except Exception as e:          # noqa: BLE001
@@ -572,10 +604,18 @@ def main():
                 rec["speedup_vs_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
             except Exception as e:              # noqa: BLE001 - the line is still worth printing without it
                 rec["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        failed = gate_failures(rec)
+        if failed:
+            rec["gate_failures"] = failed
         emit(rec)
+    else:
+        failed = []
     sdist.barrier()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    if failed:
+        print("bench.py: PARITY GATE FAILED: " + "; ".join(failed), file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -89,10 +89,14 @@ struct bool_c { static constexpr bool value = V; };
                           // epilogue: removes 512 of the 1.7 KB per frame the kernel moves; costs end-to-end agreement (measured:
                           // profiles/r03_v2_gcfn_resx_experiment.txt).  Off in the product build.
 #endif
-template <int F, int MT, int NW, int MODE = 0, bool TRAIN = false>
+// ONE (training precision "bf16" only): plain bf16 operands - the normalised frames, the weights and the gated tensor are used
+// as their bf16 hi plane alone, ONE MFMA per product instead of three, no lo-plane split on the VALU, and only the hi-plane
+// blocks of every packed weight chunk are copied to LDS (half the L2 -> LDS stream).  Same packed weights, same LDS layout.
+template <int F, int MT, int NW, int MODE = 0, bool TRAIN = false, bool ONE = false>
 __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
   constexpr bool PLAIN = MODE == 1;   // frames are independent: no halo, no seam exchange, no conv
   static_assert(!(TRAIN && PLAIN), "the train instantiation is the GCFN block");
+  static_assert(!ONE || TRAIN, "plain bf16 operands do not pass the inference parity gate: a training arithmetic only");
   const bool drop = TRAIN && a.drop_thr > 0u;
   DropKey dk0 = {0u, 0u}, dk1 = {0u, 0u};
   if (drop) {
@@ -150,11 +154,29 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
       }
     }
   };
+  auto dma_hi = [&](const uint4* gbase, uint4* lbase, int nblk) {   // ONE: the even (bf16 hi plane) 1 KiB blocks only
+    unsigned loff = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(loff));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (2 * i * NW >= nblk) break;
+      const int blk = 2 * (i * NW + w);
+      if (blk < nblk) {
+        const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+      }
+    }
+  };
   auto dma_w1 = [&](int c) {
-    dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / 64);
+    if constexpr (ONE) dma_hi(W1g + (long long)c * W1_U4, wl, W1F_U4 / 64);
+    else dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / 64);
     dma(W1g + (long long)c * W1_U4 + W1F_U4, csl + (c & 1) * CS_U4, CS_U4 / 64);
   };
-  auto dma_w2 = [&](int c) { dma(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / 64); };
+  auto dma_w2 = [&](int c) {
+    if constexpr (ONE) dma_hi(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / 64);
+    else dma(W2g + (long long)c * W2_U4, wl + W1F_U4, W2_U4 / 64);
+  };
   auto dma_barrier = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!(SEPR_GF_ABL & 4)) __syncthreads();
@@ -164,13 +186,13 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     const uint4* p = w1s + ((((g & 1) * 2 + j) * KS + (g >> 1)) * 2) * 64 + lane;
     if ((SEPR_GF_ABL & 8) && (j | g)) return;   // ablation: one fragment read per chunk
     d[0] = p[0];
-    d[1] = p[64];
+    if constexpr (!ONE) d[1] = p[64];
   };
   auto ld_dn = [&](int ft, uint4 (&d)[2]) {
     const uint4* p = w2s + (ft * 2) * 64 + lane;
     if ((SEPR_GF_ABL & 8) && ft) return;
     d[0] = p[0];
-    d[1] = p[64];
+    if constexpr (!ONE) d[1] = p[64];
   };
 
   // De-phase the two workgroups that share a CU: dispatched together they run their MFMA bursts (up- / down-projection)
@@ -247,10 +269,10 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
           const float xn = (v[ks][e] - mean) * rstd;
           const __bf16 hh = (__bf16)xn;
           h[e] = hh;
-          l[e] = (__bf16)(xn - (float)hh);
+          if constexpr (!ONE) l[e] = (__bf16)(xn - (float)hh);
         }
         xh[mt][ks] = h;
-        xl[mt][ks] = l;
+        if constexpr (!ONE) xl[mt][ks] = l;
       }
     }
     const bool edge = __builtin_amdgcn_ballot_w64(edge_lane) != 0ull;   // wave-uniform
@@ -293,22 +315,26 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
             if (g + RD < 2 * KS) ld_up(j, g + RD, fb[(g + RD) % (RD + 1)]);
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[g % (RD + 1)][0]);
-            const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[g % (RD + 1)][1]);
+            [[maybe_unused]] const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[g % (RD + 1)][ONE ? 0 : 1]);
             const int ks = g >> 1;
             if ((g & 1) == 0) {
 #pragma unroll
               for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hv[mt], 0, 0, 0);
+              if constexpr (!ONE) {
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hv[mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hv[mt], 0, 0, 0);
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hv[mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hv[mt], 0, 0, 0);
+              }
             } else {
 #pragma unroll
               for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], hg[mt], 0, 0, 0);
+              if constexpr (!ONE) {
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hg[mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], hg[mt], 0, 0, 0);
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hg[mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hg[mt], 0, 0, 0);
+              }
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -424,7 +450,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
             for (int r = 0; r < 4; ++r) {
               const __bf16 hh = (__bf16)gl[mt][r];
               gh[mt][4 * j + r] = hh;
-              gw[mt][4 * j + r] = (__bf16)(gl[mt][r] - (float)hh);
+              if constexpr (!ONE) gw[mt][4 * j + r] = (__bf16)(gl[mt][r] - (float)hh);
             }
         }
         // ---- down-projection K step of this chunk -----------------------------------------------------------
@@ -434,13 +460,15 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
           if (ft + RD < FT) ld_dn(ft + RD, fb[(ft + RD) % (RD + 1)]);
           __builtin_amdgcn_sched_barrier(0);
           const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[ft % (RD + 1)][0]);
-          const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[ft % (RD + 1)][1]);
+          [[maybe_unused]] const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[ft % (RD + 1)][ONE ? 0 : 1]);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[mt], acc[ft][mt], 0, 0, 0);
+          if constexpr (!ONE) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gw[mt], acc[ft][mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gw[mt], acc[ft][mt], 0, 0, 0);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[mt], acc[ft][mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[mt], acc[ft][mt], 0, 0, 0);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         if (SEPR_GF3_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -575,8 +603,9 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
   }();
   GcfnFusedArgs a = a_in;
   a.stagger = stagger;
-  if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || !a.ls || a.T <= 0) return SEPR_EINVAL;
+  if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || !a.ls || a.T <= 0 || (F != 64 && F != 128)) return SEPR_EINVAL;
   if (a.x == a.y) return SEPR_EINVAL;   // halo frames of a tile are outputs of its neighbours
+  if (a.planes == 1 && !a.train) return SEPR_EINVAL;   // plain bf16 operands: a training arithmetic only
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
   // Small launches (fewer 120-frame tiles than workgroup slots, e.g. batch 1 or the bottleneck stage) take the
@@ -591,10 +620,12 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
     const int ntiles = (a.M + tile_rows - 1) / tile_rows;
     const int cap = persistent_grid();
     const int grid = ntiles < cap ? ntiles : cap;
-    if (a.train) {
+    if (a.train && a.planes == 1) {
+      if (F == 128) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 0, true, true>), dim3(grid), dim3(384), 0, stream, a);
+      else hipLaunchKernelGGL((gcfn_fused3_kernel<64, 1, 6, 0, true, true>), dim3(grid), dim3(384), 0, stream, a);
+    } else if (a.train) {
       if (F == 128) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 0, true>), dim3(grid), dim3(384), 0, stream, a);
-      else if (F == 64) hipLaunchKernelGGL((gcfn_fused3_kernel<64, 1, 6, 0, true>), dim3(grid), dim3(384), 0, stream, a);
-      else return SEPR_EINVAL;
+      else hipLaunchKernelGGL((gcfn_fused3_kernel<64, 1, 6, 0, true>), dim3(grid), dim3(384), 0, stream, a);
     } else if (F == 128) {
       hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6>), dim3(grid), dim3(384), 0, stream, a);
     } else if (F == 64) {
@@ -608,10 +639,12 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
       const int ntiles = (a.M + tile_rows - 1) / tile_rows;
       const int cap = persistent_grid();
       const int grid = ntiles < cap ? ntiles : cap;
-      if (a.train) {
+      if (a.train && a.planes == 1) {
+        if (F == 128) hipLaunchKernelGGL((gcfn_fused3_kernel<128, GF3_MT, GF3_NW, 0, true, true>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
+        else hipLaunchKernelGGL((gcfn_fused3_kernel<64, GF3_MT, GF3_NW, 0, true, true>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
+      } else if (a.train) {
         if (F == 128) hipLaunchKernelGGL((gcfn_fused3_kernel<128, GF3_MT, GF3_NW, 0, true>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
-        else if (F == 64) hipLaunchKernelGGL((gcfn_fused3_kernel<64, GF3_MT, GF3_NW, 0, true>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
-        else return SEPR_EINVAL;
+        else hipLaunchKernelGGL((gcfn_fused3_kernel<64, GF3_MT, GF3_NW, 0, true>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
       } else if (F == 128) {
         hipLaunchKernelGGL((gcfn_fused3_kernel<128, GF3_MT, GF3_NW>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
       } else if (F == 64) {

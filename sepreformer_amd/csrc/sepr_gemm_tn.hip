@@ -17,6 +17,7 @@
 //     crop / nearest-upsample / overlapping-frame row maps), so no normalised or gathered copy is ever materialised;
 //   * the column sums of A (bias gradients) ride along in the staging registers.
 #include "sepr_train.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 #ifndef SEPR_TN_ABL
@@ -359,16 +360,32 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   float* part = static_cast<float*>(ws);
   float* cpart = part + (size_t)p.nsplit * a.N * a.K;
   const int grid = p.tn * p.tk * p.nsplit;
+  const bool gen = a.rows_out > 0 || a.B2 != nullptr || a.idx != nullptr || a.mask_a != 0 || a.stat_seq != 0;
+  if (gen && (a.a16 || a.b16)) return SEPR_EINVAL;      // (checked before the profiling slot opens)
   long long slot = -1;
   const bool timed = prof_begin(SEPR_SITE_WGRAD, s, &slot);
-  const bool gen = a.rows_out > 0 || a.B2 != nullptr || a.idx != nullptr || a.mask_a != 0 || a.stat_seq != 0;
-  if (gen && (a.a16 || a.b16)) return SEPR_EINVAL;
   float* cp = a.colsum ? cpart : nullptr;
-  // The general loader with statistics runs ONE workgroup per CU (16 KB of dynamic LDS on top of the static 74 KB make a second
-  // one not fit): with two co-resident workgroups its bf16 instantiations returned wrong, run-to-run different values in
-  // the even components of lanes 16-31 / 48-63 of the B staging waves (M >= ~20 000 rows; found by the full-size
-  // determinism test of round 3, reproduced by tools/det_tn.py, root cause not established).  One or two launches per step.
-  const int dyn = (gen && a.stats) ? 16384 : 0;
+  // The general loader runs ONE workgroup per CU (16 KB of dynamic LDS on top of the static 74 KB make a second one not fit): with
+  // two co-resident workgroups and statistics its bf16 instantiations returned wrong, run-to-run different values in the even
+  // components of lanes 16-31 / 48-63 of the B staging waves (M >= ~20 000 rows; found by the full-size determinism test of
+  // round 3, reproduced by tools/det_tn.py, root cause not established).  Round 4: ALL general-loader launches take the pad (not
+  // only those with statistics: a handful of launches per step), and the occupancy it is meant to produce is verified once per
+  // instantiation instead of assumed - if a toolchain / driver ever fits two such workgroups on a CU the launch fails loudly.
+  const int dyn = gen ? 16384 : 0;
+  if (gen) {
+    static const bool one_per_cu = [] {
+      int n0 = 0, n1 = 0, n2 = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, gemm_tn_kernel<0, true, false>, TN_THREADS, 16384) != hipSuccess) return false;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, gemm_tn_kernel<1, true, false>, TN_THREADS, 16384) != hipSuccess) return false;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, gemm_tn_kernel<2, true, false>, TN_THREADS, 16384) != hipSuccess) return false;
+      return n0 == 1 && n1 == 1 && n2 == 1;
+    }();
+    if (!one_per_cu) {
+      if (timed) prof_end(slot, 0.0, s);
+      fprintf(stderr, "sepr: gemm_tn general loader: expected exactly one workgroup per CU with the LDS pad\n");
+      return SEPR_EHIP;
+    }
+  }
 #define SEPR_TN_LAUNCH(MD)                                                                                                   \
   do {                                                                                                                       \
     if (gen) hipLaunchKernelGGL((gemm_tn_kernel<MD, true, false>), dim3(grid), dim3(TN_THREADS), dyn, s, a, p, part, cp);    \

@@ -40,12 +40,16 @@ int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t st
     if (src_rows * a.lda >= (1LL << 32)) return SEPR_EINVAL;
     if (pro == PRO_CAT2 && (long long)a.M * a.lda2 >= (1LL << 32)) return SEPR_EINVAL;
   }
+  const int key = pro * 16 + epi;
+  // every argument check comes BEFORE prof_begin: an early return inside an open profiling slot would leave a start event without
+  // its end event (sepr_prof_stop would then read an unrecorded event)
+  if (epi == EPI_LNBWD && (a.N > GEMM_BN || !a.aux || !a.stats || (a.aux2 && (a.T <= 0 || a.Tp <= 0 || a.fac <= 0)))) return SEPR_EINVAL;
+  if (a.bf1 && a.a16 && ((key != PRO_PLAIN * 16 + EPI_STORE && key != PRO_PLAIN * 16 + EPI_LNBWD) || a.rows_out > 0 || (a.lda % 8) != 0)) return SEPR_EINVAL;
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
-  const int key = pro * 16 + epi;
-  if (epi == EPI_LNBWD && (a.N > GEMM_BN || !a.aux || !a.stats || (a.aux2 && (a.T <= 0 || a.Tp <= 0 || a.fac <= 0)))) return SEPR_EINVAL;
+  // (an unknown prologue / epilogue combination below closes the slot before it reports the error)
+#define SEPR_X3_BAD_KEY do { if (timed) prof_end(slot, 0.0, stream); return SEPR_EINVAL; } while (0)
   if (a.bf1 && a.a16) {
-    if ((key != PRO_PLAIN * 16 + EPI_STORE && key != PRO_PLAIN * 16 + EPI_LNBWD) || a.rows_out > 0 || (a.lda % 8) != 0) return SEPR_EINVAL;
     if (epi == EPI_LNBWD) launch_x3_inst<PRO_PLAIN, EPI_LNBWD, 16 | 32>(a, stream);
     else launch_x3_inst<PRO_PLAIN, EPI_STORE, 16 | 32>(a, stream);
   } else if (a.bf1) {   // plain bf16 operands: the projections of the training path's "bf16" precision
@@ -56,7 +60,7 @@ int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t st
       case PRO_PLAIN * 16 + EPI_LNBWD: launch_x3_inst<PRO_PLAIN, EPI_LNBWD, 16>(a, stream); break;
       case PRO_NORM * 16 + EPI_STORE:  launch_x3_inst<PRO_NORM, EPI_STORE, 16>(a, stream); break;
       case PRO_CAT2 * 16 + EPI_STORE:  launch_x3_inst<PRO_CAT2, EPI_STORE, 16>(a, stream); break;
-      default: return SEPR_EINVAL;
+      default: SEPR_X3_BAD_KEY;
     }
   } else if (site == SEPR_SITE_GCFN_UP && key == PRO_NORM * 16 + EPI_DWGLU) {
     launch_x3_inst<PRO_NORM, EPI_DWGLU, 1>(a, stream);
@@ -75,8 +79,9 @@ int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t st
     case PRO_NORM * 16 + EPI_GLU:    launch_x3_inst<PRO_NORM, EPI_GLU>(a, stream); break;
     case PRO_NORM * 16 + EPI_GATE:   launch_x3_inst<PRO_NORM, EPI_GATE>(a, stream); break;
     case PRO_CAT2 * 16 + EPI_STORE:  launch_x3_inst<PRO_CAT2, EPI_STORE>(a, stream); break;
-    default: return SEPR_EINVAL;
+    default: SEPR_X3_BAD_KEY;
   }
+#undef SEPR_X3_BAD_KEY
   if (timed) prof_end(slot, 2.0 * (double)a.M * (double)a.N * (double)a.K, stream);
   SEPR_CHECK_LAUNCH("gemm_x3_kernel");
   return SEPR_OK;

@@ -125,6 +125,7 @@ int gcfn_fused_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcf
   f.w1p = w->fused_w1p; f.w2p = w->fused_w2p;
   f.b2 = w->b2; f.ls = w->ls; f.eps = LN_EPS_T;
   f.train = 1; f.stats = stats;
+  f.planes = w->up.planes == 1 ? 1 : 3;      // precision "bf16": the single-plane instantiation (round 4)
   f.drop_thr = p > 0.f ? sepr_drop_thr16(p) : 0u;
   f.drop_scale = p > 0.f ? sepr_drop_scale16(p) : 1.0f;
   f.seed = seed; f.salt = drop_salt();

@@ -48,10 +48,12 @@ def init_from_env(backend: Optional[str] = None, single_rank_group: bool = False
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        # torch's default collective timeouts (600 s nccl / 1800 s gloo) unless SEPR_DIST_TIMEOUT_S bounds them
-        kw = {}
-        if os.environ.get("SEPR_DIST_TIMEOUT_S"):
-            kw["timeout"] = datetime.timedelta(seconds=int(os.environ["SEPR_DIST_TIMEOUT_S"]))
+        # bounded collective timeout: a dead rank must fail the job, not hang it (torch's defaults are 600 s nccl / 1800 s gloo);
+        # the longest legitimate wait between collectives here is a whole-step hipGraph capture (~30 s).  SEPR_DIST_TIMEOUT_S overrides.
+        kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("SEPR_DIST_TIMEOUT_S", "300") or 300))}
+        if world == 1:
+            global _SINGLE_RANK_COLLECTIVES
+            _SINGLE_RANK_COLLECTIVES = True      # the caller asked for a one-rank group in order to exercise the collectives
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
@@ -60,9 +62,19 @@ def init_from_env(backend: Optional[str] = None, single_rank_group: bool = False
     return rank, world, local
 
 
+# A ONE-rank process group runs the path's collectives only when it was created for that purpose by
+# ``init_from_env(single_rank_group=True)`` (bench.py: RCCL is then exercised on a 1-GPU box); a one-rank group made by anything else
+# (a launcher with WORLD_SIZE=1) skips them - they would be pure overhead.
+_SINGLE_RANK_COLLECTIVES = False
+
+
+def collectives_active(group=None) -> bool:
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or _SINGLE_RANK_COLLECTIVES)
+
+
 def reduce_metric_sums(values: torch.Tensor) -> torch.Tensor:
     """Sum a small vector of metric accumulators (e.g. [sum SI-SNR, sum SI-SNRi, count]) over ranks."""
-    if dist.is_initialized():                      # a one-rank group still runs the collective (RCCL on a 1-GPU box)
+    if collectives_active():
         dist.all_reduce(values, op=dist.ReduceOp.SUM)
     return values
 
@@ -142,7 +154,7 @@ class GradSync:
         self._pending = None
 
     def _active(self) -> bool:
-        return dist.is_initialized()               # also with ONE rank: the all-reduce then still goes through RCCL
+        return collectives_active(self.group)      # one rank: only in a group made by init_from_env(single_rank_group=True)
 
     def abort(self) -> None:
         """Drop an early all-reduce whose backward did not finish (exception between ``begin`` and ``__call__``)."""

@@ -108,6 +108,9 @@ class _TrainGraph:
             eng.backward(self.tape, self.dims, self.d_wav, self.d_aux, self.tp, self.p)
         # the capture itself executed nothing: BatchNorm state is still the pre-warm-up one
         self.replays = 0
+        # the captured launches carry raw pointers into the engine's scratch workspace: hold the tensor, so that a later, larger
+        # shape (which makes the engine allocate a bigger workspace) cannot hand this memory back to the allocator under the graph
+        self.ws = eng._ws
 
     def forward(self, x: torch.Tensor, seed: int):
         self.x.copy_(x)
@@ -151,7 +154,7 @@ class _SeparatorFn(torch.autograd.Function):
                 seed = model._next_dropout_seed() if model.dropout_p > 0.0 else 0
                 outs = tg.forward(x.detach().to(torch.float32), seed)
             model.invalidate_packed()
-            ctx.state = ("graph", model, tg)
+            ctx.state = ("graph", model, tg, tg.replays)
             return outs
         with torch.cuda.device(dev):
             eng = model.__dict__.get("_train_engine")
@@ -176,8 +179,12 @@ class _SeparatorFn(torch.autograd.Function):
         if ctx.state is None:
             raise RuntimeError("the HIP training path keeps one tape per forward: backward twice needs a second forward")
         if ctx.state[0] == "graph":
-            _, model, tg = ctx.state
+            _, model, tg, replay_no = ctx.state
             ctx.state = None
+            if tg.replays != replay_no:
+                # one static tape per shape: a second same-shape forward has overwritten the activations this backward needs
+                raise RuntimeError("train_graphs mode keeps ONE static tape per input shape: another forward of the same shape ran before this "
+                                   "backward (e.g. (model(x1) + model(x2)).backward()); use the eager train path (train_graphs = False) for that")
             with torch.cuda.device(tg.x.device):
                 flat = tg.backward(d_wav, d_aux)
                 if model.grad_sync is not None:
@@ -235,8 +242,9 @@ class Model(torch.nn.Module):
         # latency mode: replay the forward from a captured hipGraph per input shape (engine.forward_graphed); the
         # returned tensors are then static buffers that the next same-shape call overwrites
         self.use_graphs = os.environ.get("SEPR_GRAPHS", "0") == "1"
-        # throughput mode for batches: the batch as N independent pipelines on N streams (engine.forward_split)
-        self.pipelines = int(os.environ.get("SEPR_PIPELINES", "1"))
+        # throughput mode for batches: the batch as N independent pipelines on N streams (engine.forward_split; bit-identical
+        # results).  0 = auto: two pipelines from 16 utterances up (+2.5 ... +6 % at batch 32), one below; SEPR_PIPELINES overrides.
+        self.pipelines = int(os.environ.get("SEPR_PIPELINES", "0") or 0)
         # projection arithmetic: "fp32" = exact f32 MFMA; "bf16x3" = split-fp32 on the bf16 MFMA (3 MFMAs per
         # product, ~100 dB agreement with fp32, 5x less matrix time); "bf16" = plain bf16 operands with fp32 accumulation
         # and fp32 master weights - a TRAINING precision (BASELINE configs[4]); eval() forwards of a "bf16" model run in
@@ -392,14 +400,19 @@ class Model(torch.nn.Module):
         with torch.cuda.device(x.device):
             if self.use_graphs:
                 wav, aux = eng.forward_graphed(x.to(torch.float32), with_aux=self.compute_aux)
-            elif self.pipelines > 1 and x.shape[0] >= 8 * self.pipelines:
-                wav, aux = eng.forward_split(x.to(torch.float32), with_aux=self.compute_aux, parts=self.pipelines)
+            elif self.effective_pipelines(x.shape[0]) > 1:
+                wav, aux = eng.forward_split(x.to(torch.float32), with_aux=self.compute_aux, parts=self.effective_pipelines(x.shape[0]))
             else:
                 wav, aux = eng.forward(x.to(torch.float32), with_aux=self.compute_aux)
         T = x.shape[-1]
         audio = [wav[s] for s in range(self.num_spks)]
         audio_aux = [[a[s][..., :T] for s in range(self.num_spks)] for a in aux]
         return audio, audio_aux
+
+    def effective_pipelines(self, batch: int) -> int:
+        """Number of sub-batch pipelines ``forward`` uses for ``batch`` utterances in eval mode (``pipelines`` = 0: auto)."""
+        pl = self.pipelines if self.pipelines > 0 else (2 if batch >= 16 and not self._is_replica_module() else 1)
+        return pl if (pl > 1 and batch >= 8 * pl) else 1
 
     def _forward_train(self, x: torch.Tensor):
         """Reference ``Model.forward`` under ``model.train()`` (engine.py:51,64): same return structure, autograd-connected."""

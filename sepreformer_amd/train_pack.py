@@ -162,6 +162,9 @@ class TrainPack:
         out_p = ["out_layer"] + [f"out_layer_bn.{i}" for i in range(R)]
         dec_w = ["audio_decoder.weight"] + [f"decoder_bn.{i}.weight" for i in range(R)]
 
+        # state_dict prefixes in pack order: self.gcfn[i] belongs to block_prefixes["gcfn"][i] (tests address single blocks by name)
+        self.block_prefixes = {"gcfn": gcfn_p, "ega": ega_p, "cla": cla_p, "spk": spk_p}
+
         def st(names, suffix, view=None):
             ts = [sd[n + suffix] for n in names]
             t = torch.stack([x.reshape(view) if view is not None else x for x in ts], 0).to(torch.float32)

@@ -93,6 +93,10 @@ class CapturedTrainStep:
         with torch.cuda.graph(self.g_opt, pool=pool, capture_error_mode=CAPTURE_MODE):
             self.grad_norm = torch.nn.utils.clip_grad_norm_(self.params, max_norm) if max_norm is not None else None
             optimizer.step()
+        # the captured launches point into the train engine's scratch workspace: keep that tensor alive for the graphs' lifetime
+        # (a later, larger eager shape makes the engine allocate a new one; the old one must not go back to the allocator)
+        eng = model.__dict__.get("_train_engine")
+        self._ws_keep = eng._ws if eng is not None else None
         self.audio, self.aux = audio, aux            # static outputs of the last replay (detached views are the caller's business)
 
     def _refresh_salt(self):

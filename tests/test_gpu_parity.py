@@ -514,12 +514,12 @@ def test_full_size_batch_properties(precision):
 
 @pytest.mark.parametrize("B,T,parts", [(32, 32000, 2), (17, 8000, 2), (24, 4000, 3)])
 def test_batch_pipelines_are_bit_identical(B, T, parts):
-    """model.pipelines > 1 (engine.forward_split: the batch as independent sub-batches on their own streams, what bench.py's timed
-    region uses): utterances are independent in eval mode and no kernel's arithmetic depends on the batch composition, so the main
+    """model.pipelines > 1 (engine.forward_split: the batch as independent sub-batches on their own streams, the product default for batches of 16 and more, hence what bench.py times): utterances are independent in eval mode and no kernel's arithmetic depends on the batch composition, so the main
     AND the auxiliary outputs equal the single-pipeline ones BITWISE - also for batches that do not split evenly."""
     m, _ = gpu_model("SepReformer_Base_WSJ0", "bf16x3")
     xd = synth_mixture(B, T, seed=77).cuda()
-    assert m.pipelines == 1
+    assert m.pipelines == 0 and m.effective_pipelines(32) == 2 and m.effective_pipelines(15) == 1      # the product default: auto
+    m.pipelines = 1
     audio1, aux1 = m(xd)
     audio1 = [a.clone() for a in audio1]
     aux1 = [[a.clone() for a in lvl] for lvl in aux1]
@@ -527,8 +527,12 @@ def test_batch_pipelines_are_bit_identical(B, T, parts):
     try:
         audio2, aux2 = m(xd)
         audio3, _ = m(xd)                                   # and again (the peers' arenas are reused)
+        m.pipelines = 0
+        audio4, _ = m(xd)                                   # auto (two pipelines from 16 utterances up)
     finally:
-        m.pipelines = 1
+        m.pipelines = 0
+    for a, d in zip(audio1, audio4):
+        assert torch.equal(a, d)
     for a, b, c in zip(audio1, audio2, audio3):
         assert a.shape == b.shape and torch.equal(a, b) and torch.equal(a, c)
     for l1, l2 in zip(aux1, aux2):
