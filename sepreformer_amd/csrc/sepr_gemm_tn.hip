@@ -72,7 +72,13 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
   constexpr bool X3 = MD != 0, ONE = MD == 2;
   __shared__ __attribute__((aligned(16))) unsigned char smem[X3 ? 4 * TN_T * TN_LDM * 2 : 2 * TN_SLAB * TN_LDF * 4];
   __shared__ float csum_s[4][TN_T];
-  __shared__ float2 st_s[TN_SLAB];          // (mean, rstd) of the slab's rows (!GEN && STATS)
+  // DBUF: TWO slabs of operand rows in flight in registers (the loads of slab s+2 issued before the MFMAs of slab s, consumed two
+  // barriers later).  Built in round 4 for the plain-bf16 instantiation and NOT enabled: next to the 64 accumulator and 32 fragment
+  // registers a second 64-register row set spills 67 dwords per lane into the slab loop (scratch traffic shares vmcnt with the
+  // operand stream), and the launch is HBM-stream-bound at two workgroups per CU anyway (64 KB per slab per workgroup against
+  // ~500 cycles of MFMAs).  The code path is kept behind the constant for the day the accumulator tile shrinks.
+  constexpr bool DBUF = false;
+  __shared__ float2 st_s[DBUF ? 2 : 1][TN_SLAB];          // (mean, rstd) of the slab's rows (!GEN && STATS)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int fi = lane & 15, fg = lane >> 4;
@@ -98,13 +104,13 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
   const int cg = (SEPR_TN_LANEMAP && MD != 0) ? (t7 >> 2) : (t7 & 31), mg = (SEPR_TN_LANEMAP && MD != 0) ? (t7 & 3) : (t7 >> 5);
   const int col = (roleA ? n0 : k0) + 4 * cg;
   const bool col_ok = col < (roleA ? a.N : a.K);
-  float4 r[8 * TN_NB];
+  float4 rA[8 * TN_NB], rB[DBUF ? 8 * TN_NB : 1];
   float4 csum = zero4();
   float2 my_st = make_float2(0.f, 1.f);      // wave 2 only: statistics of row (slab base + lane) for the next slab
 
   const int row_safe = m_beg < a.M ? m_beg : 0;
   const int col_c = col_ok ? col : 0;
-  auto load_slab = [&](int mb) {
+  auto load_slab = [&](int mb, float4 (&r)[8 * TN_NB]) {
     if (SEPR_TN_ABL & 4) return;
     if constexpr (!GEN) {
       const float* base = roleA ? a.A : a.B;                      // wave-uniform
@@ -130,11 +136,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
         my_st = *reinterpret_cast<const float2*>(a.stats + 2LL * (m < m_end ? m : row_safe));
         if (m >= m_end) my_st = make_float2(0.f, 0.f);           // rows past the slice: (0 - 0) * 0
       }
-#pragma unroll
-      for (int e = 0; e < 8 * TN_NB; ++e) {
-        const int m = mb + 32 * (e >> 3) + 8 * mg + (e & 7);
-        if (!(m < m_end && col_ok)) r[e] = zero4();
-      }
+      // (row / column validity is a select at CONSUMPTION, in store_slab: a select here would tie the loads' completion to this
+      //  point of the instruction stream)
     } else {
       const bool useB2 = !roleA && a.B2 != nullptr && col_ok && col >= a.ksplit;
 #pragma unroll
@@ -175,11 +178,18 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
   };
   // the statistics a slab's B rows are normalised with travel wave 2 -> LDS -> every staging thread of B (published by the
   // barrier at the top of the loop; the previous slab's readers are past the barrier in the middle of the loop)
-  auto publish_stats = [&]() {
-    if (!GEN && STATS && wid == 2) st_s[lane] = my_st;
+  auto publish_stats = [&](int buf) {
+    if (!GEN && STATS && wid == 2) st_s[buf][lane] = my_st;
   };
-  auto store_slab = [&]() {
+  auto store_slab = [&](float4 (&r)[8 * TN_NB], int sbuf, int mb) {
 #pragma clang fp contract(off)
+    if constexpr (!GEN) {
+#pragma unroll
+      for (int e = 0; e < 8 * TN_NB; ++e) {
+        const int m = mb + 32 * (e >> 3) + 8 * mg + (e & 7);
+        if (!(m < m_end && col_ok)) r[e] = zero4();
+      }
+    }
     if (SEPR_TN_ABL & 2) {
 #pragma unroll
       for (int e = 0; e < 8 * TN_NB; ++e) asm volatile("" ::"v"(r[e].x), "v"(r[e].y), "v"(r[e].z), "v"(r[e].w));
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
 #pragma unroll
       for (int e = 0; e < 8 * TN_NB; ++e) {
         // (columns past K hold (0 - mean) * rstd garbage: they only ever reach accumulator columns that are never stored)
-        const float2 st = st_s[32 * (e >> 3) + 8 * mg + (e & 7)];
+        const float2 st = st_s[sbuf][32 * (e >> 3) + 8 * mg + (e & 7)];
         r[e].x = (r[e].x - st.x) * st.y; r[e].y = (r[e].y - st.x) * st.y; r[e].z = (r[e].z - st.x) * st.y; r[e].w = (r[e].w - st.x) * st.y;
       }
     }
@@ -228,13 +238,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (m_beg < m_end) load_slab(m_beg);
-  publish_stats();
-  for (int mb = m_beg; mb < m_end; mb += TN_SLAB) {
-    __syncthreads();            // every wave is done reading the previous slab
-    store_slab();
-    __syncthreads();
-    if (mb + TN_SLAB < m_end) load_slab(mb + TN_SLAB);
+  // one slab's MFMAs out of the staged planes / tiles
+  auto mma_slab = [&]() {
     if (X3) {
       const unsigned short* Ahi = reinterpret_cast<const unsigned short*>(smem);
       const unsigned short* Alo = Ahi + TN_T * TN_LDM;
@@ -284,7 +289,40 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
             acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv[kt], acc[nt][kt], 0, 0, 0);
       }
     }
-    publish_stats();            // statistics of the slab just requested (no reader of st_s between the two barriers above and the next)
+  };
+
+  if constexpr (DBUF) {
+    // slab s lives in rA for even s, rB for odd s; its statistics in st_s[s & 1]
+    if (m_beg < m_end) load_slab(m_beg, rA);
+    publish_stats(0);
+    if (m_beg + TN_SLAB < m_end) load_slab(m_beg + TN_SLAB, rB);
+    publish_stats(1);
+    for (int mb = m_beg; mb < m_end; mb += 2 * TN_SLAB) {
+      __syncthreads();            // every wave is done reading the previous slab
+      store_slab(rA, 0, mb);
+      __syncthreads();
+      if (mb + 2 * TN_SLAB < m_end) load_slab(mb + 2 * TN_SLAB, rA);
+      mma_slab();
+      publish_stats(0);           // statistics of slab mb + 2 slabs (readers of st_s[0] are past the barrier above)
+      if (mb + TN_SLAB >= m_end) break;
+      __syncthreads();
+      store_slab(rB, 1, mb + TN_SLAB);
+      __syncthreads();
+      if (mb + 3 * TN_SLAB < m_end) load_slab(mb + 3 * TN_SLAB, rB);
+      mma_slab();
+      publish_stats(1);
+    }
+  } else {
+    if (m_beg < m_end) load_slab(m_beg, rA);
+    publish_stats(0);
+    for (int mb = m_beg; mb < m_end; mb += TN_SLAB) {
+      __syncthreads();            // every wave is done reading the previous slab
+      store_slab(rA, 0, mb);
+      __syncthreads();
+      if (mb + TN_SLAB < m_end) load_slab(mb + TN_SLAB, rA);
+      mma_slab();
+      publish_stats(0);           // statistics of the slab just requested (no reader of st_s between the two barriers above and the next)
+    }
   }
 
   // ---- partial tile -> workspace: part[split][n][k] ----

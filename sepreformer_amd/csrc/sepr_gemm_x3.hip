@@ -1,5 +1,5 @@
 // Instantiations + host launcher of the bf16x3 projection core.
-#include "sepr_gemm_x3.h"
+#include "sepr_gemm_x3w.h"
 #include <stdlib.h>
 
 namespace sepr {
@@ -17,10 +17,29 @@ static int x3_grid_cap() {
   return v;
 }
 
+// SEPR_X3_WIDE: 0 = the 128 x 128 core only, 1 (default) = the 128 x 256 core (sepr_gemm_x3w.h) for launches with an even number of
+// 128-column tiles and at least two wide tiles per CU, 2 = for every launch with an even number of column tiles (A/B)
+// (read per launch, not cached: the parity tests flip it inside one process to compare the two cores bit for bit)
+static int x3_wide_mode() {
+  const char* e = getenv("SEPR_X3_WIDE");
+  return e && e[0] ? atoi(e) : 1;
+}
+
 template <int PRO, int EPI, int TAG = 0>
 static void launch_x3_inst(const GemmArgs& a, hipStream_t stream) {
-  const int tiles = gemm_tiles(a, EPI);
   const int cap = x3_grid_cap();
+  if constexpr (EPI != EPI_LNBWD) {
+    const bool glu = (EPI == EPI_GLU) || (EPI == EPI_DWGLU);
+    const int NB = glu ? (a.N / 2 + 63) / 64 : (a.N + GEMM_BN - 1) / GEMM_BN;
+    const int wmode = x3_wide_mode();
+    const int wtiles = gemm_tiles_wide(a, EPI);
+    if (wmode > 0 && NB >= 2 && (NB % 2) == 0 && (wmode == 2 || wtiles >= persistent_grid())) {
+      const int grid = (cap <= 0 || wtiles < cap) ? wtiles : cap;
+      hipLaunchKernelGGL((gemm_x3w_kernel<PRO, EPI, TAG>), dim3(grid), dim3(GEMM_THREADS), 0, stream, a);
+      return;
+    }
+  }
+  const int tiles = gemm_tiles(a, EPI);
   const int grid = (cap <= 0 || tiles < cap) ? tiles : cap;
   hipLaunchKernelGGL((gemm_x3_kernel<PRO, EPI, TAG>), dim3(grid), dim3(GEMM_THREADS), 0, stream, a);
 }

@@ -32,11 +32,37 @@ def _static_traffic(prec, launches):
 GFLOP_FWD = {"SepReformer_Base_WSJ0": 182.16, "SepReformer_Large_DM_WHAMR": 684.14}     # per 4 s utterance, forward incl. aux heads
 
 
+XGMI_LINK_GBS = 153.0       # per-direction bandwidth of one xGMI link (7 per GPU, fully connected; MI355X_MICROARCH.md / SURVEY.md section 5)
+
+
+def dp8_prediction(step_ms, batch, ar_bytes, ar_ms_here, world_here, overlapped):
+    """What the first real 8-GPU run of this step should show, from pieces measured here (no multi-GPU node was available to the builder):
+    per-rank compute = this run's step time (weak scaling: the per-rank batch does not change), plus the gradient all-reduce -
+    ring model 2 (N-1)/N bytes / link bandwidth (RCCL's ring is per-link bound on point-to-point xGMI), lower bound = a direct
+    reduce-scatter + all-gather over all 7 links - which in the captured step runs BETWEEN the two graph replays, i.e. not overlapped
+    with the backward (the eager step overlaps the decoder half's bucket)."""
+    n = 8
+    ring_ms = 2.0 * (n - 1) / n * ar_bytes / (XGMI_LINK_GBS * 1e9) * 1e3
+    direct_ms = 2.0 * (ar_bytes / n) / (XGMI_LINK_GBS * 1e9) * 1e3
+    floor_ms = ar_ms_here if (ar_ms_here is not None and world_here == 1) else 0.0     # launch / RCCL-kernel floor measured on the 1-rank group
+    exposed = max(ring_ms, floor_ms) * (0.5 if overlapped else 1.0)
+    pred = step_ms + exposed - (floor_ms if world_here == 1 else 0.0)                   # this run's step already contains the 1-rank floor
+    return {"n_gpus": n, "per_rank_step_ms_measured": round(step_ms, 3), "allreduce_bytes": int(ar_bytes),
+            "allreduce_ms_measured_here": None if ar_ms_here is None else round(ar_ms_here, 3), "allreduce_ranks_here": world_here,
+            "allreduce_ms_ring_model": round(ring_ms, 3), "allreduce_ms_direct_lower_bound": round(direct_ms, 3),
+            "overlap": "decoder-half bucket under the encoder half of the backward (eager step)" if overlapped else
+                       "none: the all-reduce runs between the two hipGraph replays of the captured step",
+            "predicted_step_ms": round(pred, 3), "predicted_utt_per_s": round(n * batch / pred * 1e3, 1),
+            "predicted_scaling_efficiency": round(step_ms / pred, 4),
+            "note": "prediction, not a measurement: per-rank BatchNorm statistics, no parameter broadcast, one 58.8 MB all-reduce per step; host-side "
+                    "launch jitter across 8 processes is not modelled"}
+
+
 DTYPES = {
     "bf16x3": ("bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate); fp32 master weights, "
                "gradients and optimizer state"),
-    "bf16": ("bf16 (plain bf16 operands in every projection, input-gradient projection and weight-gradient contraction: ONE bf16 MFMA per "
-             "product, fp32 accumulate; the fused GCFN forward keeps the bf16x3 kernel); fp32 master weights, gradients and optimizer state"),
+    "bf16": ("bf16 (plain bf16 operands in every projection, the fused GCFN forward, input-gradient projection and weight-gradient contraction: "
+             "ONE bf16 MFMA per product, fp32 accumulate); fp32 master weights, gradients and optimizer state"),
     "fp32": "f32",
 }
 
@@ -141,6 +167,20 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
     L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
     algo_bytes = float(lib.sepr_prof_last_bytes())
     elapsed = sdist.max_over_ranks(elapsed, dev)
+    # the gradient all-reduce on its own (the collective of this path): wall time of one synchronised call on the flat buffer,
+    # median of 5 - at world size 1 the floor RCCL adds to a step, at N > 1 the real exchange
+    ar_ms = None
+    if sync.calls:
+        probe = torch.zeros(sum(p_.numel() for p_ in params), dtype=torch.float32, device=dev)
+        ts = []
+        for _ in range(6):
+            torch.cuda.synchronize(dev)
+            ta = time.perf_counter()
+            torch.distributed.all_reduce(probe)
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - ta)
+        ar_ms = 1e3 * sorted(ts[1:])[2]
+        del probe
     rec = None
     if rank == 0:
         utt_per_s = world * B * steps / elapsed
@@ -173,6 +213,8 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
             "allreduce_bytes_per_step": (sync.bytes // max(sync.calls, 1)) if sync.calls else 0,
             "model_tflops": round(utt_per_s * gflop / 1e3 / world, 2),
             "model_frac_algorithmic": round(utt_per_s * gflop / 1e3 / world / peak, 4),
+            "dp8_prediction": dp8_prediction(1e3 * elapsed / max(steps, 1), B, (sync.bytes // max(sync.calls, 1)) if sync.calls else 0, ar_ms, world,
+                                             overlapped=(mode == "off")),
             # The contraction over M = batch x frames rows reads both operands once for a [N,K] result with N, K <= 1024: at
             # 2 N K / (4 (N + K)) = 50-130 FLOP per byte it sits under the ridge of the bf16 MFMA (312 FLOP/B) - HBM is its roofline.
             # achieved = algorithmic bytes of the timed launches / their hipEvent durations; the matrix-pipe view rides along.

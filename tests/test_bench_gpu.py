@@ -57,3 +57,64 @@ def test_bench_measures_hbm_traffic_live():
     assert roof["traffic_source"].startswith("measured in this run"), roof["traffic_source"]
     assert 1.0 < roof["traffic_over_algorithmic"] < 3.0, roof
     assert roof["traffic"] == round(roof["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# data-parallel gradients: two ranks (sharing GPU 0, gloo) against the single-rank computation
+# ---------------------------------------------------------------------------------------------------------------------
+def _dp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import dataclasses
+    import numpy as np
+    import torch
+    from sepreformer_amd import dist as sd
+    from sepreformer_amd.config import VARIANTS
+    from sepreformer_amd.model import Model
+    from sepreformer_amd.synth import synth_sources
+    sd.init_from_env("gloo")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cfg = dataclasses.replace(VARIANTS["tiny"], dropout=0.0)
+    src = torch.from_numpy(synth_sources(2, 1500, seed=50 + rank) * 4.0).to(dev)
+    x = src.sum(1).contiguous()
+
+    def step(sync):
+        m = Model.from_config(cfg, init_seed=0).load_synthetic_(0).to(dev).train()
+        m.grad_sync = sync
+        audio, aux = m(x)
+        loss = sum(((a - src[:, s, : a.shape[-1]]) ** 2).mean() for s, a in enumerate(audio)) + 0.1 * sum(torch.stack(a_).abs().mean() for a_ in aux)
+        loss.backward()
+        flat = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+        bn = torch.cat([v.reshape(-1).float() for k, v in m.state_dict().items() if "running_" in k])
+        return flat, bn
+
+    g_local, bn_local = step(None)
+    sync = sd.GradSync()
+    g_sync, bn_sync = step(sync)
+    assert sync.calls == 1 and sync.bytes == g_sync.numel() * 4
+    np.savez(os.path.join(out_dir, f"dp{rank}.npz"), local=g_local.cpu().numpy(), synced=g_sync.cpu().numpy(),
+             bn_local=bn_local.cpu().numpy(), bn_sync=bn_sync.cpu().numpy())
+    sd.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradients_are_the_mean_of_the_single_rank_gradients(tmp_path):
+    """configs[4]'s data-parallel step, checked without a multi-GPU node: two ranks (sharing GPU 0, gloo - the same GradSync code path
+    the RCCL run takes) each back-propagate their own batch through the HIP training path; the synchronised gradient on BOTH ranks must
+    be exactly (g_0 + g_1) / 2 of the two single-rank gradients (fp32 sum of two terms: order-independent, so the check is bitwise),
+    i.e. the gradient of the batch-mean loss over the union of the shards with per-rank BatchNorm statistics - the reference's
+    per-replica statistics (engine.py:64).  BatchNorm running statistics stay per rank: untouched by the synchronisation."""
+    import socket
+    import numpy as np
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "dp0.npz"), np.load(tmp_path / "dp1.npz")
+    want = (r0["local"] + r1["local"]) / np.float32(2.0)
+    assert np.abs(r0["local"] - r1["local"]).max() > 0             # the shards differ
+    assert np.array_equal(r0["synced"], want) and np.array_equal(r1["synced"], want)
+    assert np.array_equal(r0["bn_sync"], r0["bn_local"]) and np.array_equal(r1["bn_sync"], r1["bn_local"])
+    assert np.abs(r0["bn_local"] - r1["bn_local"]).max() > 0       # per-rank statistics

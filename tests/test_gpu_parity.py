@@ -112,6 +112,63 @@ def test_linear_core_bf16x3(M, N, K):
     agree(f"linear_x3.{M}x{N}x{K}", y, want, 85.0)
 
 
+@pytest.mark.parametrize("M,N,K", [(4099, 768, 128), (300, 256, 256), (70001, 1536, 256), (1000, 512, 384), (129, 1024, 64), (40000, 256, 768)])
+def test_linear_core_bf16x3_wide_equals_narrow(M, N, K, monkeypatch):
+    """The 128 x 256 projection core (sepr_gemm_x3w.h: 64-column wave tiles, K slabs of 32, plane-split weight prefetch) against the
+    128 x 128 core on the same launch: same staging arithmetic and the same MFMA order per output element, so the results are
+    BIT-identical - which is what lets the launcher pick either by tile count without a batch of 32 differing from 32 single runs."""
+    from sepreformer_amd.pack import pack_x3
+    lib = L.load()
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2) / K ** 0.5, rnd(N, seed=3)
+    xd, bd = x.cuda(), b.cuda()
+    wp = pack_x3(w.cuda())
+    ys = []
+    for mode in ("0", "2"):
+        monkeypatch.setenv("SEPR_X3_WIDE", mode)
+        y = torch.full((M, N), float("nan"), device="cuda")
+        L.check(lib.sepr_linear_x3_fwd(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), M, N, K,
+                                       torch.cuda.current_stream().cuda_stream), "sepr_linear_x3_fwd")
+        ys.append(y)
+    assert torch.equal(ys[0], ys[1])
+    agree(f"linear_x3w.{M}x{N}x{K}", ys[1], (x.double() @ w.double().t() + b.double()).float(), 85.0)
+
+
+@pytest.mark.parametrize("variant", ["SepReformer_Large_DM_WHAMR", "SepReformer_Base_WSJ0"])
+def test_blocks_wide_core_equals_narrow(variant, monkeypatch):
+    """Every block that runs on the generic bf16x3 projection core (all of Large; Base: EGA, speaker split, fusion, heads) with the wide
+    core forced on for every eligible launch vs forced off: bitwise equal outputs - covers the wide core under every prologue /
+    epilogue pair the model uses (LayerNorm prologue, two-source concat, row maps; conv+GLU, GLU, GELU, LayerScale+residual, gate,
+    speaker split, ReLU mask) including ragged last row tiles."""
+    m, sd = gpu_model(variant, "bf16x3")
+    cfg = m.cfg
+    F, S, N = cfg.feat, cfg.num_spks, cfg.enc_channels
+    eng = m.engine()
+    B, T = 3, 520
+    Tp = T >> 2
+    eng.prepare(B, 4 * T, 4 * T)
+    pk = eng.pk
+    x = rnd(B, T, F, seed=3).cuda()
+    xs = rnd(B * S, T, F, seed=4).cuda()
+    lo = rnd(B * S, T // 2, F, seed=5).cuda()
+    enc = rnd(B, T - 3, N, seed=6).cuda()
+
+    def run():
+        out = [eng.gcfn(x, pk.enc_stages[0]["g"][0][1], B, T), eng.cla(x, pk.enc_stages[0]["l"][0][0], B, T),
+               eng.ega(x, pk.enc_stages[0]["g"][0][0], B, T, Tp), eng.spkattn(xs, pk.dec_stages[0]["spk"][0][0], B * S, T),
+               eng.spksplit(x, pk.splits[0], B, T), eng.fuse(lo, xs, pk.fuse[0], B * S, T),
+               eng.head(xs, pk.out_main, B * S, T, T - 3, None, None, B),
+               eng.head(lo, pk.out_aux[1], B * S, T // 2, T - 3, eng._idx(T // 2, T - 3), enc, B)]
+        torch.cuda.synchronize()
+        return [o.clone() for o in out]
+
+    monkeypatch.setenv("SEPR_X3_WIDE", "0")
+    narrow = run()
+    monkeypatch.setenv("SEPR_X3_WIDE", "2")
+    wide = run()
+    for i, (a_, b_) in enumerate(zip(narrow, wide)):
+        assert torch.isfinite(a_).all() and torch.equal(a_, b_), i
+
+
 # ---------------------------------------------------------------------------------------------------
 # every fused block against the oracle's restatement of the same reference module
 # ---------------------------------------------------------------------------------------------------
