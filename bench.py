@@ -173,7 +173,10 @@ def self_launch(args) -> int:
 PMC_KERNEL_RE = "gcfn_fused3_kernel<[0-9]+, [0-9], [0-9], 0, false>"     # the GCFN instantiations of the fused kernel (not the plain GLU-MLP mode)
 
 
-def measure_pmc_traffic(budget_s=90.0):
+TN_KERNEL_RE = "gemm_tn_kernel"      # every instantiation of the weight-gradient contraction (the training line's roofline kernel)
+
+
+def measure_pmc_traffic(budget_s=90.0, kernel_re=None, sub_args=None):
     """HBM bytes per launch of the fused GCFN kernel, measured NOW: ``rocprofv3 --pmc FETCH_SIZE`` and ``--pmc WRITE_SIZE`` in separate
     passes (kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short sub-run of this script at the same batch.  Returns
     (record, None) or (None, reason).  FETCH_SIZE x2: the guide's gfx950 correction for 16 B/lane streaming reads; counters are KiB."""
@@ -187,8 +190,8 @@ def measure_pmc_traffic(budget_s=90.0):
     sums, launches, algo = {}, 0, None
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix=f"sepr_pmc_{ctr}_", dir="/tmp")
-        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--kernel-include-regex", PMC_KERNEL_RE, "--output-format", "csv", "-d", d, "-o", "t", "--",
-               sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-alt-precision", "--pmc", "off"]
+        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--kernel-include-regex", kernel_re or PMC_KERNEL_RE, "--output-format", "csv", "-d", d, "-o", "t", "--",
+               sys.executable, os.path.abspath(__file__)] + (sub_args or ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-alt-precision", "--pmc", "off"])
         env = dict(os.environ, TMPDIR="/tmp", SEPR_PIPELINES="1")      # one pipeline: every counted launch has the full-batch size
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
@@ -205,7 +208,7 @@ def measure_pmc_traffic(budget_s=90.0):
             rows = [r for r in csv.DictReader(f) if r.get("Counter_Name") == ctr]
         shutil.rmtree(d, ignore_errors=True)
         if not rows:
-            return None, f"{ctr} pass: no rows for {PMC_KERNEL_RE}"
+            return None, f"{ctr} pass: no rows for {kernel_re or PMC_KERNEL_RE}"
         sums[ctr], launches = sum(float(r["Counter_Value"]) for r in rows), len(rows)
         for line in out.stdout.splitlines():
             if line.startswith("{"):
@@ -600,6 +603,26 @@ def main():
                     rec["train"][name] = {k: tr.get(k) for k in keys}
                 except Exception as e:          # noqa: BLE001
                     rec["train"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            # the training roofline's HBM traffic measured in THIS run as well (the contraction kernels of two eager bf16 steps at batch 16)
+            tb16 = rec["train"].get("bf16") or {}
+            if args.pmc != "off" and isinstance(tb16.get("roofline"), dict) and tb16["roofline"].get("algorithmic_bytes_per_launch"):
+                t_pmc = time.perf_counter()
+                try:
+                    pm, why = measure_pmc_traffic(120.0, TN_KERNEL_RE, ["--mode", "train", "--batch", "16", "--steps", "1", "--warmup", "0", "--precision", "bf16",
+                                                                       "--train-graphs", "off"])
+                except Exception as e:          # noqa: BLE001
+                    pm, why = None, f"{type(e).__name__}: {e}"[:200]
+                roof = tb16["roofline"]
+                if pm and pm.get("traffic_over_algorithmic"):
+                    roof["traffic"] = round(pm["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"])
+                    roof["traffic_over_algorithmic"] = pm["traffic_over_algorithmic"]
+                    roof["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) over the "
+                                              f"{pm['launches']} gemm_tn launches of an eager 2-step sub-run at the same batch; FETCH_SIZE x2 (gfx950 correction of "
+                                              f"MI355X_MICROARCH.md), KiB units; fetch {pm['fetch_bytes_per_launch']} + write {pm['write_bytes_per_launch']} B per launch "
+                                              f"there = {pm['traffic_over_algorithmic']} x the algorithmic operand bytes (the write side is the split-M partial tiles)")
+                else:
+                    roof["traffic_source"] = (roof.get("traffic_source") or "") + f" (live PMC passes failed: {why})"
+                rec["train_pmc_s"] = round(time.perf_counter() - t_pmc, 1)
             rec["sub_records_s"] = round(time.perf_counter() - t_sub, 1)
         if world == 1 and (args.pmc == "on" or (args.pmc == "auto" and default_run)) and rec["roofline"].get("algorithmic_bytes_per_launch"):
             # traffic re-measured in THIS run (two short PMC sub-runs at the same batch: every launch they count has the timed launches' size)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SEPR_VERSION 301 /* major*10000 + minor*100 + patch */
+#define SEPR_VERSION 302 /* major*10000 + minor*100 + patch */
 
 #define SEPR_OK 0
 #define SEPR_EINVAL (-1)     /* bad shape / unsupported size / null pointer */
@@ -121,6 +121,8 @@ typedef struct {
   sepr_x3_w x3_gate;      /* block.linear.1 (LayerNorm folded) */
   const void* fused_gate_p; /* optional (bf16x3, F = 128; pack.py::pack_gate_fused): per 64 output channels
                                [4 tiles][F/32][plane][64][8] bf16 (gamma folded) + 4 KB fp32 constants [4][16] biases */
+  const void* pe_k_planes;  /* optional (bf16x3; pack.py, ABI 3.02): pe_k split ONCE into bf16 planes [2: hi, lo][2*maxlen][F/H] -
+                               the attention kernel then stages its relative-position band without a per-tile VALU split */
 } sepr_ega_w;
 
 /* DownConvLayer, modules/module.py:63-78 (eval BN folded: y = gelu(conv_nobias * scale + shift)) */

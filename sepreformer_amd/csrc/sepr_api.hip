@@ -257,7 +257,7 @@ extern "C" int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int 
     a.W = w->attn.wqkv; a.bias = w->attn.bqkv; a.Y = qkv; a.ldc = 3 * F;
     SEPR_TRY(project(PRO_NORM, EPI_STORE, a, w->attn.x3_qkv, SEPR_SITE_ATTN_PROJ, st));
   }
-  SEPR_TRY(launch_relattn(qkv, o, n, Tp, F, H, w->pe_k, w->maxlen, relattn_x3(w), st));   // (network.py:106-122)
+  SEPR_TRY(launch_relattn(qkv, o, n, Tp, F, H, w->pe_k, w->maxlen, relattn_x3(w), st, w->pe_k_planes));   // (network.py:106-122)
   {  // linear_out * LayerScale (no residual inside MHA)                    (network.py:124)
     GemmArgs a = gemm_args_zero();
     a.M = (int)Mp; a.N = F; a.K = F;

@@ -193,11 +193,15 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& l) {
 // the softmax denominator sums the undropped ones); mask of element (row = (seq*H + h)*Tp + i, key j) = 16-bit half j & 1 of
 // sepr_drop_word(dkey, row, j >> 1) >= thr (sepr_train.h).
 template <int DK, bool TRAIN = false>
-__global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict__ QKV, float* __restrict__ O, int Tp, int F,
+__global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const float* __restrict__ QKV, float* __restrict__ O, int Tp, int F,
                                                         const float* __restrict__ pe, int maxlen, float inv_sqrt_dk,
                                                         float* __restrict__ lse = nullptr, unsigned thr = 0u, float dscale = 1.0f,
-                                                        unsigned long long seed = 0ull, const unsigned long long* __restrict__ salt = nullptr) {
+                                                        unsigned long long seed = 0ull, const unsigned long long* __restrict__ salt = nullptr,
+                                                        const unsigned short* __restrict__ pe_planes = nullptr) {
   static_assert(DK == 16 || DK == 32, "head width");
+  // pe_planes (inference, round 4): the position table already split into bf16 hi / lo planes at pack time - the band rows of a key
+  // tile are then copied global -> registers -> LDS as they are (half of this kernel's staged elements lose their VALU split)
+  const bool bp = !TRAIN && pe_planes != nullptr;            // kernel-uniform
   DropKey dkey = {0u, 0u};
   if (TRAIN && thr) dkey = sepr_drop_key(seed, salt, 2u);
   constexpr int QB = 64, KT = 64;
@@ -273,7 +277,14 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
       const int rr = idx / (DK / 4) < NBAND ? idx / (DK / 4) : NBAND - 1;
       int rel = i0 - j0 - (KT - 1) + rr;                      // i - j for band row rr
       rel = rel < -maxlen ? -maxlen : (rel > maxlen - 1 ? maxlen - 1 : rel);
-      rb[u] = ld4(pe + (long long)(rel + maxlen) * DK + 4 * (idx % (DK / 4)));
+      const long long off = (long long)(rel + maxlen) * DK + 4 * (idx % (DK / 4));
+      if (bp) {       // 4 bf16 of the hi plane in .x/.y, of the lo plane in .z/.w (bit patterns carried in the float4 registers)
+        const uint2 hh = *reinterpret_cast<const uint2*>(pe_planes + off);
+        const uint2 ll = *reinterpret_cast<const uint2*>(pe_planes + 2LL * maxlen * DK + off);
+        rb[u] = make_float4(__uint_as_float(hh.x), __uint_as_float(hh.y), __uint_as_float(ll.x), __uint_as_float(ll.y));
+      } else {
+        rb[u] = ld4(pe + off);
+      }
     }
   };
   fetch(0);
@@ -300,89 +311,108 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
       for (int u = 0; u < NBU; ++u) {
         const int idx = tid + 256 * u;
         if (idx < NBAND * (DK / 4)) {
-          split4(rb[u], hh, ll);
-          *reinterpret_cast<bf16x4*>(Bh + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = hh;
-          *reinterpret_cast<bf16x4*>(Bl + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = ll;
+          if (bp) {
+            *reinterpret_cast<uint2*>(Bh + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = make_uint2(__float_as_uint(rb[u].x), __float_as_uint(rb[u].y));
+            *reinterpret_cast<uint2*>(Bl + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = make_uint2(__float_as_uint(rb[u].z), __float_as_uint(rb[u].w));
+          } else {
+            split4(rb[u], hh, ll);
+            *reinterpret_cast<bf16x4*>(Bh + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = hh;
+            *reinterpret_cast<bf16x4*>(Bl + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = ll;
+          }
         }
       }
     }
     __syncthreads();
     if (j0 + KT < Tp && !(SEPR_AT_ABL & 4)) fetch(j0 + KT);   // the next tile's rows fly under this tile's arithmetic
 
-    const int npair = (Tp - j0 >= KT) ? KT / 32 : (Tp - j0 + 31) / 32;
-    for (int p = 0; p < npair; ++p) {
-      // ---- S^T[key = 16 s + 4g + r][query ii] for the two 16-key halves s ------------------------------------------
-      f32x4 sc[2];
+    // ---- ONE online-softmax update per 64-key tile (round 4; one per 32 keys before): the scores of both 32-key pairs are formed
+    //      first - two independent MFMA -> skew -> bias chains the scheduler can interleave - then one max / exchange / rescale
+    //      round, then both P.V products.  Keys past Tp carry -1e30 (their V rows are staged as zeros), so a partial last tile
+    //      simply runs both pairs.
+    {
+      float sv[2][2][4];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int row = 32 * p + 16 * s + ii;
-        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + row * KSB + go);
-        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + row * KSB + go);
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (!(SEPR_AT_ABL & 16)) {
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh, a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql, a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh, a, 0, 0, 0);
-        } else {
-          a[0] = (float)kh[0] + (float)kl[1];
+      for (int p = 0; p < 2; ++p) {
+        // S^T[key = 16 s + 4g + r][query ii] for the two 16-key halves s
+        f32x4 sc[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int row = 32 * p + 16 * s + ii;
+          const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + row * KSB + go);
+          const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + row * KSB + go);
+          f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (!(SEPR_AT_ABL & 16)) {
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh, a, 0, 0, 0);
+          } else {
+            a[0] = (float)kh[0] + (float)kl[1];
+          }
+          sc[s] = a;
         }
-        sc[s] = a;
+        // relative-position term: P^T[b][query], band row of (query ql, key kl) is bb + b, b = ql - kl + 31
+        const int bb = 16 * w - 32 * p + 32;
+#pragma unroll
+        for (int tb = 0; tb < ((SEPR_AT_ABL & 1) ? 0 : 3); ++tb) {
+          const int row = bb + 16 * tb + ii;                    // <= 126 except unused rows of the last tile
+          const int rc = row < NBAND ? row : NBAND - 1;
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bh + rc * KSB + go);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + rc * KSB + go);
+          f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, qh, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ql, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, qh, a, 0, 0, 0);
+          st4(psk + 16 * tb + 4 * g, make_float4(a[0], a[1], a[2], a[3]));   // rows b = 16 tb + 4g + r of this query
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int b0 = ii + 31 - 16 * s - 4 * g;              // b of key 16 s + 4g + 0; r steps down
+          const int jbase = j0 + 32 * p + 16 * s + 4 * g;
+          float bias[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bias[r] = (SEPR_AT_ABL & 1) ? 0.f : psk[b0 - r];       // unconditional: the reads issue back to back
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sv[p][s][r] = (jbase + r < Tp) ? sc[s][r] + bias[r] : -1e30f;
+        }
       }
-      // ---- relative-position term: P^T[b][query], band row of (query ql, key kl) is bb + b, b = ql - kl + 31 ---------
-      const int bb = 16 * w - 32 * p + 32;
+      float mx = -1e30f;
 #pragma unroll
-      for (int tb = 0; tb < ((SEPR_AT_ABL & 1) ? 0 : 3); ++tb) {
-        const int row = bb + 16 * tb + ii;                    // <= 126 except unused rows of the last tile
-        const int rc = row < NBAND ? row : NBAND - 1;
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bh + rc * KSB + go);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + rc * KSB + go);
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, qh, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ql, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, qh, a, 0, 0, 0);
-        st4(psk + 16 * tb + 4 * g, make_float4(a[0], a[1], a[2], a[3]));   // rows b = 16 tb + 4g + r of this query
-      }
-      float sv[2][4];
+      for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int b0 = ii + 31 - 16 * s - 4 * g;              // b of key 16 s + 4g + 0; r steps down
-        const int jbase = j0 + 32 * p + 16 * s + 4 * g;
-        float bias[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias[r] = (SEPR_AT_ABL & 1) ? 0.f : psk[b0 - r];       // unconditional: the reads issue back to back
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sv[s][r] = (jbase + r < Tp) ? sc[s][r] + bias[r] : -1e30f;
-      }
-      float mx = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
-                       fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
+        for (int s = 0; s < 2; ++s)
+          mx = fmaxf(mx, fmaxf(fmaxf(sv[p][s][0], sv[p][s][1]), fmaxf(sv[p][s][2], sv[p][s][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrun, mx);
       const float corr = __expf(mrun - mnew);
-      bf16x8 ph, pl;
+      bf16x8 ph[2], pl[2];
       float psum = 0.f;
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = (SEPR_AT_ABL & 2) ? sv[s][r] - mnew : __expf(sv[s][r] - mnew);
-          psum += pv;
-          const __bf16 hh = (__bf16)pv;
-          ph[4 * s + r] = hh;
-          pl[4 * s + r] = (__bf16)(pv - (float)hh);
-        }
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = (SEPR_AT_ABL & 2) ? sv[p][s][r] - mnew : __expf(sv[p][s][r] - mnew);
+            psum += pv;
+            const __bf16 hh = (__bf16)pv;
+            ph[p][4 * s + r] = hh;
+            pl[p][4 * s + r] = (__bf16)(pv - (float)hh);
+          }
       if (TRAIN && thr) {   // dropped probabilities for the PV product only; keys 16 s + 4g + {0,1} / {2,3} are the element pairs
         const unsigned row = (unsigned)((seq * gridDim.y + h) * Tp + i);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const unsigned jp = (unsigned)(j0 + 32 * p + 16 * s + 4 * g) >> 1;
-          const unsigned d0 = sepr_drop_word(dkey, row, jp), d1 = sepr_drop_word(dkey, row, jp + 1u);
-          const bool k0 = (d0 & 0xffffu) >= thr, k1 = (d0 >> 16) >= thr, k2 = (d1 & 0xffffu) >= thr, k3 = (d1 >> 16) >= thr;
-          if (!k0) { ph[4 * s] = (__bf16)0.f; pl[4 * s] = (__bf16)0.f; }
-          if (!k1) { ph[4 * s + 1] = (__bf16)0.f; pl[4 * s + 1] = (__bf16)0.f; }
-          if (!k2) { ph[4 * s + 2] = (__bf16)0.f; pl[4 * s + 2] = (__bf16)0.f; }
-          if (!k3) { ph[4 * s + 3] = (__bf16)0.f; pl[4 * s + 3] = (__bf16)0.f; }
-        }
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const unsigned jp = (unsigned)(j0 + 32 * p + 16 * s + 4 * g) >> 1;
+            const unsigned d0 = sepr_drop_word(dkey, row, jp), d1 = sepr_drop_word(dkey, row, jp + 1u);
+            const bool k0 = (d0 & 0xffffu) >= thr, k1 = (d0 >> 16) >= thr, k2 = (d1 & 0xffffu) >= thr, k3 = (d1 >> 16) >= thr;
+            if (!k0) { ph[p][4 * s] = (__bf16)0.f; pl[p][4 * s] = (__bf16)0.f; }
+            if (!k1) { ph[p][4 * s + 1] = (__bf16)0.f; pl[p][4 * s + 1] = (__bf16)0.f; }
+            if (!k2) { ph[p][4 * s + 2] = (__bf16)0.f; pl[p][4 * s + 2] = (__bf16)0.f; }
+            if (!k3) { ph[p][4 * s + 3] = (__bf16)0.f; pl[p][4 * s + 3] = (__bf16)0.f; }
+          }
       }
       lrun = lrun * corr + psum;
       mrun = mnew;
@@ -390,19 +420,22 @@ __global__ __launch_bounds__(256) void relattn_x3_kernel(const float* __restrict
 #pragma unroll
       for (int t = 0; t < OT; ++t) {
         o[t][0] *= corr; o[t][1] *= corr; o[t][2] *= corr; o[t][3] *= corr;
-        const __bf16* vh0 = Vh + (16 * t + ii) * VSB + 32 * p + 4 * g;
-        const __bf16* vl0 = Vl + (16 * t + ii) * VSB + 32 * p + 4 * g;
-        const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(vh0), a1 = *reinterpret_cast<const bf16x4*>(vh0 + 16);
-        const bf16x4 b0v = *reinterpret_cast<const bf16x4*>(vl0), b1v = *reinterpret_cast<const bf16x4*>(vl0 + 16);
-        const bf16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        const bf16x8 vl = {b0v[0], b0v[1], b0v[2], b0v[3], b1v[0], b1v[1], b1v[2], b1v[3]};
-        if (SEPR_AT_ABL & 8) {
-          o[t][0] += (float)vh[0] * (float)ph[0] + (float)vl[1] * (float)pl[1];
-          continue;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const __bf16* vh0 = Vh + (16 * t + ii) * VSB + 32 * p + 4 * g;
+          const __bf16* vl0 = Vl + (16 * t + ii) * VSB + 32 * p + 4 * g;
+          const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(vh0), a1 = *reinterpret_cast<const bf16x4*>(vh0 + 16);
+          const bf16x4 b0v = *reinterpret_cast<const bf16x4*>(vl0), b1v = *reinterpret_cast<const bf16x4*>(vl0 + 16);
+          const bf16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          const bf16x8 vl = {b0v[0], b0v[1], b0v[2], b0v[3], b1v[0], b1v[1], b1v[2], b1v[3]};
+          if (SEPR_AT_ABL & 8) {
+            o[t][0] += (float)vh[0] * (float)ph[p][0] + (float)vl[1] * (float)pl[p][1];
+            continue;
+          }
+          o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph[p], o[t], 0, 0, 0);
+          o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl[p], o[t], 0, 0, 0);
+          o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph[p], o[t], 0, 0, 0);
         }
-        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[t], 0, 0, 0);
-        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[t], 0, 0, 0);
-        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[t], 0, 0, 0);
       }
     }
   }
@@ -436,16 +469,18 @@ int launch_relattn_x3_train_fwd(const float* QKV, float* O, float* lse, int n, i
 }
 
 int launch_relattn(const float* QKV, float* O, int n, int Tp, int F, int H, const float* pe_k, int maxlen, int x3,
-                   hipStream_t s) {
+                   hipStream_t s, const void* pe_planes) {
   if (n <= 0 || Tp <= 0) return SEPR_OK;
   if (H <= 0 || F % H != 0 || maxlen <= 0 || !pe_k || n > 65535) return SEPR_EINVAL;
   const int dk = F / H;
   const dim3 grid((Tp + 63) / 64, H, n);
   const float isd = 1.0f / sqrtf((float)dk);
   if (dk == 16 && x3) {
-    hipLaunchKernelGGL((relattn_x3_kernel<16>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd);
+    hipLaunchKernelGGL((relattn_x3_kernel<16>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, (float*)nullptr, 0u, 1.0f, 0ull,
+                       (const unsigned long long*)nullptr, static_cast<const unsigned short*>(pe_planes));
   } else if (dk == 32 && x3) {
-    hipLaunchKernelGGL((relattn_x3_kernel<32>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd);
+    hipLaunchKernelGGL((relattn_x3_kernel<32>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, (float*)nullptr, 0u, 1.0f, 0ull,
+                       (const unsigned long long*)nullptr, static_cast<const unsigned short*>(pe_planes));
   } else if (dk == 16) {
     hipLaunchKernelGGL((relattn_kernel<16>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd);
   } else if (dk == 32) {

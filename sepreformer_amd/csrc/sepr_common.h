@@ -42,6 +42,9 @@ __device__ __forceinline__ float sigmoid_f(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
+// IEEE-division sigmoid of the training path's row-wise kernels (their backward formulas use sig (1 - sig))
+__device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
+
 // GLU on a gate that arrives PRE-SCALED by -log2(e) (the packers fold the factor into the gate's conv taps and bias):
 // value * sigmoid(gate) = value * rcp(1 + exp2(gs)), one multiply less per hidden element than sigmoid_f
 __device__ __forceinline__ float glu_prescaled(float val, float gs) {
@@ -63,6 +66,29 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// ---- dropout generator pieces shared by the training kernels and the projection epilogues (documented in sepr_train.h) ----
+__device__ __forceinline__ unsigned long long sepr_mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned sepr_hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+struct DropKey { unsigned ka, kb; };
+__device__ __forceinline__ DropKey sepr_drop_key(unsigned long long seed, const unsigned long long* salt, unsigned site) {
+  const unsigned long long z = sepr_mix64(seed ^ (salt ? *salt : 0ull) ^ ((unsigned long long)(site + 1) << 56));
+  DropKey k;
+  k.ka = (unsigned)z;
+  k.kb = (unsigned)(z >> 32);
+  return k;
+}
+__device__ __forceinline__ unsigned sepr_drop_word(DropKey k, unsigned row, unsigned pair) {
+  return sepr_hash32((row * 0x9E3779B1u + k.ka) ^ (pair * 0x85EBCA77u + k.kb));
 }
 
 // ---- host side ------------------------------------------------------------------------------------

@@ -66,7 +66,12 @@ __device__ __forceinline__ float dpp_rol1(float v) {   // lane i <- lane (i+1) m
 // ---------------------------------------------------------------------------------------------------------
 #ifndef SEPR_GF_ABL
 #define SEPR_GF_ABL 0   // timing ablations (wrong results): 1 no chunk loop, 2 weight chunks copied once per tile,
-                        // 4 no chunk barriers, 8 one LDS fragment read per chunk, 16 no exp/rcp in the GLU
+                        // 4 no chunk barriers, 8 one LDS fragment read per chunk, 16 no exp/rcp in the GLU,
+                        // 32 / 64: PROXY of "fold the depthwise conv into the up-projection" (round-3 review item 6: three
+                        //   K = F MFMA passes against tap-scaled weights, the conv becomes two neighbour adds): the up-projection's
+                        //   MFMAs, its LDS fragment reads and the W1 chunk copy run THREE times, the conv keeps its neighbour
+                        //   exchange but uses adds instead of tap FMAs (32), or drops the exchange as well (64: the most
+                        //   optimistic bound - no DPP at all)
 #endif
 template <bool V>
 struct bool_c { static constexpr bool value = V; };
@@ -171,6 +176,10 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
   auto dma_w1 = [&](int c) {
     if constexpr (ONE) dma_hi(W1g + (long long)c * W1_U4, wl, W1F_U4 / 64);
     else dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / 64);
+    if (SEPR_GF_ABL & 96) {   // fold proxy: three tap-scaled weight sets = three times the up-projection copy volume
+      dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / 64);
+      dma(W1g + (long long)c * W1_U4, wl, W1F_U4 / 64);
+    }
     dma(W1g + (long long)c * W1_U4 + W1F_U4, csl + (c & 1) * CS_U4, CS_U4 / 64);
   };
   auto dma_w2 = [&](int c) {
@@ -311,7 +320,10 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
           }
           if (SEPR_GF3_PRIO) __builtin_amdgcn_s_setprio(1);   // MFMA phases win the issue arbitration over the
 #pragma unroll                                                 // other workgroup's VALU phases
+          for (int rep3 = 0; rep3 < ((SEPR_GF_ABL & 96) ? 3 : 1); ++rep3)
+#pragma unroll
           for (int g = 0; g < 2 * KS; ++g) {
+            if ((SEPR_GF_ABL & 96) && rep3 > 0 && g < RD) ld_up(j, g, fb[g % (RD + 1)]);   // (proxy: each pass re-reads its fragments)
             if (g + RD < 2 * KS) ld_up(j, g + RD, fb[(g + RD) % (RD + 1)]);
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[g % (RD + 1)][0]);
@@ -426,8 +438,10 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
             for (int mt = 0; mt < MT; ++mt) {
               const float a0v = EDGE ? wv0 * f0[mt] : wv0, a2v = EDGE ? wv2 * f2[mt] : wv2;
               const float a0g = EDGE ? wg0 * f0[mt] : wg0, a2g = EDGE ? wg2 * f2[mt] : wg2;
-              const float val = fmaf(a2v, nv[mt], fmaf(wv1, cv[mt], fmaf(a0v, pv[mt], cbv)));
-              const float gat = fmaf(a2g, ng[mt], fmaf(wg1, cg[mt], fmaf(a0g, pg[mt], cbg)));
+              float val = fmaf(a2v, nv[mt], fmaf(wv1, cv[mt], fmaf(a0v, pv[mt], cbv)));
+              float gat = fmaf(a2g, ng[mt], fmaf(wg1, cg[mt], fmaf(a0g, pg[mt], cbg)));
+              if (SEPR_GF_ABL & 32) { val = (cv[mt] + pv[mt]) + nv[mt]; gat = (cg[mt] + pg[mt]) + ng[mt]; }
+              if (SEPR_GF_ABL & 64) { val = cv[mt] + cv[mt]; gat = cg[mt] + cg[mt]; }
               gl[mt][r] = (SEPR_GF_ABL & 16) ? val * gat : glu_prescaled(val, gat);   // 16: no transcendentals (gate taps are pre-scaled)
             }
           }

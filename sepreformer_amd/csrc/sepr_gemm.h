@@ -51,7 +51,7 @@ constexpr int GEMM_BK = 32, GEMM_LDS_STRIDE = GEMM_BK + SEPR_GEMM_LDS_PAD;
 template <int PRO, int EPI, int TAG = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a) {
   constexpr bool DWGLU = (EPI == EPI_DWGLU);
-  constexpr bool GLU = (EPI == EPI_GLU) || DWGLU;   // value / gate column pairing of the weight tile
+  constexpr bool GLU = (EPI == EPI_GLU) || (EPI == EPI_GLUSAVE) || DWGLU;   // value / gate column pairing of the weight tile
   constexpr int ROWS_OUT = DWGLU ? GEMM_DW_ROWS : GEMM_BM;
   constexpr int LS = GEMM_LDS_STRIDE;
   __shared__ __attribute__((aligned(16))) float smem[2 * (GEMM_BM + GEMM_BN) * LS];

@@ -66,7 +66,9 @@ static void launch_inst(const GemmArgs& a, hipStream_t stream) {
 int launch_gemm(int pro, int epi, const GemmArgs& a, int site, hipStream_t stream) {
   if (a.M <= 0) return SEPR_OK;
   if (a.N <= 0 || a.K <= 0 || (a.K % GEMM_BK) != 0 || (a.N % 4) != 0) return SEPR_EINVAL;
-  if (epi == EPI_GLU && ((a.N / 2) % 4) != 0) return SEPR_EINVAL;
+  if ((epi == EPI_GLU || epi == EPI_GLUSAVE) && ((a.N / 2) % 4) != 0) return SEPR_EINVAL;
+  if (epi == EPI_GLUSAVE && !a.Ysave) return SEPR_EINVAL;
+  if (epi == EPI_RESDROP && a.drop_thr == 0u) return SEPR_EINVAL;
   if (!a.A || !a.W || !a.Y) return SEPR_EINVAL;
   if ((a.lda % 4) != 0 || (a.ldc % 4) != 0) return SEPR_EINVAL;
   if (pro == PRO_CAT2 && (!a.A2 || (a.ksplit % GEMM_BK) != 0 || (a.lda2 % 4) != 0)) return SEPR_EINVAL;
@@ -77,7 +79,7 @@ int launch_gemm(int pro, int epi, const GemmArgs& a, int site, hipStream_t strea
     if (src_rows * a.lda >= (1LL << 32) || (long long)a.N * a.K >= (1LL << 32)) return SEPR_EINVAL;
     if (pro == PRO_CAT2 && (long long)a.M * a.lda2 >= (1LL << 32)) return SEPR_EINVAL;
   }
-  if ((epi == EPI_GLU || epi == EPI_DWGLU) && !a.bias) return SEPR_EINVAL;
+  if ((epi == EPI_GLU || epi == EPI_GLUSAVE || epi == EPI_DWGLU) && !a.bias) return SEPR_EINVAL;
   if (epi == EPI_DWGLU && (!a.dw_w || !a.dw_b || a.T <= 0 || ((a.N / 2) % 4) != 0)) return SEPR_EINVAL;
   if (epi == EPI_LNBWD && (a.N > GEMM_BN || !a.aux || !a.stats || (a.aux2 && (a.T <= 0 || a.Tp <= 0 || a.fac <= 0)))) return SEPR_EINVAL;
 
@@ -102,6 +104,8 @@ int launch_gemm(int pro, int epi, const GemmArgs& a, int site, hipStream_t strea
     case PRO_NORM * 16 + EPI_GLU:    launch_inst<PRO_NORM, EPI_GLU>(a, stream); break;
     case PRO_NORM * 16 + EPI_GATE:   launch_inst<PRO_NORM, EPI_GATE>(a, stream); break;
     case PRO_CAT2 * 16 + EPI_STORE:  launch_inst<PRO_CAT2, EPI_STORE>(a, stream); break;
+    case PRO_NORM * 16 + EPI_GLUSAVE: launch_inst<PRO_NORM, EPI_GLUSAVE>(a, stream); break;
+    case PRO_PLAIN * 16 + EPI_RESDROP: launch_inst<PRO_PLAIN, EPI_RESDROP>(a, stream); break;
     default: return SEPR_EINVAL;
   }
   if (timed) prof_end(slot, 2.0 * (double)a.M * (double)a.N * (double)a.K, stream);

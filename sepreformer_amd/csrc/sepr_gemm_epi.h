@@ -6,7 +6,10 @@
 namespace sepr {
 
 enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_CAT2 = 2 };
-enum { EPI_STORE = 0, EPI_GLU = 1, EPI_GELU = 2, EPI_RES = 3, EPI_GATE = 4, EPI_SPLIT = 5, EPI_MASK = 6, EPI_DWGLU = 7, EPI_LNBWD = 8 };
+enum { EPI_STORE = 0, EPI_GLU = 1, EPI_GELU = 2, EPI_RES = 3, EPI_GATE = 4, EPI_SPLIT = 5, EPI_MASK = 6, EPI_DWGLU = 7, EPI_LNBWD = 8,
+       // training only (their own kinds, so that the inference instantiations of EPI_GLU / EPI_RES compile to the same code as before):
+       EPI_GLUSAVE = 9,    // EPI_GLU that also stores the pre-activation rows [M][N] to Ysave (the GLU backward needs both halves)
+       EPI_RESDROP = 10 }; // EPI_RES with inverted dropout on (acc + bias) before LayerScale + residual (16-bit generator, sepr_drop_word)
 
 struct GemmArgs {
   int M, N, K;
@@ -52,6 +55,13 @@ struct GemmArgs {
   //   Y[m] = (R ? R[m] : 0) + rstd_m (dxh - mean_f dxh - xh mean_f (dxh xh)) + (aux2 ? aux2[(m / T) Tp + (m % T) / fac] / fac : 0)
   // with xh = (aux[m] - mean_m) rstd_m, (mean, rstd) = stats[2m..]; aux = the LayerNorm's input x, aux2 = a pooled gradient (EGA)
   const float* aux2;
+  // EPI_GLUSAVE: pre-activation rows (value | gate, bias added) [M][N], leading dimension N
+  float* Ysave;
+  // EPI_RESDROP: element (m, col) is kept iff its 16-bit draw of sepr_drop_word(key(seed, salt, site), m, col >> 1) >= drop_thr
+  unsigned drop_thr, drop_site;
+  float drop_scale;
+  unsigned long long drop_seed;
+  const unsigned long long* drop_salt;
 };
 
 
@@ -62,7 +72,7 @@ constexpr int GEMM_DW_ROWS = GEMM_BM - 2;
 constexpr int GEMM_HS = GEMM_BN + 4;   // row stride (floats) of the LDS-staged accumulator tile
 
 inline int gemm_tiles(const GemmArgs& a, int epi) {
-  const bool glu = (epi == EPI_GLU) || (epi == EPI_DWGLU);
+  const bool glu = (epi == EPI_GLU) || (epi == EPI_GLUSAVE) || (epi == EPI_DWGLU);
   const int rows = (epi == EPI_DWGLU) ? GEMM_DW_ROWS : GEMM_BM;
   const int NB = glu ? (a.N / 2 + 63) / 64 : (a.N + GEMM_BN - 1) / GEMM_BN;
   const int MB = (a.M + rows - 1) / rows;
@@ -188,7 +198,7 @@ __device__ __forceinline__ void epilogue_from_lds(const GemmArgs& a, const float
         }
       }
     }
-  } else if (EPI == EPI_GLU) {
+  } else if (EPI == EPI_GLU || EPI == EPI_GLUSAVE) {
     const int q4 = tid & 15, rg = tid >> 4;       // 16 float4 columns (64 outputs) x 16 strips of 8 rows
     const int ncol = nb * 64 + 4 * q4;
     if (ncol >= a.N / 2) return;
@@ -199,6 +209,10 @@ __device__ __forceinline__ void epilogue_from_lds(const GemmArgs& a, const float
       const int m = m0 + r;
       if (m >= a.M) break;
       const float4 v = ld4(Hs + r * HS + 4 * q4), g = ld4(Hs + r * HS + 64 + 4 * q4);
+      if (EPI == EPI_GLUSAVE) {   // the same (acc + bias) values the GLU below consumes
+        st4(a.Ysave + (long long)m * a.N + ncol, make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w));
+        st4(a.Ysave + (long long)m * a.N + a.N / 2 + ncol, make_float4(g.x + bg.x, g.y + bg.y, g.z + bg.z, g.w + bg.w));
+      }
       st4(a.Y + (long long)m * a.ldc + ncol,
           make_float4((v.x + bv.x) * sigmoid_f(g.x + bg.x), (v.y + bv.y) * sigmoid_f(g.y + bg.y),
                       (v.z + bv.z) * sigmoid_f(g.z + bg.z), (v.w + bv.w) * sigmoid_f(g.w + bg.w)));
@@ -209,14 +223,19 @@ __device__ __forceinline__ void epilogue_from_lds(const GemmArgs& a, const float
     if (ncol >= a.N) return;
     const float4 bias = a.bias ? ld4(a.bias + ncol) : zero4();
     float4 lsv = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (EPI == EPI_RES && a.ls) lsv = ld4(a.ls + ncol);
+    if ((EPI == EPI_RES || EPI == EPI_RESDROP) && a.ls) lsv = ld4(a.ls + ncol);
+    DropKey dkey = {0u, 0u};
+    if (EPI == EPI_RESDROP) {
+      dkey = sepr_drop_key(a.drop_seed, a.drop_salt, a.drop_site);
+      lsv.x *= a.drop_scale; lsv.y *= a.drop_scale; lsv.z *= a.drop_scale; lsv.w *= a.drop_scale;   // keep scale rides in the LayerScale
+    }
     const int split_s = (EPI == EPI_SPLIT) ? ncol / a.Fs : 0;
     const int split_f = (EPI == EPI_SPLIT) ? ncol - split_s * a.Fs : 0;
     // Rows go in batches of 8: the side operands of a batch (residual, gate inputs, encoder frames) are
     // requested together from clamped, branch-free addresses BEFORE any of them is consumed, so a tile pays two
     // global-load latencies instead of sixteen (a load guarded by "row < M" cannot be hoisted above the guard of
     // the previous row; that serialisation was ~40 % of these kernels).  Only the stores are predicated.
-    const bool has_r = (EPI != EPI_RES) || a.R != nullptr;
+    const bool has_r = (EPI != EPI_RES && EPI != EPI_RESDROP) || a.R != nullptr;
 #pragma unroll
     for (int ib = 0; ib < 16; ib += 8) {
       if (m0 + rg * 16 + ib >= a.M) break;          // whole batch past the last row
@@ -227,7 +246,7 @@ __device__ __forceinline__ void epilogue_from_lds(const GemmArgs& a, const float
         const int m = mr < a.M ? mr : a.M - 1;
         s1[i] = zero4();
         s2[i] = zero4();
-        if (EPI == EPI_RES) {
+        if (EPI == EPI_RES || EPI == EPI_RESDROP) {
           if (has_r) s1[i] = ld4(a.R + (long long)m * a.ldc + ncol);
         } else if (EPI == EPI_GATE) {
           const int seq = m / a.T;
@@ -252,7 +271,14 @@ __device__ __forceinline__ void epilogue_from_lds(const GemmArgs& a, const float
             st4(out, v);
           } else if (EPI == EPI_GELU) {
             st4(out, make_float4(gelu_exact(v.x), gelu_exact(v.y), gelu_exact(v.z), gelu_exact(v.w)));
-          } else if (EPI == EPI_RES) {
+          } else if (EPI == EPI_RES || EPI == EPI_RESDROP) {
+            if (EPI == EPI_RESDROP) {   // reference network.py:171,187 (CLA) under train(): Dropout on the projection's output
+              const unsigned d0 = sepr_drop_word(dkey, (unsigned)m, (unsigned)(ncol >> 1)), d1 = sepr_drop_word(dkey, (unsigned)m, (unsigned)(ncol >> 1) + 1u);
+              v.x = (d0 & 0xffffu) >= a.drop_thr ? v.x : 0.f;
+              v.y = (d0 >> 16) >= a.drop_thr ? v.y : 0.f;
+              v.z = (d1 & 0xffffu) >= a.drop_thr ? v.z : 0.f;
+              v.w = (d1 >> 16) >= a.drop_thr ? v.w : 0.f;
+            }
             if (has_r) {
               const float4 rr = s1[i];
               v.x = fmaf(v.x, lsv.x, rr.x); v.y = fmaf(v.y, lsv.y, rr.y);

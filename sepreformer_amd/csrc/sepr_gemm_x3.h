@@ -48,7 +48,7 @@ constexpr int X3_PLANE = GEMM_BM * X3_LDK;  // elements of one plane of one buff
 template <int PRO, int EPI, int TAG = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs a) {
   constexpr bool DWGLU = (EPI == EPI_DWGLU);
-  constexpr bool GLU = (EPI == EPI_GLU) || DWGLU;
+  constexpr bool GLU = (EPI == EPI_GLU) || (EPI == EPI_GLUSAVE) || DWGLU;
   // TAG bit 4: plain bf16 operands ("bf16" training precision): activations rounded to bf16 (hi plane only), weights'
   // hi plane only, ONE MFMA per product instead of three; everything else (staging, tile walk, epilogues) is shared
   constexpr bool ONE = (TAG & 16) != 0;

@@ -29,7 +29,7 @@ template <int PRO, int EPI, int TAG = 0>
 static void launch_x3_inst(const GemmArgs& a, hipStream_t stream) {
   const int cap = x3_grid_cap();
   if constexpr (EPI != EPI_LNBWD) {
-    const bool glu = (EPI == EPI_GLU) || (EPI == EPI_DWGLU);
+    const bool glu = (EPI == EPI_GLU) || (EPI == EPI_GLUSAVE) || (EPI == EPI_DWGLU);
     const int NB = glu ? (a.N / 2 + 63) / 64 : (a.N + GEMM_BN - 1) / GEMM_BN;
     const int wmode = x3_wide_mode();
     const int wtiles = gemm_tiles_wide(a, EPI);
@@ -47,7 +47,9 @@ static void launch_x3_inst(const GemmArgs& a, hipStream_t stream) {
 int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t stream) {
   if (a.M <= 0) return SEPR_OK;
   if (a.N <= 0 || a.K <= 0 || (a.K % X3_BKS) != 0 || (a.N % 16) != 0) return SEPR_EINVAL;
-  const bool glu = (epi == EPI_GLU || epi == EPI_DWGLU);
+  const bool glu = (epi == EPI_GLU || epi == EPI_GLUSAVE || epi == EPI_DWGLU);
+  if (epi == EPI_GLUSAVE && !a.Ysave) return SEPR_EINVAL;
+  if (epi == EPI_RESDROP && a.drop_thr == 0u) return SEPR_EINVAL;
   if (glu && (((a.N / 2) % 16) != 0 || !a.bias)) return SEPR_EINVAL;
   if (!a.A || !a.Wp || !a.Y) return SEPR_EINVAL;
   if ((a.lda % 4) != 0 || (a.ldc % 4) != 0) return SEPR_EINVAL;
@@ -79,6 +81,8 @@ int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t st
       case PRO_PLAIN * 16 + EPI_LNBWD: launch_x3_inst<PRO_PLAIN, EPI_LNBWD, 16>(a, stream); break;
       case PRO_NORM * 16 + EPI_STORE:  launch_x3_inst<PRO_NORM, EPI_STORE, 16>(a, stream); break;
       case PRO_CAT2 * 16 + EPI_STORE:  launch_x3_inst<PRO_CAT2, EPI_STORE, 16>(a, stream); break;
+      case PRO_NORM * 16 + EPI_GLUSAVE: launch_x3_inst<PRO_NORM, EPI_GLUSAVE, 16>(a, stream); break;
+      case PRO_PLAIN * 16 + EPI_RESDROP: launch_x3_inst<PRO_PLAIN, EPI_RESDROP, 16>(a, stream); break;
       default: SEPR_X3_BAD_KEY;
     }
   } else if (site == SEPR_SITE_GCFN_UP && key == PRO_NORM * 16 + EPI_DWGLU) {
@@ -98,6 +102,8 @@ int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t st
     case PRO_NORM * 16 + EPI_GLU:    launch_x3_inst<PRO_NORM, EPI_GLU>(a, stream); break;
     case PRO_NORM * 16 + EPI_GATE:   launch_x3_inst<PRO_NORM, EPI_GATE>(a, stream); break;
     case PRO_CAT2 * 16 + EPI_STORE:  launch_x3_inst<PRO_CAT2, EPI_STORE>(a, stream); break;
+    case PRO_NORM * 16 + EPI_GLUSAVE: launch_x3_inst<PRO_NORM, EPI_GLUSAVE>(a, stream); break;
+    case PRO_PLAIN * 16 + EPI_RESDROP: launch_x3_inst<PRO_PLAIN, EPI_RESDROP>(a, stream); break;
     default: SEPR_X3_BAD_KEY;
   }
 #undef SEPR_X3_BAD_KEY

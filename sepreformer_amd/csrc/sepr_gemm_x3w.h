@@ -28,7 +28,7 @@ constexpr int XW_PLANE = GEMM_BM * XW_LDK;       // elements of one plane of one
 template <int PRO, int EPI, int TAG = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_kernel(const GemmArgs a) {
   constexpr bool DWGLU = (EPI == EPI_DWGLU);
-  constexpr bool GLU = (EPI == EPI_GLU) || DWGLU;
+  constexpr bool GLU = (EPI == EPI_GLU) || (EPI == EPI_GLUSAVE) || DWGLU;
   constexpr bool ONE = (TAG & 16) != 0;          // plain bf16 operands (training precision "bf16")
   constexpr bool A16 = (TAG & 32) != 0;          // the A operand is a bf16 tensor
   static_assert(EPI != EPI_LNBWD, "the LayerNorm-backward epilogue needs whole rows in one 128-column tile");
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_kernel(const GemmArg
 }
 
 inline int gemm_tiles_wide(const GemmArgs& a, int epi) {
-  const bool glu = (epi == EPI_GLU) || (epi == EPI_DWGLU);
+  const bool glu = (epi == EPI_GLU) || (epi == EPI_GLUSAVE) || (epi == EPI_DWGLU);
   const int rows = (epi == EPI_DWGLU) ? GEMM_DW_ROWS : GEMM_BM;
   const int NB = glu ? (a.N / 2 + 63) / 64 : (a.N + GEMM_BN - 1) / GEMM_BN;
   const int MB = (a.M + rows - 1) / rows;

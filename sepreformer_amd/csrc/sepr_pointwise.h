@@ -24,6 +24,8 @@ int launch_dwglu(const float* H, float* G, int n, int T, int F, const float* w, 
 
 // CLA middle: depthwise 'same' conv (K odd, K <= 65) along frames.  U [n,T,F] -> C [n,T,F]
 int launch_dwconv_same(const float* U, float* C, int n, int T, int F, int K, const float* w, const float* b, hipStream_t s);
+int launch_dwconv_same_glu_bwd(const float* dc, const float* a, float* da, int n, int T, int F, int K, const float* w, const float* zero_bias,
+                               hipStream_t s);
 
 // DownConv: depthwise K=5 stride 2 + folded BN + GELU.  X [n,T,F] -> Y [n,To,F]
 int launch_downconv(const float* X, float* Y, int n, int T, int To, int F, int K, const float* w,
@@ -42,7 +44,8 @@ int launch_decoder(const float* O2, int nS, int S, int L, int N, int K, int stri
                    int Tout, const int* idx, int Tsrc, const float* enc, hipStream_t s);
 
 // EGA attention with relative-position bias.  QKV [n,Tp,3F] -> O [n,Tp,F]
+// pe_planes (optional, x3 only): pe_k pre-split into bf16 planes [2: hi, lo][2*maxlen][F/H] (sepr_ega_w.pe_k_planes)
 int launch_relattn(const float* QKV, float* O, int n, int Tp, int F, int H, const float* pe_k, int maxlen, int x3,
-                   hipStream_t s);
+                   hipStream_t s, const void* pe_planes = nullptr);
 
 }  // namespace sepr

@@ -424,10 +424,14 @@ __global__ __launch_bounds__(TPB) void dwconv_same_kernel(const float* __restric
 // dwconv_same_kernel, so the two kernels agree bit for bit.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int KW>
+// GLUB (training, CLA backward): the conv's output du [rows][F] (the gradient w.r.t. the GLU output) does not go to HBM - the epilogue is
+// the GLU backward: with the saved pre-activation rows A [rows][2F] (value | gate), DA [rows][2F] = (du sig(g), du v sig(g) (1 - sig(g)))
+// (glu_bwd_kernel's arithmetic); C is unused.
+template <int KW, bool GLUB = false>
 __global__ __launch_bounds__(256, 2) void dwconv_same_pk_kernel(const float* __restrict__ U, float* __restrict__ C, int T, int F,
                                                                int tiles_per_seq, int ntiles, const float* __restrict__ w,
-                                                               const float* __restrict__ b) {
+                                                               const float* __restrict__ b, const float* __restrict__ A = nullptr,
+                                                               float* __restrict__ DA = nullptr) {
   constexpr int HALO = KW / 2, TT = 128, ROWS = TT + KW - 1, CH = 64, OPT = 16, NT = 256, NWV = NT / 64;
   static_assert(ROWS % (4 * NWV) == 0, "DMA loop: 4 waves x 4 rows per instruction");
   __shared__ __attribute__((aligned(16))) float tile[ROWS * CH];
@@ -510,10 +514,33 @@ __global__ __launch_bounds__(256, 2) void dwconv_same_pk_kernel(const float* __r
         for (int o = 0; o < 15; ++o) acc[o] = __builtin_elementwise_fma(wl, xc[o], acc[o]);
         acc[15] = __builtin_elementwise_fma(wl, xl, acc[15]);
       }
-      float* dst = C + ((long long)seq * T + t0 + rb) * F + c0 + cp;
+      if constexpr (GLUB) {
+        const long long row0 = (long long)seq * T + t0 + rb;
+        const float* ap = A + row0 * 2 * F + c0 + cp;
+        float* dp = DA + row0 * 2 * F + c0 + cp;
+        f32x2 av[OPT], ag[OPT];
 #pragma unroll
-      for (int o = 0; o < OPT; ++o)
-        if (t0 + rb + o < T) *reinterpret_cast<f32x2*>(dst + (long long)o * F) = acc[o];
+        for (int o = 0; o < OPT; ++o) {        // clamped rows: all loads issue back to back
+          const long long ro = (t0 + rb + o < T) ? o : 0;
+          av[o] = *reinterpret_cast<const f32x2*>(ap + ro * 2 * F);
+          ag[o] = *reinterpret_cast<const f32x2*>(ap + ro * 2 * F + F);
+        }
+#pragma unroll
+        for (int o = 0; o < OPT; ++o) {
+          if (t0 + rb + o < T) {
+            const float s0 = sigmoid_exact(ag[o][0]), s1 = sigmoid_exact(ag[o][1]);
+            const f32x2 dv = {acc[o][0] * s0, acc[o][1] * s1};
+            const f32x2 dg = {acc[o][0] * av[o][0] * s0 * (1.f - s0), acc[o][1] * av[o][1] * s1 * (1.f - s1)};
+            *reinterpret_cast<f32x2*>(dp + (long long)o * 2 * F) = dv;
+            *reinterpret_cast<f32x2*>(dp + (long long)o * 2 * F + F) = dg;
+          }
+        }
+      } else {
+        float* dst = C + ((long long)seq * T + t0 + rb) * F + c0 + cp;
+#pragma unroll
+        for (int o = 0; o < OPT; ++o)
+          if (t0 + rb + o < T) *reinterpret_cast<f32x2*>(dst + (long long)o * F) = acc[o];
+      }
     }
     __syncthreads();   // tile fully consumed before the next DMA overwrites it
   }
@@ -535,6 +562,22 @@ int launch_dwconv_same(const float* U, float* C, int n, int T, int F, int K, con
     hipLaunchKernelGGL((dwconv_same_kernel<65, 64>), dim3(tiles * (F / 64), n), dim3(TPB), 0, s, U, C, T, F, w, b);
   }
   SEPR_CHECK_LAUNCH("dwconv_same_kernel");
+  return SEPR_OK;
+}
+
+// CLA backward: da [rows][2F] = GLU'(a) applied to du = depthwise_k65(dc) (taps w: the forward taps reversed; no bias) - the conv's
+// output never reaches HBM (round 4; replaces launch_dwconv_same + launch_glu_bwd and the [rows][F] round trip between them)
+int launch_dwconv_same_glu_bwd(const float* dc, const float* a, float* da, int n, int T, int F, int K, const float* w, const float* zero_bias,
+                               hipStream_t s) {
+  if (n <= 0 || T <= 0) return SEPR_OK;
+  if (K != 65 || F % 128 != 0 || !dc || !a || !da || !w || !zero_bias) return SEPR_EINVAL;
+  const int tiles = (T + 127) / 128;
+  const long long nt = (long long)tiles * n * (F / 64);
+  if (nt > 0x7fffffffLL) return SEPR_EINVAL;
+  const int cap = persistent_grid();
+  const int grid = (int)(nt < cap ? nt : cap);
+  hipLaunchKernelGGL((dwconv_same_pk_kernel<65, true>), dim3(grid), dim3(256), 0, s, dc, nullptr, T, F, tiles, (int)nt, w, zero_bias, a, da);
+  SEPR_CHECK_LAUNCH("dwconv_same_pk_kernel<glu_bwd>");
   return SEPR_OK;
 }
 

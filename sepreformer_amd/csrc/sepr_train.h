@@ -10,12 +10,6 @@ namespace sepr {
 // ---- dropout generator (shared by every dropout site of the training path) ---------------------------------------------
 // Counter-based: one 64-bit mix (splitmix64 finaliser) of (seed, element index) per element - stateless, so the backward
 // regenerates the mask of any element from the same (seed, index) without storing it.
-__device__ __forceinline__ unsigned long long sepr_mix64(unsigned long long z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
 __device__ __forceinline__ bool sepr_keep(unsigned long long seed, unsigned long long index, unsigned int thr) {
   return (unsigned int)(sepr_mix64(seed ^ sepr_mix64(index)) >> 32) >= thr;
 }
@@ -42,21 +36,7 @@ inline unsigned int sepr_drop_threshold(float p) {
 // element (~30 instructions) would double its VALU stream.  Here one 32-bit hash (lowbias32) of (site key, row, channel
 // pair) yields TWO 16-bit draws, ~6 instructions per element; element (row, c) of a site is kept iff its 16-bit draw
 // (low half for even c) >= thr16 = round(p * 65536), so p_eff = thr16 / 65536 and the keep scale is 65536 / (65536 - thr16).
-__device__ __forceinline__ unsigned sepr_hash32(unsigned x) {
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-  return x;
-}
-struct DropKey { unsigned ka, kb; };
-__device__ __forceinline__ DropKey sepr_drop_key(unsigned long long seed, const unsigned long long* salt, unsigned site) {
-  const unsigned long long z = sepr_mix64(seed ^ (salt ? *salt : 0ull) ^ ((unsigned long long)(site + 1) << 56));
-  DropKey k;
-  k.ka = (unsigned)z;
-  k.kb = (unsigned)(z >> 32);
-  return k;
-}
-__device__ __forceinline__ unsigned sepr_drop_word(DropKey k, unsigned row, unsigned pair) {
-  return sepr_hash32((row * 0x9E3779B1u + k.ka) ^ (pair * 0x85EBCA77u + k.kb));
-}
+// (sepr_hash32, DropKey, sepr_drop_key, sepr_drop_word live in sepr_common.h: the projection epilogues use them too)
 inline unsigned sepr_drop_thr16(float p) {
   const double t = (double)p * 65536.0 + 0.5;
   return t <= 0.0 ? 0u : (t >= 65535.0 ? 65535u : (unsigned)t);
@@ -180,6 +160,9 @@ int launch_res_ls(const float* x, const float* v, const float* ls, float* y, lon
 // inverted dropout with a counter-based generator: y[i] = keep(seed, offset + i) ? x[i] / (1 - p) : 0 (in place allowed)
 int launch_dropout(const float* x, float* y, long long count, float p, unsigned long long seed, unsigned long long offset,
                    hipStream_t s);
+
+// the same with the 16-bit generator of the fused epilogues (EPI_RESDROP): y[m][c] = keep16(seed, site, m, c) ? x[m][c] * scale16 : 0
+int launch_dropout16(const float* x, float* y, long long M, int F, float p, unsigned long long seed, unsigned site, hipStream_t s);
 
 // ---- waveform ends (encoder / decoder) -------------------------------------------------------------------------------
 // dwav [S,B,Tout] -> dwp [B*S,Tout] (sequence order b*S + s, the order of every decoder-side tensor)

@@ -238,6 +238,7 @@ int gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, co
 // =====================================================================================================================
 // CLA  (network.py:159-187), train-mode BatchNorm
 // =====================================================================================================================
+constexpr unsigned CLA_DROP_SITE = 3u;   // 16-bit generator site of the CLA output dropout (0, 1: fused GCFN; 2: attention probabilities)
 struct ClaCtx { float *stats, *a, *u, *c, *z, *bn, *d; };
 ClaCtx cla_ctx(Carve& cx, long long M, int F) {
   ClaCtx k;
@@ -256,19 +257,26 @@ int cla_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_cla
   ClaCtx k = cla_ctx(cx, M, F);
   const size_t csb = colstats_ws(M, 2 * F);
   void* csw = ws.take(csb);
-  float* out = p > 0.f ? ws.f32((long long)F * M) : nullptr;
   if (cx.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
   SEPR_TRY(launch_rowstats(x, k.stats, M, F, LN_EPS_T, st));
-  SEPR_TRY(normed(x, F, k.stats, k.a, 2 * F, M, 2 * F, F, w->l1, st));                        // network.py:175-176
-  SEPR_TRY(launch_glu_fwd(k.a, k.u, M, F, st));                                               // :177
+  {   // network.py:175-177 in ONE launch (round 4): LayerNorm prologue, F -> 2F, GLU in the epilogue, which stores BOTH the
+      // pre-activation rows (the GLU backward needs value and gate) and the gated rows
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = 2 * F; a.K = F;
+    a.A = x; a.lda = F; a.stats = k.stats; a.Y = k.u; a.ldc = F; a.Ysave = k.a;
+    SEPR_TRY(lin(PRO_NORM, EPI_GLUSAVE, a, w->l1, SEPR_SITE_NONE, st));
+  }
   SEPR_TRY(launch_dwconv_same(k.u, k.c, n, T, F, K, w->dw_w, w->dw_b, st));                   // :178-180
   SEPR_TRY(plain(k.c, F, k.z, 2 * F, M, 2 * F, F, w->l2, nullptr, st));                       // :181
   SEPR_TRY(launch_colstats(k.z, M, 2 * F, BN_EPS_T, BN_MOM, k.bn, w->bn_rm, w->bn_rv, csw, csb, st));   // :183 (batch statistics)
   SEPR_TRY(launch_bn_gelu_fwd(k.z, k.bn, w->bn_g, w->bn_b, k.d, M, 2 * F, st));               // :183,185 (GELU)
-  if (p > 0.f) {
-    SEPR_TRY(plain(k.d, 2 * F, out, F, M, F, 2 * F, w->l3, nullptr, st));
-    SEPR_TRY(launch_res_ls(x, out, w->ls, y, M, F, p, seed, site_off(0), st));                // linear3[2] dropout, :187
+  if (p > 0.f) {   // :185-187 with the dropout of linear3[2] in the projection's epilogue (round 4; 16-bit generator, site CLA_DROP_SITE)
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = F; a.K = 2 * F;
+    a.A = k.d; a.lda = 2 * F; a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
+    a.drop_thr = sepr_drop_thr16(p); a.drop_scale = sepr_drop_scale16(p); a.drop_seed = seed; a.drop_salt = drop_salt(); a.drop_site = CLA_DROP_SITE;
+    SEPR_TRY(lin(PRO_PLAIN, EPI_RESDROP, a, w->l3, SEPR_SITE_NONE, st));
   } else {
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = F; a.K = 2 * F;
@@ -299,7 +307,7 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
   const int x3 = tn_mode(w->l1);
   const float* dyq = dy;
   if (p > 0.f) {
-    SEPR_TRY(launch_dropout(dy, dyp, (long long)F * M, p, seed, site_off(0), st));
+    SEPR_TRY(launch_dropout16(dy, dyp, M, F, p, seed, CLA_DROP_SITE, st));                    // the mask of cla_fwd's EPI_RESDROP
     dyq = dyp;
   }
   SEPR_TRY(wgrad(dyq, F, k.d, 2 * F, nullptr, Gr, s, M, F, 2 * F, 0, x3, tnw, tnb, st));
@@ -309,8 +317,12 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
   SEPR_TRY(wgrad(dd, 2 * F, k.c, F, nullptr, g->w2, g->b2, M, 2 * F, F, 1, x3, tnw, tnb, st));                   // linear2 (direct)
   SEPR_TRY(plain(dd, 2 * F, dc, F, M, F, 2 * F, w->l2_t, nullptr, st));
   SEPR_TRY(launch_dwconv_wgrad(k.u, dc, n, T, F, K, g->dw_w, g->dw_b, wgw, wgb, st));
-  SEPR_TRY(launch_dwconv_same(dc, du, n, T, F, K, w->dw_wf, w->zeros, st));                   // correlation with reversed taps
-  SEPR_TRY(launch_glu_bwd(du, k.a, dd, M, F, st));                                             // dd := da [M][2F]
+  if (F % 128 == 0 && K == 65) {   // correlation with reversed taps, GLU backward in its epilogue (round 4): dd := da [M][2F]
+    SEPR_TRY(launch_dwconv_same_glu_bwd(dc, k.a, dd, n, T, F, K, w->dw_wf, w->zeros, st));
+  } else {
+    SEPR_TRY(launch_dwconv_same(dc, du, n, T, F, K, w->dw_wf, w->zeros, st));                 // correlation with reversed taps
+    SEPR_TRY(launch_glu_bwd(du, k.a, dd, M, F, st));                                           // dd := da [M][2F]
+  }
   SEPR_TRY(wgrad(dd, 2 * F, x, F, k.stats, Gr, s, M, 2 * F, F, 0, x3, tnw, tnb, st));
   SEPR_TRY(launch_finish_norm_linear(Gr, s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, st));
   return dgrad_ln(dd, 2 * F, 2 * F, w->l1_t, 0, x, k.stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);

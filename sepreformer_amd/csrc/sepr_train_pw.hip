@@ -26,7 +26,6 @@ __device__ __forceinline__ float reduce16(float v) {
   return v;
 }
 __device__ __forceinline__ float sum4(float4 v) { return (v.x + v.y) + (v.z + v.w); }
-__device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
 // d/dx of the exact-erf GELU: Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_grad(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
@@ -1188,7 +1187,35 @@ __global__ __launch_bounds__(TPB) void dropout_kernel(const float* __restrict__ 
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < count; i += (long long)gridDim.x * TPB)
     y[i] = sepr_keep(seed, offset + (unsigned long long)i, thr) ? x[i] * scale : 0.f;
 }
+// the 16-bit generator of the fused epilogues (EPI_RESDROP, sepr_gemm_epi.h) applied to a [M][F] tensor: element (m, c) keeps iff the
+// 16-bit half c & 1 of sepr_drop_word(key, m, c >> 1) >= thr; what the backward of such a block applies to dy
+__global__ __launch_bounds__(TPB) void dropout16_kernel(const float* __restrict__ x, float* __restrict__ y, long long M, int F, unsigned thr,
+                                                       float scale, unsigned long long seed, const unsigned long long* __restrict__ salt,
+                                                       unsigned site) {
+  const DropKey key = sepr_drop_key(seed, salt, site);
+  const int f4 = F >> 2;
+  const long long total = M * f4;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const long long m = i / f4;
+    const int c = (int)(i - m * f4) * 4;
+    float4 v = ld4(x + 4 * i);
+    const unsigned d0 = sepr_drop_word(key, (unsigned)m, (unsigned)(c >> 1)), d1 = sepr_drop_word(key, (unsigned)m, (unsigned)(c >> 1) + 1u);
+    v.x = (d0 & 0xffffu) >= thr ? v.x * scale : 0.f;
+    v.y = (d0 >> 16) >= thr ? v.y * scale : 0.f;
+    v.z = (d1 & 0xffffu) >= thr ? v.z * scale : 0.f;
+    v.w = (d1 >> 16) >= thr ? v.w * scale : 0.f;
+    st4(y + 4 * i, v);
+  }
+}
 }  // namespace
+int launch_dropout16(const float* x, float* y, long long M, int F, float p, unsigned long long seed, unsigned site, hipStream_t s) {
+  if (M <= 0) return SEPR_OK;
+  if (!x || !y || F % 4 || !(p > 0.f) || !(p < 1.f) || M > 0x7fffffffLL) return SEPR_EINVAL;
+  hipLaunchKernelGGL(dropout16_kernel, dim3(grid_for(M * (F >> 2), TPB, 1 << 16)), dim3(TPB), 0, s, x, y, M, F, sepr_drop_thr16(p),
+                     sepr_drop_scale16(p), seed, drop_salt(), site);
+  SEPR_CHECK_LAUNCH("dropout16_kernel");
+  return SEPR_OK;
+}
 int launch_add_inplace(float* y, const float* a, long long count, hipStream_t s) {
   if (count <= 0) return SEPR_OK;
   if (!y || !a || count % 4) return SEPR_EINVAL;

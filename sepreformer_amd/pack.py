@@ -410,12 +410,12 @@ def pack_mha(pk: Packed, sd, p: str, spk_fused: dict = None) -> L.MhaW:
         **(spk_fused or {}))
 
 
-def pack_ega(pk: Packed, sd, p: str, pe_ptr: int, maxlen: int) -> L.EgaW:
+def pack_ega(pk: Packed, sd, p: str, pe_ptr: int, maxlen: int, pe_planes_ptr: int = 0) -> L.EgaW:
     return L.EgaW(
         attn=pack_mha(pk, sd, p + ".block.self_attn"),
         gate_ln_g=pk.t(sd[p + ".block.linear.0.weight"]), gate_ln_b=pk.t(sd[p + ".block.linear.0.bias"]),
         gate_w=pk.t(sd[p + ".block.linear.1.weight"]), gate_b=pk.t(sd[p + ".block.linear.1.bias"]),
-        pe_k=pe_ptr, maxlen=maxlen,
+        pe_k=pe_ptr, maxlen=maxlen, pe_k_planes=pe_planes_ptr,
         x3_gate=pk.x3(sd[p + ".block.linear.1.weight"], sd[p + ".block.linear.1.bias"],
                       sd[p + ".block.linear.0.weight"], sd[p + ".block.linear.0.bias"]),
         **pk.gate_fused(sd, p))
@@ -464,9 +464,17 @@ class PackedModel(Packed):
         self.proj_b = self.t(sd["feature_projector.norm.bias"])
         self.proj_w = self.t(sd["feature_projector.conv1d.weight"][:, :, 0])
         pe = self.t(sd["separator.pos_emb.pe_k.weight"])
+        pe_planes = 0
+        if precision == "bf16x3":       # the table as bf16 hi / lo planes, split once here instead of per key tile in the attention kernel
+            pe32 = sd["separator.pos_emb.pe_k.weight"].to(torch.float32)
+            hi = pe32.to(torch.bfloat16)
+            lo = (pe32 - hi.to(torch.float32)).to(torch.bfloat16)
+            planes = torch.stack([hi, lo], 0).contiguous()
+            self.keep.append(planes)
+            pe_planes = planes.data_ptr()
 
         def glob(p):
-            return pack_ega(self, sd, p + ".block.ega", pe, cfg.maxlen), pack_gcfn(self, sd, p + ".block.gcfn")
+            return pack_ega(self, sd, p + ".block.ega", pe, cfg.maxlen, pe_planes), pack_gcfn(self, sd, p + ".block.gcfn")
 
         def loc(p):
             return pack_cla(self, sd, p + ".block.cla"), pack_gcfn(self, sd, p + ".block.gcfn")

@@ -234,6 +234,8 @@ def test_cla_train(variant, precision):
     p = "separator.enc_stages.0.l_block_1.block.cla"
     for n, T in ((2, 24), (2, 150), (3, 700)):
         gb.flat.zero_()
+        sdd[p + ".BN.running_mean"].copy_(sd[p + ".BN.running_mean"])       # (shared device state: see test_cla_train_full_size)
+        sdd[p + ".BN.running_var"].copy_(sd[p + ".BN.running_var"])
         rm0, rv0 = sdd[p + ".BN.running_mean"].clone(), sdd[p + ".BN.running_var"].clone()
         x, dy = rnd(n, T, F, seed=T), rnd(n, T, F, seed=T + 7)
         y, rec = eng.block_fwd("cla", x.cuda(), tp.cla[0], n, T)
@@ -1105,6 +1107,10 @@ def test_cla_train_full_size(precision):
     soft = Soft(f"full_size.{precision}.cla.n{n}.T{T}", precision)
     p = "separator.enc_stages.0.l_block_1.block.cla"
     gb.flat.zero_()
+    # (the device state_dict is shared with other tests of this precision, e.g. test_dropout_contract, which run CLA blocks without
+    #  restoring the running statistics: start from the pristine values the oracle starts from)
+    sdd[p + ".BN.running_mean"].copy_(sd[p + ".BN.running_mean"])
+    sdd[p + ".BN.running_var"].copy_(sd[p + ".BN.running_var"])
     rm0, rv0 = sdd[p + ".BN.running_mean"].clone(), sdd[p + ".BN.running_var"].clone()
     x, dy = rnd(n, T, F, seed=T), rnd(n, T, F, seed=T + 7)
     y, rec = eng.block_fwd("cla", x.cuda(), tp.cla[0], n, T)

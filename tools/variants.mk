@@ -33,3 +33,6 @@ $(OUTDIR)/libsepr_hip_%.so: $(SRCS) $(HDRS)
 	@mkdir -p $(OUTDIR)
 	$(HIPCC) $(CXXFLAGS) $(VARIANT_$*) -shared $(SRCS) -o $@
 VARIANT_resx = -DSEPR_GF3_RESX=1
+# conv-fold proxies of the fused GCFN (round-4 review item 6; wrong results, timing only)
+VARIANT_gfold32 = -DSEPR_GF_ABL=32
+VARIANT_gfold64 = -DSEPR_GF_ABL=64
