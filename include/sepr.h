@@ -395,7 +395,9 @@ typedef struct { float* w_enc /* [N,1,K] */; float* gn_g; float* gn_b; float* pr
 
 enum { SEPR_TOP_GCFN = 0, SEPR_TOP_CLA, SEPR_TOP_EGA, SEPR_TOP_SPKATTN, SEPR_TOP_DOWN, SEPR_TOP_SPLIT, SEPR_TOP_FUSE, SEPR_TOP_OUT,
        SEPR_TOP_FRONT, SEPR_TOP_GCFN_FUSED /* sizes of the fused GCFN pair (sepr_gcfn_tw.fused_w1p != NULL) */,
-       SEPR_TOP_EGA_X3 /* sizes of EGA when its attention runs on the bf16 MFMA (packed-bf16 precisions, dk 16 / 32) */, SEPR_TOP_COUNT };
+       SEPR_TOP_EGA_X3 /* sizes of EGA when its attention runs on the bf16 MFMA (packed-bf16 precisions, dk 16 / 32) */,
+       SEPR_TOP_GCFN_FUSED16 /* the fused GCFN pair in the plain-bf16 precision (sepr_lin.planes == 1): its context also keeps the
+                                normalised rows as bf16 [n*T][F] for the plane-staged backward (ABI 3.02) */, SEPR_TOP_COUNT };
 /* n sequences of T frames (Tp: pooled frames for EGA, source frames for OUT, padded frames Lp for FRONT), width F, encoder
  * channels N, S speakers, K = depthwise taps where the op has them (CLA 65, DOWN 5; else ignored). */
 size_t sepr_train_ctx_bytes(int op, int n, int T, int Tp, int F, int N, int S, int H);

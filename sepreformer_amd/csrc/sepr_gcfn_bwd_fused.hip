@@ -68,6 +68,10 @@ struct GcfnBwdArgs {
   float drop_scale;     // 1 / (1 - p_eff)
   unsigned long long seed;
   const unsigned long long* salt;
+  // PL instantiation (plain-bf16 precision, round 4): both MFMA operands arrive as bf16 rows [M][F] - xh16 written by the fused forward
+  // (sepr_gcfn_fused.hip xhat16), dy16 = bf16(dropout1(dy)) written by gcfn_dyplane_kernel below - and are staged by LDS-DMA
+  const unsigned short* xh16;
+  const unsigned short* dy16;
 };
 
 // NSL = F / 64 slabs per operand.  All 2 * NSL activation slabs of a tile (x, then dy) are requested TOGETHER, one tile ahead:
@@ -76,9 +80,15 @@ struct GcfnBwdArgs {
 //  an exposed L2 / HBM latency and a 64-row tile took 16 us.  Also measured, round 3: giving up the tile-ahead prefetch for a third
 //  workgroup per CU - 168 VGPRs, 46 dwords spilled once per tile - is SLOWER, 337 us against 283 us per launch at batch 16: the tile
 //  is not latency-bound but the sum of ~1 650 VALU instructions, ~250 LDS instructions and 144 MFMAs per wave between 9 barriers.)
-template <int PLANES, int NSL>
-__global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnBwdArgs a) {
+// PL (round 4; ONE only): the 2 * NSL slabs of a tile are bf16 already and go global -> LDS by LDS-DMA (global_load_lds, 16 B per
+// lane, per-lane global address, linear LDS image = [64 rows][160 B]: 10 lane slots per row, the last two masked off as the row pad).
+// No staging VALU at all (39 % of the VALU stream of the register-staged form, profiles/r03_v5_pmc_train_kernels.txt) and no 64-register
+// tile-ahead prefetch: the kernel fits three workgroups per CU (51 KB of LDS each), which cover the DMA latency a tile now pays at its
+// start (the slab buffers alias the epilogue tiles, so the next tile's slabs cannot fly under the epilogue).
+template <int PLANES, int NSL, bool PL = false>
+__global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(const GcfnBwdArgs a) {
   constexpr bool ONE = PLANES == 1;
+  static_assert(!PL || ONE, "plane staging exists for the plain-bf16 arithmetic");
   constexpr int NP = ONE ? 1 : 2;                              // bf16 planes per LDS buffer
   constexpr int PLANE_E = GB_BM * GB_LDK;                      // elements of one plane
   constexpr size_t SLAB_B = sizeof(unsigned short) * 2 * NP * PLANE_E;
@@ -114,9 +124,34 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnB
     nb = u % NB;
     return mb < MB;
   };
-  float4 ra[2 * NSL][4];                                       // this tile's slabs (x: 0..NSL-1, dy: NSL..2NSL-1), 16 k per thread each
+  float4 ra[PL ? 1 : 2 * NSL][4];                              // this tile's slabs (x: 0..NSL-1, dy: NSL..2NSL-1), 16 k per thread each
   float2 rst = make_float2(0.f, 0.f);                          // (mean, rstd) of the staged row
+  // PL: slab q of row tile mb_ -> slab buffer q & 1.  Rows outside [0, M) read a clamped (finite) row: everything they feed is either
+  // masked by the sequence-end flags of the conv or belongs to rows the epilogue skips.
+  auto dma_slab = [&](int q, int mb_) {
+    if constexpr (PL) {
+      const unsigned short* plane = (q < NSL ? a.xh16 : a.dy16) + (q < NSL ? q : q - NSL) * GB_BKS;
+      unsigned char* dst = smem + (size_t)(q & 1) * PLANE_E * sizeof(unsigned short);
+      constexpr int LPR = GB_LDK * 2 / 16;                     // 16-byte lane slots per LDS row (10: 8 data + 2 pad)
+      static_assert(GB_BM * LPR % 64 == 0, "whole wave instructions");
+#pragma unroll
+      for (int i0 = 0; i0 < GB_BM * LPR / 64; i0 += 4) {
+        const int i = i0 + wn;                                 // wave-uniform
+        if (i < GB_BM * LPR / 64) {
+          const int slot = i * 64 + lane, row = slot / LPR, c = slot - row * LPR;
+          int msn = mb_ * GB_OUT - 2 + row;
+          msn = msn < 0 ? 0 : (msn > a.M - 1 ? a.M - 1 : msn);
+          if (c < 8) {
+            const char* src = reinterpret_cast<const char*>(plane + (long long)msn * F) + c * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+          }
+        }
+      }
+    }
+  };
   auto load_tile = [&](int mb_) {
+    if constexpr (PL) return;
     const int msn = mb_ * GB_OUT - 2 + srow;
     const long long row = (msn >= 0 && msn < a.M) ? msn : 0;
     const float* px = a.x + row * F + kq;
@@ -140,6 +175,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnB
     const float mean = rst.x, rstd = rst.y;
     auto store_slab = [&](int q) {
 #pragma clang fp contract(off)
+      if constexpr (PL) return;
       float v[16];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v[4 * j] = ra[q][j].x; v[4 * j + 1] = ra[q][j].y; v[4 * j + 2] = ra[q][j].z; v[4 * j + 3] = ra[q][j].w; }
@@ -199,19 +235,38 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gcfn_bwd_mid_kernel(const GcfnB
     const int tv = 4 * nb + wn, tg = C3 / 16 + 4 * nb + wn;     // this wave's value / gate tile of W1, tv also its W2^T tile
 
     __syncthreads();   // the previous tile's epilogue is done with the LDS tiles that alias the slab buffers
+    uint4 wset[2][2][2][2];                                    // [q & 1][a | b][K step of the slab][plane]; a: value (or W2^T), b: gate
+    auto load_wq = [&](int q, uint4 (&ws_)[2][2][2]) {
+      const bool up_ = q < nsl;
+      const int s_ = up_ ? q : q - nsl;
+      load_w(up_ ? W1 : W2, tv, 2 * s_, ws_[0][0]);
+      load_w(up_ ? W1 : W2, tv, 2 * s_ + 1, ws_[0][1]);
+      if (up_) {
+        load_w(W1, tg, 2 * s_, ws_[1][0]);
+        load_w(W1, tg, 2 * s_ + 1, ws_[1][1]);
+      }
+    };
+    if constexpr (PL) {
+      dma_slab(0, mb);
+      load_wq(0, wset[0]);
+    }
 #pragma unroll
     for (int q = 0; q < 2 * nsl; ++q) {
       const bool up = q < nsl;
-      const int s = up ? q : q - nsl;
-      uint4 wa[2][2], wb[2][2];                                // [K step of the slab][plane]; a: value (or W2^T), b: gate
-      load_w(up ? W1 : W2, tv, 2 * s, wa[0]);
-      load_w(up ? W1 : W2, tv, 2 * s + 1, wa[1]);
-      if (up) {
-        load_w(W1, tg, 2 * s, wb[0]);
-        load_w(W1, tg, 2 * s + 1, wb[1]);
+      uint4 (&wa)[2][2] = wset[q & 1][0];
+      uint4 (&wb)[2][2] = wset[q & 1][1];
+      if constexpr (PL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab q (and this step's weight fragments) have landed
+        __syncthreads();                                       // ... for every wave; every wave is past the MFMAs of slab q - 1
+        if (q + 1 < 2 * nsl) {
+          dma_slab(q + 1, mb);
+          load_wq(q + 1, wset[(q + 1) & 1]);
+        }
+      } else {
+        load_wq(q, wset[q & 1]);
+        store_slab(q);
+        __syncthreads();
       }
-      store_slab(q);
-      __syncthreads();
       const unsigned short* ph = slab + ((q & 1) * NP + 0) * PLANE_E;
       const unsigned short* pl = slab + ((q & 1) * NP + (NP - 1)) * PLANE_E;
 #pragma unroll
@@ -417,9 +472,49 @@ size_t gcfn_bwd_fused_ws(long long M, int F) {   // partials + the pre-reduction
   return align_up((size_t)MB * 3 * F * 8 * sizeof(float)) + gcfn_mid_reduce_ws(3 * F);
 }
 
+namespace {
+// dy [M][F] fp32 -> out [M][F] bf16 = bf16(dropout1(dy)) (network.py:57's mask, 16-bit generator site 1, keep scale folded in; p = 0: a
+// plain conversion): the dy operand of the PL middle kernel and the A operand of net2.2's weight-gradient contraction
+__global__ __launch_bounds__(256) void gcfn_dyplane_kernel(const float* __restrict__ dy, unsigned short* __restrict__ out, long long M, int F,
+                                                           unsigned thr, float scale, unsigned long long seed,
+                                                           const unsigned long long* __restrict__ salt) {
+  const DropKey dk1 = sepr_drop_key(seed, salt, 1u);
+  const int f8 = F >> 3;
+  const long long total = M * f8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long m = i / f8;
+    const int c = (int)(i - m * f8) * 8;
+    const float4 p0 = ld4(dy + m * F + c), p1 = ld4(dy + m * F + c + 4);
+    float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    if (thr) {
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const unsigned d = sepr_drop_word(dk1, (unsigned)m, (unsigned)((c + e) >> 1));
+        v[e] = (d & 0xffffu) >= thr ? v[e] * scale : 0.f;
+        v[e + 1] = (d >> 16) >= thr ? v[e + 1] * scale : 0.f;
+      }
+    }
+    gb_bf16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (__bf16)v[e];
+    *reinterpret_cast<gb_bf16x8*>(out + m * F + c) = h;
+  }
+}
+}  // namespace
+int launch_gcfn_dyplane(const float* dy, void* out16, long long M, int F, float p, unsigned long long seed, const unsigned long long* salt,
+                        hipStream_t st) {
+  if (M <= 0) return SEPR_OK;
+  if (!dy || !out16 || F % 8 || !(p >= 0.f) || !(p < 1.f) || M > 0x7fffffffLL) return SEPR_EINVAL;
+  const long long blocks = (M * (F >> 3) + 255) / 256;
+  hipLaunchKernelGGL(gcfn_dyplane_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, dy,
+                     static_cast<unsigned short*>(out16), M, F, p > 0.f ? sepr_drop_thr16(p) : 0u, p > 0.f ? sepr_drop_scale16(p) : 1.0f, seed, salt);
+  SEPR_CHECK_LAUNCH("gcfn_dyplane_kernel");
+  return SEPR_OK;
+}
+
 int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, int n, int T, int F, const sepr_gcfn_tw* w, void* g,
                           void* dh1, int out16, float* dyq, float* dw_g, float* db_g, float p, unsigned long long seed,
-                          const unsigned long long* salt, void* ws, size_t ws_bytes, hipStream_t st) {
+                          const unsigned long long* salt, void* ws, size_t ws_bytes, hipStream_t st, const void* xh16, const void* dy16) {
   const long long M = (long long)n * T;
   if (M <= 0) return SEPR_OK;
   if (!x || !stats || !dy || !w || !w->up.wp || !w->up.b || !w->down_t.wp || !w->dw_w || !w->dw_b || !g || !dh1 || !dw_g || !db_g ||
@@ -435,7 +530,7 @@ int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, i
   a.drop_thr = p > 0.f ? sepr_drop_thr16(p) : 0u;
   a.drop_scale = p > 0.f ? sepr_drop_scale16(p) : 1.0f;
   a.seed = seed; a.salt = salt;
-  if (p > 0.f && !dyq) return SEPR_EINVAL;
+  if (p > 0.f && !dyq && !(xh16 && dy16)) return SEPR_EINVAL;      // (the plane-staged form gets dropout1(dy) as dy16)
   const int MB = (int)((M + GB_OUT - 1) / GB_OUT), NB = 3 * F / 64;
   const int ntiles = ((MB + 7) / 8) * 8 * NB;
   const int cap = persistent_grid();
@@ -443,7 +538,14 @@ int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, i
   long long slot = -1;
   const bool timed = prof_begin(SEPR_SITE_GCFN_BWD, st, &slot);
   const bool one = w->up.planes == 1;
-  if (F == 128) {
+  a.xh16 = static_cast<const unsigned short*>(xh16);
+  a.dy16 = static_cast<const unsigned short*>(dy16);
+  const bool pl = one && xh16 && dy16;
+  if (pl) {
+    const int g3 = (ntiles < cap / 2 * 3) ? ntiles : cap / 2 * 3;   // three workgroups per CU
+    if (F == 128) hipLaunchKernelGGL((gcfn_bwd_mid_kernel<1, 2, true>), dim3(g3), dim3(GB_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((gcfn_bwd_mid_kernel<1, 1, true>), dim3(g3), dim3(GB_THREADS), 0, st, a);
+  } else if (F == 128) {
     if (one) hipLaunchKernelGGL((gcfn_bwd_mid_kernel<1, 2>), dim3(grid), dim3(GB_THREADS), 0, st, a);
     else hipLaunchKernelGGL((gcfn_bwd_mid_kernel<3, 2>), dim3(grid), dim3(GB_THREADS), 0, st, a);
   } else if (F == 64) {

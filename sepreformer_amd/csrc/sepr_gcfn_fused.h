@@ -29,6 +29,8 @@ struct GcfnFusedArgs {
   // drop_thr > 0 (sepr_train.h sepr_drop_word: site 0 = gated tensor [M][3F], site 1 = block output [M][F]; the keep scale
   // drop_scale = 1 / (1 - p_eff) of both sites is applied in the epilogue, where it costs nothing)
   int train;
+  void* xhat16;       // TRAIN + planes == 1 only (optional): [M][F] bf16 = the normalised rows as the kernel's MFMAs consume them; the
+                      // backward's middle kernel stages them by LDS-DMA and the first weight-gradient contraction reads them (round 4)
   int planes;         // TRAIN only: 1 = plain bf16 operands (precision "bf16": the hi planes alone, one MFMA per product); else bf16x3
   float* stats;
   unsigned drop_thr;

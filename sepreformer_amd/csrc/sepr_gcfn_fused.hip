@@ -265,9 +265,11 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
       mu_[mt] = mean;
       sg_[mt] = PLAIN ? 1.0f : sqrtf(d * (1.0f / F) + a.eps);
 #endif
+      bool own_row = false;
       if (TRAIN) {   // the frames this workgroup OUTPUTS (not its halo) report their statistics: all the backward needs
         const int lr = MT * fi + mt, bf = w * WSTR + lr;
         const bool own = XCH ? (bf >= 1 && bf <= GF_TILE) : (lr >= 1 && lr <= 16 * MT - 2);
+        own_row = own && valid;
         if (a.stats && fg == 0 && valid && own) *reinterpret_cast<float2*>(a.stats + 2LL * m) = make_float2(mean, rstd);
       }
 #pragma unroll
@@ -282,6 +284,9 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
         }
         xh[mt][ks] = h;
         if constexpr (!ONE) xl[mt][ks] = l;
+        if constexpr (TRAIN && ONE) {   // side output for the backward: the bf16 rows exactly as the MFMAs read them (16 B per lane and K step)
+          if (a.xhat16 && own_row) *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(a.xhat16) + (long long)m * F + 32 * ks + 8 * fg) = h;
+        }
       }
     }
     const bool edge = __builtin_amdgcn_ballot_w64(edge_lane) != 0ull;   // wave-uniform

@@ -108,7 +108,11 @@ size_t gcfn_mid_reduce_ws(int C);
 // depthwise weight / bias gradients accumulated.  Arithmetic follows w->up.planes (bf16x3 or plain bf16).
 int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, int n, int T, int F, const sepr_gcfn_tw* w, void* g,
                           void* dh1, int out16 /* g, dh1 stored as bf16 */, float* dyq, float* dw_g, float* db_g, float p, unsigned long long seed,
-                          const unsigned long long* salt, void* ws, size_t ws_bytes, hipStream_t st);
+                          const unsigned long long* salt, void* ws, size_t ws_bytes, hipStream_t st, const void* xh16 = nullptr,
+                          const void* dy16 = nullptr);
+// dy [M][F] -> bf16(dropout1(dy)) [M][F]: the dy plane of the plane-staged middle kernel (plain-bf16 precision)
+int launch_gcfn_dyplane(const float* dy, void* out16, long long M, int F, float p, unsigned long long seed, const unsigned long long* salt,
+                        hipStream_t st);
 size_t gcfn_bwd_fused_ws(long long M, int F);
 // depthwise conv weight gradient, stride 1, 'same' zero padding: dw[c][k] += sum_{seq,t} dy[t][c] * x[t + k - K/2][c];
 // db[c] += sum dy.  x, dy [n,T,C]; dw in parameter layout [C][K]

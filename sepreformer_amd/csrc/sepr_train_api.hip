@@ -113,10 +113,21 @@ GcfnCtx gcfn_ctx(Carve& c, long long M, int F) {
 // (sepr_gcfn_bwd_fused.hip), then runs the two weight-gradient contractions, their finishers, the F-wide input-gradient
 // projection and the LayerNorm backward of the unfused form.
 bool gcfn_is_fused(const sepr_gcfn_tw* w, int F) { return w && w->fused_w1p && w->fused_w2p && (F == 64 || F == 128); }
+// pl16 (the plain-bf16 precision, w->up.planes == 1; sizing op SEPR_TOP_GCFN_FUSED16): the forward additionally keeps the normalised
+// rows as bf16 [M][F] (256 B per row at F = 128) - the backward's middle kernel stages them (and bf16(dropout1(dy)), written by a
+// pre-pass) by LDS-DMA with no VALU, and both weight-gradient contractions read bf16 operands only (round 4).  pl_dry: sizing runs.
+bool gcfn_pl16(const sepr_gcfn_tw* w, int pl_dry) {
+  if (pl_dry >= 0) return pl_dry != 0;
+  const char* e = getenv("SEPR_TRAIN_GCFN_PLANES");      // (read per call: the A/B test flips it inside one process)
+  const bool off = e && e[0] == '0';
+  return !off && w && w->up.planes == 1;
+}
 int gcfn_fused_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, Carve& cx, float p, sepr_u64 seed,
-                   hipStream_t st) {
+                   hipStream_t st, int pl_dry = -1) {
   const long long M = (long long)n * T;
   float* stats = cx.f32(2 * M);
+  const bool pl = gcfn_pl16(w, pl_dry);
+  void* xh16 = pl ? cx.take((size_t)M * F * 2) : nullptr;
   if (cx.dry) return SEPR_OK;
   if (!cx.ok()) return SEPR_EWORKSPACE;
   if (!w->up.wp || !w->down_t.wp) return SEPR_EINVAL;   // the backward's middle kernel runs on the packed-bf16 cores
@@ -126,15 +137,19 @@ int gcfn_fused_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcf
   f.b2 = w->b2; f.ls = w->ls; f.eps = LN_EPS_T;
   f.train = 1; f.stats = stats;
   f.planes = w->up.planes == 1 ? 1 : 3;      // precision "bf16": the single-plane instantiation (round 4)
+  f.xhat16 = xh16;
   f.drop_thr = p > 0.f ? sepr_drop_thr16(p) : 0u;
   f.drop_scale = p > 0.f ? sepr_drop_scale16(p) : 1.0f;
   f.seed = seed; f.salt = drop_salt();
   return launch_gcfn_fused(f, F, SEPR_SITE_GCFN_UP, st);
 }
 int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, const sepr_gcfn_tw* w, const sepr_gcfn_grad* g,
-                   Carve& cx, Carve& ws, float p, sepr_u64 seed, hipStream_t st) {
+                   Carve& cx, Carve& ws, float p, sepr_u64 seed, hipStream_t st, int pl_dry = -1) {
   const long long M = (long long)n * T;
   float* stats = cx.f32(2 * M);
+  const bool pl = gcfn_pl16(w, pl_dry);
+  void* xh16 = pl ? cx.take((size_t)M * F * 2) : nullptr;
+  void* dy16 = pl ? ws.take((size_t)M * F * 2) : nullptr;
   // plain-bf16 precision: the two big intermediates are STORED as bf16 (their consumers round them to bf16 anyway)
   const bool o16 = ws.dry ? false : (w->up.planes == 1);
   void* gd = ws.take((size_t)3 * F * M * sizeof(float));       // (sized for fp32 in both cases: one workspace plan)
@@ -153,13 +168,16 @@ int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int
   if (ws.dry) return SEPR_OK;
   if (!cx.ok() || !ws.ok()) return SEPR_EWORKSPACE;
   const int x3 = tn_mode(w->up);
-  SEPR_TRY(launch_gcfn_bwd_fused(x, stats, dy, n, T, F, w, gd, dh1, o16 ? 1 : 0, dyp, g->dw_w, g->dw_b, p, seed, drop_salt(), midw, midb, st));
+  if (pl) SEPR_TRY(launch_gcfn_dyplane(dy, dy16, M, F, p, seed, drop_salt(), st));
+  SEPR_TRY(launch_gcfn_bwd_fused(x, stats, dy, n, T, F, w, gd, dh1, o16 ? 1 : 0, pl ? nullptr : dyp, g->dw_w, g->dw_b, p, seed, drop_salt(), midw,
+                                 midb, st, xh16, dy16));
   const float* dyq = p > 0.f ? dyp : dy;
   // net2.2 + LayerScale
   {
     TnArgs t = tn_args_zero();
     t.M = (int)M; t.N = F; t.K = 3 * F;
-    t.A = dyq; t.lda = F; t.B = static_cast<const float*>(gd); t.ldb = 3 * F; t.b16 = o16 ? 1 : 0;
+    t.A = pl ? static_cast<const float*>(dy16) : dyq; t.lda = F; t.a16 = pl ? 1 : 0;
+    t.B = static_cast<const float*>(gd); t.ldb = 3 * F; t.b16 = o16 ? 1 : 0;
     t.G = Gr; t.ldg = 3 * F; t.colsum = s2;
     SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
   }
@@ -168,7 +186,9 @@ int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int
   {
     TnArgs t = tn_args_zero();
     t.M = (int)M; t.N = 6 * F; t.K = F;
-    t.A = static_cast<const float*>(dh1); t.lda = 6 * F; t.a16 = o16 ? 1 : 0; t.B = x; t.ldb = F; t.stats = stats;
+    t.A = static_cast<const float*>(dh1); t.lda = 6 * F; t.a16 = o16 ? 1 : 0;
+    if (pl) { t.B = static_cast<const float*>(xh16); t.ldb = F; t.b16 = 1; }     // the saved bf16 rows: no statistics prologue, half the bytes
+    else { t.B = x; t.ldb = F; t.stats = stats; }
     t.G = dWh; t.ldg = F; t.colsum = s1;
     SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
   }
@@ -955,8 +975,12 @@ static void train_sizes(int op, int n, int T, int Tp, int F, int N, int S, int H
       gcfn_bwd(nullptr, nullptr, nullptr, n, T, F, nullptr, nullptr, cb, wb, p1, 0, nullptr);
       break;
     case SEPR_TOP_GCFN_FUSED:
-      gcfn_fused_fwd(nullptr, nullptr, n, T, F, nullptr, cf, p1, 0, nullptr);
-      gcfn_fused_bwd(nullptr, nullptr, nullptr, n, T, F, nullptr, nullptr, cb, wb, p1, 0, nullptr);
+      gcfn_fused_fwd(nullptr, nullptr, n, T, F, nullptr, cf, p1, 0, nullptr, 0);
+      gcfn_fused_bwd(nullptr, nullptr, nullptr, n, T, F, nullptr, nullptr, cb, wb, p1, 0, nullptr, 0);
+      break;
+    case SEPR_TOP_GCFN_FUSED16:
+      gcfn_fused_fwd(nullptr, nullptr, n, T, F, nullptr, cf, p1, 0, nullptr, 1);
+      gcfn_fused_bwd(nullptr, nullptr, nullptr, n, T, F, nullptr, nullptr, cb, wb, p1, 0, nullptr, 1);
       break;
     case SEPR_TOP_CLA:
       cla_fwd(nullptr, nullptr, n, T, F, K, nullptr, cf, wf, p1, 0, nullptr);

@@ -109,7 +109,8 @@ OutTW = _tstruct("OutTW", ["@l1", "@l1_t", "@l2", "@l2_t", "wdec"])
 OutGrad = _tstruct("OutGrad", ["w1", "b1", "w2", "b2", "wdec"])
 FrontTW = _tstruct("FrontTW", ["w_enc", "proj_w", "gn_g", "gn_b", "@proj_t", "ones"])
 FrontGrad = _tstruct("FrontGrad", ["w_enc", "gn_g", "gn_b", "proj_w"])
-(TOP_GCFN, TOP_CLA, TOP_EGA, TOP_SPKATTN, TOP_DOWN, TOP_SPLIT, TOP_FUSE, TOP_OUT, TOP_FRONT, TOP_GCFN_FUSED, TOP_EGA_X3) = range(11)
+(TOP_GCFN, TOP_CLA, TOP_EGA, TOP_SPKATTN, TOP_DOWN, TOP_SPLIT, TOP_FUSE, TOP_OUT, TOP_FRONT, TOP_GCFN_FUSED, TOP_EGA_X3,
+ TOP_GCFN_FUSED16) = range(12)
 
 # name -> (restype, argtypes); must list every symbol include/sepr.h declares (tests check this)
 SIGNATURES = {

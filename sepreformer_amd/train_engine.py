@@ -73,6 +73,13 @@ class TrainEngine:
             self._idx[key] = (torch.from_numpy(idx).to(self.device), torch.from_numpy(inverse_index_start(idx, src)).to(self.device))
         return self._idx[key]
 
+    def _gcfn_op(self, tw) -> int:
+        """Sizing op of a GCFN block; mirrors ``gcfn_is_fused`` / ``gcfn_pl16`` of csrc/sepr_train_api.hip."""
+        if not (tw.fused_w1p and self.cfg.feat in (64, 128)):
+            return L.TOP_GCFN
+        planes16 = tw.up.planes == 1 and os.environ.get("SEPR_TRAIN_GCFN_PLANES", "1") != "0"
+        return L.TOP_GCFN_FUSED16 if planes16 else L.TOP_GCFN_FUSED
+
     def _ega_op(self, tw) -> int:
         """Sizing op of an EGA block: the packed-bf16 precisions run the attention flash-style on the bf16 MFMA (context = one
         log-sum-exp per query row instead of the [Tp, Tp] probabilities); mirrors ``ega_mfma`` of csrc/sepr_train_api.hip."""
@@ -88,7 +95,7 @@ class TrainEngine:
         st = torch.cuda.current_stream(self.device).cuda_stream
         y = torch.empty_like(xin)
         if kind == "gcfn":
-            op = L.TOP_GCFN_FUSED if (w[0].fused_w1p and F in (64, 128)) else L.TOP_GCFN     # statistics-only context when fused
+            op = self._gcfn_op(w[0])                     # statistics-only context when fused (+ the bf16 rows in the plain-bf16 precision)
             cx = self._ctx(op, n, Tc)
             L.check(lib.sepr_gcfn_train_fwd(xin.data_ptr(), y.data_ptr(), n, Tc, F, C.byref(w[0]), cx.data_ptr(), cx.numel(),
                                             *self._wsfor(op, n, Tc), p_drop, seed, st), "sepr_gcfn_train_fwd")
@@ -117,7 +124,7 @@ class TrainEngine:
         st = torch.cuda.current_stream(self.device).cuda_stream
         dx = torch.empty_like(xin)
         if kind == "gcfn":
-            op = L.TOP_GCFN_FUSED if (w[0].fused_w1p and F in (64, 128)) else L.TOP_GCFN
+            op = self._gcfn_op(w[0])
             L.check(lib.sepr_gcfn_bwd(xin.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, Tc, F, C.byref(w[0]), C.byref(w[1]), cx.data_ptr(),
                                       cx.numel(), *self._wsfor(op, n, Tc), p_drop, seed, st), "sepr_gcfn_bwd")
         elif kind == "cla":

@@ -1434,3 +1434,44 @@ def test_train_graphs_survive_a_larger_shape():
     with pytest.raises(RuntimeError, match="ONE static tape"):
         torch.stack(a1).sum().backward()
     torch.stack(a2).sum().backward()
+
+
+@pytest.mark.parametrize("variant,n,T", [("SepReformer_Base_WSJ0", 3, 1201), ("SepReformer_Base_WSJ0", 5, 4000), ("tiny", 4, 333)])
+def test_gcfn_bf16_plane_staged_backward_equals_register_staged(variant, n, T, monkeypatch):
+    """The plain-bf16 GCFN pair in its two backward forms - (a) round 3: x / dy staged through registers (normalise / mask / round in
+    the middle kernel, fp32 operands in the contractions), (b) round 4: the forward keeps the bf16 rows, a pre-pass writes
+    bf16(dropout(dy)), the middle kernel stages both by LDS-DMA (three workgroups per CU) and the contractions read bf16 - round the
+    same values at the same places and run the same MFMA order, so with dropout live (p = 0.3, same seed) the block output, the input
+    gradient and every parameter gradient are BITWISE equal - except net2.2's bias gradient (and the LayerScale gradient that contains
+    it), whose column sums are taken over the bf16 rows in form (b): bf16-level agreement there."""
+    from sepreformer_amd.train_engine import TrainEngine
+    from sepreformer_amd.train_pack import GradBuffer, TrainPack
+    cfg = dataclasses.replace(VARIANTS[variant], dropout=0.3)
+    sd = synth_state_dict(cfg, 0)
+    dev = torch.device("cuda:0")
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    F = cfg.feat
+    x, dy = rnd(n, T, F, seed=T).cuda(), rnd(n, T, F, seed=T + 7).cuda()
+    outs = []
+    pfx = "separator.enc_stages.0.g_block_1.block.gcfn"
+    for planes in ("0", "1"):
+        monkeypatch.setenv("SEPR_TRAIN_GCFN_PLANES", planes)
+        gb = GradBuffer(cfg, dev)
+        tp = TrainPack(cfg, sdd, gb, "bf16")
+        eng = TrainEngine(cfg, dev)
+        y, rec = eng.block_fwd("gcfn", x, tp.gcfn[0], n, T, 0, 0.3, 4242)
+        assert (rec[2].numel() > n * T * F * 2) == (planes == "1")          # the context keeps the bf16 rows only in the plane form
+        dx = eng.block_bwd(rec, dy)
+        torch.cuda.synchronize()
+        grads = {k[len(pfx) + 1:]: gb.view(k).clone() for k in sd if k.startswith(pfx + ".")}
+        outs.append((y.clone(), dx.clone(), grads))
+    assert torch.isfinite(outs[0][1]).all() and all(float(v.abs().max()) > 0 for v in outs[0][2].values())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k, a_ in outs[0][2].items():
+        b_ = outs[1][2][k]
+        if k in ("net2.2.bias", "Layer_scale.layer_scale"):
+            # the one place the two forms round differently: the column sums of dropout(dy) (bias gradient of net2.2, and through it
+            # the LayerScale gradient) ride in the contraction's staging registers - fp32 values in form (a), the bf16 rows in form (b)
+            assert orc.agreement_db(b_.cpu(), a_.cpu()) >= 45.0, (k, orc.agreement_db(b_.cpu(), a_.cpu()))
+        else:
+            assert torch.equal(a_, b_), (k, int((a_ != b_).sum()), float((a_ - b_).abs().max()))
