@@ -35,6 +35,22 @@ __device__ __forceinline__ void gb_store4(void* base, long long idx, const float
   }
 }
 
+typedef unsigned gb_u32x4 __attribute__((ext_vector_type(4)));
+// PL form: the weight fragments are loaded by inline asm, i.e. hidden from hipcc's vmcnt bookkeeping - beside LDS-DMA in flight hipcc waits
+// vmcnt(0) for ANY ordinary VGPR-destination load, which would drain the whole slab pipeline at the first MFMA (guide: "three .s-level
+// traps" (b)).  The waits below are the counted ones and name the destination registers ("+v") so that no consumer can move above them.
+__device__ __forceinline__ void gb_asm_load(gb_u32x4& d, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gb_wait_vm4(gb_u32x4& a, gb_u32x4& b, gb_u32x4& c, gb_u32x4& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gb_wait_vm2(gb_u32x4& a, gb_u32x4& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
 namespace {
 constexpr int GB_BM = 64;            // rows per tile (incl. halo)
 constexpr int GB_OUT = GB_BM - 4;    // rows a tile outputs
@@ -91,7 +107,8 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
   static_assert(!PL || ONE, "plane staging exists for the plain-bf16 arithmetic");
   constexpr int NP = ONE ? 1 : 2;                              // bf16 planes per LDS buffer
   constexpr int PLANE_E = GB_BM * GB_LDK;                      // elements of one plane
-  constexpr size_t SLAB_B = sizeof(unsigned short) * 2 * NP * PLANE_E;
+  constexpr int DMA_PER_WAVE = GB_BM * 128 / 1024 / 4;                  // PL: LDS-DMA instructions per wave and slab (2)
+  constexpr size_t SLAB_B = PL ? (size_t)2 * NSL * GB_BM * 128 : sizeof(unsigned short) * 2 * NP * PLANE_E;
   constexpr size_t TILE_B = sizeof(float) * GB_BM * (GB_HS + GB_DS);
   __shared__ __attribute__((aligned(16))) unsigned char smem[SLAB_B > TILE_B ? SLAB_B : TILE_B];
   unsigned short* const slab = reinterpret_cast<unsigned short*>(smem);
@@ -130,23 +147,22 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
   // masked by the sequence-end flags of the conv or belongs to rows the epilogue skips.
   auto dma_slab = [&](int q, int mb_) {
     if constexpr (PL) {
-      const unsigned short* plane = (q < NSL ? a.xh16 : a.dy16) + (q < NSL ? q : q - NSL) * GB_BKS;
-      unsigned char* dst = smem + (size_t)(q & 1) * PLANE_E * sizeof(unsigned short);
-      constexpr int LPR = GB_LDK * 2 / 16;                     // 16-byte lane slots per LDS row (10: 8 data + 2 pad)
-      static_assert(GB_BM * LPR % 64 == 0, "whole wave instructions");
+      // (wave-uniform base + 32-bit per-lane byte offset: SGPR-base addressing, no 64-bit per-lane pointers to keep alive)
+      const char* plane = reinterpret_cast<const char*>(q < NSL ? a.xh16 : a.dy16) + (q < NSL ? q : q - NSL) * (GB_BKS * 2);
+      // Every slab of the tile has its own 8 KB buffer (all aliasing the epilogue tiles): [64 rows][128 B], the 16-byte chunk c of row r
+      // stored at chunk position c ^ (r & 7).  The XOR swizzle makes the MFMA fragment reads (16-lane groups of ds_read_b128: rows
+      // fi, chunks {2j, 2j+1}) hit 16 distinct 16-byte slots of the 256-byte bank row WITHOUT row padding - so the image is exactly 8
+      // LDS-DMA instructions, two per wave, no masked lanes and no divergent issue code (hipcc counts vmcnt across straight-line code
+      // only; anything conditional in here turns every later wait into vmcnt(0)).
+      unsigned char* dst = smem + (size_t)q * (GB_BM * 128) + wn * (DMA_PER_WAVE * 1024);
 #pragma unroll
-      for (int i0 = 0; i0 < GB_BM * LPR / 64; i0 += 4) {
-        const int i = i0 + wn;                                 // wave-uniform
-        if (i < GB_BM * LPR / 64) {
-          const int slot = i * 64 + lane, row = slot / LPR, c = slot - row * LPR;
-          int msn = mb_ * GB_OUT - 2 + row;
-          msn = msn < 0 ? 0 : (msn > a.M - 1 ? a.M - 1 : msn);
-          if (c < 8) {
-            const char* src = reinterpret_cast<const char*>(plane + (long long)msn * F) + c * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-          }
-        }
+      for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        const int pos = (wn * DMA_PER_WAVE + i) * 64 + lane, row = pos >> 3, c = (pos & 7) ^ (row & 7);
+        int msn = mb_ * GB_OUT - 2 + row;
+        msn = msn < 0 ? 0 : (msn > a.M - 1 ? a.M - 1 : msn);
+        const unsigned off = (unsigned)msn * (unsigned)(2 * F) + (unsigned)(c * 16);     // M * F * 2 < 2^32 (checked by the launcher)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(plane + off),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
       }
     }
   };
@@ -219,10 +235,14 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
       }
     };
     // weight fragments of one 16-row tile at K step ks: (hi, lo) planes, one coalesced 1 KiB read each
-    auto load_w = [&](const uint4* W, int t16, int ks, uint4 (&w)[2]) {
+    auto load_w = [&](const uint4* W, int t16, int ks, gb_u32x4 (&w)[2]) {
       const uint4* p = W + ((long long)(t16 * kst + ks) * 2) * 64 + lane;
-      w[0] = p[0];
-      if (!ONE) w[1] = p[64];
+      if constexpr (PL) {
+        gb_asm_load(w[0], p);
+      } else {
+        w[0] = *reinterpret_cast<const gb_u32x4*>(p);
+        if (!ONE) w[1] = *reinterpret_cast<const gb_u32x4*>(p + 64);
+      }
     };
 
     f32x4 hv[4], hg[4], dd[4];
@@ -235,8 +255,8 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
     const int tv = 4 * nb + wn, tg = C3 / 16 + 4 * nb + wn;     // this wave's value / gate tile of W1, tv also its W2^T tile
 
     __syncthreads();   // the previous tile's epilogue is done with the LDS tiles that alias the slab buffers
-    uint4 wset[2][2][2][2];                                    // [q & 1][a | b][K step of the slab][plane]; a: value (or W2^T), b: gate
-    auto load_wq = [&](int q, uint4 (&ws_)[2][2][2]) {
+    gb_u32x4 wset[2][2][2][2];                                 // [q & 1][a | b][K step of the slab][plane]; a: value (or W2^T), b: gate
+    auto load_wq = [&](int q, gb_u32x4 (&ws_)[2][2][2]) {
       const bool up_ = q < nsl;
       const int s_ = up_ ? q : q - nsl;
       load_w(up_ ? W1 : W2, tv, 2 * s_, ws_[0][0]);
@@ -246,35 +266,54 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
         load_w(W1, tg, 2 * s_ + 1, ws_[1][1]);
       }
     };
+    // PL: ALL slabs of the tile go in flight at once (one exposed DMA latency per tile instead of one per slab).  Issue order per wave:
+    //   D0 W0 D1 W1 D2 .. D(2 NSL - 1), then W(q + 2) right after the MFMAs of step q - so "slab q and the weights of step q have landed"
+    // is a compile-time vmcnt (DMA_PER_WAVE copies per slab, 4 fragment loads per up-projection step, 2 per dgd step; vmcnt retires in order)
     if constexpr (PL) {
-      dma_slab(0, mb);
-      load_wq(0, wset[0]);
+#pragma unroll
+      for (int q = 0; q < 2 * nsl; ++q) {
+        dma_slab(q, mb);
+        if (q < 2) load_wq(q, wset[q]);
+      }
     }
 #pragma unroll
     for (int q = 0; q < 2 * nsl; ++q) {
       const bool up = q < nsl;
-      uint4 (&wa)[2][2] = wset[q & 1][0];
-      uint4 (&wb)[2][2] = wset[q & 1][1];
+      gb_u32x4 (&wa)[2][2] = wset[q & 1][0];
+      gb_u32x4 (&wb)[2][2] = wset[q & 1][1];
       if constexpr (PL) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab q (and this step's weight fragments) have landed
-        __syncthreads();                                       // ... for every wave; every wave is past the MFMAs of slab q - 1
-        if (q + 1 < 2 * nsl) {
-          dma_slab(q + 1, mb);
-          load_wq(q + 1, wset[(q + 1) & 1]);
+        constexpr int NQ = 2 * NSL;
+        constexpr int C0 = DMA_PER_WAVE * (NQ - 1) + (NQ > 1 ? (1 < NSL ? 4 : 2) : 0);      // behind W0: D1 W1 D2 ..
+        constexpr int C1 = DMA_PER_WAVE * (NQ - 2) + (NQ > 2 ? (2 < NSL ? 4 : 2) : 0);      // behind W1: D2 .. and W2 (issued after step 0)
+        constexpr int C2 = (NQ > 3) ? (3 < NSL ? 4 : 2) : 0;                                // behind W2: W3 (issued after step 1)
+        if (up) {
+          if (q == 0) gb_wait_vm4<C0>(wa[0][0], wa[1][0], wb[0][0], wb[1][0]);
+          else if (q == 1) gb_wait_vm4<C1>(wa[0][0], wa[1][0], wb[0][0], wb[1][0]);
+          else if (q == 2) gb_wait_vm4<C2>(wa[0][0], wa[1][0], wb[0][0], wb[1][0]);
+          else gb_wait_vm4<0>(wa[0][0], wa[1][0], wb[0][0], wb[1][0]);
+        } else {
+          if (q == 0) gb_wait_vm2<C0>(wa[0][0], wa[1][0]);
+          else if (q == 1) gb_wait_vm2<C1>(wa[0][0], wa[1][0]);
+          else if (q == 2) gb_wait_vm2<C2>(wa[0][0], wa[1][0]);
+          else gb_wait_vm2<0>(wa[0][0], wa[1][0]);
         }
+        // a bare s_barrier, not __syncthreads(): the fence of __syncthreads() makes hipcc drain vmcnt to 0 (the LDS-DMA of the later
+        // slabs with it).  What the barrier must order is exactly what the counted wait above covers: this wave's share of slab q.
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
       } else {
         load_wq(q, wset[q & 1]);
         store_slab(q);
         __syncthreads();
       }
-      const unsigned short* ph = slab + ((q & 1) * NP + 0) * PLANE_E;
+      const unsigned short* ph = PL ? slab + q * (GB_BM * 64) : slab + ((q & 1) * NP + 0) * PLANE_E;      // PL: own buffer per slab, swizzled rows
       const unsigned short* pl = slab + ((q & 1) * NP + (NP - 1)) * PLANE_E;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         gb_bf16x8 xh[4], xl[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-          const int off = (mt * 16 + fi) * GB_LDK + kk * 32 + 8 * fg;
+          const int off = PL ? (mt * 16 + fi) * 64 + (((kk * 4 + fg) ^ (fi & 7)) * 8) : (mt * 16 + fi) * GB_LDK + kk * 32 + 8 * fg;
           xh[mt] = *reinterpret_cast<const gb_bf16x8*>(ph + off);
           if (!ONE) xl[mt] = *reinterpret_cast<const gb_bf16x8*>(pl + off);
         }
@@ -310,6 +349,9 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
             for (int mt = 0; mt < 4; ++mt) dd[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[mt], dd[mt], 0, 0, 0);
           }
         }
+      }
+      if constexpr (PL) {
+        if (q + 2 < 2 * nsl) load_wq(q + 2, wset[q & 1]);      // this step's fragment registers are free again
       }
     }
     __syncthreads();   // every wave is done with the slab buffers: they become the h1 / dgd tiles
@@ -521,6 +563,7 @@ int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, i
       (F != 64 && F != 128) || !(p >= 0.f) || !(p < 1.f))
     return SEPR_EINVAL;
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
+  if (xh16 && dy16 && M * F * 2 >= (1LL << 32)) return SEPR_EINVAL;   // 32-bit byte offsets of the plane-staged form
   if (!ws || ws_bytes < gcfn_bwd_fused_ws(M, F)) return SEPR_EWORKSPACE;
   GcfnBwdArgs a;
   a.x = x; a.stats = stats; a.dy = dy; a.M = (int)M; a.T = T; a.F = F;
