@@ -215,6 +215,6 @@ size_t relattn_x3_bwd_ws(int n, int Tp, int F, int H);
 // dO [n,Tp,F] -> dQKV [n,Tp,3F]; dpe [2*maxlen][dk] accumulated
 int launch_relattn_x3_bwd(const float* QKV, const float* lse, const float* O, const float* dO, float* dQKV, float* dpe_g, int n, int Tp,
                           int F, int H, const float* pe_k, int maxlen, float p, unsigned long long seed, const unsigned long long* salt,
-                          void* ws, size_t ws_bytes, hipStream_t s);
+                          void* ws, size_t ws_bytes, hipStream_t s, int ds16 = 0 /* dS rows as bf16: the plain-bf16 precision */);
 
 }  // namespace sepr

@@ -460,7 +460,8 @@ int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, in
   if (p > 0.f) SEPR_TRY(launch_dropout(datt, datt, (long long)F * Mp, p, seed, site_off(1), st));   // attention-output dropout mask
   // attention branch first (its input gradient is added while the gate branch's LayerNorm backward writes dx)
   SEPR_TRY(mha_out_bwd(datt, k.o, dO, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, st));
-  if (mfma) SEPR_TRY(launch_relattn_x3_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, drop_salt(), atw, atb, st));
+  if (mfma) SEPR_TRY(launch_relattn_x3_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, drop_salt(), atw, atb, st,
+                                           w->attn.qkv.planes == 1 ? 1 : 0));
   else SEPR_TRY(launch_relattn_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), atw, atb, st));
   SEPR_TRY(mha_qkv_bwd(dqkv, xp, k.stats_p, dxh_p, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, nullptr, dxd, st));
   // gate projection behind its own LayerNorm

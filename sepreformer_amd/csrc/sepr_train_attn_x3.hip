@@ -72,6 +72,8 @@ struct AxArgs {
   float dscale;
   unsigned long long seed;
   const unsigned long long* salt;
+  int ds16;            // 1 (plain-bf16 precision, round 4): the dS rows travel to the table-gradient kernel as bf16 - that kernel is a pure
+                       // HBM stream over [n*H, Tp, Tp] (512 MB in fp32 at 64 sequences), the only consumer rounds to bf16-level accuracy anyway
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -260,7 +262,17 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_x3_kernel(const AxArgs a) {
           ds[4 * s + r] = pv * (dp[s][r] * keep[r] - Di) * a.isd;
         }
         // the dS rows go to HBM once, for the table gradient (16 bytes per lane, 64 contiguous bytes per query)
-        if (active && jbase + 3 < Tp && (Tp & 3) == 0) st4(dsrow + jbase, make_float4(ds[4 * s], ds[4 * s + 1], ds[4 * s + 2], ds[4 * s + 3]));
+        if (a.ds16) {       // kernel-uniform
+          __bf16* d16 = reinterpret_cast<__bf16*>(a.dS) + (nh * Tp + (active ? i : 0)) * Tp;
+          if (active && jbase + 3 < Tp && (Tp & 3) == 0) {
+            ax_bf16x4 h4 = {(__bf16)ds[4 * s], (__bf16)ds[4 * s + 1], (__bf16)ds[4 * s + 2], (__bf16)ds[4 * s + 3]};
+            *reinterpret_cast<ax_bf16x4*>(d16 + jbase) = h4;
+          } else if (active) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (jbase + r < Tp) d16[jbase + r] = (__bf16)ds[4 * s + r];
+          }
+        } else if (active && jbase + 3 < Tp && (Tp & 3) == 0) st4(dsrow + jbase, make_float4(ds[4 * s], ds[4 * s + 1], ds[4 * s + 2], ds[4 * s + 3]));
         else if (active) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -537,7 +549,7 @@ constexpr int AXB_GROUP = 4;
 // lanes = consecutive rel = consecutive (descending) keys: 256-byte coalesced reads of every dS row, each element once.
 template <int DK>
 __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restrict__ QKV, const float* __restrict__ dS, float* __restrict__ band,
-                                                          int NH, int Tp, int F, int H) {
+                                                          int NH, int Tp, int F, int H, int ds16) {
   __shared__ float red[4][64][DK + 1];
   const int rl = threadIdx.x & 63;
   const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -552,10 +564,12 @@ __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restri
     const int n = nh / H, h = nh - n * H;
     const float* qb = QKV + (long long)n * Tp * 3 * F + h * DK;
     const float* sb = dS + (long long)nh * Tp * Tp;
+    const unsigned short* sb16 = reinterpret_cast<const unsigned short*>(dS) + (long long)nh * Tp * Tp;
 #pragma unroll 4
     for (int i = part; i < Tp; i += 4) {
       const int j = i - rel;
-      const float s = (j >= 0 && j < Tp) ? sb[(long long)i * Tp + j] : 0.f;
+      const bool in = j >= 0 && j < Tp;
+      const float s = !in ? 0.f : (ds16 ? __uint_as_float((unsigned)sb16[(long long)i * Tp + j] << 16) : sb[(long long)i * Tp + j]);
       const float* q = qb + (long long)i * 3 * F;
 #pragma unroll
       for (int d = 0; d < DK; ++d) acc[d] = fmaf(s, q[d], acc[d]);
@@ -602,7 +616,7 @@ size_t relattn_x3_bwd_ws(int n, int Tp, int F, int H) {
 
 int launch_relattn_x3_bwd(const float* QKV, const float* lse, const float* O, const float* dO, float* dQKV, float* dpe_g, int n, int Tp,
                           int F, int H, const float* pe_k, int maxlen, float p, unsigned long long seed, const unsigned long long* salt,
-                          void* ws, size_t ws_bytes, hipStream_t s) {
+                          void* ws, size_t ws_bytes, hipStream_t s, int ds16) {
   if (n <= 0) return SEPR_OK;
   if (!QKV || !lse || !O || !dO || !dQKV || !dpe_g || !pe_k || Tp <= 0 || H <= 0 || F % H || n > 65535 || !(p >= 0.f) || !(p < 1.f))
     return SEPR_EINVAL;
@@ -623,16 +637,17 @@ int launch_relattn_x3_bwd(const float* QKV, const float* lse, const float* O, co
   a.thr = p > 0.f ? sepr_drop_thr16(p) : 0u;
   a.dscale = p > 0.f ? sepr_drop_scale16(p) : 1.0f;
   a.seed = seed; a.salt = salt;
+  a.ds16 = ds16 ? 1 : 0;
   const dim3 grid((Tp + 63) / 64, H, n);
   const dim3 bgrid((2 * Tp - 1 + 63) / 64, ngroups);
   if (DK == 16) {
     hipLaunchKernelGGL((relattn_bwd_q_x3_kernel<16>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL((relattn_bwd_kv_x3_kernel<16>), grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL((relattn_band_kernel<16>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H);
+    hipLaunchKernelGGL((relattn_band_kernel<16>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H, a.ds16);
   } else {
     hipLaunchKernelGGL((relattn_bwd_q_x3_kernel<32>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL((relattn_bwd_kv_x3_kernel<32>), grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL((relattn_band_kernel<32>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H);
+    hipLaunchKernelGGL((relattn_band_kernel<32>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H, a.ds16);
   }
   hipLaunchKernelGGL(relattn_band_reduce2_kernel, dim3((2 * maxlen * DK + 255) / 256), dim3(256), 0, s, band, ngroups, Tp, DK, maxlen, dpe_g);
   SEPR_CHECK_LAUNCH("relattn_x3 backward kernels");
