@@ -351,148 +351,6 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// gemm_tn16_kernel (round 4): the contraction when BOTH operands are bf16 tensors and the arithmetic is plain bf16 (the GCFN pair of
-// the "bf16" training precision: dh1 x x-hat, dropout(dy) x gated tensor - 112 of a step's 299 contractions and its largest).  The
-// general kernel widens bf16 rows to fp32 registers, sums them for the bias gradient on the VALU and rounds them back while
-// transposing: ~170 VALU instructions per thread and slab against 32 MFMAs per wave.  Here
-//   * a staged row piece stays a packed uint2 (4 bf16): the 8-row x 4-column transpose is 32 v_perm_b32 per slab, nothing else;
-//   * the column sums of A (bias gradients) take one v_dot2_f32_bf16 per transposed row PAIR (fp32 accumulate of the same values);
-//   * rows cost half the registers, so TWO slabs are in flight in registers (what DBUF above could not afford) and the LDS planes
-//     are double buffered: one barrier per slab, and the HBM stream never pauses for the staging of a slab.
-// Same tile plan, same partial-tile / fixed-order reduction, same MFMA order per element as gemm_tn_kernel<2, false, false>: G is
-// bit-identical; the column sums differ in summation order only.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn16_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part,
-                                                                 float* __restrict__ cpart) {
-  constexpr int PLANE = TN_T * TN_LDM;                       // bf16 elements of one [128 columns][64 rows + pad] plane
-  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * 2 * PLANE];      // [buffer][A | B]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int fi = lane & 15, fg = lane >> 4;
-  const int gq = gridDim.x >> 3, gr = gridDim.x & 7, bx = blockIdx.x & 7;
-  const int vb = bx * gq + (bx < gr ? bx : gr) + (blockIdx.x >> 3);
-  const int tile = vb % (p.tn * p.tk), split = vb / (p.tn * p.tk);
-  const int n0 = (tile / p.tk) * TN_T, k0 = (tile % p.tk) * TN_T;
-  const int m_beg = split * p.rows_per_split;
-  const int m_end = min(a.M, m_beg + p.rows_per_split);
-  const bool roleA = __builtin_amdgcn_readfirstlane(wid) < 2;       // wave-uniform (waves 0, 1 stage A; 2, 3 stage B): scalar base pointer
-  const int t7 = tid & 127;
-  const int cg = t7 & 31, mg = t7 >> 5;
-  const int col = (roleA ? n0 : k0) + 4 * cg;
-  const bool col_ok = col < (roleA ? a.N : a.K);
-  const int row_safe = m_beg < a.M ? m_beg : 0;
-  const char* base = reinterpret_cast<const char*>(roleA ? a.A : a.B);             // SGPR base + 32-bit byte offsets (checked by the launcher)
-  const unsigned ld2 = 2u * (unsigned)(roleA ? a.lda : a.ldb), coff = 2u * (unsigned)(col_ok ? col : 0);
-
-  uint2 r0[8 * TN_NB], r1[8 * TN_NB];
-  float csum[4] = {0.f, 0.f, 0.f, 0.f};
-  auto load_slab = [&](int mb, uint2 (&r)[8 * TN_NB]) {
-#pragma unroll
-    for (int e = 0; e < 8 * TN_NB; ++e) {
-      const int m = mb + 32 * (e >> 3) + 8 * mg + (e & 7);
-      r[e] = *reinterpret_cast<const uint2*>(base + ((unsigned)(m < m_end ? m : row_safe) * ld2 + coff));
-    }
-  };
-  auto store_slab = [&](int mb, uint2 (&r)[8 * TN_NB], int buf) {
-#pragma unroll
-    for (int e = 0; e < 8 * TN_NB; ++e) {                    // branch-free validity (rows past the slice, columns past N / K): selects
-      const int m = mb + 32 * (e >> 3) + 8 * mg + (e & 7);
-      const bool ok = m < m_end && col_ok;
-      r[e].x = ok ? r[e].x : 0u;
-      r[e].y = ok ? r[e].y : 0u;
-    }
-    unsigned short* dst = smem + (buf * 2 + (roleA ? 0 : 1)) * PLANE;
-#pragma unroll
-    for (int nb = 0; nb < TN_NB; ++nb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint4 v;
-        unsigned d[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                        // rows 2q, 2q + 1 of this 8-row group: element j of both, packed
-          const unsigned lo = (j < 2) ? r[8 * nb + 2 * q].x : r[8 * nb + 2 * q].y;
-          const unsigned hi = (j < 2) ? r[8 * nb + 2 * q + 1].x : r[8 * nb + 2 * q + 1].y;
-          d[q] = __builtin_amdgcn_perm(hi, lo, (j & 1) ? 0x07060302u : 0x05040100u);
-          // column sum of column j over the two rows (the B-role threads' sums are never read)
-          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-          csum[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, d[q]), __builtin_bit_cast(bf16x2_t, 0x3f803f80u), csum[j], false);
-        }
-        v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3];
-        *reinterpret_cast<uint4*>(dst + (4 * cg + j) * TN_LDM + 32 * nb + 8 * mg) = v;
-      }
-  };
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  auto mma_slab = [&](int buf) {
-    const unsigned short* Ah = smem + (buf * 2 + 0) * PLANE;
-    const unsigned short* Bh = smem + (buf * 2 + 1) * PLANE;
-#pragma unroll
-    for (int nb = 0; nb < TN_NB; ++nb) {
-      tn_bf16x8 ah[4], bh[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        ah[t] = *reinterpret_cast<const tn_bf16x8*>(Ah + (wm * 64 + t * 16 + fi) * TN_LDM + 32 * nb + 8 * fg);
-        bh[t] = *reinterpret_cast<const tn_bf16x8*>(Bh + (wn * 64 + t * 16 + fi) * TN_LDM + 32 * nb + 8 * fg);
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh[kt], acc[nt][kt], 0, 0, 0);
-    }
-  };
-  // pipeline: slab s is multiplied out of LDS buffer s & 1 while slab s + 1 waits in one register set and slab s + 2 is in flight into
-  // the other; one barrier per slab
-  if (m_beg < m_end) {
-    load_slab(m_beg, r0);
-    load_slab(m_beg + TN_SLAB, r1);                          // (past m_end: clamped addresses, zeroed at the store)
-    store_slab(m_beg, r0, 0);
-    load_slab(m_beg + 2 * TN_SLAB, r0);
-    __syncthreads();
-    for (int mb = m_beg; mb < m_end; mb += 2 * TN_SLAB) {
-      mma_slab(0);                                           // slab mb
-      if (mb + TN_SLAB < m_end) {
-        store_slab(mb + TN_SLAB, r1, 1);
-        load_slab(mb + 3 * TN_SLAB, r1);
-      }
-      __syncthreads();
-      if (mb + TN_SLAB >= m_end) break;
-      mma_slab(1);                                           // slab mb + 64
-      if (mb + 2 * TN_SLAB < m_end) {
-        store_slab(mb + 2 * TN_SLAB, r0, 0);
-        load_slab(mb + 4 * TN_SLAB, r0);
-      }
-      __syncthreads();
-    }
-  }
-  float* pt = part + (long long)split * a.N * a.K;
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const int k = k0 + wn * 64 + kt * 16 + fi;
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int n = n0 + wm * 64 + nt * 16 + 4 * fg + rr;
-        if (n < a.N && k < a.K) pt[(long long)n * a.K + k] = acc[nt][kt][rr];
-      }
-    }
-  if (cpart && k0 == 0) {                                    // column sums of A: the four row groups of a column through LDS, fixed order
-    float* cs = reinterpret_cast<float*>(smem);              // (the last barrier of the loop is behind every wave's LDS reads)
-    __syncthreads();
-    if (roleA) {
-      cs[mg * TN_T + 4 * cg + 0] = csum[0]; cs[mg * TN_T + 4 * cg + 1] = csum[1];
-      cs[mg * TN_T + 4 * cg + 2] = csum[2]; cs[mg * TN_T + 4 * cg + 3] = csum[3];
-    }
-    __syncthreads();
-    if (tid < TN_T && n0 + tid < a.N)
-      cpart[(long long)split * a.N + n0 + tid] = (cs[tid] + cs[TN_T + tid]) + (cs[2 * TN_T + tid] + cs[3 * TN_T + tid]);
-  }
-}
-
 // block = 64 output elements x 4 lanes over the slices (fixed order inside a lane, lanes combined in a fixed order)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart, int nsplit,
                                                        int N, int K, float* __restrict__ G, int ldg, int accumulate,
@@ -572,15 +430,10 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
     else if (a.stats) hipLaunchKernelGGL((gemm_tn_kernel<MD, false, true>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp); \
     else hipLaunchKernelGGL((gemm_tn_kernel<MD, false, false>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp);         \
   } while (0)
-  // both operands bf16, plain-bf16 arithmetic, plain loader: the packed-row kernel (SEPR_TN16=0 keeps the general one: A/B, tests)
-  static const bool tn16_off = [] {
-    const char* e = getenv("SEPR_TN16");
-    return e && e[0] == '0';
-  }();
-  if (x3 == 2 && !gen && !a.stats && a.a16 && a.b16 && !tn16_off && (a.lda % 4) == 0 && (a.ldb % 4) == 0 &&
-      (long long)a.M * a.lda * 2 < (1LL << 32) && (long long)a.M * a.ldb * 2 < (1LL << 32))
-    hipLaunchKernelGGL(gemm_tn16_kernel, dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp);
-  else if (x3 == 2) SEPR_TN_LAUNCH(2);
+  // (A packed-row kernel for two bf16 operands - v_perm transpose, v_dot2 column sums, two slabs in flight, 5x fewer staging VALU
+  //  instructions, bit-identical G - was built and measured in round 4: 182.55 vs 182.55 utt/s, no gain; git history 'gemm_tn16'.
+  //  The contraction is not bound by its staging arithmetic.)
+  if (x3 == 2) SEPR_TN_LAUNCH(2);
   else if (x3) SEPR_TN_LAUNCH(1);
   else SEPR_TN_LAUNCH(0);
 #undef SEPR_TN_LAUNCH
