@@ -173,6 +173,7 @@ def self_launch(args) -> int:
 PMC_KERNEL_RE = "gcfn_fused3_kernel<[0-9]+, [0-9], [0-9], 0, false>"     # the GCFN instantiations of the fused kernel (not the plain GLU-MLP mode)
 
 
+LARGE_KERNEL_RE = "gemm_x3w?_kernel<1, 7, 1>"       # Large's GCFN up-projection (wide or narrow core), TAG 1
 TN_KERNEL_RE = "gemm_tn_kernel"      # every instantiation of the weight-gradient contraction (the training line's roofline kernel)
 
 
@@ -309,6 +310,17 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
         single = {"value": round(world * B * steps / e1, 3), "unit": "utt/s", "ms_per_step": round(1e3 * e1 / max(steps, 1), 3), "steps": steps}
         model.pipelines = pl_setting
     elapsed = sdist.max_over_ranks(elapsed, dev)
+    # the path's collective on its own, EVERY rank takes part: wall time of one synchronised 3-scalar all-reduce, median of 10
+    ar_ms = None
+    if not args.no_metric:
+        ts, probe = [], torch.zeros(3, dtype=torch.float64, device=dev)
+        for _ in range(12):
+            torch.cuda.synchronize(dev)
+            ta = time.perf_counter()
+            sdist.reduce_metric_sums(probe)
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - ta)
+        ar_ms = 1e3 * sorted(ts[2:])[5]
     rccl_ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
 
@@ -348,7 +360,10 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
     # rows per launch: the fused kernel reports 18F^2 + 36F FLOPs per row (both projections + the conv), the generic
     # up-projection 2 * 6F * F per row
     rows = fl.value / (18.0 * F * F + 36.0 * F) if fused else fl.value / (12.0 * F * F)
-    algo_bytes_launch = rows / n_launch * 8.0 * F if fused else None
+    # algorithmic HBM bytes per row of the profiled launch: fused block = x in + y out (8F); generic up-projection = x in + the gated
+    # tensor out (4F + 12F)
+    bytes_per_row = 8.0 * F if fused else 16.0 * F
+    algo_bytes_launch = rows / n_launch * bytes_per_row
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_gcfn_up.json")
     if fused and variant == DEFAULT_VARIANT and os.path.exists(pmc):
@@ -373,8 +388,8 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
         kern = ("gcfn_fused3_kernel<F,2,4> (and its <F,1,6> instantiation for launches under 17000 rows; whole GCFN block in "
                 "one launch: LayerNorm, F->6F MFMA, depthwise conv k=3 + GLU, 3F->F MFMA, LayerScale, residual)"
                 if fused else
-                "gemm_x3_kernel<PRO_NORM,EPI_DWGLU,1> (GCFN F->6F projection of the generic path: LayerNorm prologue, "
-                "bf16x3 MFMA, depthwise-conv+GLU epilogue)")
+                "gemm_x3w_kernel<PRO_NORM,EPI_DWGLU,1> (GCFN F->6F projection of the generic path on the 128x256 wide core - "
+                "gemm_x3_kernel for launches too small for it: LayerNorm prologue, bf16x3 MFMA, depthwise-conv+GLU epilogue)")
     # matrix FLOPs only (the conv's 36F per row ride on the VALU) for the pipe-occupancy figure
     mfma_tf = mult * (rows * 18.0 * F * F if fused else fl.value) / 1e12 / sec if sec > 0 else 0.0
     roof = {"kernel": kern, "bound": "mfma", "achieved": round(algo_tf, 2), "peak": peak, "unit": "TFLOP/s",
@@ -389,7 +404,7 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
                             "device: per-launch durations inside the timed region would not describe one kernel); rocprofv3 summary: the same "
                             "command with SEPR_PIPELINES=1")}
     if algo_bytes_launch:
-        gbs = rows * 8.0 * F / 1e9 / sec if sec > 0 else 0.0
+        gbs = rows * bytes_per_row / 1e9 / sec if sec > 0 else 0.0
         roof.update({"algorithmic_bytes_per_launch": round(algo_bytes_launch), "hbm_gbs": round(gbs, 1),
                      "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
     cfg_idx = {DEFAULT_VARIANT: 1 if world == 1 else 2, "SepReformer_Large_DM_WHAMR": 3}.get(variant)
@@ -428,15 +443,6 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
     if not args.no_metric and variant == DEFAULT_VARIANT:
         # configs[2] (batch 256 over 8 GPUs = this per-rank workload x 8) from measured pieces: the data path has no collective, the
         # per-step exchange is the 24-byte metric all-reduce (latency-bound: a few tens of microseconds over xGMI against a >= 24 ms step)
-        ts = []
-        probe = torch.zeros(3, dtype=torch.float64, device=dev)
-        for _ in range(12):
-            torch.cuda.synchronize(dev)
-            ta = time.perf_counter()
-            sdist.reduce_metric_sums(probe)
-            torch.cuda.synchronize(dev)
-            ts.append(time.perf_counter() - ta)
-        ar_ms = 1e3 * sorted(ts[2:])[len(ts[2:]) // 2]
         step_ms = 1e3 * elapsed / max(steps, 1)
         lat8 = max(ar_ms, 0.06)                  # <= ~60 us for an 8-rank latency-bound all-reduce over xGMI
         rec["dp8_prediction"] = {"n_gpus": 8, "per_rank_step_ms_measured": round(step_ms, 3), "metric_allreduce_bytes": 24,
@@ -573,12 +579,45 @@ def main():
             # configs[3] (Large_DM_WHAMR inference, with its own parity gate) and configs[4] (the training step).
             t_sub = time.perf_counter()
             try:
-                sub = measure_infer(args, "SepReformer_Large_DM_WHAMR", 2, 1, rank, world, dev, lib, full=False)
+                sub = measure_infer(args, "SepReformer_Large_DM_WHAMR", 3, 1, rank, world, dev, lib, full=False)
                 rec["large"] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "parity_db_vs_golden",
                                                      "pit_si_snr_max_abs_delta_db", "parity_ok", "model_tflops", "model_frac_algorithmic",
                                                      "model_mfma_frac", "roofline")}
             except Exception as e:              # noqa: BLE001
                 rec["large"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if "error" not in rec["large"] and args.pmc != "off" and rec["large"]["roofline"].get("algorithmic_bytes_per_launch"):
+                # HBM traffic of Large's dominant kernel (the GCFN up-projection with the conv + GLU epilogue), measured in this run
+                try:
+                    pm, why = measure_pmc_traffic(90.0, LARGE_KERNEL_RE, ["--variant", "SepReformer_Large_DM_WHAMR", "--steps", "1", "--warmup", "1",
+                                                                         "--no-cpu-baseline", "--no-alt-precision", "--pmc", "off"])
+                except Exception as e:          # noqa: BLE001
+                    pm, why = None, f"{type(e).__name__}: {e}"[:200]
+                roof = rec["large"]["roofline"]
+                if pm and pm.get("traffic_over_algorithmic"):
+                    roof["traffic"] = round(pm["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"])
+                    roof["traffic_over_algorithmic"] = pm["traffic_over_algorithmic"]
+                    roof["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) over {pm['launches']} "
+                                              f"launches of a 1-step Large sub-run; fetch {pm['fetch_bytes_per_launch']} + write {pm['write_bytes_per_launch']} B per launch")
+                else:
+                    roof["traffic_source"] = f"live PMC passes failed: {why}"
+            if "error" not in rec["large"] and not args.no_cpu_baseline:
+                # the oracle on the host for this variant: ONE forward of one utterance, no warm-up (a Large forward takes seconds)
+                try:
+                    from oracle import sepreformer_oracle as orc
+                    from sepreformer_amd.synth import synth_mixture, synth_state_dict
+                    lcfg = VARIANTS["SepReformer_Large_DM_WHAMR"]
+                    sd_l = synth_state_dict(lcfg, 0)
+                    x1 = synth_mixture(1, SAMPLES, seed=1234)
+                    torch.set_num_threads(16)
+                    with torch.inference_mode():
+                        tc = time.perf_counter()
+                        orc.model_forward(sd_l, lcfg, x1)
+                        tc = time.perf_counter() - tc
+                    rec["large"]["cpu_baseline"] = {"value": round(1.0 / tc, 4), "unit": "utt/s", "cores": 16, "kind": "port",
+                                                    "sample": f"oracle.model_forward, fp32, B=1 x {SAMPLES} samples, ONE forward without warm-up: {tc:.2f} s at 16 threads"}
+                    del sd_l
+                except Exception as e:          # noqa: BLE001
+                    rec["large"]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             # the training lines run in their own processes: a fault of the training path cannot take the headline line with it
             rec["train"] = {}
             keys = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "capture_fallback", "host_enqueue_ms_per_step",
