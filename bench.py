@@ -170,7 +170,7 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-PMC_KERNEL_RE = "gcfn_fused3_kernel<[0-9]+, [0-9], [0-9], 0, false>"     # the GCFN instantiations of the fused kernel (not the plain GLU-MLP mode)
+PMC_KERNEL_RE = "gcfn_fused3_kernel<[0-9]+, [0-9], [0-9], 0, false, false>"     # the GCFN instantiations of the fused kernel (not the plain GLU-MLP mode)
 
 
 LARGE_KERNEL_RE = "gemm_x3w?_kernel<1, 7, 1>"       # Large's GCFN up-projection (wide or narrow core), TAG 1
