@@ -1475,3 +1475,38 @@ def test_gcfn_bf16_plane_staged_backward_equals_register_staged(variant, n, T, m
             assert orc.agreement_db(b_.cpu(), a_.cpu()) >= 45.0, (k, orc.agreement_db(b_.cpu(), a_.cpu()))
         else:
             assert torch.equal(a_, b_), (k, int((a_ != b_).sum()), float((a_ - b_).abs().max()))
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("variant", ["SepReformer_Base_WSJ0", "SepReformer_Large_DM_WHAMR"])
+def test_train_blocks_wide_core_equals_narrow(variant, precision, monkeypatch):
+    """The training path's projections on the 128 x 256 wide core (what a batch-16 step runs from 65 000 rows up) vs the 128 x 128
+    core: forced on for every eligible launch (SEPR_X3_WIDE=2) vs off (0), dropout live so that the residual + dropout epilogue
+    (EPI_RESDROP) and the GLU + saved pre-activation epilogue (EPI_GLUSAVE) run on both cores, plain-bf16 (TAG 16 / bf16-input TAG 48)
+    and bf16x3 instantiations: block outputs, input gradients and ALL parameter gradients are bitwise equal."""
+    from sepreformer_amd.train_engine import TrainEngine
+    from sepreformer_amd.train_pack import GradBuffer, TrainPack
+    cfg = dataclasses.replace(VARIANTS[variant], dropout=0.3)
+    sd = synth_state_dict(cfg, 0)
+    dev = torch.device("cuda:0")
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    F = cfg.feat
+    n, T = 2 * cfg.num_spks, 777
+    x, dy = rnd(n, T, F, seed=3).cuda(), rnd(n, T, F, seed=4).cuda()
+    outs = []
+    for mode in ("0", "2"):
+        monkeypatch.setenv("SEPR_X3_WIDE", mode)
+        sdm = {k: v.clone() for k, v in sdd.items()}                       # (BatchNorm running statistics are updated by the CLA forward)
+        gb = GradBuffer(cfg, dev)
+        tp = TrainPack(cfg, sdm, gb, precision)
+        eng = TrainEngine(cfg, dev)
+        res = []
+        for kind, w, Tp in (("gcfn", tp.gcfn[0], 0), ("cla", tp.cla[0], 0), ("ega", tp.ega[0], T // 7), ("spk", tp.spk[0], 0)):
+            y, rec = eng.block_fwd(kind, x, w, n, T, Tp, 0.3, 99)
+            dx = eng.block_bwd(rec, dy)
+            res += [y.clone(), dx.clone()]
+        torch.cuda.synchronize()
+        outs.append(res + [gb.flat.clone()])
+    for i, (a_, b_) in enumerate(zip(outs[0], outs[1])):
+        assert torch.isfinite(a_).all() and torch.equal(a_, b_), (i, int((a_ != b_).sum()))
+    assert float(outs[0][-1].abs().max()) > 0
