@@ -1491,7 +1491,7 @@ def test_train_blocks_wide_core_equals_narrow(variant, precision, monkeypatch):
     dev = torch.device("cuda:0")
     sdd = {k: v.to(dev) for k, v in sd.items()}
     F = cfg.feat
-    n, T = 2 * cfg.num_spks, 777
+    n, T = 2 * cfg.num_spks, 800
     x, dy = rnd(n, T, F, seed=3).cuda(), rnd(n, T, F, seed=4).cuda()
     outs = []
     for mode in ("0", "2"):
@@ -1501,7 +1501,7 @@ def test_train_blocks_wide_core_equals_narrow(variant, precision, monkeypatch):
         tp = TrainPack(cfg, sdm, gb, precision)
         eng = TrainEngine(cfg, dev)
         res = []
-        for kind, w, Tp in (("gcfn", tp.gcfn[0], 0), ("cla", tp.cla[0], 0), ("ega", tp.ega[0], T // 7), ("spk", tp.spk[0], 0)):
+        for kind, w, Tp in (("gcfn", tp.gcfn[0], 0), ("cla", tp.cla[0], 0), ("ega", tp.ega[0], T // 8), ("spk", tp.spk[0], 0)):
             y, rec = eng.block_fwd(kind, x, w, n, T, Tp, 0.3, 99)
             dx = eng.block_bwd(rec, dy)
             res += [y.clone(), dx.clone()]
