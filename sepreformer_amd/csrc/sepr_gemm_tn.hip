@@ -351,6 +351,68 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// tn_smallk_kernel (round 4): G[N][16] (+)= sum_m A[m][n] * B'[m][k] for the two filter gradients of the waveform ends - the
+// ConvTranspose1d decoder weights (5 heads) and the Conv1d encoder weights: K = 16 taps, N = 256 basis channels, M = sequences x
+// frames (256 000 rows at batch 16), B' = 16 consecutive samples of the frame's window (row map: seq * seq_stride + r * ldb).
+// On the 128 x 128 MFMA tile core 7/8 of the B tile is padding, the general loader runs one workgroup per CU and the launch took
+// 379 us (0.7 TB/s) for what is one pass over A.  Here: exact fp32 on the VALU (16 FMAs per A element: still far below the
+// stream), a wave walks rows, lane = 4 consecutive columns (float4, 1 KB coalesced per row), the frame's 16 samples are
+// wave-uniform (scalar loads), the 4 waves of a workgroup combine through LDS in a fixed order, row slices combine in
+// tn_reduce_kernel as for every other contraction (same partial layout, same workspace plan, no atomics).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tn_smallk_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part) {
+  constexpr int KK = 16;
+  __shared__ float red[4][64][4 * KK + 4];        // [wave][lane][4 columns x 16 taps] (+ pad: 272-byte rows)
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int split = blockIdx.x;
+  const int m_beg = split * p.rows_per_split;
+  const int m_end = min(a.M, m_beg + p.rows_per_split);
+  const bool col_ok = 4 * lane < a.N;
+  float acc[4][KK];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < KK; ++k) acc[c][k] = 0.f;
+  const float* Ap = a.A + (col_ok ? 4 * lane : 0);
+  constexpr int UN = 4;                           // rows in flight per wave
+  for (int m0 = m_beg + w; m0 < m_end; m0 += 4 * UN) {
+    float4 av[UN];
+    float bv[UN][KK];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int m = m0 + 4 * u;                   // wave-uniform
+      const int mc = m < m_end ? m : m_beg;
+      av[u] = ld4(Ap + (long long)mc * a.lda);
+      const int seq = mc / a.rows_out, r = mc - seq * a.rows_out;
+      const float* bp = a.B + (long long)seq * a.seq_stride + (long long)r * a.ldb;       // wave-uniform address: scalar loads
+#pragma unroll
+      for (int k = 0; k < KK; ++k) bv[u][k] = bp[k];
+      if (!(m < m_end && col_ok && r < a.rows_valid)) av[u] = zero4();
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int k = 0; k < KK; ++k) {
+        acc[0][k] = fmaf(av[u].x, bv[u][k], acc[0][k]);
+        acc[1][k] = fmaf(av[u].y, bv[u][k], acc[1][k]);
+        acc[2][k] = fmaf(av[u].z, bv[u][k], acc[2][k]);
+        acc[3][k] = fmaf(av[u].w, bv[u][k], acc[3][k]);
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < KK; k += 4) st4(&red[w][lane][c * KK + k], make_float4(acc[c][k], acc[c][k + 1], acc[c][k + 2], acc[c][k + 3]));
+  __syncthreads();
+  // part[split][n][k], n = 4 * lane + c: 64 consecutive floats per lane; thread t sums element t + 256 j of the 4096
+  float* pt = part + (long long)split * a.N * KK;
+  for (int e = threadIdx.x; e < 64 * 4 * KK; e += 256) {
+    const int l = e / (4 * KK), q = e - l * (4 * KK);
+    if (4 * l + q / KK < a.N) pt[e] = (red[0][l][q] + red[1][l][q]) + (red[2][l][q] + red[3][l][q]);
+  }
+}
+
 // block = 64 output elements x 4 lanes over the slices (fixed order inside a lane, lanes combined in a fixed order)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart, int nsplit,
                                                        int N, int K, float* __restrict__ G, int ldg, int accumulate,
@@ -402,6 +464,24 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   if (gen && (a.a16 || a.b16)) return SEPR_EINVAL;      // (checked before the profiling slot opens)
   long long slot = -1;
   const bool timed = prof_begin(SEPR_SITE_WGRAD, s, &slot);
+  // the filter gradients of the waveform ends (K = 16 taps, exact arithmetic, windowed-frame row map): one pass over A on the VALU
+  static const bool smallk_off = [] {
+    const char* e = getenv("SEPR_TN_SMALLK");
+    return e && e[0] == '0';
+  }();
+  if (x3 == 0 && a.K == 16 && a.N <= 256 && a.rows_out > 0 && !a.B2 && !a.idx && !a.stats && !a.mask_a && a.b_shift == 0 && !a.colsum &&
+      !a.a16 && !a.b16 && p.tn * p.tk <= 2 && !smallk_off) {
+    hipLaunchKernelGGL(tn_smallk_kernel, dim3(p.nsplit), dim3(256), 0, s, a, p, part);
+    if (timed) {
+      prof_end(slot, 2.0 * (double)a.M * (double)a.N * (double)a.K, s);
+      prof_bytes((double)a.M * ((double)a.N * 4.0 + 64.0));
+    }
+    const long long total_e = (long long)a.N * a.K;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)((total_e + 63) / 64)), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
+                       (float*)nullptr, 0);
+    SEPR_CHECK_LAUNCH("tn_smallk_kernel");
+    return SEPR_OK;
+  }
   float* cp = a.colsum ? cpart : nullptr;
   // The general loader runs ONE workgroup per CU (16 KB of dynamic LDS on top of the static 74 KB make a second one not fit): with
   // two co-resident workgroups and statistics its bf16 instantiations returned wrong, run-to-run different values in the even
