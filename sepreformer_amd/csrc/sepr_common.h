@@ -55,6 +55,12 @@ __device__ __forceinline__ float glu_prescaled(float val, float gs) {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// 4 fp32 -> 4 bf16 (round to nearest even), one 8-byte store at element index idx of a bf16 tensor addressed through a float*
+__device__ __forceinline__ void st4_bf16(float* base, long long idx, float4 v) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  const bf16x4_t h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(base) + idx) = h;
+}
 
 // butterfly sums over the lanes of a wave64
 __device__ __forceinline__ float wave_sum(float v) {

@@ -65,13 +65,16 @@ int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t st
   // every argument check comes BEFORE prof_begin: an early return inside an open profiling slot would leave a start event without
   // its end event (sepr_prof_stop would then read an unrecorded event)
   if (epi == EPI_LNBWD && (a.N > GEMM_BN || !a.aux || !a.stats || (a.aux2 && (a.T <= 0 || a.Tp <= 0 || a.fac <= 0)))) return SEPR_EINVAL;
-  if (a.bf1 && a.a16 && ((key != PRO_PLAIN * 16 + EPI_STORE && key != PRO_PLAIN * 16 + EPI_LNBWD) || a.rows_out > 0 || (a.lda % 8) != 0)) return SEPR_EINVAL;
+  if (a.bf1 && a.a16 && ((key != PRO_PLAIN * 16 + EPI_STORE && key != PRO_PLAIN * 16 + EPI_LNBWD && key != PRO_PLAIN * 16 + EPI_RES &&
+                          key != PRO_PLAIN * 16 + EPI_RESDROP) || a.rows_out > 0 || (a.lda % 8) != 0)) return SEPR_EINVAL;
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
   // (an unknown prologue / epilogue combination below closes the slot before it reports the error)
 #define SEPR_X3_BAD_KEY do { if (timed) prof_end(slot, 0.0, stream); return SEPR_EINVAL; } while (0)
   if (a.bf1 && a.a16) {
     if (epi == EPI_LNBWD) launch_x3_inst<PRO_PLAIN, EPI_LNBWD, 16 | 32>(a, stream);
+    else if (epi == EPI_RES) launch_x3_inst<PRO_PLAIN, EPI_RES, 16 | 32>(a, stream);
+    else if (epi == EPI_RESDROP) launch_x3_inst<PRO_PLAIN, EPI_RESDROP, 16 | 32>(a, stream);
     else launch_x3_inst<PRO_PLAIN, EPI_STORE, 16 | 32>(a, stream);
   } else if (a.bf1) {   // plain bf16 operands: the projections of the training path's "bf16" precision
     switch (key) {

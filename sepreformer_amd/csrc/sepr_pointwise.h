@@ -25,7 +25,8 @@ int launch_dwglu(const float* H, float* G, int n, int T, int F, const float* w, 
 // CLA middle: depthwise 'same' conv (K odd, K <= 65) along frames.  U [n,T,F] -> C [n,T,F]
 int launch_dwconv_same(const float* U, float* C, int n, int T, int F, int K, const float* w, const float* b, hipStream_t s);
 int launch_dwconv_same_glu_bwd(const float* dc, const float* a, float* da, int n, int T, int F, int K, const float* w, const float* zero_bias,
-                               hipStream_t s);
+                               hipStream_t s, int out16 = 0 /* da as bf16 */);
+int launch_dwconv_same16(const float* U, float* C, int n, int T, int F, int K, const float* w, const float* b, hipStream_t s);   // C as bf16
 
 // DownConv: depthwise K=5 stride 2 + folded BN + GELU.  X [n,T,F] -> Y [n,To,F]
 int launch_downconv(const float* X, float* Y, int n, int T, int To, int F, int K, const float* w,

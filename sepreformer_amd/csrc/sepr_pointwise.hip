@@ -427,7 +427,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // GLUB (training, CLA backward): the conv's output du [rows][F] (the gradient w.r.t. the GLU output) does not go to HBM - the epilogue is
 // the GLU backward: with the saved pre-activation rows A [rows][2F] (value | gate), DA [rows][2F] = (du sig(g), du v sig(g) (1 - sig(g)))
 // (glu_bwd_kernel's arithmetic); C is unused.
-template <int KW, bool GLUB = false>
+// OUT16 (training, plain-bf16 precision): the output rows (C, or DA with GLUB) are stored as bf16 - their only readers are MFMA operand
+// loaders that round to bf16 anyway (linear2 and its weight gradient; linear1's weight gradient and input-gradient projection).
+template <int KW, bool GLUB = false, bool OUT16 = false>
 __global__ __launch_bounds__(256, 2) void dwconv_same_pk_kernel(const float* __restrict__ U, float* __restrict__ C, int T, int F,
                                                                int tiles_per_seq, int ntiles, const float* __restrict__ w,
                                                                const float* __restrict__ b, const float* __restrict__ A = nullptr,
@@ -531,15 +533,30 @@ __global__ __launch_bounds__(256, 2) void dwconv_same_pk_kernel(const float* __r
             const float s0 = sigmoid_exact(ag[o][0]), s1 = sigmoid_exact(ag[o][1]);
             const f32x2 dv = {acc[o][0] * s0, acc[o][1] * s1};
             const f32x2 dg = {acc[o][0] * av[o][0] * s0 * (1.f - s0), acc[o][1] * av[o][1] * s1 * (1.f - s1)};
-            *reinterpret_cast<f32x2*>(dp + (long long)o * 2 * F) = dv;
-            *reinterpret_cast<f32x2*>(dp + (long long)o * 2 * F + F) = dg;
+            if constexpr (OUT16) {
+              typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+              __bf16* d16 = reinterpret_cast<__bf16*>(DA) + (row0 + o) * 2 * F + c0 + cp;
+              *reinterpret_cast<bf16x2_t*>(d16) = (bf16x2_t){(__bf16)dv[0], (__bf16)dv[1]};
+              *reinterpret_cast<bf16x2_t*>(d16 + F) = (bf16x2_t){(__bf16)dg[0], (__bf16)dg[1]};
+            } else {
+              *reinterpret_cast<f32x2*>(dp + (long long)o * 2 * F) = dv;
+              *reinterpret_cast<f32x2*>(dp + (long long)o * 2 * F + F) = dg;
+            }
           }
         }
       } else {
-        float* dst = C + ((long long)seq * T + t0 + rb) * F + c0 + cp;
+        if constexpr (OUT16) {
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          __bf16* d16 = reinterpret_cast<__bf16*>(C) + ((long long)seq * T + t0 + rb) * F + c0 + cp;
 #pragma unroll
-        for (int o = 0; o < OPT; ++o)
-          if (t0 + rb + o < T) *reinterpret_cast<f32x2*>(dst + (long long)o * F) = acc[o];
+          for (int o = 0; o < OPT; ++o)
+            if (t0 + rb + o < T) *reinterpret_cast<bf16x2_t*>(d16 + (long long)o * F) = (bf16x2_t){(__bf16)acc[o][0], (__bf16)acc[o][1]};
+        } else {
+          float* dst = C + ((long long)seq * T + t0 + rb) * F + c0 + cp;
+#pragma unroll
+          for (int o = 0; o < OPT; ++o)
+            if (t0 + rb + o < T) *reinterpret_cast<f32x2*>(dst + (long long)o * F) = acc[o];
+        }
       }
     }
     __syncthreads();   // tile fully consumed before the next DMA overwrites it
@@ -567,8 +584,21 @@ int launch_dwconv_same(const float* U, float* C, int n, int T, int F, int K, con
 
 // CLA backward: da [rows][2F] = GLU'(a) applied to du = depthwise_k65(dc) (taps w: the forward taps reversed; no bias) - the conv's
 // output never reaches HBM (round 4; replaces launch_dwconv_same + launch_glu_bwd and the [rows][F] round trip between them)
+// C as a bf16 tensor [n*T][F] (F % 128 == 0 only)
+int launch_dwconv_same16(const float* U, float* C, int n, int T, int F, int K, const float* w, const float* b, hipStream_t s) {
+  if (n <= 0 || T <= 0) return SEPR_OK;
+  if (K != 65 || F % 128 != 0 || !U || !C || !w || !b) return SEPR_EINVAL;
+  const int tiles = (T + 127) / 128;
+  const long long nt = (long long)tiles * n * (F / 64);
+  if (nt > 0x7fffffffLL) return SEPR_EINVAL;
+  const int cap = persistent_grid();
+  hipLaunchKernelGGL((dwconv_same_pk_kernel<65, false, true>), dim3((int)(nt < cap ? nt : cap)), dim3(256), 0, s, U, C, T, F, tiles, (int)nt, w, b);
+  SEPR_CHECK_LAUNCH("dwconv_same_pk_kernel<out16>");
+  return SEPR_OK;
+}
+
 int launch_dwconv_same_glu_bwd(const float* dc, const float* a, float* da, int n, int T, int F, int K, const float* w, const float* zero_bias,
-                               hipStream_t s) {
+                               hipStream_t s, int out16) {
   if (n <= 0 || T <= 0) return SEPR_OK;
   if (K != 65 || F % 128 != 0 || !dc || !a || !da || !w || !zero_bias) return SEPR_EINVAL;
   const int tiles = (T + 127) / 128;
@@ -576,7 +606,8 @@ int launch_dwconv_same_glu_bwd(const float* dc, const float* a, float* da, int n
   if (nt > 0x7fffffffLL) return SEPR_EINVAL;
   const int cap = persistent_grid();
   const int grid = (int)(nt < cap ? nt : cap);
-  hipLaunchKernelGGL((dwconv_same_pk_kernel<65, true>), dim3(grid), dim3(256), 0, s, dc, nullptr, T, F, tiles, (int)nt, w, zero_bias, a, da);
+  if (out16) hipLaunchKernelGGL((dwconv_same_pk_kernel<65, true, true>), dim3(grid), dim3(256), 0, s, dc, nullptr, T, F, tiles, (int)nt, w, zero_bias, a, da);
+  else hipLaunchKernelGGL((dwconv_same_pk_kernel<65, true>), dim3(grid), dim3(256), 0, s, dc, nullptr, T, F, tiles, (int)nt, w, zero_bias, a, da);
   SEPR_CHECK_LAUNCH("dwconv_same_pk_kernel<glu_bwd>");
   return SEPR_OK;
 }

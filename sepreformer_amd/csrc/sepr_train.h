@@ -125,11 +125,13 @@ int launch_colstats(const float* z, long long M, int C, float eps, float momentu
                     void* ws, size_t ws_bytes, hipStream_t s);
 size_t colstats_ws(long long M, int C);
 // y = gelu(gamma * (z - mean) * rstd + beta)   (BatchNorm apply + exact GELU)
+// out16 = 1: y is written as bf16 [M][C] (plain-bf16 precision: its readers are MFMA operand loaders)
 int launch_bn_gelu_fwd(const float* z, const float* stats, const float* g, const float* b, float* y, long long M, int C,
-                       hipStream_t s);
+                       hipStream_t s, int out16 = 0);
 // backward of the above w.r.t. z, plus dgamma / dbeta accumulation
+// out16 = 1: dz is written as bf16 [M][C] (dz must then not alias dy)
 int launch_bn_gelu_bwd(const float* dy, const float* z, const float* stats, const float* g, const float* b, float* dz, float* dg_g,
-                       float* db_g, long long M, int C, void* ws, size_t ws_bytes, hipStream_t s);
+                       float* db_g, long long M, int C, void* ws, size_t ws_bytes, hipStream_t s, int out16 = 0);
 // EGA gate: y = x + sigmoid(zg) * att[(m / T) * Tp + (m % T) / fac]
 int launch_gate_fwd(const float* x, const float* zg, const float* att, float* y, int n, int T, int Tp, int F, hipStream_t s);
 // dzg = dy * att_up * sigmoid'(zg) [M][F]; datt[Mp][F] = sum over the fac frames of a pooled frame of dy * sigmoid(zg)

@@ -258,6 +258,14 @@ int gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, co
 // =====================================================================================================================
 // CLA  (network.py:159-187), train-mode BatchNorm
 // =====================================================================================================================
+// Plain-bf16 precision (round 4): four of the block's intermediates are STORED as bf16 - c (conv output), d = gelu(bn(z)), dz and da
+// (the gradients w.r.t. linear2's / linear1's outputs).  Every reader of those four is an MFMA operand loader that rounds to bf16
+// anyway (linear2 / linear3 and their weight gradients, the two input-gradient projections), so results are bit-identical to the
+// fp32-stored form (tested) while ~5.4 KB of the block's ~27 KB of HBM traffic per row disappear.  SEPR_TRAIN_CLA16=0: fp32 (A/B, test).
+bool cla_h16(const sepr_cla_tw* w, int F, int K) {
+  const char* e = getenv("SEPR_TRAIN_CLA16");
+  return !(e && e[0] == '0') && w && w->l1.wp && w->l1.planes == 1 && F % 128 == 0 && K == 65;
+}
 constexpr unsigned CLA_DROP_SITE = 3u;   // 16-bit generator site of the CLA output dropout (0, 1: fused GCFN; 2: attention probabilities)
 struct ClaCtx { float *stats, *a, *u, *c, *z, *bn, *d; };
 ClaCtx cla_ctx(Carve& cx, long long M, int F) {
@@ -287,20 +295,29 @@ int cla_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_cla
     a.A = x; a.lda = F; a.stats = k.stats; a.Y = k.u; a.ldc = F; a.Ysave = k.a;
     SEPR_TRY(lin(PRO_NORM, EPI_GLUSAVE, a, w->l1, SEPR_SITE_NONE, st));
   }
-  SEPR_TRY(launch_dwconv_same(k.u, k.c, n, T, F, K, w->dw_w, w->dw_b, st));                   // :178-180
-  SEPR_TRY(plain(k.c, F, k.z, 2 * F, M, 2 * F, F, w->l2, nullptr, st));                       // :181
+  const bool h16 = cla_h16(w, F, K);
+  if (h16) {
+    SEPR_TRY(launch_dwconv_same16(k.u, k.c, n, T, F, K, w->dw_w, w->dw_b, st));               // :178-180, c as bf16
+    GemmArgs a = gemm_args_zero();
+    a.M = (int)M; a.N = 2 * F; a.K = F;
+    a.A = k.c; a.lda = F; a.a16 = 1; a.Y = k.z; a.ldc = 2 * F;
+    SEPR_TRY(lin(PRO_PLAIN, EPI_STORE, a, w->l2, SEPR_SITE_NONE, st));                        // :181
+  } else {
+    SEPR_TRY(launch_dwconv_same(k.u, k.c, n, T, F, K, w->dw_w, w->dw_b, st));                 // :178-180
+    SEPR_TRY(plain(k.c, F, k.z, 2 * F, M, 2 * F, F, w->l2, nullptr, st));                     // :181
+  }
   SEPR_TRY(launch_colstats(k.z, M, 2 * F, BN_EPS_T, BN_MOM, k.bn, w->bn_rm, w->bn_rv, csw, csb, st));   // :183 (batch statistics)
-  SEPR_TRY(launch_bn_gelu_fwd(k.z, k.bn, w->bn_g, w->bn_b, k.d, M, 2 * F, st));               // :183,185 (GELU)
+  SEPR_TRY(launch_bn_gelu_fwd(k.z, k.bn, w->bn_g, w->bn_b, k.d, M, 2 * F, st, h16 ? 1 : 0));  // :183,185 (GELU); d as bf16 when h16
   if (p > 0.f) {   // :185-187 with the dropout of linear3[2] in the projection's epilogue (round 4; 16-bit generator, site CLA_DROP_SITE)
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = F; a.K = 2 * F;
-    a.A = k.d; a.lda = 2 * F; a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
+    a.A = k.d; a.lda = 2 * F; a.a16 = h16 ? 1 : 0; a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
     a.drop_thr = sepr_drop_thr16(p); a.drop_scale = sepr_drop_scale16(p); a.drop_seed = seed; a.drop_salt = drop_salt(); a.drop_site = CLA_DROP_SITE;
     SEPR_TRY(lin(PRO_PLAIN, EPI_RESDROP, a, w->l3, SEPR_SITE_NONE, st));
   } else {
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = F; a.K = 2 * F;
-    a.A = k.d; a.lda = 2 * F; a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
+    a.A = k.d; a.lda = 2 * F; a.a16 = h16 ? 1 : 0; a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
     SEPR_TRY(lin(PRO_PLAIN, EPI_RES, a, w->l3, SEPR_SITE_NONE, st));                          // :185-187
   }
   return SEPR_OK;
@@ -315,6 +332,7 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
   float* dd = ws.f32(2LL * F * M);      // d(gelu out), later dz in place, later da
   float* dc = ws.f32((long long)F * M);
   float* du = ws.f32((long long)F * M);
+  float* h16buf = ws.f32(2LL * F * M);  // plain-bf16 precision: dz [M][2F] bf16 in its first half, da [M][2F] bf16 in its second half
   float* dxh = dc;                      // dc is dead once du / the conv weight gradient are formed
   const size_t tnb = tn_workspace_bytes((int)M, 2 * F, F);
   void* tnw = ws.take(tnb);
@@ -329,6 +347,44 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
   if (p > 0.f) {
     SEPR_TRY(launch_dropout16(dy, dyp, M, F, p, seed, CLA_DROP_SITE, st));                    // the mask of cla_fwd's EPI_RESDROP
     dyq = dyp;
+  }
+  if (cla_h16(w, F, K)) {   // the bf16-stored form: c, d from the forward; dz, da here (see cla_h16)
+    float* dz16 = h16buf;
+    float* da16 = h16buf + (long long)F * M;                    // (2F bf16 per row = F floats per row)
+    {
+      TnArgs t = tn_args_zero();
+      t.M = (int)M; t.N = F; t.K = 2 * F;
+      t.A = dyq; t.lda = F; t.B = k.d; t.ldb = 2 * F; t.b16 = 1;
+      t.G = Gr; t.ldg = 2 * F; t.colsum = s;
+      SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
+    }
+    SEPR_TRY(launch_finish_linear_ls(Gr, s, w->w3, w->b3, w->ls, g->w3, g->b3, g->ls, F, 2 * F, st));
+    SEPR_TRY(plain(dyq, F, dd, 2 * F, M, 2 * F, F, w->l3_t, nullptr, st));
+    SEPR_TRY(launch_bn_gelu_bwd(dd, k.z, k.bn, w->bn_g, w->bn_b, dz16, g->bn_g, g->bn_b, M, 2 * F, csw, csb, st, 1));
+    {
+      TnArgs t = tn_args_zero();
+      t.M = (int)M; t.N = 2 * F; t.K = F;
+      t.A = dz16; t.lda = 2 * F; t.a16 = 1; t.B = k.c; t.ldb = F; t.b16 = 1;
+      t.G = g->w2; t.ldg = F; t.accumulate = 1; t.colsum = g->b2; t.colsum_accumulate = 1;
+      SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));                                                              // linear2 (direct)
+    }
+    {
+      GemmArgs a = gemm_args_zero();
+      a.M = (int)M; a.N = F; a.K = 2 * F;
+      a.A = dz16; a.lda = 2 * F; a.a16 = 1; a.Y = dc; a.ldc = F;
+      SEPR_TRY(lin(PRO_PLAIN, EPI_STORE, a, w->l2_t, SEPR_SITE_NONE, st));
+    }
+    SEPR_TRY(launch_dwconv_wgrad(k.u, dc, n, T, F, K, g->dw_w, g->dw_b, wgw, wgb, st));
+    SEPR_TRY(launch_dwconv_same_glu_bwd(dc, k.a, da16, n, T, F, K, w->dw_wf, w->zeros, st, 1));
+    {
+      TnArgs t = tn_args_zero();
+      t.M = (int)M; t.N = 2 * F; t.K = F;
+      t.A = da16; t.lda = 2 * F; t.a16 = 1; t.B = x; t.ldb = F; t.stats = k.stats;
+      t.G = Gr; t.ldg = F; t.colsum = s;
+      SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
+    }
+    SEPR_TRY(launch_finish_norm_linear(Gr, s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, st));
+    return dgrad_ln(da16, 2 * F, 2 * F, w->l1_t, 1, x, k.stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
   }
   SEPR_TRY(wgrad(dyq, F, k.d, 2 * F, nullptr, Gr, s, M, F, 2 * F, 0, x3, tnw, tnb, st));
   SEPR_TRY(launch_finish_linear_ls(Gr, s, w->w3, w->b3, w->ls, g->w3, g->b3, g->ls, F, 2 * F, st));

@@ -555,21 +555,23 @@ __global__ __launch_bounds__(TPB) void colred_final2_kernel(const double* __rest
 
 __global__ __launch_bounds__(TPB) void bn_gelu_fwd_kernel(const float* __restrict__ z, const float* __restrict__ stats,
                                                          const float* __restrict__ g, const float* __restrict__ b, float* __restrict__ y,
-                                                         long long M, int C) {
+                                                         long long M, int C, int out16) {
   const int c4 = C >> 2;
   const long long total = M * c4;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
     const long long m = i / c4;
     const int c = (int)(i - m * c4) * 4;
     const float4 v = ld4(z + m * C + c), mu = ld4(stats + c), rs = ld4(stats + C + c), ga = ld4(g + c), be = ld4(b + c);
-    st4(y + m * C + c, make_float4(gelu_exact(fmaf(ga.x, (v.x - mu.x) * rs.x, be.x)), gelu_exact(fmaf(ga.y, (v.y - mu.y) * rs.y, be.y)),
-                                   gelu_exact(fmaf(ga.z, (v.z - mu.z) * rs.z, be.z)), gelu_exact(fmaf(ga.w, (v.w - mu.w) * rs.w, be.w))));
+    const float4 o = make_float4(gelu_exact(fmaf(ga.x, (v.x - mu.x) * rs.x, be.x)), gelu_exact(fmaf(ga.y, (v.y - mu.y) * rs.y, be.y)),
+                                 gelu_exact(fmaf(ga.z, (v.z - mu.z) * rs.z, be.z)), gelu_exact(fmaf(ga.w, (v.w - mu.w) * rs.w, be.w)));
+    if (out16) st4_bf16(y, m * C + c, o);      // plain-bf16 precision: the only readers are MFMA operand loaders that round to bf16
+    else st4(y + m * C + c, o);
   }
 }
 __global__ __launch_bounds__(TPB) void bn_gelu_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                                const float* __restrict__ stats, const float* __restrict__ g,
                                                                const float* __restrict__ b, const float* __restrict__ sums,
-                                                               float* __restrict__ dz, long long M, int C) {
+                                                               float* __restrict__ dz, long long M, int C, int out16) {
   const int c4 = C >> 2;
   const long long total = M * c4;
   const float invM = 1.0f / (float)M;
@@ -589,7 +591,8 @@ __global__ __launch_bounds__(TPB) void bn_gelu_bwd_apply_kernel(const float* __r
       const float dpre = dd[j] * gelu_grad(fmaf(g_[j], zh, b_[j]));
       o[j] = g_[j] * r_[j] * (dpre - a1[j] * invM - zh * (a2[j] * invM));
     }
-    st4(dz + m * C + c, make_float4(o[0], o[1], o[2], o[3]));
+    if (out16) st4_bf16(dz, m * C + c, make_float4(o[0], o[1], o[2], o[3]));
+    else st4(dz + m * C + c, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 }  // namespace
@@ -612,15 +615,16 @@ int launch_colstats(const float* z, long long M, int C, float eps, float momentu
   SEPR_CHECK_LAUNCH("colstats kernels");
   return SEPR_OK;
 }
-int launch_bn_gelu_fwd(const float* z, const float* stats, const float* g, const float* b, float* y, long long M, int C, hipStream_t s) {
+int launch_bn_gelu_fwd(const float* z, const float* stats, const float* g, const float* b, float* y, long long M, int C, hipStream_t s,
+                       int out16) {
   if (M <= 0) return SEPR_OK;
   if (!z || !stats || !g || !b || !y || C <= 0 || C % 4) return SEPR_EINVAL;
-  hipLaunchKernelGGL(bn_gelu_fwd_kernel, dim3(grid_for(M * (C >> 2), TPB, 1 << 16)), dim3(TPB), 0, s, z, stats, g, b, y, M, C);
+  hipLaunchKernelGGL(bn_gelu_fwd_kernel, dim3(grid_for(M * (C >> 2), TPB, 1 << 16)), dim3(TPB), 0, s, z, stats, g, b, y, M, C, out16);
   SEPR_CHECK_LAUNCH("bn_gelu_fwd_kernel");
   return SEPR_OK;
 }
 int launch_bn_gelu_bwd(const float* dy, const float* z, const float* stats, const float* g, const float* b, float* dz, float* dg_g,
-                       float* db_g, long long M, int C, void* ws, size_t ws_bytes, hipStream_t s) {
+                       float* db_g, long long M, int C, void* ws, size_t ws_bytes, hipStream_t s, int out16) {
   if (M <= 0) return SEPR_OK;
   if (!dy || !z || !stats || !g || !b || !dz || C <= 0 || C % 4) return SEPR_EINVAL;
   if (!ws || ws_bytes < colstats_ws(M, C)) return SEPR_EWORKSPACE;
@@ -629,8 +633,9 @@ int launch_bn_gelu_bwd(const float* dy, const float* z, const float* stats, cons
   float* sums = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)nblk * C * 2 * sizeof(double)));
   hipLaunchKernelGGL((colred_kernel<1>), dim3(nblk, (C + 63) / 64), dim3(TPB), 0, s, z, dy, stats, g, b, M, C, part);
   hipLaunchKernelGGL(colred_final2_kernel, dim3((C + 15) / 16), dim3(TPB), 0, s, part, nblk, C, sums, dg_g, db_g);
+  if (out16 && static_cast<const void*>(dz) == static_cast<const void*>(dy)) return SEPR_EINVAL;      // a bf16 dz cannot overwrite the fp32 dy in place
   hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel, dim3(grid_for(M * (C >> 2), TPB, 1 << 16)), dim3(TPB), 0, s, dy, z, stats, g, b, sums, dz,
-                     M, C);
+                     M, C, out16);
   SEPR_CHECK_LAUNCH("bn_gelu_bwd kernels");
   return SEPR_OK;
 }

@@ -1510,3 +1510,45 @@ def test_train_blocks_wide_core_equals_narrow(variant, precision, monkeypatch):
     for i, (a_, b_) in enumerate(zip(outs[0], outs[1])):
         assert torch.isfinite(a_).all() and torch.equal(a_, b_), (i, int((a_ != b_).sum()))
     assert float(outs[0][-1].abs().max()) > 0
+
+
+@pytest.mark.parametrize("n,T", [(3, 1201), (4, 8000)])
+def test_cla_bf16_stored_intermediates_equal_fp32_stored(n, T, monkeypatch):
+    """Plain-bf16 precision, CLA block: c, d = gelu(bn(z)), dz and da stored as bf16 (SEPR_TRAIN_CLA16, default) vs as fp32.  Every reader
+    of those four tensors is an MFMA operand loader that rounds to bf16, so the block output, the input gradient and every parameter
+    gradient that does not pass through a column sum of da are BITWISE equal; linear1's bias gradient is the column sum of da (taken
+    over the bf16 rows in the new form), and linear1.weight / the LayerNorm affine contain it: bf16-level agreement there."""
+    from sepreformer_amd.train_engine import TrainEngine
+    from sepreformer_amd.train_pack import GradBuffer, TrainPack
+    cfg = dataclasses.replace(VARIANTS["SepReformer_Base_WSJ0"], dropout=0.3)
+    sd = synth_state_dict(cfg, 0)
+    dev = torch.device("cuda:0")
+    F = cfg.feat
+    x, dy = rnd(n, T, F, seed=T).cuda(), rnd(n, T, F, seed=T + 7).cuda()
+    pfx = "separator.enc_stages.0.l_block_1.block.cla"
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SEPR_TRAIN_CLA16", mode)
+        sdd = {k: v.to(dev) for k, v in sd.items()}
+        gb = GradBuffer(cfg, dev)
+        tp = TrainPack(cfg, sdd, gb, "bf16")
+        eng = TrainEngine(cfg, dev)
+        y, rec = eng.block_fwd("cla", x, tp.cla[0], n, T, 0, 0.3, 4242)
+        dx = eng.block_bwd(rec, dy)
+        torch.cuda.synchronize()
+        outs.append((y.clone(), dx.clone(), {k[len(pfx) + 1:]: gb.view(k).clone() for k in sd if k.startswith(pfx + ".") and k in gb.offsets},
+                     sdd[pfx + ".BN.running_var"].clone()))
+    assert torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][3], outs[1][3])
+    scale = max(float(v.abs().max()) for v in outs[0][2].values())
+    for k, a_ in outs[0][2].items():
+        b_ = outs[1][2][k]
+        if k == "linear2.bias":
+            # column sum of dz in front of a train-mode BatchNorm: identically zero in exact arithmetic (STRUCTURAL_ZERO), rounding noise in
+            # both forms (fp32 dz vs bf16 dz rows)
+            assert float(a_.abs().max()) <= 3e-2 * scale and float(b_.abs().max()) <= 3e-2 * scale, (k, float(a_.abs().max()), float(b_.abs().max()), scale)
+        elif k.startswith(("linear1.", "layer_norm.")):
+            if float(a_.abs().max()) > 0:
+                assert orc.agreement_db(b_.cpu(), a_.cpu()) >= 45.0, (k, orc.agreement_db(b_.cpu(), a_.cpu()))
+        else:
+            assert torch.equal(a_, b_), (k, int((a_ != b_).sum()), float((a_ - b_).abs().max()), float(a_.abs().max()))
