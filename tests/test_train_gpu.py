@@ -1333,7 +1333,7 @@ def test_train_step_base_4s_gradients_match_oracle():
 BF16_STEP_MIN_DB, BF16_STEP_MEDIAN_DB = 20.0, 30.0   # measured (round 4): min 27.2 / 27.6, median 35.0 / 41.1 dB
 
 
-@pytest.mark.parametrize("B,T", [(2, 4000), (1, 32000)])
+@pytest.mark.parametrize("B,T", [(1, 32000)])        # (round 4 also ran (2, 4000): median 35.0 dB, min 27.2 dB; dropped for suite time)
 def test_train_step_base_bf16_matches_oracle(B, T):
     """precision="bf16" (the arithmetic BASELINE configs[4] names) at Base width: the whole step at 0.5 s x 2 and at 4 s x 1 against
     the fp32 oracle (frozen gates).  A bf16 step is a different rounding of the same function, not a parity claim at 80 dB: the
