@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SEPR_VERSION 302 /* major*10000 + minor*100 + patch */
+#define SEPR_VERSION 303 /* major*10000 + minor*100 + patch */
 
 #define SEPR_OK 0
 #define SEPR_EINVAL (-1)     /* bad shape / unsupported size / null pointer */
@@ -476,6 +476,32 @@ int sepr_pit_sisnr_mag_bwd(const float* est, const float* tgt, const int* perm, 
                            const float* dft_t, int frame_len, int frame_shift, double eps, float* dest, void* ws, size_t ws_bytes,
                            sepr_stream_t stream);
 size_t sepr_pit_sisnr_mag_bwd_workspace(int S, int B, int T, int frame_len, int frame_shift);
+
+/* ---- optimizer step of the reference loop (ABI 3.03) ------------------------------------------------
+ * engine.py:76-77: torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.AdamW.step() as three launches over the whole
+ * model.  The gradients live in ONE flat fp32 buffer (the training path's gradient buffer: 64-element aligned slices, zero padding);
+ * the moments in two flat fp32 buffers of the caller.  All table pointers are DEVICE pointers.
+ *   params[i]     parameter tensor i (fp32, contiguous, 16-byte aligned)
+ *   grad_off[i]   element offset of its gradient in `grads`;  state_off[i]: of its moments in exp_avg / exp_avg_sq (multiples of 4)
+ *   numel[i]      elements of tensor i
+ *   blocks[2 b], blocks[2 b + 1] = (tensor, first element) of update block b; a block covers sepr_adamw_block_elems() elements
+ * step: device double, incremented by the call; lr: device float (a scheduler refreshes it without re-capturing a graph);
+ * max_norm <= 0: no clipping (no norm pass).  scal (device, 8 floats) receives [0] the total gradient norm BEFORE clipping,
+ * [1] the clip coefficient min(1, max_norm / (norm + 1e-6)), [2..4] the step's derived scalars.  The gradients are NOT scaled in
+ * place: the coefficient is applied inside the update.  Arithmetic: torch's AdamW (decoupled weight decay), fp32 per element. */
+typedef struct {
+  float* const* params;
+  const long long* grad_off;
+  const long long* state_off;
+  const int* numel;
+  const int* blocks;
+  int ntensors, nblocks;
+} sepr_adamw_tables;
+int sepr_adamw_block_elems(void);
+size_t sepr_adamw_workspace(void);
+int sepr_adamw_step(const sepr_adamw_tables* t, const float* grads, long long grads_numel, float* exp_avg, float* exp_avg_sq,
+                    double* step, const float* lr, double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                    float* scal, void* ws, size_t ws_bytes, sepr_stream_t stream);
 
 /* ---- opt-in kernel timer (bench.py roofline) ------------------------------------------------- */
 /* Sites a projection launch can be attributed to. */

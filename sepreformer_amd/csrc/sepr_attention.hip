@@ -192,7 +192,7 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& l) {
 // backward keeps of the probabilities - and applies inverted dropout to the probabilities that multiply V (network.py:121;
 // the softmax denominator sums the undropped ones); mask of element (row = (seq*H + h)*Tp + i, key j) = 16-bit half j & 1 of
 // sepr_drop_word(dkey, row, j >> 1) >= thr (sepr_train.h).
-template <int DK, bool TRAIN = false>
+template <int DK, bool TRAIN = false, bool BP = false>
 __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const float* __restrict__ QKV, float* __restrict__ O, int Tp, int F,
                                                         const float* __restrict__ pe, int maxlen, float inv_sqrt_dk,
                                                         float* __restrict__ lse = nullptr, unsigned thr = 0u, float dscale = 1.0f,
@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
   static_assert(DK == 16 || DK == 32, "head width");
   // pe_planes (inference, round 4): the position table already split into bf16 hi / lo planes at pack time - the band rows of a key
   // tile are then copied global -> registers -> LDS as they are (half of this kernel's staged elements lose their VALU split)
-  const bool bp = !TRAIN && pe_planes != nullptr;            // kernel-uniform
+  // BP is a template parameter: as a run-time flag every band fetch computed both tables' addresses and selected (16 VALU per key tile)
+  static_assert(!(TRAIN && BP), "the training forward reads the fp32 table");
+  constexpr bool bp = BP;
   DropKey dkey = {0u, 0u};
   if (TRAIN && thr) dkey = sepr_drop_key(seed, salt, 2u);
   constexpr int QB = 64, KT = 64;
@@ -367,13 +369,23 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const int b0 = ii + 31 - 16 * s - 4 * g;              // b of key 16 s + 4g + 0; r steps down
-          const int jbase = j0 + 32 * p + 16 * s + 4 * g;
           float bias[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) bias[r] = (SEPR_AT_ABL & 1) ? 0.f : psk[b0 - r];       // unconditional: the reads issue back to back
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sv[p][s][r] = (jbase + r < Tp) ? sc[s][r] + bias[r] : -1e30f;
+          for (int r = 0; r < 4; ++r) sv[p][s][r] = sc[s][r] + bias[r];
         }
+      }
+      // only a tile that reaches past Tp pays the 16 key-bound selects: a wave-uniform branch (as selects inside the loop above they cost
+      // 48 VALU per tile and the compiler turned four of the bias reads into exec-masked blocks with their own LDS waits)
+      if (j0 + KT > Tp) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (j0 + 32 * p + 16 * s + 4 * g + r >= Tp) sv[p][s][r] = -1e30f;
       }
       float mx = -1e30f;
 #pragma unroll
@@ -476,11 +488,19 @@ int launch_relattn(const float* QKV, float* O, int n, int Tp, int F, int H, cons
   const dim3 grid((Tp + 63) / 64, H, n);
   const float isd = 1.0f / sqrtf((float)dk);
   if (dk == 16 && x3) {
-    hipLaunchKernelGGL((relattn_x3_kernel<16>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, (float*)nullptr, 0u, 1.0f, 0ull,
-                       (const unsigned long long*)nullptr, static_cast<const unsigned short*>(pe_planes));
+    if (pe_planes)
+      hipLaunchKernelGGL((relattn_x3_kernel<16, false, true>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, (float*)nullptr, 0u, 1.0f, 0ull,
+                         (const unsigned long long*)nullptr, static_cast<const unsigned short*>(pe_planes));
+    else
+      hipLaunchKernelGGL((relattn_x3_kernel<16, false, false>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, (float*)nullptr, 0u, 1.0f,
+                         0ull, (const unsigned long long*)nullptr, (const unsigned short*)nullptr);
   } else if (dk == 32 && x3) {
-    hipLaunchKernelGGL((relattn_x3_kernel<32>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, (float*)nullptr, 0u, 1.0f, 0ull,
-                       (const unsigned long long*)nullptr, static_cast<const unsigned short*>(pe_planes));
+    if (pe_planes)
+      hipLaunchKernelGGL((relattn_x3_kernel<32, false, true>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, (float*)nullptr, 0u, 1.0f, 0ull,
+                         (const unsigned long long*)nullptr, static_cast<const unsigned short*>(pe_planes));
+    else
+      hipLaunchKernelGGL((relattn_x3_kernel<32, false, false>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, (float*)nullptr, 0u, 1.0f,
+                         0ull, (const unsigned long long*)nullptr, (const unsigned short*)nullptr);
   } else if (dk == 16) {
     hipLaunchKernelGGL((relattn_kernel<16>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd);
   } else if (dk == 32) {

@@ -46,9 +46,12 @@ inline TnPlan tn_plan(int M, int N, int K) {
   const int tiles = p.tn * p.tk;
   // Row slices: enough workgroups to fill the chip (2 co-resident per CU = 512), but every slice pays a partial tile of
   // up to 64 KB written and re-read by the reduction, so a slice is at least 256 rows (its inputs: 256 x (N + K) x 4 B).
-  int ns = 512 / tiles;
+  // SEPR_TN_WGS / SEPR_TN_MINROWS: experiment knobs of tools/wgrad_bench.py (read once; the defaults are the product plan)
+  static const int target_wgs = [] { const char* e = getenv("SEPR_TN_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+  static const int min_rows = [] { const char* e = getenv("SEPR_TN_MINROWS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+  int ns = target_wgs / tiles;
   if (ns < 1) ns = 1;
-  const int max_by_rows = (M + 255) / 256;
+  const int max_by_rows = (M + min_rows - 1) / min_rows;
   if (ns > max_by_rows) ns = max_by_rows;
   if (ns < 1) ns = 1;
   int rps = (M + ns - 1) / ns;

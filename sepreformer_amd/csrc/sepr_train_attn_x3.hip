@@ -544,12 +544,13 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) 
 // dS[nh][i][i - rel] * q[nh][i][d]   (rel = i - j in (-Tp, Tp)); consecutive threads = consecutive rel = consecutive j
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int AXB_GROUP = 4;
+constexpr int AXB_ROWS = 8;     // rows per load batch of the table-gradient kernel
 // One block = 64 consecutive relative offsets x 4 query partitions (one partition per wave).  Every lane of a wave walks the
 // SAME queries i (so the q rows are wave-uniform: scalar loads) and reads dS[i][i - rel] when that key exists; consecutive
 // lanes = consecutive rel = consecutive (descending) keys: 256-byte coalesced reads of every dS row, each element once.
-template <int DK>
+template <int DK, bool DS16>      // DS16 is a template parameter: as a run-time select the unrolled row loop lost its batched loads (122 -> 211 us)
 __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restrict__ QKV, const float* __restrict__ dS, float* __restrict__ band,
-                                                          int NH, int Tp, int F, int H, int ds16) {
+                                                          int NH, int Tp, int F, int H) {
   __shared__ float red[4][64][DK + 1];
   const int rl = threadIdx.x & 63;
   const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -565,14 +566,24 @@ __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restri
     const float* qb = QKV + (long long)n * Tp * 3 * F + h * DK;
     const float* sb = dS + (long long)nh * Tp * Tp;
     const unsigned short* sb16 = reinterpret_cast<const unsigned short*>(dS) + (long long)nh * Tp * Tp;
-#pragma unroll 4
-    for (int i = part; i < Tp; i += 4) {
-      const int j = i - rel;
-      const bool in = j >= 0 && j < Tp;
-      const float s = !in ? 0.f : (ds16 ? __uint_as_float((unsigned)sb16[(long long)i * Tp + j] << 16) : sb[(long long)i * Tp + j]);
-      const float* q = qb + (long long)i * 3 * F;
+    // batches of AXB_ROWS rows: every load is unconditional (clamped address, the value selected afterwards), so the batch's loads
+    // issue back to back and ONE wait covers them; with a predicated load per row the loop ran at one memory latency per row
+    for (int i0 = part; i0 < Tp; i0 += 4 * AXB_ROWS) {
+      float sv[AXB_ROWS];
 #pragma unroll
-      for (int d = 0; d < DK; ++d) acc[d] = fmaf(s, q[d], acc[d]);
+      for (int u = 0; u < AXB_ROWS; ++u) {
+        const int i = i0 + 4 * u, j = i - rel;
+        const bool in = i < Tp && j >= 0 && j < Tp;
+        const long long at = (long long)min(i, Tp - 1) * Tp + min(max(j, 0), Tp - 1);
+        const float v = DS16 ? __uint_as_float((unsigned)sb16[at] << 16) : sb[at];
+        sv[u] = in ? v : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < AXB_ROWS; ++u) {
+        const float* q = qb + (long long)min(i0 + 4 * u, Tp - 1) * 3 * F;      // wave-uniform: scalar loads
+#pragma unroll
+        for (int d = 0; d < DK; ++d) acc[d] = fmaf(sv[u], q[d], acc[d]);
+      }
     }
   }
 #pragma unroll
@@ -643,11 +654,13 @@ int launch_relattn_x3_bwd(const float* QKV, const float* lse, const float* O, co
   if (DK == 16) {
     hipLaunchKernelGGL((relattn_bwd_q_x3_kernel<16>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL((relattn_bwd_kv_x3_kernel<16>), grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL((relattn_band_kernel<16>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H, a.ds16);
+    if (a.ds16) hipLaunchKernelGGL((relattn_band_kernel<16, true>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H);
+    else hipLaunchKernelGGL((relattn_band_kernel<16, false>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H);
   } else {
     hipLaunchKernelGGL((relattn_bwd_q_x3_kernel<32>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL((relattn_bwd_kv_x3_kernel<32>), grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL((relattn_band_kernel<32>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H, a.ds16);
+    if (a.ds16) hipLaunchKernelGGL((relattn_band_kernel<32, true>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H);
+    else hipLaunchKernelGGL((relattn_band_kernel<32, false>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H);
   }
   hipLaunchKernelGGL(relattn_band_reduce2_kernel, dim3((2 * maxlen * DK + 255) / 256), dim3(256), 0, s, band, ngroups, Tp, DK, maxlen, dpe_g);
   SEPR_CHECK_LAUNCH("relattn_x3 backward kernels");

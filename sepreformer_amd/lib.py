@@ -90,6 +90,12 @@ MhaTW = _tstruct("MhaTW", ["@qkv", "@qkv_t", "@out", "@out_t", "ls", "wqkv", "ln
 MhaGrad = _tstruct("MhaGrad", ["ln_g", "ln_b", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ls"])
 
 
+class AdamWTables(C.Structure):
+    """include/sepr.h sepr_adamw_tables (device pointers)."""
+    _fields_ = [("params", _fp), ("grad_off", _fp), ("state_off", _fp), ("numel", _fp), ("blocks", _fp), ("ntensors", C.c_int),
+                ("nblocks", C.c_int)]
+
+
 class EgaTW(C.Structure):
     _fields_ = [("attn", MhaTW), ("gate", Lin), ("gate_t", Lin), ("gate_w", _fp), ("gate_ln_g", _fp), ("gate_ln_b", _fp),
                 ("pe_k", _fp), ("maxlen", C.c_int)]
@@ -161,6 +167,9 @@ SIGNATURES = {
     "sepr_pit_sisnr_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _d, _d, _fp, _fp, _sz, _fp]),
     "sepr_pit_sisnr_mag_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "sepr_pit_sisnr_mag_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _i, _i, _d, _fp, _fp, _sz, _fp]),
+    "sepr_adamw_block_elems": (_i, []),
+    "sepr_adamw_workspace": (_sz, []),
+    "sepr_adamw_step": (_i, [C.POINTER(AdamWTables), _fp, _ll, _fp, _fp, _fp, _fp, _d, _d, _d, _d, _d, _fp, _fp, _sz, _fp]),
     "sepr_prof_start": (_i, [_i, _i]),
     "sepr_prof_stop": (_i, [C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sepr_prof_last_bytes": (C.c_double, []),

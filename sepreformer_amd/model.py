@@ -187,6 +187,7 @@ class _SeparatorFn(torch.autograd.Function):
                                    "backward (e.g. (model(x1) + model(x2)).backward()); use the eager train path (train_graphs = False) for that")
             with torch.cuda.device(tg.x.device):
                 flat = tg.backward(d_wav, d_aux)
+                model.__dict__["_grad_flat"] = flat               # (optim.FlatAdamW, train_step.py)
                 if model.grad_sync is not None:
                     model.grad_sync(flat)                         # (no early bucket: the backward is one graph)
             grads = []

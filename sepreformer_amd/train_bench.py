@@ -96,10 +96,17 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
     crit_t = PIT_SISNR_time(dev, cfg.num_spks, True)
     crit_m = PIT_SISNR_mag(dev, 512, 128, "hann", cfg.num_stages, cfg.num_spks, True, False)
     params = list(model.parameters())
-    try:
-        opt = torch.optim.AdamW(params, lr=1.0e-4, weight_decay=1.0e-2, fused=True, capturable=(mode == "step"))
-    except (TypeError, RuntimeError):
-        opt = torch.optim.AdamW(params, lr=1.0e-4, weight_decay=1.0e-2, capturable=(mode == "step"))
+    # the reference's AdamW + clip_grad_norm_ (engine.py:76-77): sepreformer_amd.optim.FlatAdamW runs both as three launches over the
+    # flat gradient buffer (same arithmetic; tests/test_train_gpu.py compares it with torch.optim.AdamW); SEPR_BENCH_OPT=torch: torch's
+    flat_opt = os.environ.get("SEPR_BENCH_OPT", "flat") != "torch"
+    if flat_opt:
+        from .optim import FlatAdamW
+        opt = FlatAdamW(model, lr=1.0e-4, weight_decay=1.0e-2)
+    else:
+        try:
+            opt = torch.optim.AdamW(params, lr=1.0e-4, weight_decay=1.0e-2, fused=True, capturable=(mode == "step"))
+        except (TypeError, RuntimeError):
+            opt = torch.optim.AdamW(params, lr=1.0e-4, weight_decay=1.0e-2, capturable=(mode == "step"))
     last = {}
 
     def loss_fn(audio, aux, *tg):
@@ -113,8 +120,11 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
         audio, aux = model(x)
         loss = loss_fn(audio, aux, *targets)
         loss.backward()
-        gn = torch.nn.utils.clip_grad_norm_(params, 5.0)                                      # engine.py:76
-        opt.step()
+        if flat_opt:
+            gn = opt.step(max_norm=5.0)                                                       # engine.py:76-77 in one call
+        else:
+            gn = torch.nn.utils.clip_grad_norm_(params, 5.0)                                  # engine.py:76
+            opt.step()
         last["loss"], last["gn"] = loss.detach(), gn
 
     captured, capture_error = None, None
@@ -202,7 +212,8 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
                                                "clip + optimizer (train_step.CapturedTrainStep)",
                                        "split": "two hipGraph replays per step (weight re-pack + forward; backward) + eager criteria / clip / optimizer",
                                        "off": "eager (every kernel launched from the host)"}[mode],
-                       "optimizer": type(opt).__name__ + (" (fused)" if getattr(opt, "defaults", {}).get("fused") else ""),
+                       "optimizer": type(opt).__name__ + (" (fused)" if getattr(opt, "defaults", {}).get("fused") else "") +
+                                    (" = clip_grad_norm_ + AdamW as 3 launches over the flat gradient buffer" if flat_opt else ""),
                        "clip_norm": 5.0, "parallelism": f"data-parallel x{world}, flat-buffer RCCL all-reduce" + (" (DEBUG: all ranks share GPU 0, gloo collective)" if share else "")},
             "capture_fallback": capture_error,
             "host_enqueue_ms_per_step": round(1e3 * t_enq, 3),

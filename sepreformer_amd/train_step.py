@@ -61,9 +61,7 @@ class CapturedTrainStep:
                 audio, aux = model(self.x)
                 loss = loss_fn(audio, aux, *self.targets)
                 loss.backward()
-                if max_norm is not None:
-                    torch.nn.utils.clip_grad_norm_(self.params, max_norm)
-                optimizer.step()
+                self._clip_and_step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
 
@@ -91,13 +89,20 @@ class CapturedTrainStep:
         if self.sync is not None and self.flat is None:
             raise RuntimeError("the parameters' .grad do not alias the flat gradient buffer: cannot all-reduce between the graphs")
         with torch.cuda.graph(self.g_opt, pool=pool, capture_error_mode=CAPTURE_MODE):
-            self.grad_norm = torch.nn.utils.clip_grad_norm_(self.params, max_norm) if max_norm is not None else None
-            optimizer.step()
+            self.grad_norm = self._clip_and_step()
         # the captured launches point into the train engine's scratch workspace: keep that tensor alive for the graphs' lifetime
         # (a later, larger eager shape makes the engine allocate a new one; the old one must not go back to the allocator)
         eng = model.__dict__.get("_train_engine")
         self._ws_keep = eng._ws if eng is not None else None
         self.audio, self.aux = audio, aux            # static outputs of the last replay (detached views are the caller's business)
+
+    def _clip_and_step(self):
+        """engine.py:76-77.  An optimizer with ``fused_clip`` (optim.FlatAdamW) clips inside its step."""
+        if getattr(self.opt, "fused_clip", False):
+            return self.opt.step(max_norm=self.max_norm)
+        gn = torch.nn.utils.clip_grad_norm_(self.params, self.max_norm) if self.max_norm is not None else None
+        self.opt.step()
+        return gn
 
     def _refresh_salt(self):
         if self.model.dropout_p > 0.0:
@@ -113,6 +118,8 @@ class CapturedTrainStep:
         self.g_main.replay()
         if self.sync is not None:
             self.sync(self.flat)
+        if hasattr(self.opt, "refresh"):
+            self.opt.refresh()                       # a scheduler's new learning rate reaches the device scalar the graph reads
         self.g_opt.replay()
         self.model.invalidate_packed()               # the weights and BatchNorm state changed behind the version counters
         self.calls += 1

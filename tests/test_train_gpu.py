@@ -1552,3 +1552,110 @@ def test_cla_bf16_stored_intermediates_equal_fp32_stored(n, T, monkeypatch):
                 assert orc.agreement_db(b_.cpu(), a_.cpu()) >= 45.0, (k, orc.agreement_db(b_.cpu(), a_.cpu()))
         else:
             assert torch.equal(a_, b_), (k, int((a_ != b_).sum()), float((a_ - b_).abs().max()), float(a_.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# optimizer step (round 4): clip_grad_norm_ + AdamW over the flat gradient buffer (sepr_adamw_step, sepreformer_amd.optim)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("max_norm", [None, 0.05, 1.0e4])
+def test_flat_adamw_matches_torch_adamw(max_norm):
+    """engine.py:76-77 as three launches: after each of 4 steps every parameter, both moments and the returned norm equal
+    torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW fed the SAME gradients (fp32 rounding of one update apart: 1e-5 of the
+    learning rate + 2 ulp of the parameter); max_norm 0.05 clips on every step, 1e4 never does, None skips the norm pass."""
+    from sepreformer_amd.model import Model
+    from sepreformer_amd.optim import FlatAdamW
+    cfg = dataclasses.replace(VARIANTS["tiny"], dropout=0.0)
+    dev = torch.device("cuda:0")
+    lr = 1.0e-2
+    ma = Model.from_config(cfg, init_seed=0).load_synthetic_(0).to(dev).train()
+    mb = Model.from_config(cfg, init_seed=0).load_synthetic_(0).to(dev).train()
+    oa = FlatAdamW(ma, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1.0e-2)
+    ob = torch.optim.AdamW(mb.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1.0e-2)
+    pa, pb = list(ma.parameters()), list(mb.parameters())
+    for it in range(4):
+        x = torch.from_numpy(synth_sources(2, 1500, seed=70 + it).sum(1) * 4.0).to(dev)
+        oa.zero_grad(set_to_none=True)
+        audio, aux = ma(x)
+        (torch.stack(audio).pow(2).mean() + 0.1 * sum(torch.stack(a).abs().mean() for a in aux)).backward()
+        for a_, b_ in zip(pa, pb):
+            b_.grad = a_.grad.detach().clone()
+        if it == 2:
+            for g_ in (oa.param_groups[0], ob.param_groups[0]):       # a scheduler's update reaches the device scalar
+                g_["lr"] = lr / 4
+        gn_b = torch.nn.utils.clip_grad_norm_(pb, max_norm) if max_norm is not None else None
+        ob.step()
+        gn_a = oa.step(max_norm=max_norm)
+        cur = lr / 4 if it >= 2 else lr
+        if max_norm is not None:
+            assert abs(float(gn_a) - float(gn_b)) <= 2e-6 * float(gn_b), (it, float(gn_a), float(gn_b))
+            want = min(1.0, max_norm / (float(gn_b) + 1e-6))
+            assert abs(float(oa.clip_coef) - want) <= 1e-6 * want
+            assert (want < 1.0) == (max_norm == 0.05)
+        else:
+            assert gn_a is None
+        worst = 0.0
+        for a_, b_ in zip(pa, pb):
+            tol = 1e-5 * cur + 2.4e-7 * float(b_.detach().abs().max())
+            d = float((a_.detach() - b_.detach()).abs().max())
+            worst = max(worst, d / tol)
+        assert worst <= 1.0, (it, worst)
+        for a_, b_ in zip(pa, pb):
+            sa, sb = oa.state[a_], ob.state[b_]
+            assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-12)
+            assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-20)
+        assert float(oa.state[pa[0]]["step"]) == it + 1
+    # the state dict has torch.optim.AdamW's layout: loading it into a fresh FlatAdamW continues the same trajectory
+    sd = oa.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and len(sd["state"]) == len(pa)
+    mc = Model.from_config(cfg, init_seed=0).load_synthetic_(0).to(dev).train()
+    mc.load_state_dict(ma.state_dict())
+    oc = FlatAdamW(mc, lr=lr / 4, weight_decay=1.0e-2)
+    oc.load_state_dict(sd)
+    x = torch.from_numpy(synth_sources(2, 1500, seed=99).sum(1) * 4.0).to(dev)
+    for m_, o_ in ((ma, oa), (mc, oc)):
+        o_.zero_grad(set_to_none=True)
+        audio, aux = m_(x)
+        (torch.stack(audio).pow(2).mean() + 0.1 * sum(torch.stack(a).abs().mean() for a in aux)).backward()
+        o_.step(max_norm=max_norm)
+    for a_, c_ in zip(pa, mc.parameters()):
+        assert torch.equal(a_.detach(), c_.detach())
+
+
+def test_captured_step_with_flat_adamw_follows_torch_adamw():
+    """CapturedTrainStep with optim.FlatAdamW (clip inside the optimizer graph) against the same captured step with torch's fused
+    AdamW + clip_grad_norm_: 5 replays on the tiny model without dropout; the losses agree to 1e-5 relative (the two optimizers differ
+    by fp32 rounding of the update), the reported gradient norms to 1e-5."""
+    from sepreformer_amd.criterion import PIT_SISNR_time
+    from sepreformer_amd.model import Model
+    from sepreformer_amd.optim import FlatAdamW
+    from sepreformer_amd.train_step import CapturedTrainStep
+    cfg = dataclasses.replace(VARIANTS["tiny"], dropout=0.0)
+    dev = torch.device("cuda:0")
+    B, T = 2, 2000
+    srcn = synth_sources(B, T, seed=12) * 4.0
+    src = [torch.from_numpy(srcn[:, s].copy()).to(dev) for s in range(2)]
+    x = (src[0] + src[1]).contiguous()
+    sizes = torch.full((B,), T)
+
+    def run(flat):
+        m = Model.from_config(cfg, init_seed=0).load_synthetic_(0).to(dev).train()
+        crit = PIT_SISNR_time(dev, 2, True)
+        opt = FlatAdamW(m, lr=1.0e-3, weight_decay=1.0e-2) if flat else torch.optim.AdamW(m.parameters(), lr=1.0e-3, weight_decay=1.0e-2,
+                                                                                             capturable=True)
+
+        def loss_fn(audio, aux, *tg):
+            return crit(estims=audio, input_sizes=sizes, target_attr=list(tg)) + 0.05 * sum(torch.stack(a).abs().mean() for a in aux)
+
+        st = CapturedTrainStep(m, loss_fn, opt, x, src, max_norm=0.5, warmup=1)
+        out = []
+        for _ in range(5):
+            loss, gn = st(x, src)
+            out.append((float(loss), float(gn)))
+        st.release()
+        return out
+
+    a, b = run(True), run(False)
+    for (la, ga), (lb, gb_) in zip(a, b):
+        assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (a, b)
+        assert abs(ga - gb_) <= 1e-5 * gb_, (a, b)
+    assert a[-1][0] < a[0][0]
