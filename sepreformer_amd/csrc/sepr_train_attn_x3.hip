@@ -545,12 +545,20 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) 
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int AXB_GROUP = 4;
 constexpr int AXB_ROWS = 8;     // rows per load batch of the table-gradient kernel
+constexpr int AXB_BPC = 4;      // batches per LDS chunk of q rows
 // One block = 64 consecutive relative offsets x 4 query partitions (one partition per wave).  Every lane of a wave walks the
-// SAME queries i (so the q rows are wave-uniform: scalar loads) and reads dS[i][i - rel] when that key exists; consecutive
-// lanes = consecutive rel = consecutive (descending) keys: 256-byte coalesced reads of every dS row, each element once.
-template <int DK, bool DS16>      // DS16 is a template parameter: as a run-time select the unrolled row loop lost its batched loads (122 -> 211 us)
+// SAME queries i and reads dS[i][i - rel] when that key exists; consecutive lanes = consecutive rel = consecutive (descending)
+// keys: coalesced reads of every dS row, each element once.  The q rows are wave-uniform: they are staged 128 rows at a time in
+// LDS (coalesced) and read back as broadcasts.  Round 4 history of this loop, all on the same 32 MB of dS: a predicated load per
+// row + scalar q loads = one memory latency per row (122 us; 211 us when the bf16 / fp32 choice was a run-time select); loads in
+// batches of 8 unconditional rows (clamped address, value selected afterwards) with scalar q loads 136 us - the s_load chain was
+// the latency; q through LDS + the next batch's dS loads issued before this batch's FMAs 116 us (1.1 TB/s, and 2 x the
+// useful FMAs: half of the (row, offset) pairs have no key); rows limited to the ones that can meet the block's offsets: see profiles.
+template <int DK, bool DS16>
 __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restrict__ QKV, const float* __restrict__ dS, float* __restrict__ band,
                                                           int NH, int Tp, int F, int H) {
+  constexpr int CH = 4 * AXB_ROWS * AXB_BPC;                 // q rows per LDS chunk (128)
+  __shared__ __attribute__((aligned(16))) float qs[CH * DK];
   __shared__ float red[4][64][DK + 1];
   const int rl = threadIdx.x & 63;
   const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -566,23 +574,51 @@ __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restri
     const float* qb = QKV + (long long)n * Tp * 3 * F + h * DK;
     const float* sb = dS + (long long)nh * Tp * Tp;
     const unsigned short* sb16 = reinterpret_cast<const unsigned short*>(dS) + (long long)nh * Tp * Tp;
-    // batches of AXB_ROWS rows: every load is unconditional (clamped address, the value selected afterwards), so the batch's loads
-    // issue back to back and ONE wait covers them; with a predicated load per row the loop ran at one memory latency per row
-    for (int i0 = part; i0 < Tp; i0 += 4 * AXB_ROWS) {
-      float sv[AXB_ROWS];
+    // batch b of this wave = rows part + 4 (AXB_ROWS b + u), u < AXB_ROWS; every load is unconditional (clamped address) and RAW: the
+    // bf16 widening and the validity select happen where the value is consumed, one batch later - nothing touches the registers of the
+    // batch in flight before that, so its loads stay outstanding under the current batch's FMAs
+    auto load_batch = [&](int b, unsigned (&raw)[AXB_ROWS]) {
 #pragma unroll
       for (int u = 0; u < AXB_ROWS; ++u) {
-        const int i = i0 + 4 * u, j = i - rel;
-        const bool in = i < Tp && j >= 0 && j < Tp;
+        const int i = part + 4 * (AXB_ROWS * b + u), j = i - rel;
         const long long at = (long long)min(i, Tp - 1) * Tp + min(max(j, 0), Tp - 1);
-        const float v = DS16 ? __uint_as_float((unsigned)sb16[at] << 16) : sb[at];
-        sv[u] = in ? v : 0.f;
+        raw[u] = DS16 ? (unsigned)sb16[at] : __float_as_uint(sb[at]);
       }
+    };
+    // rows that can meet this block's 64 offsets: j = i - rel in [0, Tp)  =>  i in [r0, r0 + 63 + Tp) - half of the (row, offset)
+    // grid of the launch is empty, and whole chunks of it are skipped here
+    const int r0 = blockIdx.x * 64 - (Tp - 1);
+    const int i_lo = max(0, r0), i_hi = min(Tp, r0 + 63 + Tp);
+    unsigned cur[AXB_ROWS], nx[AXB_ROWS];
+    const int c_lo = i_lo / CH * CH;
+    load_batch(c_lo / (4 * AXB_ROWS), cur);
+    for (int c0 = c_lo, b = c_lo / (4 * AXB_ROWS); c0 < i_hi; c0 += CH) {
+      __syncthreads();                                         // the previous chunk's rows are consumed
+      for (int e = threadIdx.x; e < CH * (DK / 4); e += 256) {
+        const int r = e / (DK / 4), c4 = e - r * (DK / 4);
+        st4(qs + r * DK + 4 * c4, ld4(qb + (long long)min(c0 + r, Tp - 1) * 3 * F + 4 * c4));
+      }
+      __syncthreads();
 #pragma unroll
-      for (int u = 0; u < AXB_ROWS; ++u) {
-        const float* q = qb + (long long)min(i0 + 4 * u, Tp - 1) * 3 * F;      // wave-uniform: scalar loads
+      for (int bb = 0; bb < AXB_BPC; ++bb, ++b) {
+        load_batch(b + 1, nx);                                 // (past the end: clamped addresses, discarded)
 #pragma unroll
-        for (int d = 0; d < DK; ++d) acc[d] = fmaf(sv[u], q[d], acc[d]);
+        for (int u = 0; u < AXB_ROWS; ++u) {
+          const int i = part + 4 * (AXB_ROWS * b + u), j = i - rel;
+          const float v = DS16 ? __uint_as_float(cur[u] << 16) : __uint_as_float(cur[u]);
+          const float sv = (i < Tp && j >= 0 && j < Tp) ? v : 0.f;
+          const float* q = qs + (part + 4 * (AXB_ROWS * bb + u)) * DK;      // wave-uniform: LDS broadcast
+#pragma unroll
+          for (int d4 = 0; d4 < DK; d4 += 4) {
+            const float4 qv = ld4(q + d4);
+            acc[d4] = fmaf(sv, qv.x, acc[d4]);
+            acc[d4 + 1] = fmaf(sv, qv.y, acc[d4 + 1]);
+            acc[d4 + 2] = fmaf(sv, qv.z, acc[d4 + 2]);
+            acc[d4 + 3] = fmaf(sv, qv.w, acc[d4 + 3]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < AXB_ROWS; ++u) cur[u] = nx[u];
       }
     }
   }

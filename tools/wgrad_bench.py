@@ -8,7 +8,7 @@ from sepreformer_amd import lib as L
 
 lib = L.load()
 dev = torch.device("cuda:0")
-shapes = [(128000, 768, 128), (128000, 128, 384), (32000, 768, 128), (32000, 128, 384), (32000, 384, 128), (32000, 128, 128), (64000, 768, 128), (64000, 128, 384),
+shapes = [(256000, 768, 128), (256000, 128, 384), (128000, 768, 128), (128000, 128, 384), (32000, 768, 128), (32000, 128, 384), (32000, 384, 128), (32000, 128, 128), (64000, 768, 128), (64000, 128, 384),
           (16000, 768, 128), (8000, 768, 128), (4000, 384, 128), (2000, 128, 128)]
 for M, N, K in shapes:
     A = torch.randn(M, N, device=dev)
