@@ -192,7 +192,7 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& l) {
 // backward keeps of the probabilities - and applies inverted dropout to the probabilities that multiply V (network.py:121;
 // the softmax denominator sums the undropped ones); mask of element (row = (seq*H + h)*Tp + i, key j) = 16-bit half j & 1 of
 // sepr_drop_word(dkey, row, j >> 1) >= thr (sepr_train.h).
-template <int DK, bool TRAIN = false, bool BP = false>
+template <int DK, bool TRAIN = false, bool BP = false, bool ONE = false>
 __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const float* __restrict__ QKV, float* __restrict__ O, int Tp, int F,
                                                         const float* __restrict__ pe, int maxlen, float inv_sqrt_dk,
                                                         float* __restrict__ lse = nullptr, unsigned thr = 0u, float dscale = 1.0f,
@@ -203,6 +203,8 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
   // tile are then copied global -> registers -> LDS as they are (half of this kernel's staged elements lose their VALU split)
   // BP is a template parameter: as a run-time flag every band fetch computed both tables' addresses and selected (16 VALU per key tile)
   static_assert(!(TRAIN && BP), "the training forward reads the fp32 table");
+  // ONE (training forward of the plain-bf16 precision): operands rounded to bf16 once, one MFMA per product, no lo planes in LDS
+  static_assert(TRAIN || !ONE, "inference keeps the split-fp32 products");
   constexpr bool bp = BP;
   DropKey dkey = {0u, 0u};
   if (TRAIN && thr) dkey = sepr_drop_key(seed, salt, 2u);
@@ -214,9 +216,13 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
   constexpr int VSB = KT + 8;         // V^T row stride in bf16 (144 B)
   constexpr int NBAND = QB + KT - 1;
   constexpr int PSK = 52;             // skew scratch row stride in floats (48 used)
-  __shared__ __attribute__((aligned(16))) __bf16 Kh[KT * KSB], Kl[KT * KSB];
-  __shared__ __attribute__((aligned(16))) __bf16 Vh[DK * VSB], Vl[DK * VSB];
-  __shared__ __attribute__((aligned(16))) __bf16 Bh[NBAND * KSB], Bl[NBAND * KSB];
+  constexpr int LO = ONE ? 0 : 1;
+  __shared__ __attribute__((aligned(16))) __bf16 Kh[KT * KSB], Kl_[LO * KT * KSB + 8];
+  __shared__ __attribute__((aligned(16))) __bf16 Vh[DK * VSB], Vl_[LO * DK * VSB + 8];
+  __shared__ __attribute__((aligned(16))) __bf16 Bh[NBAND * KSB], Bl_[LO * NBAND * KSB + 8];
+  __bf16* const Kl = ONE ? Kh : Kl_;          // ONE: dead aliases (the reads through them stay in bounds and feed nothing)
+  __bf16* const Vl = ONE ? Vh : Vl_;
+  __bf16* const Bl = ONE ? Bh : Bl_;
   __shared__ __attribute__((aligned(16))) float Psk[4 * 16 * PSK];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -231,11 +237,17 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
   const int go = DK == 32 ? 8 * g : 8 * (g < 2 ? g : 2);
   for (int r = tid; r < KT; r += 256) {
 #pragma unroll
-    for (int e = DK; e < KSB; ++e) Kh[r * KSB + e] = Kl[r * KSB + e] = (__bf16)0.f;
+    for (int e = DK; e < KSB; ++e) {
+      Kh[r * KSB + e] = (__bf16)0.f;
+      if constexpr (!ONE) Kl[r * KSB + e] = (__bf16)0.f;
+    }
   }
   for (int r = tid; r < NBAND; r += 256) {
 #pragma unroll
-    for (int e = DK; e < KSB; ++e) Bh[r * KSB + e] = Bl[r * KSB + e] = (__bf16)0.f;
+    for (int e = DK; e < KSB; ++e) {
+      Bh[r * KSB + e] = (__bf16)0.f;
+      if constexpr (!ONE) Bl[r * KSB + e] = (__bf16)0.f;
+    }
   }
 
   // B fragments of this lane's query (scaled), shared by the q.k and the q.band products
@@ -301,12 +313,12 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
         const int sjj = idx / (DK / 4), sc4 = idx % (DK / 4);
         split4(rk[u], hh, ll);
         *reinterpret_cast<bf16x4*>(Kh + sjj * KSB + 4 * sc4) = hh;
-        *reinterpret_cast<bf16x4*>(Kl + sjj * KSB + 4 * sc4) = ll;
+        if constexpr (!ONE) *reinterpret_cast<bf16x4*>(Kl + sjj * KSB + 4 * sc4) = ll;
         split4(rv[u], hh, ll);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           Vh[(4 * sc4 + e) * VSB + sjj] = hh[e];
-          Vl[(4 * sc4 + e) * VSB + sjj] = ll[e];
+          if constexpr (!ONE) Vl[(4 * sc4 + e) * VSB + sjj] = ll[e];
         }
       }
 #pragma unroll
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
           } else {
             split4(rb[u], hh, ll);
             *reinterpret_cast<bf16x4*>(Bh + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = hh;
-            *reinterpret_cast<bf16x4*>(Bl + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = ll;
+            if constexpr (!ONE) *reinterpret_cast<bf16x4*>(Bl + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = ll;
           }
         }
       }
@@ -345,8 +357,10 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
           f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (!(SEPR_AT_ABL & 16)) {
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh, a, 0, 0, 0);
+            if constexpr (!ONE) {
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql, a, 0, 0, 0);
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh, a, 0, 0, 0);
+            }
           } else {
             a[0] = (float)kh[0] + (float)kl[1];
           }
@@ -362,8 +376,10 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
           const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + rc * KSB + go);
           f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
           a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, qh, a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ql, a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, qh, a, 0, 0, 0);
+          if constexpr (!ONE) {
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ql, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, qh, a, 0, 0, 0);
+          }
           st4(psk + 16 * tb + 4 * g, make_float4(a[0], a[1], a[2], a[3]));   // rows b = 16 tb + 4g + r of this query
         }
 #pragma unroll
@@ -445,8 +461,10 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
             continue;
           }
           o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph[p], o[t], 0, 0, 0);
-          o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl[p], o[t], 0, 0, 0);
-          o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph[p], o[t], 0, 0, 0);
+          if constexpr (!ONE) {
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl[p], o[t], 0, 0, 0);
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph[p], o[t], 0, 0, 0);
+          }
         }
       }
     }
@@ -465,7 +483,7 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
 
 // train forward on the bf16x3 kernel: O, lse [n*H*Tp]; p > 0: dropout of the probabilities (16-bit generator, site 2)
 int launch_relattn_x3_train_fwd(const float* QKV, float* O, float* lse, int n, int Tp, int F, int H, const float* pe_k, int maxlen,
-                                float p, unsigned long long seed, const unsigned long long* salt, hipStream_t s) {
+                                float p, unsigned long long seed, const unsigned long long* salt, hipStream_t s, int one) {
   if (n <= 0 || Tp <= 0) return SEPR_OK;
   if (H <= 0 || F % H != 0 || maxlen <= 0 || !pe_k || !lse || n > 65535 || !(p >= 0.f) || !(p < 1.f)) return SEPR_EINVAL;
   const int dk = F / H;
@@ -473,8 +491,11 @@ int launch_relattn_x3_train_fwd(const float* QKV, float* O, float* lse, int n, i
   const float isd = 1.0f / sqrtf((float)dk);
   const unsigned thr = p > 0.f ? sepr_drop_thr16(p) : 0u;
   const float dscale = p > 0.f ? sepr_drop_scale16(p) : 1.0f;
-  if (dk == 16) hipLaunchKernelGGL((relattn_x3_kernel<16, true>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, lse, thr, dscale, seed, salt);
-  else if (dk == 32) hipLaunchKernelGGL((relattn_x3_kernel<32, true>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, lse, thr, dscale, seed, salt);
+  const unsigned short* none = nullptr;
+  if (dk == 16 && one) hipLaunchKernelGGL((relattn_x3_kernel<16, true, false, true>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, lse, thr, dscale, seed, salt, none);
+  else if (dk == 16) hipLaunchKernelGGL((relattn_x3_kernel<16, true, false, false>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, lse, thr, dscale, seed, salt, none);
+  else if (dk == 32 && one) hipLaunchKernelGGL((relattn_x3_kernel<32, true, false, true>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, lse, thr, dscale, seed, salt, none);
+  else if (dk == 32) hipLaunchKernelGGL((relattn_x3_kernel<32, true, false, false>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, lse, thr, dscale, seed, salt, none);
   else return SEPR_EINVAL;
   SEPR_CHECK_LAUNCH("relattn_x3_kernel<train>");
   return SEPR_OK;

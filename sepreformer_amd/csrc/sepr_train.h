@@ -212,11 +212,12 @@ int launch_relattn_bwd(const float* QKV, const float* P, const float* O, const f
 // ---- EGA attention on the bf16 MFMA, flash style (sepr_attention.hip TRAIN instantiation + sepr_train_attn_x3.hip) ------------
 // forward: QKV [n,Tp,3F] -> O [n,Tp,F], lse [n*H,Tp] (all the backward keeps of the probabilities)
 int launch_relattn_x3_train_fwd(const float* QKV, float* O, float* lse, int n, int Tp, int F, int H, const float* pe_k, int maxlen,
-                                float p, unsigned long long seed, const unsigned long long* salt, hipStream_t s);
+                                float p, unsigned long long seed, const unsigned long long* salt, hipStream_t s, int one = 0);
 size_t relattn_x3_bwd_ws(int n, int Tp, int F, int H);
 // dO [n,Tp,F] -> dQKV [n,Tp,3F]; dpe [2*maxlen][dk] accumulated
 int launch_relattn_x3_bwd(const float* QKV, const float* lse, const float* O, const float* dO, float* dQKV, float* dpe_g, int n, int Tp,
                           int F, int H, const float* pe_k, int maxlen, float p, unsigned long long seed, const unsigned long long* salt,
-                          void* ws, size_t ws_bytes, hipStream_t s, int ds16 = 0 /* dS rows as bf16: the plain-bf16 precision */);
+                          void* ws, size_t ws_bytes, hipStream_t s, int ds16 = 0 /* dS rows as bf16: the plain-bf16 precision */,
+                          int one = 0 /* ONE bf16 MFMA per product instead of the bf16x3 triple (plain-bf16 precision) */);
 
 }  // namespace sepr

@@ -122,6 +122,13 @@ bool gcfn_pl16(const sepr_gcfn_tw* w, int pl_dry) {
   const bool off = e && e[0] == '0';
   return !off && w && w->up.planes == 1;
 }
+// EGA attention of the plain-bf16 precision (sepr_lin.planes == 1): ONE bf16 MFMA per product in the forward and both backward
+// kernels instead of the bf16x3 triple (round 4; SEPR_TRAIN_ATTN_ONE=0 keeps the triple - the A/B test flips it inside one process)
+int attn_one(const sepr_lin& qkv) {
+  const char* e = getenv("SEPR_TRAIN_ATTN_ONE");
+  const bool off = e && e[0] == '0';
+  return (!off && qkv.planes == 1) ? 1 : 0;
+}
 int gcfn_fused_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, Carve& cx, float p, sepr_u64 seed,
                    hipStream_t st, int pl_dry = -1) {
   const long long M = (long long)n * T;
@@ -471,7 +478,7 @@ int ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const 
   }
   SEPR_TRY(launch_rowstats(xp, k.stats_p, Mp, F, LN_EPS_T, st));
   SEPR_TRY(normed(xp, F, k.stats_p, k.qkv, 3 * F, Mp, 3 * F, F, w->attn.qkv, st));             // :99-102
-  if (mfma) SEPR_TRY(launch_relattn_x3_train_fwd(k.qkv, k.o, k.P, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, drop_salt(), st));
+  if (mfma) SEPR_TRY(launch_relattn_x3_train_fwd(k.qkv, k.o, k.P, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, drop_salt(), st, attn_one(w->attn.qkv)));
   else SEPR_TRY(launch_relattn_train_fwd(k.qkv, k.o, k.P, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), st));   // :106-122
   if (p > 0.f) {
     SEPR_TRY(plain(k.o, F, tmp, F, Mp, F, F, w->attn.out, nullptr, st));                        // :124 linear_out
@@ -517,7 +524,7 @@ int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, in
   // attention branch first (its input gradient is added while the gate branch's LayerNorm backward writes dx)
   SEPR_TRY(mha_out_bwd(datt, k.o, dO, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, st));
   if (mfma) SEPR_TRY(launch_relattn_x3_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, drop_salt(), atw, atb, st,
-                                           w->attn.qkv.planes == 1 ? 1 : 0));
+                                           w->attn.qkv.planes == 1 ? 1 : 0, attn_one(w->attn.qkv)));
   else SEPR_TRY(launch_relattn_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), atw, atb, st));
   SEPR_TRY(mha_qkv_bwd(dqkv, xp, k.stats_p, dxh_p, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, nullptr, dxd, st));
   // gate projection behind its own LayerNorm

@@ -50,10 +50,16 @@ __device__ __forceinline__ void ax_split8(const float (&x)[8], ax_bf16x8& h, ax_
     l[e] = (__bf16)(x[e] - (float)hh);
   }
 }
-__device__ __forceinline__ f32x4 ax_mma3(const ax_bf16x8 ah, const ax_bf16x8 al, const ax_bf16x8 bh, const ax_bf16x8 bl, f32x4 c) {
+
+// ONE (the plain-bf16 training precision, sepr_lin.planes == 1): operands rounded to bf16 once, ONE MFMA per product - no lo planes
+// in LDS (the backward kernels then fit three workgroups per CU instead of two), no lo halves to split.
+template <bool ONE>
+__device__ __forceinline__ f32x4 ax_mma(const ax_bf16x8 ah, const ax_bf16x8 al, const ax_bf16x8 bh, const ax_bf16x8 bl, f32x4 c) {
   c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  if constexpr (!ONE) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  }
   return c;
 }
 
@@ -72,6 +78,7 @@ struct AxArgs {
   float dscale;
   unsigned long long seed;
   const unsigned long long* salt;
+  int one;             // 1: the ONE instantiations (plain-bf16 precision)
   int ds16;            // 1 (plain-bf16 precision, round 4): the dS rows travel to the table-gradient kernel as bf16 - that kernel is a pure
                        // HBM stream over [n*H, Tp, Tp] (512 MB in fp32 at 64 sequences), the only consumer rounds to bf16-level accuracy anyway
 };
@@ -79,17 +86,24 @@ struct AxArgs {
 // ---------------------------------------------------------------------------------------------------------------------
 // query-major: D, dS rows, dQ
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DK>
+template <int DK, bool ONE>
 __global__ __launch_bounds__(256) void relattn_bwd_q_x3_kernel(const AxArgs a) {
   static_assert(DK == 16 || DK == 32, "head width");
   constexpr int QB = AX_QB, KT = AX_KT, NBAND = AX_NBAND;
   constexpr int KSB = DK + 8, VSB = KT + 8, OT = DK / 16;
   constexpr int NU = KT * (DK / 4) / 256, NBU = (127 * (DK / 4) + 255) / 256;
-  __shared__ __attribute__((aligned(16))) __bf16 Kh[KT * KSB], Kl[KT * KSB];       // K rows (scores)
-  __shared__ __attribute__((aligned(16))) __bf16 Vh[KT * KSB], Vl[KT * KSB];       // V rows (dP)
-  __shared__ __attribute__((aligned(16))) __bf16 Kth[DK * VSB], Ktl[DK * VSB];     // K^T (dQ)
-  __shared__ __attribute__((aligned(16))) __bf16 Bh[NBAND * KSB], Bl[NBAND * KSB]; // band rows (bias)
-  __shared__ __attribute__((aligned(16))) __bf16 Bth[DK * AX_BTS], Btl[DK * AX_BTS];   // band^T (dQ, position part)
+  constexpr int LO = ONE ? 0 : 1;                                                  // (the lo planes exist in the bf16x3 form only)
+  __shared__ __attribute__((aligned(16))) __bf16 Kh[KT * KSB], Kl_[LO * KT * KSB + 8];       // K rows (scores)
+  __shared__ __attribute__((aligned(16))) __bf16 Vh[KT * KSB], Vl_[LO * KT * KSB + 8];       // V rows (dP)
+  __shared__ __attribute__((aligned(16))) __bf16 Kth[DK * VSB], Ktl_[LO * DK * VSB + 8];     // K^T (dQ)
+  __shared__ __attribute__((aligned(16))) __bf16 Bh[NBAND * KSB], Bl_[LO * NBAND * KSB + 8]; // band rows (bias)
+  __shared__ __attribute__((aligned(16))) __bf16 Bth[DK * AX_BTS], Btl_[LO * DK * AX_BTS + 8];   // band^T (dQ, position part)
+  // ONE: every "lo" name aliases its hi plane - the reads below stay in bounds and are dead (ax_mma<true> ignores them)
+  __bf16* const Kl = ONE ? Kh : Kl_;
+  __bf16* const Vl = ONE ? Vh : Vl_;
+  __bf16* const Ktl = ONE ? Kth : Ktl_;
+  __bf16* const Bl = ONE ? Bh : Bl_;
+  __bf16* const Btl = ONE ? Bth : Btl_;
   __shared__ __attribute__((aligned(16))) float Psk[4 * 16 * AX_PSK];
   __shared__ __attribute__((aligned(16))) float Psd[4 * 16 * AX_PSD];
 
@@ -109,13 +123,22 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_x3_kernel(const AxArgs a) {
   if (a.thr) dkey = sepr_drop_key(a.seed, a.salt, 2u);
   for (int r = tid; r < KT; r += 256) {
 #pragma unroll
-    for (int e = DK; e < KSB; ++e) Kh[r * KSB + e] = Kl[r * KSB + e] = Vh[r * KSB + e] = Vl[r * KSB + e] = (__bf16)0.f;
+    for (int e = DK; e < KSB; ++e) {
+      Kh[r * KSB + e] = Vh[r * KSB + e] = (__bf16)0.f;
+      if constexpr (!ONE) Kl[r * KSB + e] = Vl[r * KSB + e] = (__bf16)0.f;
+    }
   }
   for (int r = tid; r < NBAND; r += 256) {
 #pragma unroll
-    for (int e = DK; e < KSB; ++e) Bh[r * KSB + e] = Bl[r * KSB + e] = (__bf16)0.f;
+    for (int e = DK; e < KSB; ++e) {
+      Bh[r * KSB + e] = (__bf16)0.f;
+      if constexpr (!ONE) Bl[r * KSB + e] = (__bf16)0.f;
+    }
   }
-  for (int e = tid; e < DK * AX_BTS; e += 256) Bth[e] = Btl[e] = (__bf16)0.f;
+  for (int e = tid; e < DK * AX_BTS; e += 256) {
+    Bth[e] = (__bf16)0.f;
+    if constexpr (!ONE) Btl[e] = (__bf16)0.f;
+  }
 
   // B fragments of this lane's query: q (scaled) and dO; D_i; lse_i
   ax_bf16x8 qh, ql, gh, gl;
@@ -184,15 +207,15 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_x3_kernel(const AxArgs a) {
         const int sjj = idx / (DK / 4), sc4 = idx % (DK / 4);
         ax_split4(rk[u], hh, ll);
         *reinterpret_cast<ax_bf16x4*>(Kh + sjj * KSB + 4 * sc4) = hh;
-        *reinterpret_cast<ax_bf16x4*>(Kl + sjj * KSB + 4 * sc4) = ll;
+        if constexpr (!ONE) *reinterpret_cast<ax_bf16x4*>(Kl + sjj * KSB + 4 * sc4) = ll;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           Kth[(4 * sc4 + e) * VSB + sjj] = hh[e];
-          Ktl[(4 * sc4 + e) * VSB + sjj] = ll[e];
+          if constexpr (!ONE) Ktl[(4 * sc4 + e) * VSB + sjj] = ll[e];
         }
         ax_split4(rv[u], hh, ll);
         *reinterpret_cast<ax_bf16x4*>(Vh + sjj * KSB + 4 * sc4) = hh;
-        *reinterpret_cast<ax_bf16x4*>(Vl + sjj * KSB + 4 * sc4) = ll;
+        if constexpr (!ONE) *reinterpret_cast<ax_bf16x4*>(Vl + sjj * KSB + 4 * sc4) = ll;
       }
 #pragma unroll
       for (int u = 0; u < NBU; ++u) {
@@ -201,11 +224,11 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_x3_kernel(const AxArgs a) {
           const int rr = idx / (DK / 4), sc4 = idx % (DK / 4);
           ax_split4(rb[u], hh, ll);
           *reinterpret_cast<ax_bf16x4*>(Bh + rr * KSB + 4 * sc4) = hh;
-          *reinterpret_cast<ax_bf16x4*>(Bl + rr * KSB + 4 * sc4) = ll;
+          if constexpr (!ONE) *reinterpret_cast<ax_bf16x4*>(Bl + rr * KSB + 4 * sc4) = ll;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             Bth[(4 * sc4 + e) * AX_BTS + rr] = hh[e];
-            Btl[(4 * sc4 + e) * AX_BTS + rr] = ll[e];
+            if constexpr (!ONE) Btl[(4 * sc4 + e) * AX_BTS + rr] = ll[e];
           }
         }
       }
@@ -224,8 +247,8 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_x3_kernel(const AxArgs a) {
         const ax_bf16x8 kl = *reinterpret_cast<const ax_bf16x8*>(Kl + row * KSB + go);
         const ax_bf16x8 vh = *reinterpret_cast<const ax_bf16x8*>(Vh + row * KSB + go);
         const ax_bf16x8 vl = *reinterpret_cast<const ax_bf16x8*>(Vl + row * KSB + go);
-        sc[s] = ax_mma3(kh, kl, qh, ql, (f32x4){0.f, 0.f, 0.f, 0.f});
-        dp[s] = ax_mma3(vh, vl, gh, gl, (f32x4){0.f, 0.f, 0.f, 0.f});
+        sc[s] = ax_mma<ONE>(kh, kl, qh, ql, (f32x4){0.f, 0.f, 0.f, 0.f});
+        dp[s] = ax_mma<ONE>(vh, vl, gh, gl, (f32x4){0.f, 0.f, 0.f, 0.f});
       }
       // ---- relative-position bias: P^T[b][query] = band[bb + b] . q, b = ql - kl + 31 --------------------------------------
       const int bb = 16 * w - 32 * p + 32;
@@ -235,7 +258,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_x3_kernel(const AxArgs a) {
         const int rc = row < NBAND ? row : NBAND - 1;
         const ax_bf16x8 bh = *reinterpret_cast<const ax_bf16x8*>(Bh + rc * KSB + go);
         const ax_bf16x8 bl = *reinterpret_cast<const ax_bf16x8*>(Bl + rc * KSB + go);
-        const f32x4 r4 = ax_mma3(bh, bl, qh, ql, (f32x4){0.f, 0.f, 0.f, 0.f});
+        const f32x4 r4 = ax_mma<ONE>(bh, bl, qh, ql, (f32x4){0.f, 0.f, 0.f, 0.f});
         st4(psk + 16 * tb + 4 * g, make_float4(r4[0], r4[1], r4[2], r4[3]));
       }
       float ds[8];
@@ -290,7 +313,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_x3_kernel(const AxArgs a) {
         const ax_bf16x4 b0v = *reinterpret_cast<const ax_bf16x4*>(kl0), b1v = *reinterpret_cast<const ax_bf16x4*>(kl0 + 16);
         const ax_bf16x8 kth = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         const ax_bf16x8 ktl = {b0v[0], b0v[1], b0v[2], b0v[3], b1v[0], b1v[1], b1v[2], b1v[3]};
-        dq[t] = ax_mma3(kth, ktl, dsh, dsl, dq[t]);
+        dq[t] = ax_mma<ONE>(kth, ktl, dsh, dsl, dq[t]);
       }
       // ---- position part: un-skew dS into band slots b = ql - kl + 31 of this query's scratch row, contract with band^T -------
       st4(psd + 16 * g, zero4());
@@ -312,7 +335,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_x3_kernel(const AxArgs a) {
           const int col = bb + 32 * tb + 8 * g;
           const ax_bf16x8 bth = *reinterpret_cast<const ax_bf16x8*>(Bth + (16 * t + ii) * AX_BTS + col);
           const ax_bf16x8 btl = *reinterpret_cast<const ax_bf16x8*>(Btl + (16 * t + ii) * AX_BTS + col);
-          dq[t] = ax_mma3(bth, btl, bsh, bsl, dq[t]);
+          dq[t] = ax_mma<ONE>(bth, btl, bsh, bsl, dq[t]);
         }
       }
     }
@@ -327,18 +350,24 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_x3_kernel(const AxArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // key-major: dK, dV
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DK>
+template <int DK, bool ONE>
 __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) {
   static_assert(DK == 16 || DK == 32, "head width");
   constexpr int KB = AX_QB, QT = AX_KT, NBAND = AX_NBAND;       // 64 keys per workgroup, query tiles of 64
   constexpr int KSB = DK + 8, VSB = QT + 8, OT = DK / 16;
   constexpr int NU = QT * (DK / 4) / 256, NBU = (127 * (DK / 4) + 255) / 256;
   constexpr int PS2 = 52;
-  __shared__ __attribute__((aligned(16))) __bf16 Qh[QT * KSB], Ql[QT * KSB];       // Q rows (scores, bias)
-  __shared__ __attribute__((aligned(16))) __bf16 Gh[QT * KSB], Gl[QT * KSB];       // dO rows (dP)
-  __shared__ __attribute__((aligned(16))) __bf16 Qth[DK * VSB], Qtl[DK * VSB];     // Q^T (dK)
-  __shared__ __attribute__((aligned(16))) __bf16 Gth[DK * VSB], Gtl[DK * VSB];     // dO^T (dV)
-  __shared__ __attribute__((aligned(16))) __bf16 Bh[NBAND * KSB], Bl[NBAND * KSB]; // band rows
+  constexpr int LO = ONE ? 0 : 1;
+  __shared__ __attribute__((aligned(16))) __bf16 Qh[QT * KSB], Ql_[LO * QT * KSB + 8];       // Q rows (scores, bias)
+  __shared__ __attribute__((aligned(16))) __bf16 Gh[QT * KSB], Gl_[LO * QT * KSB + 8];       // dO rows (dP)
+  __shared__ __attribute__((aligned(16))) __bf16 Qth[DK * VSB], Qtl_[LO * DK * VSB + 8];     // Q^T (dK)
+  __shared__ __attribute__((aligned(16))) __bf16 Gth[DK * VSB], Gtl_[LO * DK * VSB + 8];     // dO^T (dV)
+  __shared__ __attribute__((aligned(16))) __bf16 Bh[NBAND * KSB], Bl_[LO * NBAND * KSB + 8]; // band rows
+  __bf16* const Ql = ONE ? Qh : Ql_;          // (ONE: dead aliases, see the query-major kernel)
+  __bf16* const Gl = ONE ? Gh : Gl_;
+  __bf16* const Qtl = ONE ? Qth : Qtl_;
+  __bf16* const Gtl = ONE ? Gth : Gtl_;
+  __bf16* const Bl = ONE ? Bh : Bl_;
   __shared__ __attribute__((aligned(16))) float Ps2[4 * 32 * PS2];                 // [wave][query of the step][b]
   __shared__ __attribute__((aligned(16))) float lse_s[QT];
   __shared__ __attribute__((aligned(16))) float D_s[QT];
@@ -360,11 +389,17 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) 
   if (a.thr) dkey = sepr_drop_key(a.seed, a.salt, 2u);
   for (int r = tid; r < QT; r += 256) {
 #pragma unroll
-    for (int e = DK; e < KSB; ++e) Qh[r * KSB + e] = Ql[r * KSB + e] = Gh[r * KSB + e] = Gl[r * KSB + e] = (__bf16)0.f;
+    for (int e = DK; e < KSB; ++e) {
+      Qh[r * KSB + e] = Gh[r * KSB + e] = (__bf16)0.f;
+      if constexpr (!ONE) Ql[r * KSB + e] = Gl[r * KSB + e] = (__bf16)0.f;
+    }
   }
   for (int r = tid; r < NBAND; r += 256) {
 #pragma unroll
-    for (int e = DK; e < KSB; ++e) Bh[r * KSB + e] = Bl[r * KSB + e] = (__bf16)0.f;
+    for (int e = DK; e < KSB; ++e) {
+      Bh[r * KSB + e] = (__bf16)0.f;
+      if constexpr (!ONE) Bl[r * KSB + e] = (__bf16)0.f;
+    }
   }
   // B fragments of this lane's key: k (scaled: (q isd) . k == q . (k isd)) and v
   ax_bf16x8 kh, kl, vh, vl;
@@ -428,19 +463,19 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) 
         const int sii = idx / (DK / 4), sc4 = idx % (DK / 4);
         ax_split4(rq[u], hh, ll);
         *reinterpret_cast<ax_bf16x4*>(Qh + sii * KSB + 4 * sc4) = hh;
-        *reinterpret_cast<ax_bf16x4*>(Ql + sii * KSB + 4 * sc4) = ll;
+        if constexpr (!ONE) *reinterpret_cast<ax_bf16x4*>(Ql + sii * KSB + 4 * sc4) = ll;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           Qth[(4 * sc4 + e) * VSB + sii] = hh[e];
-          Qtl[(4 * sc4 + e) * VSB + sii] = ll[e];
+          if constexpr (!ONE) Qtl[(4 * sc4 + e) * VSB + sii] = ll[e];
         }
         ax_split4(rg[u], hh, ll);
         *reinterpret_cast<ax_bf16x4*>(Gh + sii * KSB + 4 * sc4) = hh;
-        *reinterpret_cast<ax_bf16x4*>(Gl + sii * KSB + 4 * sc4) = ll;
+        if constexpr (!ONE) *reinterpret_cast<ax_bf16x4*>(Gl + sii * KSB + 4 * sc4) = ll;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           Gth[(4 * sc4 + e) * VSB + sii] = hh[e];
-          Gtl[(4 * sc4 + e) * VSB + sii] = ll[e];
+          if constexpr (!ONE) Gtl[(4 * sc4 + e) * VSB + sii] = ll[e];
         }
       }
 #pragma unroll
@@ -449,7 +484,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) 
         if (idx < NBAND * (DK / 4)) {
           ax_split4(rb[u], hh, ll);
           *reinterpret_cast<ax_bf16x4*>(Bh + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = hh;
-          *reinterpret_cast<ax_bf16x4*>(Bl + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = ll;
+          if constexpr (!ONE) *reinterpret_cast<ax_bf16x4*>(Bl + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = ll;
         }
       }
       if (tid < QT) {
@@ -472,8 +507,8 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) 
         const ax_bf16x8 ql_ = *reinterpret_cast<const ax_bf16x8*>(Ql + row * KSB + go);
         const ax_bf16x8 gh_ = *reinterpret_cast<const ax_bf16x8*>(Gh + row * KSB + go);
         const ax_bf16x8 gl_ = *reinterpret_cast<const ax_bf16x8*>(Gl + row * KSB + go);
-        sc[s] = ax_mma3(qh_, ql_, kh, kl, (f32x4){0.f, 0.f, 0.f, 0.f});
-        dp[s] = ax_mma3(gh_, gl_, vh, vl, (f32x4){0.f, 0.f, 0.f, 0.f});
+        sc[s] = ax_mma<ONE>(qh_, ql_, kh, kl, (f32x4){0.f, 0.f, 0.f, 0.f});
+        dp[s] = ax_mma<ONE>(gh_, gl_, vh, vl, (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
         for (int tb = 0; tb < 3; ++tb) {
           const int brow = bbc + 16 * tb + ii;
@@ -481,7 +516,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) 
           const ax_bf16x8 bh = *reinterpret_cast<const ax_bf16x8*>(Bh + rc * KSB + go);
           const ax_bf16x8 bl = *reinterpret_cast<const ax_bf16x8*>(Bl + rc * KSB + go);
           // the band fragment is the B operand here (n = slot b): its rows hold DK values (+ zero pad), the query rows carry isd
-          const f32x4 r4 = ax_mma3(qh_, ql_, bh, bl, (f32x4){0.f, 0.f, 0.f, 0.f});
+          const f32x4 r4 = ax_mma<ONE>(qh_, ql_, bh, bl, (f32x4){0.f, 0.f, 0.f, 0.f});
           // D[m = query 4g + r of half s][n = slot 16 tb + ii]
 #pragma unroll
           for (int r = 0; r < 4; ++r) ps2[(16 * s + 4 * g + r) * PS2 + 16 * tb + ii] = r4[r];
@@ -519,12 +554,12 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) 
         const ax_bf16x4 b0v = *reinterpret_cast<const ax_bf16x4*>(Qtl + off), b1v = *reinterpret_cast<const ax_bf16x4*>(Qtl + off + 16);
         const ax_bf16x8 qth = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         const ax_bf16x8 qtl = {b0v[0], b0v[1], b0v[2], b0v[3], b1v[0], b1v[1], b1v[2], b1v[3]};
-        dk_[t] = ax_mma3(qth, qtl, dsh, dsl, dk_[t]);
+        dk_[t] = ax_mma<ONE>(qth, qtl, dsh, dsl, dk_[t]);
         const ax_bf16x4 c0 = *reinterpret_cast<const ax_bf16x4*>(Gth + off), c1 = *reinterpret_cast<const ax_bf16x4*>(Gth + off + 16);
         const ax_bf16x4 e0 = *reinterpret_cast<const ax_bf16x4*>(Gtl + off), e1 = *reinterpret_cast<const ax_bf16x4*>(Gtl + off + 16);
         const ax_bf16x8 gth = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
         const ax_bf16x8 gtl = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
-        dv_[t] = ax_mma3(gth, gtl, pdh, pdl, dv_[t]);
+        dv_[t] = ax_mma<ONE>(gth, gtl, pdh, pdl, dv_[t]);
       }
     }
   }
@@ -663,7 +698,7 @@ size_t relattn_x3_bwd_ws(int n, int Tp, int F, int H) {
 
 int launch_relattn_x3_bwd(const float* QKV, const float* lse, const float* O, const float* dO, float* dQKV, float* dpe_g, int n, int Tp,
                           int F, int H, const float* pe_k, int maxlen, float p, unsigned long long seed, const unsigned long long* salt,
-                          void* ws, size_t ws_bytes, hipStream_t s, int ds16) {
+                          void* ws, size_t ws_bytes, hipStream_t s, int ds16, int one) {
   if (n <= 0) return SEPR_OK;
   if (!QKV || !lse || !O || !dO || !dQKV || !dpe_g || !pe_k || Tp <= 0 || H <= 0 || F % H || n > 65535 || !(p >= 0.f) || !(p < 1.f))
     return SEPR_EINVAL;
@@ -685,16 +720,27 @@ int launch_relattn_x3_bwd(const float* QKV, const float* lse, const float* O, co
   a.dscale = p > 0.f ? sepr_drop_scale16(p) : 1.0f;
   a.seed = seed; a.salt = salt;
   a.ds16 = ds16 ? 1 : 0;
+  a.one = one ? 1 : 0;
   const dim3 grid((Tp + 63) / 64, H, n);
   const dim3 bgrid((2 * Tp - 1 + 63) / 64, ngroups);
   if (DK == 16) {
-    hipLaunchKernelGGL((relattn_bwd_q_x3_kernel<16>), grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL((relattn_bwd_kv_x3_kernel<16>), grid, dim3(256), 0, s, a);
+    if (a.one) {
+      hipLaunchKernelGGL((relattn_bwd_q_x3_kernel<16, true>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((relattn_bwd_kv_x3_kernel<16, true>), grid, dim3(256), 0, s, a);
+    } else {
+      hipLaunchKernelGGL((relattn_bwd_q_x3_kernel<16, false>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((relattn_bwd_kv_x3_kernel<16, false>), grid, dim3(256), 0, s, a);
+    }
     if (a.ds16) hipLaunchKernelGGL((relattn_band_kernel<16, true>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H);
     else hipLaunchKernelGGL((relattn_band_kernel<16, false>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H);
   } else {
-    hipLaunchKernelGGL((relattn_bwd_q_x3_kernel<32>), grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL((relattn_bwd_kv_x3_kernel<32>), grid, dim3(256), 0, s, a);
+    if (a.one) {
+      hipLaunchKernelGGL((relattn_bwd_q_x3_kernel<32, true>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((relattn_bwd_kv_x3_kernel<32, true>), grid, dim3(256), 0, s, a);
+    } else {
+      hipLaunchKernelGGL((relattn_bwd_q_x3_kernel<32, false>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((relattn_bwd_kv_x3_kernel<32, false>), grid, dim3(256), 0, s, a);
+    }
     if (a.ds16) hipLaunchKernelGGL((relattn_band_kernel<32, true>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H);
     else hipLaunchKernelGGL((relattn_band_kernel<32, false>), bgrid, dim3(256), 0, s, QKV, a.dS, band, (int)NH, Tp, F, H);
   }

@@ -1554,6 +1554,48 @@ def test_cla_bf16_stored_intermediates_equal_fp32_stored(n, T, monkeypatch):
             assert torch.equal(a_, b_), (k, int((a_ != b_).sum()), float((a_ - b_).abs().max()), float(a_.abs().max()))
 
 
+@pytest.mark.parametrize("variant,n,T,Tp", [("SepReformer_Base_WSJ0", 4, 2000, 500), ("SepReformer_Large_DM_WHAMR", 2, 520, 130)])
+def test_ega_bf16_single_mfma_attention_agrees_with_the_triple(variant, n, T, Tp, monkeypatch):
+    """Plain-bf16 precision, EGA block: the attention kernels with ONE bf16 MFMA per product (SEPR_TRAIN_ATTN_ONE, default) against the
+    bf16x3 triple they ran with before (the projections around them are plain bf16 in both).  Two roundings of the same function at
+    the precision's own level: the block output agrees to >= 55 dB (the residual dominates it), the input gradient to >= 45 dB and
+    every parameter gradient to >= BF16_DB; dk = 16 (Base) and dk = 32 (Large), dropout on (the same masks in both forms)."""
+    from sepreformer_amd.train_engine import TrainEngine
+    from sepreformer_amd.train_pack import GradBuffer, TrainPack
+    cfg = dataclasses.replace(VARIANTS[variant], dropout=0.1)
+    sd = synth_state_dict(cfg, 0)
+    dev = torch.device("cuda:0")
+    F = cfg.feat
+    x, dy = rnd(n, T, F, seed=T).cuda(), rnd(n, T, F, seed=T + 7).cuda()
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SEPR_TRAIN_ATTN_ONE", mode)
+        sdd = {k: v.to(dev) for k, v in sd.items()}
+        gb = GradBuffer(cfg, dev)
+        tp = TrainPack(cfg, sdd, gb, "bf16")
+        eng = TrainEngine(cfg, dev)
+        y, rec = eng.block_fwd("ega", x, tp.ega[0], n, T, Tp, 0.1, 777)
+        dx = eng.block_bwd(rec, dy)
+        torch.cuda.synchronize()
+        pfx = tp.block_prefixes["ega"][0]
+        outs.append((y.clone(), dx.clone(), {k[len(pfx) + 1:]: gb.view(k).clone() for k in sd if k.startswith(pfx + ".") and k in gb.offsets}))
+    assert torch.isfinite(outs[1][0]).all() and torch.isfinite(outs[1][1]).all()
+    assert not torch.equal(outs[0][0], outs[1][0])                      # the switch is live
+    tag = f"ega_one_vs_triple.{variant}"
+    y_db, dx_db = orc.agreement_db(outs[1][0].cpu(), outs[0][0].cpu()), orc.agreement_db(outs[1][1].cpu(), outs[0][1].cpu())
+    record(f"{tag}.y", y_db)
+    record(f"{tag}.dx", dx_db)
+    assert y_db >= 55.0 and dx_db >= 45.0, (y_db, dx_db)
+    worst = 1e9
+    for k, a_ in outs[0][2].items():
+        if float(a_.abs().max()) == 0.0 or k.endswith("linear_k.bias"):      # (linear_k.bias: structurally zero gradient)
+            continue
+        db = orc.agreement_db(outs[1][2][k].cpu(), a_.cpu())
+        worst = min(worst, db)
+        assert db >= BF16_DB, (k, db)
+    record(f"{tag}.grad_db_min", worst)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # optimizer step (round 4): clip_grad_norm_ + AdamW over the flat gradient buffer (sepr_adamw_step, sepreformer_amd.optim)
 # ---------------------------------------------------------------------------------------------------------------------
