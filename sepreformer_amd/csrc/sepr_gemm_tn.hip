@@ -447,83 +447,10 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 }
 }  // namespace
 
-// ---- post stream (see sepr_train.h) ------------------------------------------------------------------------------------------
-namespace {
-struct PostState {
-  hipStream_t ps = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done[2] = {nullptr, nullptr};
-  hipStream_t origin = nullptr;      // the stream the open fork belongs to
-  int k = 0;                         // contractions forked since the last join
-  bool ok = false;
-};
-thread_local PostState g_post;
-thread_local bool g_post_failed = false;      // a stream / event call of the post machinery failed: the next contraction reports it
-#define SEPR_PCHK(x)                                   \
-  do {                                                 \
-    hipError_t e__ = (x);                              \
-    if (e__ != hipSuccess) {                           \
-      ::sepr::set_hip_error(e__, "post stream");       \
-      g_post_failed = true;                            \
-    }                                                  \
-  } while (0)
-bool post_init() {
-  PostState& p = g_post;
-  if (p.ok) return true;
-  if (hipStreamCreateWithFlags(&p.ps, hipStreamNonBlocking) != hipSuccess) return false;
-  bool good = hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&p.ev_join, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&p.ev_done[0], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&p.ev_done[1], hipEventDisableTiming) == hipSuccess;
-  p.ok = good;
-  return good;
-}
-// before the main kernel of contraction k on s: its partial slot was last read by the post work of contraction k - 2
-int post_pre_main(hipStream_t s) {
-  PostState& p = g_post;
-  if (p.k > 0 && p.origin != s) post_join(p.origin);           // (one origin stream at a time)
-  if (p.k >= 2) SEPR_PCHK(hipStreamWaitEvent(s, p.ev_done[p.k & 1], 0));
-  return p.k & 1;
-}
-// after it: the post stream waits for the main kernel; everything launched on the post stream so far is post work <= k - 1
-hipStream_t post_fork(hipStream_t s) {
-  PostState& p = g_post;
-  if (p.k > 0) SEPR_PCHK(hipEventRecord(p.ev_done[(p.k - 1) & 1], p.ps));
-  SEPR_PCHK(hipEventRecord(p.ev_fork, s));
-  SEPR_PCHK(hipStreamWaitEvent(p.ps, p.ev_fork, 0));
-  p.origin = s;
-  ++p.k;
-  return p.ps;
-}
-}  // namespace
-bool post_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("SEPR_TRAIN_POST");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-hipStream_t post_stream(hipStream_t s) {
-  const PostState& p = g_post;
-  return (post_enabled() && p.k > 0 && p.origin == s) ? p.ps : s;
-}
-void post_join(hipStream_t s) {
-  PostState& p = g_post;
-  if (p.k == 0) return;
-  SEPR_PCHK(hipEventRecord(p.ev_join, p.ps));
-  SEPR_PCHK(hipStreamWaitEvent(p.origin ? p.origin : s, p.ev_join, 0));
-  p.k = 0;
-  p.origin = nullptr;
-}
-
-namespace {
-size_t tn_slot_bytes(int M, int N, int K) {
-  const TnPlan p = tn_plan(M, N, K);
-  return align_up((size_t)p.nsplit * ((size_t)N * K + N) * sizeof(float));
-}
-}  // namespace
 size_t tn_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (post_enabled() ? 2 : 1) * tn_slot_bytes(M, N, K);      // two slots of split-M partials with the post stream
+  const TnPlan p = tn_plan(M, N, K);
+  return align_up((size_t)p.nsplit * ((size_t)N * K + N) * sizeof(float));
 }
 
 int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -533,12 +460,7 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   const TnPlan p = tn_plan(a.M, a.N, a.K);
   const size_t need = tn_workspace_bytes(a.M, a.N, a.K);
   if (!ws || ws_bytes < need) return SEPR_EWORKSPACE;
-  const bool post = post_enabled() && post_init();
-  if (post_enabled() && !post) return SEPR_EHIP;
-  if (g_post_failed) return SEPR_EHIP;
-  const int slot_i = post ? post_pre_main(s) : 0;
-  const size_t slot_bytes = post ? (ws_bytes / 2) / 256 * 256 : 0;      // (the caller may have sized ws for a larger shape)
-  float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)slot_i * slot_bytes);
+  float* part = static_cast<float*>(ws);
   float* cpart = part + (size_t)p.nsplit * a.N * a.K;
   const int grid = p.tn * p.tk * p.nsplit;
   const bool gen = a.rows_out > 0 || a.B2 != nullptr || a.idx != nullptr || a.mask_a != 0 || a.stat_seq != 0;
@@ -558,8 +480,7 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
       prof_bytes((double)a.M * ((double)a.N * 4.0 + 64.0));
     }
     const long long total_e = (long long)a.N * a.K;
-    hipStream_t rs = post ? post_fork(s) : s;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)((total_e + 63) / 64)), dim3(256), 0, rs, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)((total_e + 63) / 64)), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
                        (float*)nullptr, 0);
     SEPR_CHECK_LAUNCH("tn_smallk_kernel");
     return SEPR_OK;
@@ -606,8 +527,7 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   }
   const long long total = (long long)a.N * a.K + a.N;
   const int rgrid = (int)((total + 63) / 64);
-  hipStream_t rs = post ? post_fork(s) : s;
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3(rgrid), dim3(256), 0, rs, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
                      a.colsum, a.colsum_accumulate);
   SEPR_CHECK_LAUNCH("gemm_tn_kernel");
   return SEPR_OK;

@@ -84,27 +84,6 @@ size_t tn_workspace_bytes(int M, int N, int K);
 // x3: 1 = bf16x3 split arithmetic (3 bf16 MFMAs per product), 2 = plain bf16 operands (1 MFMA), 0 = exact f32 MFMA
 int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream_t s);
 
-// ---- post stream (round 4) -------------------------------------------------------------------------------------------------
-// Every contraction is followed by 2-4 tiny launches (the split-M reduction, the parameter-gradient finishers): ~1 000 launches of
-// 5-10 us per Base step that nothing depends on until the optimizer.  launch_gemm_tn forks them onto a second stream behind its
-// main kernel (hipEvent fork; inside a captured step this becomes a parallel branch of the graph), so they run beside the next
-// contraction / projection instead of between them.  Rules that keep it race-free without per-buffer bookkeeping:
-//   * the post stream is in-order: reduction k, its finishers, reduction k + 1 ... - the temporaries they share (G, column sums)
-//     are only ever touched there;
-//   * the split-M partials are double-buffered (tn_workspace_bytes is two slots; contraction k uses slot k & 1 and its main
-//     kernel first waits for the post work of contraction k - 2);
-//   * every extern "C" backward entry point JOINS before it returns (PostJoin): the caller's workspace is free for the next op,
-//     and a capture never ends with an unjoined branch.
-// SEPR_TRAIN_POST=0 (read once per process): everything on the caller's stream as before, bit-identical results either way.
-bool post_enabled();
-hipStream_t post_stream(hipStream_t s);     // the stream for the reduction / finishers of the contraction launched last on s
-void post_join(hipStream_t s);
-struct PostJoin {
-  hipStream_t s;
-  explicit PostJoin(hipStream_t st) : s(st) {}
-  ~PostJoin() { post_join(s); }
-};
-
 // ---- row-wise / element-wise pieces (sepr_train_pw.hip) -------------------------------------------------------------
 // dx[m][f] = (dres ? dres[m][f] : 0) + rstd_m * (dxh[m][f] - mean_f(dxh[m]) - xh[m][f] * mean_f(dxh[m] * xh[m])),
 // xh = (x - mean_m) * rstd_m  (LayerNorm backward w.r.t. its input, affine already folded into dxh);

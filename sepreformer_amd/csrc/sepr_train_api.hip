@@ -188,7 +188,7 @@ int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int
     t.G = Gr; t.ldg = 3 * F; t.colsum = s2;
     SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
   }
-  SEPR_TRY(launch_finish_linear_ls(Gr, s2, w->w2, w->b2, w->ls, g->w2, g->b2, g->ls, F, 3 * F, post_stream(st)));
+  SEPR_TRY(launch_finish_linear_ls(Gr, s2, w->w2, w->b2, w->ls, g->w2, g->b2, g->ls, F, 3 * F, st));
   // net1 behind the LayerNorm
   {
     TnArgs t = tn_args_zero();
@@ -199,7 +199,7 @@ int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int
     t.G = dWh; t.ldg = F; t.colsum = s1;
     SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
   }
-  SEPR_TRY(launch_finish_norm_linear(dWh, s1, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 6 * F, F, post_stream(st)));
+  SEPR_TRY(launch_finish_norm_linear(dWh, s1, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 6 * F, F, st));
   return dgrad_ln(static_cast<const float*>(dh1), 6 * F, 6 * F, w->up_t, o16 ? 1 : 0, x, stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
 int gcfn_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, Carve& cx, Carve& ws, float p, sepr_u64 seed,
@@ -252,13 +252,13 @@ int gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, co
   }
   // net2.2 + LayerScale: raw contraction, then dW2 / db2 / dls
   SEPR_TRY(wgrad(dyq, F, k.g, 3 * F, nullptr, Gr, s2, M, F, 3 * F, 0, x3, tnw, tnb, st));
-  SEPR_TRY(launch_finish_linear_ls(Gr, s2, w->w2, w->b2, w->ls, g->w2, g->b2, g->ls, F, 3 * F, post_stream(st)));
+  SEPR_TRY(launch_finish_linear_ls(Gr, s2, w->w2, w->b2, w->ls, g->w2, g->b2, g->ls, F, 3 * F, st));
   SEPR_TRY(plain(dyq, F, dg, 3 * F, M, 3 * F, F, w->down_t, nullptr, st));
   // GLU + depthwise conv (the dropout mask of the gated tensor is applied while dg is read)
   SEPR_TRY(launch_gcfn_mid_bwd(k.h1, dg, dh1, n, T, 3 * F, w->dw_w, w->dw_b, g->dw_w, g->dw_b, p, seed, site_off(0), midw, midb, st));
   // net1: LayerNorm-folded projection
   SEPR_TRY(wgrad(dh1, 6 * F, x, F, k.stats, dWh, s1, M, 6 * F, F, 0, x3, tnw, tnb, st));
-  SEPR_TRY(launch_finish_norm_linear(dWh, s1, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 6 * F, F, post_stream(st)));
+  SEPR_TRY(launch_finish_norm_linear(dWh, s1, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 6 * F, F, st));
   return dgrad_ln(dh1, 6 * F, 6 * F, w->up_t, 0, x, k.stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
 
@@ -365,7 +365,7 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
       t.G = Gr; t.ldg = 2 * F; t.colsum = s;
       SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
     }
-    SEPR_TRY(launch_finish_linear_ls(Gr, s, w->w3, w->b3, w->ls, g->w3, g->b3, g->ls, F, 2 * F, post_stream(st)));
+    SEPR_TRY(launch_finish_linear_ls(Gr, s, w->w3, w->b3, w->ls, g->w3, g->b3, g->ls, F, 2 * F, st));
     SEPR_TRY(plain(dyq, F, dd, 2 * F, M, 2 * F, F, w->l3_t, nullptr, st));
     SEPR_TRY(launch_bn_gelu_bwd(dd, k.z, k.bn, w->bn_g, w->bn_b, dz16, g->bn_g, g->bn_b, M, 2 * F, csw, csb, st, 1));
     {
@@ -390,11 +390,11 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
       t.G = Gr; t.ldg = F; t.colsum = s;
       SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
     }
-    SEPR_TRY(launch_finish_norm_linear(Gr, s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, post_stream(st)));
+    SEPR_TRY(launch_finish_norm_linear(Gr, s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, st));
     return dgrad_ln(da16, 2 * F, 2 * F, w->l1_t, 1, x, k.stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
   }
   SEPR_TRY(wgrad(dyq, F, k.d, 2 * F, nullptr, Gr, s, M, F, 2 * F, 0, x3, tnw, tnb, st));
-  SEPR_TRY(launch_finish_linear_ls(Gr, s, w->w3, w->b3, w->ls, g->w3, g->b3, g->ls, F, 2 * F, post_stream(st)));
+  SEPR_TRY(launch_finish_linear_ls(Gr, s, w->w3, w->b3, w->ls, g->w3, g->b3, g->ls, F, 2 * F, st));
   SEPR_TRY(plain(dyq, F, dd, 2 * F, M, 2 * F, F, w->l3_t, nullptr, st));
   SEPR_TRY(launch_bn_gelu_bwd(dd, k.z, k.bn, w->bn_g, w->bn_b, dd, g->bn_g, g->bn_b, M, 2 * F, csw, csb, st));   // dd := dz
   SEPR_TRY(wgrad(dd, 2 * F, k.c, F, nullptr, g->w2, g->b2, M, 2 * F, F, 1, x3, tnw, tnb, st));                   // linear2 (direct)
@@ -407,7 +407,7 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
     SEPR_TRY(launch_glu_bwd(du, k.a, dd, M, F, st));                                           // dd := da [M][2F]
   }
   SEPR_TRY(wgrad(dd, 2 * F, x, F, k.stats, Gr, s, M, 2 * F, F, 0, x3, tnw, tnb, st));
-  SEPR_TRY(launch_finish_norm_linear(Gr, s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, post_stream(st)));
+  SEPR_TRY(launch_finish_norm_linear(Gr, s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, st));
   return dgrad_ln(dd, 2 * F, 2 * F, w->l1_t, 0, x, k.stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
 
@@ -418,7 +418,7 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
 int mha_out_bwd(const float* dyq, const float* o, float* dO, long long M, int F, const sepr_mha_tw* w, const sepr_mha_grad* g, float* Gr,
                 float* s, int x3, void* tnw, size_t tnb, hipStream_t st) {
   SEPR_TRY(wgrad(dyq, F, o, F, nullptr, Gr, s, M, F, F, 0, x3, tnw, tnb, st));
-  SEPR_TRY(launch_finish_linear_ls(Gr, s, w->wo, w->bo, w->ls, g->wo, g->bo, g->ls, F, F, post_stream(st)));
+  SEPR_TRY(launch_finish_linear_ls(Gr, s, w->wo, w->bo, w->ls, g->wo, g->bo, g->ls, F, F, st));
   return plain(dyq, F, dO, F, M, F, F, w->out_t, nullptr, st);
 }
 // d(q/k/v projection behind the LayerNorm): dWh [3F][F] -> three finishers (shared dgamma / dbeta), dxh = dqkv . (Wqkv * gamma)
@@ -429,7 +429,7 @@ int mha_qkv_bwd(const float* dqkv, const float* xin, const float* stats, float* 
   float* gb[3] = {g->bq, g->bk, g->bv};
   for (int i = 0; i < 3; ++i)
     SEPR_TRY(launch_finish_norm_linear(dWh + (long long)i * F * F, s + i * F, w->wqkv + (long long)i * F * F, w->ln_g, w->ln_b, gw[i],
-                                       gb[i], g->ln_g, g->ln_b, F, F, post_stream(st)));
+                                       gb[i], g->ln_g, g->ln_b, F, F, st));
   // dx = dres + LayerNorm'(dqkv . (Wqkv gamma))   (dxh: scratch of the two-launch form for F > 128)
   return dgrad_ln(dqkv, 3 * F, 3 * F, w->qkv_t, 0, xin, stats, dres, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
@@ -530,7 +530,7 @@ int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, in
   // gate projection behind its own LayerNorm
   SEPR_TRY(wgrad(dzg, F, x, F, k.stats, dWh, s, M, F, F, 0, x3, tnw, tnb, st));
   SEPR_TRY(launch_finish_norm_linear(dWh, s, w->gate_w, w->gate_ln_g, w->gate_ln_b, g->gate_w, g->gate_b, g->gate_ln_g, g->gate_ln_b, F, F,
-                                     post_stream(st)));
+                                     st));
   // dx = dy + LN'(dzg . (Wgate gamma)) + avg-pool backward of dxd
   return dgrad_ln(dzg, F, F, w->gate_t, 0, x, k.stats, dy, dxd, T, Tp, fac, dx, dxh, M, F, st);
 }
@@ -707,7 +707,6 @@ extern "C" int sepr_gcfn_train_fwd(const float* x, float* y, int n, int T, int F
 extern "C" int sepr_gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, const sepr_gcfn_tw* w,
                              const sepr_gcfn_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop,
                              sepr_u64 seed, sepr_stream_t stream) {
-  PostJoin post_scope(SEPR_ST);      // the reductions / finishers forked below are joined before the workspace changes hands
   if (!x || !dy || !dx || !w || !g || n <= 0 || T <= 0 || F <= 0 || F % 32 || !rows_ok((long long)n * T)) return SEPR_EINVAL;
   DropSaltScope salt_scope(w->seed_salt);
   Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
@@ -724,7 +723,6 @@ extern "C" int sepr_cla_train_fwd(const float* x, float* y, int n, int T, int F,
 extern "C" int sepr_cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int K, const sepr_cla_tw* w,
                             const sepr_cla_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop,
                             sepr_u64 seed, sepr_stream_t stream) {
-  PostJoin post_scope(SEPR_ST);      // the reductions / finishers forked below are joined before the workspace changes hands
   if (!x || !dy || !dx || !w || !g || n <= 0 || T <= 0 || F <= 0 || F % 64 || !rows_ok((long long)n * T)) return SEPR_EINVAL;
   DropSaltScope salt_scope(w->seed_salt);
   Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
@@ -742,7 +740,6 @@ extern "C" int sepr_ega_train_fwd(const float* x, float* y, int n, int T, int Tp
 extern "C" int sepr_ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, int F, int H, const sepr_ega_tw* w,
                             const sepr_ega_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop,
                             sepr_u64 seed, sepr_stream_t stream) {
-  PostJoin post_scope(SEPR_ST);      // the reductions / finishers forked below are joined before the workspace changes hands
   if (!x || !dy || !dx || !w || !g || n <= 0 || T <= 0 || Tp <= 0 || T % Tp || F <= 0 || F % 32 || H <= 0 || F % H ||
       !rows_ok((long long)n * T))
     return SEPR_EINVAL;
@@ -761,7 +758,6 @@ extern "C" int sepr_spkattn_train_fwd(const float* x, float* y, int nS, int S, i
 extern "C" int sepr_spkattn_bwd(const float* x, const float* dy, float* dx, int nS, int S, int T, int F, int H, const sepr_mha_tw* w,
                                 const sepr_mha_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, float p_drop,
                                 sepr_u64 seed, sepr_stream_t stream) {
-  PostJoin post_scope(SEPR_ST);      // the reductions / finishers forked below are joined before the workspace changes hands
   if (!x || !dy || !dx || !w || !g || nS <= 0 || S <= 0 || nS % S || T <= 0 || F <= 0 || F % 32 || H <= 0 || F % H ||
       !rows_ok((long long)nS * T))
     return SEPR_EINVAL;
@@ -778,7 +774,6 @@ extern "C" int sepr_downconv_train_fwd(const float* x, float* y, int n, int T, i
 extern "C" int sepr_downconv_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int K, const sepr_down_tw* w,
                                  const sepr_down_grad* g, const void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes,
                                  sepr_stream_t stream) {
-  PostJoin post_scope(SEPR_ST);      // the reductions / finishers forked below are joined before the workspace changes hands
   if (!x || !dy || !dx || !w || !g || n <= 0 || T <= 0 || F <= 0 || F % 4 || K <= 0 || !(K & 1)) return SEPR_EINVAL;
   Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
   return down_bwd(x, dy, dx, n, T, F, K, w, g, cx, wk, SEPR_ST);
@@ -792,7 +787,6 @@ extern "C" int sepr_spksplit_train_fwd(const float* x, float* y, int B, int S, i
 extern "C" int sepr_spksplit_bwd(const float* x, const float* dy, float* dx, int dx_accumulate, int B, int S, int T, int F,
                                  const sepr_split_tw* w, const sepr_split_grad* g, const void* ctx, size_t ctx_bytes, void* ws,
                                  size_t ws_bytes, sepr_stream_t stream) {
-  PostJoin post_scope(SEPR_ST);      // the reductions / finishers forked below are joined before the workspace changes hands
   if (!x || !dy || !dx || !w || !g || B <= 0 || S <= 0 || T <= 0 || F <= 0 || F % 32 || !rows_ok((long long)B * T * S)) return SEPR_EINVAL;
   Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);
   return split_bwd(x, dy, dx, dx_accumulate, B, S, T, F, w, g, cx, wk, SEPR_ST);
@@ -801,14 +795,12 @@ extern "C" int sepr_spksplit_bwd(const float* x, const float* dy, float* dx, int
 extern "C" size_t sepr_linear_wgrad_workspace(int M, int N, int K) { return tn_workspace_bytes(M, N, K); }
 extern "C" int sepr_linear_wgrad(const float* A, const float* B, float* G, float* colsum, int M, int N, int K, int accumulate, int x3,
                                  void* ws, size_t ws_bytes, sepr_stream_t stream) {
-  PostJoin post_scope(SEPR_ST);      // the reductions / finishers forked below are joined before the workspace changes hands
   if (!A || !B || !G || M <= 0) return SEPR_EINVAL;
   return wgrad(A, N, B, K, nullptr, G, colsum, M, N, K, accumulate, x3 < 0 || x3 > 2 ? 1 : x3, ws, ws_bytes, SEPR_ST);
 }
 
 extern "C" int sepr_linear_wgrad_norm(const float* A, const float* B, const float* stats, float* G, float* colsum, int M, int N, int K,
                                       int accumulate, int x3, void* ws, size_t ws_bytes, sepr_stream_t stream) {
-  PostJoin post_scope(SEPR_ST);      // the reductions / finishers forked below are joined before the workspace changes hands
   if (!A || !B || !stats || !G || M <= 0) return SEPR_EINVAL;
   return wgrad(A, N, B, K, stats, G, colsum, M, N, K, accumulate, x3 < 0 || x3 > 2 ? 1 : x3, ws, ws_bytes, SEPR_ST);
 }
@@ -968,7 +960,7 @@ int front_bwd(const float* wav, const float* enc, const float* dout, float* denc
     t.G = dWh; t.ldg = N; t.colsum = s;
     SEPR_TRY(launch_gemm_tn(t, tn_mode(w->proj_t), tnw, tnb, st));
   }
-  SEPR_TRY(launch_finish_norm_linear(dWh, s, w->proj_w, w->gn_g, w->gn_b, g->proj_w, nullptr, g->gn_g, g->gn_b, F, N, post_stream(st)));
+  SEPR_TRY(launch_finish_norm_linear(dWh, s, w->proj_w, w->gn_g, w->gn_b, g->proj_w, nullptr, g->gn_g, g->gn_b, F, N, st));
   {  // d enc_hat [B*L][N] = dout(valid rows) . (W * gamma)
     GemmArgs a = gemm_args_zero();
     a.M = (int)ML; a.N = N; a.K = F;
@@ -994,7 +986,6 @@ int front_bwd(const float* wav, const float* enc, const float* dout, float* denc
 
 extern "C" int sepr_fuse_bwd(const float* lo, const float* skip, const float* dy, float* dlo, float* dskip, int n, int T, int F,
                              const sepr_fuse_tw* w, const sepr_fuse_grad* g, void* ws, size_t ws_bytes, sepr_stream_t stream) {
-  PostJoin post_scope(SEPR_ST);      // the reductions / finishers forked below are joined before the workspace changes hands
   if (!lo || !skip || !dy || !dlo || !dskip || !w || !g || n <= 0 || T <= 0 || (T & 1) || F <= 0 || F % 32) return SEPR_EINVAL;
   Carve wk(ws, ws_bytes, false);
   return fuse_bwd(lo, skip, dy, dlo, dskip, n, T, F, w, g, wk, SEPR_ST);
@@ -1014,7 +1005,6 @@ extern "C" int sepr_outlayer_decoder_bwd(const float* x, const float* dwav, floa
                                          int Tsrc, int L, const int* idx, const int* idx_start, const float* enc, int F, int N, int K,
                                          int stride, const sepr_out_tw* w, const sepr_out_grad* g, const void* ctx, size_t ctx_bytes,
                                          void* ws, size_t ws_bytes, sepr_stream_t stream) {
-  PostJoin post_scope(SEPR_ST);      // the reductions / finishers forked below are joined before the workspace changes hands
   if (!x || !dwav || !dx || !w || !g || nS <= 0 || S <= 0 || nS % S || Tsrc <= 0 || L <= 0 || F % 32 || N % 16) return SEPR_EINVAL;
   if (K != TRAIN_ENC_K || stride != TRAIN_ENC_STRIDE) return SEPR_EINVAL;
   if (!idx && L > Tsrc) return SEPR_EINVAL;
@@ -1033,7 +1023,6 @@ extern "C" int sepr_front_train_fwd(const float* wav, int B, int T, int N, int K
 extern "C" int sepr_front_bwd(const float* wav, const float* enc, const float* dout, float* denc_aux, int B, int T, int N, int K,
                               int stride, int F, int Lp, const sepr_front_tw* w, const sepr_front_grad* g, const void* ctx,
                               size_t ctx_bytes, void* ws, size_t ws_bytes, sepr_stream_t stream) {
-  PostJoin post_scope(SEPR_ST);      // the reductions / finishers forked below are joined before the workspace changes hands
   if (!wav || !enc || !dout || !w || !g || B <= 0 || T < K || stride <= 0) return SEPR_EINVAL;
   if (K != TRAIN_ENC_K || stride != TRAIN_ENC_STRIDE) return SEPR_EINVAL;
   Carve cx(const_cast<void*>(ctx), ctx_bytes, false), wk(ws, ws_bytes, false);

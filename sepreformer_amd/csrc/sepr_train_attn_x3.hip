@@ -579,9 +579,8 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) 
 // dS[nh][i][i - rel] * q[nh][i][d]   (rel = i - j in (-Tp, Tp)); consecutive threads = consecutive rel = consecutive j
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int AXB_GROUP = 4;
-constexpr int AXB_ROWS = 16;    // rows per load batch of the table-gradient kernel: 2 batches in flight x 16 two-byte loads per lane - the
-                                // kernel is bound by bytes in flight (8 rows: 1.3 TB/s at two workgroups per CU)
-constexpr int AXB_BPC = 2;      // batches per LDS chunk of q rows
+constexpr int AXB_ROWS = 8;     // rows per load batch of the table-gradient kernel
+constexpr int AXB_BPC = 4;      // batches per LDS chunk of q rows
 // One block = 64 consecutive relative offsets x 4 query partitions (one partition per wave).  Every lane of a wave walks the
 // SAME queries i and reads dS[i][i - rel] when that key exists; consecutive lanes = consecutive rel = consecutive (descending)
 // keys: coalesced reads of every dS row, each element once.  The q rows are wave-uniform: they are staged 128 rows at a time in
@@ -589,8 +588,7 @@ constexpr int AXB_BPC = 2;      // batches per LDS chunk of q rows
 // row + scalar q loads = one memory latency per row (122 us; 211 us when the bf16 / fp32 choice was a run-time select); loads in
 // batches of 8 unconditional rows (clamped address, value selected afterwards) with scalar q loads 136 us - the s_load chain was
 // the latency; q through LDS + the next batch's dS loads issued before this batch's FMAs 116 us (1.1 TB/s, and 2 x the
-// useful FMAs: half of the (row, offset) pairs have no key); rows limited to the ones that can meet the block's offsets 100 us (1.3 TB/s:
-// 8 KB in flight per CU); 16-row batches: see profiles.
+// useful FMAs: half of the (row, offset) pairs have no key); rows limited to the ones that can meet the block's offsets: see profiles.
 template <int DK, bool DS16>
 __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restrict__ QKV, const float* __restrict__ dS, float* __restrict__ band,
                                                           int NH, int Tp, int F, int H) {

@@ -8,7 +8,6 @@ to gpurun_out/train_parity_report.json.
 import dataclasses
 import json
 import os
-import sys
 
 import numpy as np
 import pytest
@@ -1702,64 +1701,3 @@ def test_captured_step_with_flat_adamw_follows_torch_adamw():
         assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (a, b)
         assert abs(ga - gb_) <= 1e-5 * gb_, (a, b)
     assert a[-1][0] < a[0][0]
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# post stream (round 4): reductions / finishers of the weight-gradient contractions on a forked stream
-# ---------------------------------------------------------------------------------------------------------------------
-_POST_SCRIPT = r"""
-import sys, dataclasses, numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from sepreformer_amd.config import VARIANTS
-from sepreformer_amd.model import Model
-from sepreformer_amd.synth import synth_sources
-from sepreformer_amd.train_step import CapturedTrainStep
-torch.manual_seed(7)                     # (the dropout seed stream derives from it)
-dev = torch.device("cuda:0")
-out = {}
-for variant, B, T, prec in (("tiny", 2, 1500, "bf16x3"), ("SepReformer_Base_WSJ0", 2, 4000, "bf16")):
-    cfg = VARIANTS[variant]
-    m = Model.from_config(cfg, init_seed=0, precision=prec).load_synthetic_(0).to(dev).train()
-    src = torch.from_numpy(synth_sources(B, T, seed=8) * 4.0).to(dev)
-    x = src.sum(1).contiguous()
-    audio, aux = m(x)
-    (torch.stack(audio).pow(2).mean() + 0.1 * sum(torch.stack(a).abs().mean() for a in aux)).backward()
-    out[variant + ".eager"] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
-# the same through a captured step (the fork / join become branches of the graph): parameters after two replays
-cfg = VARIANTS["tiny"]
-m = Model.from_config(cfg, init_seed=0).load_synthetic_(0).to(dev).train()
-src = torch.from_numpy(synth_sources(2, 1500, seed=9) * 4.0).to(dev)
-x = src.sum(1).contiguous()
-tg = [src[:, s].contiguous() for s in range(2)]
-opt = torch.optim.SGD(m.parameters(), lr=1e-3)
-opt.param_groups[0]["capturable"] = True
-def loss_fn(audio, aux, *t):
-    return sum(((a - t[s][:, : a.shape[-1]]) ** 2).mean() for s, a in enumerate(audio)) + 0.1 * sum(torch.stack(a_).abs().mean() for a_ in aux)
-st = CapturedTrainStep(m, loss_fn, opt, x, tg, max_norm=None, warmup=1)
-for _ in range(2):
-    st(x, tg)
-torch.cuda.synchronize()
-out["tiny.captured"] = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy()
-np.savez(sys.argv[2], **out)
-"""
-
-
-def test_post_stream_gradients_equal_single_stream(tmp_path):
-    """SEPR_TRAIN_POST (default on: the split-M reductions and parameter-gradient finishers of every contraction run on a forked
-    stream beside the next kernels, joined at the end of each backward entry point) against SEPR_TRAIN_POST=0 (everything on the
-    caller's stream): every gradient of an eager tiny step (bf16x3) and an eager Base step (plain bf16, dropout on), and the
-    parameters after two replays of a captured tiny step, are BITWISE equal - the switch moves launches, not arithmetic.  Two
-    processes (the switch is read once per process)."""
-    import subprocess
-    res = {}
-    for mode in ("0", "1"):
-        env = dict(os.environ, SEPR_TRAIN_POST=mode)
-        f = tmp_path / f"post{mode}.npz"
-        r = subprocess.run([sys.executable, "-c", _POST_SCRIPT, ROOT, str(f)], capture_output=True, text=True, timeout=600, env=env)
-        assert r.returncode == 0, r.stderr[-3000:]
-        res[mode] = np.load(f)
-    assert set(res["0"].files) == {"tiny.eager", "SepReformer_Base_WSJ0.eager", "tiny.captured"}
-    for k in res["0"].files:
-        a, b = res["0"][k], res["1"][k]
-        assert np.isfinite(a).all() and np.abs(a).max() > 0
-        assert np.array_equal(a, b), (k, int((a != b).sum()), float(np.abs(a - b).max()))
