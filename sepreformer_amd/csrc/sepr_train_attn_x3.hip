@@ -579,8 +579,12 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) 
 // dS[nh][i][i - rel] * q[nh][i][d]   (rel = i - j in (-Tp, Tp)); consecutive threads = consecutive rel = consecutive j
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int AXB_GROUP = 4;
-constexpr int AXB_ROWS = 8;     // rows per load batch of the table-gradient kernel
-constexpr int AXB_BPC = 4;      // batches per LDS chunk of q rows
+#ifndef SEPR_AXB_ROWS
+#define SEPR_AXB_ROWS 8         // (tools/variants.mk builds the 16-row form for the A/B)
+#define SEPR_AXB_BPC 4
+#endif
+constexpr int AXB_ROWS = SEPR_AXB_ROWS;   // rows per load batch of the table-gradient kernel
+constexpr int AXB_BPC = SEPR_AXB_BPC;     // batches per LDS chunk of q rows (4 * AXB_ROWS * AXB_BPC = 128 rows)
 // One block = 64 consecutive relative offsets x 4 query partitions (one partition per wave).  Every lane of a wave walks the
 // SAME queries i and reads dS[i][i - rel] when that key exists; consecutive lanes = consecutive rel = consecutive (descending)
 // keys: coalesced reads of every dS row, each element once.  The q rows are wave-uniform: they are staged 128 rows at a time in

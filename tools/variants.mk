@@ -36,3 +36,5 @@ VARIANT_resx = -DSEPR_GF3_RESX=1
 # conv-fold proxies of the fused GCFN (round-4 review item 6; wrong results, timing only)
 VARIANT_gfold32 = -DSEPR_GF_ABL=32
 VARIANT_gfold64 = -DSEPR_GF_ABL=64
+# table-gradient kernel of the EGA attention backward: 16-row load batches (round 4 A/B)
+VARIANT_band16 = -DSEPR_AXB_ROWS=16 -DSEPR_AXB_BPC=2
