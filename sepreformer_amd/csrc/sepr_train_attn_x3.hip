@@ -592,10 +592,13 @@ constexpr int AXB_BPC = SEPR_AXB_BPC;     // batches per LDS chunk of q rows (4 
 // row + scalar q loads = one memory latency per row (122 us; 211 us when the bf16 / fp32 choice was a run-time select); loads in
 // batches of 8 unconditional rows (clamped address, value selected afterwards) with scalar q loads 136 us - the s_load chain was
 // the latency; q through LDS + the next batch's dS loads issued before this batch's FMAs 116 us (1.1 TB/s, and 2 x the
-// useful FMAs: half of the (row, offset) pairs have no key); rows limited to the ones that can meet the block's offsets: see profiles.
+// useful FMAs: half of the (row, offset) pairs have no key); rows limited to the ones that can meet the block's offsets 99 us; 16-row
+// batches (more bytes in flight) 124 us - NOT latency-bound any more: ~35 instructions per (row, wave) at 4 cycles each are the
+// bound, so: packed FMAs (two channels per issue), one clamp per address, a row-range validity test: see profiles.
 template <int DK, bool DS16>
 __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restrict__ QKV, const float* __restrict__ dS, float* __restrict__ band,
                                                           int NH, int Tp, int F, int H) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   constexpr int CH = 4 * AXB_ROWS * AXB_BPC;                 // q rows per LDS chunk (128)
   __shared__ __attribute__((aligned(16))) float qs[CH * DK];
   __shared__ float red[4][64][DK + 1];
@@ -603,9 +606,18 @@ __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restri
   const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rel = blockIdx.x * 64 + rl - (Tp - 1);
   const int grp = blockIdx.y;
-  float acc[DK];
+  // rows that can meet this block's 64 offsets: j = i - rel in [0, Tp)  =>  i in [r0, r0 + 63 + Tp) - half of the (row, offset)
+  // grid of the launch is empty, and whole chunks of it are skipped here
+  const int r0 = blockIdx.x * 64 - (Tp - 1);
+  const int i_lo = max(0, r0), i_hi = min(Tp, r0 + 63 + Tp);
+  const int c_lo = i_lo / CH * CH;
+  // this lane's valid rows: i in [v_lo, v_lo + v_n)
+  const int v_lo = max(0, rel);
+  const unsigned v_n = (unsigned)max(0, min(Tp, rel + Tp) - v_lo);
+  const int TT1 = Tp * Tp - 1;
+  f32x2 acc[DK / 2];
 #pragma unroll
-  for (int d = 0; d < DK; ++d) acc[d] = 0.f;
+  for (int d = 0; d < DK / 2; ++d) acc[d] = (f32x2){0.f, 0.f};
   for (int gi = 0; gi < AXB_GROUP; ++gi) {
     const int nh = grp * AXB_GROUP + gi;
     if (nh >= NH) break;
@@ -613,23 +625,20 @@ __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restri
     const float* qb = QKV + (long long)n * Tp * 3 * F + h * DK;
     const float* sb = dS + (long long)nh * Tp * Tp;
     const unsigned short* sb16 = reinterpret_cast<const unsigned short*>(dS) + (long long)nh * Tp * Tp;
-    // batch b of this wave = rows part + 4 (AXB_ROWS b + u), u < AXB_ROWS; every load is unconditional (clamped address) and RAW: the
-    // bf16 widening and the validity select happen where the value is consumed, one batch later - nothing touches the registers of the
-    // batch in flight before that, so its loads stay outstanding under the current batch's FMAs
+    // batch b of this wave = rows part + 4 (AXB_ROWS b + u), u < AXB_ROWS.  Element (i, j = i - rel) sits at i (Tp + 1) - rel of the
+    // head's matrix; the index is clamped INTO the matrix (one v_med3: any element will do for a pair without a key - validity is a
+    // row-range test where the value is consumed), every load is unconditional and RAW (the bf16 widening happens at the consumer
+    // too): nothing touches the registers of the batch in flight, so its loads stay outstanding under the current batch's FMAs.
     auto load_batch = [&](int b, unsigned (&raw)[AXB_ROWS]) {
+      int idx = (part + 4 * AXB_ROWS * b) * (Tp + 1) - rel;
 #pragma unroll
       for (int u = 0; u < AXB_ROWS; ++u) {
-        const int i = part + 4 * (AXB_ROWS * b + u), j = i - rel;
-        const long long at = (long long)min(i, Tp - 1) * Tp + min(max(j, 0), Tp - 1);
+        const int at = min(max(idx, 0), TT1);
         raw[u] = DS16 ? (unsigned)sb16[at] : __float_as_uint(sb[at]);
+        idx += 4 * (Tp + 1);
       }
     };
-    // rows that can meet this block's 64 offsets: j = i - rel in [0, Tp)  =>  i in [r0, r0 + 63 + Tp) - half of the (row, offset)
-    // grid of the launch is empty, and whole chunks of it are skipped here
-    const int r0 = blockIdx.x * 64 - (Tp - 1);
-    const int i_lo = max(0, r0), i_hi = min(Tp, r0 + 63 + Tp);
     unsigned cur[AXB_ROWS], nx[AXB_ROWS];
-    const int c_lo = i_lo / CH * CH;
     load_batch(c_lo / (4 * AXB_ROWS), cur);
     for (int c0 = c_lo, b = c_lo / (4 * AXB_ROWS); c0 < i_hi; c0 += CH) {
       __syncthreads();                                         // the previous chunk's rows are consumed
@@ -643,17 +652,16 @@ __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restri
         load_batch(b + 1, nx);                                 // (past the end: clamped addresses, discarded)
 #pragma unroll
         for (int u = 0; u < AXB_ROWS; ++u) {
-          const int i = part + 4 * (AXB_ROWS * b + u), j = i - rel;
+          const int i = part + 4 * (AXB_ROWS * b + u);
           const float v = DS16 ? __uint_as_float(cur[u] << 16) : __uint_as_float(cur[u]);
-          const float sv = (i < Tp && j >= 0 && j < Tp) ? v : 0.f;
+          const float sv = ((unsigned)(i - v_lo) < v_n) ? v : 0.f;
+          const f32x2 s2 = (f32x2){sv, sv};
           const float* q = qs + (part + 4 * (AXB_ROWS * bb + u)) * DK;      // wave-uniform: LDS broadcast
 #pragma unroll
           for (int d4 = 0; d4 < DK; d4 += 4) {
             const float4 qv = ld4(q + d4);
-            acc[d4] = fmaf(sv, qv.x, acc[d4]);
-            acc[d4 + 1] = fmaf(sv, qv.y, acc[d4 + 1]);
-            acc[d4 + 2] = fmaf(sv, qv.z, acc[d4 + 2]);
-            acc[d4 + 3] = fmaf(sv, qv.w, acc[d4 + 3]);
+            acc[d4 / 2] = __builtin_elementwise_fma(s2, (f32x2){qv.x, qv.y}, acc[d4 / 2]);           // v_pk_fma_f32: two channels per issue
+            acc[d4 / 2 + 1] = __builtin_elementwise_fma(s2, (f32x2){qv.z, qv.w}, acc[d4 / 2 + 1]);
           }
         }
 #pragma unroll
@@ -662,7 +670,10 @@ __global__ __launch_bounds__(256) void relattn_band_kernel(const float* __restri
     }
   }
 #pragma unroll
-  for (int d = 0; d < DK; ++d) red[part][rl][d] = acc[d];
+  for (int d = 0; d < DK / 2; ++d) {
+    red[part][rl][2 * d] = acc[d][0];
+    red[part][rl][2 * d + 1] = acc[d][1];
+  }
   __syncthreads();
   // 64 offsets x DK channels summed over the 4 partitions in a fixed order
   for (int e = threadIdx.x; e < 64 * DK; e += 256) {
