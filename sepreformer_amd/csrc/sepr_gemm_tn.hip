@@ -445,6 +445,63 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     colsum[n] = colsum_acc ? colsum[n] + s : s;
   }
 }
+// The same reduction with one block per ROW n of G (64 elements x 4 slice lanes per pass, identical summation order: bit-identical
+// G and column sums) - the row is then finished in place (TnFinish): the arithmetic of finish_norm_rows_kernel / finish_ls_kernel
+// expression for expression, so the fused and the two-launch forms produce the same bits.
+template <int KIND>
+__global__ __launch_bounds__(256) void tn_reduce_rows_kernel(const float* __restrict__ part, const float* __restrict__ cpart, int nsplit,
+                                                            int N, int K, float* __restrict__ G, int ldg, float* __restrict__ colsum,
+                                                            const TnFinish f) {
+  __shared__ float sh[4][64];
+  const int n = blockIdx.x;
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long long total = (long long)N * K;
+  float s = 0.f;
+  if (el == 0) {
+#pragma unroll 4
+    for (int sp = sl; sp < nsplit; sp += 4) s += cpart[(long long)sp * N + n];
+  }
+  sh[sl][el] = s;
+  __syncthreads();
+  const float sn = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+  __syncthreads();
+  const int seg = n / f.seg_rows, r = n - seg * f.seg_rows;
+  const float l = KIND == 2 ? f.ls[n] : 0.f;
+  float a = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    const int k = k0 + el;
+    s = 0.f;
+    if (k < K) {
+      const float* pp = part + (long long)n * K + k;
+#pragma unroll 4
+      for (int sp = sl; sp < nsplit; sp += 4) s += pp[(long long)sp * total];
+    }
+    sh[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && k < K) {
+      const float gr = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
+      if (KIND == 1) {
+        G[(long long)n * ldg + k] = gr;
+        f.dW[seg][(long long)r * K + k] += fmaf(gr, f.g[k], sn * f.b[k]);
+      } else {
+        f.dW[0][(long long)n * K + k] += l * gr;
+        a = fmaf(f.W[(long long)n * K + k], gr, a);
+      }
+    }
+    __syncthreads();
+  }
+  if (sl != 0) return;
+  if (KIND == 2) a = wave_sum(a);
+  if (el == 0) {
+    if (KIND == 1) {
+      colsum[n] = sn;
+      if (f.dbias[seg]) f.dbias[seg][r] += sn;
+    } else {
+      f.dbias[0][n] += l * sn;
+      f.dls[n] += fmaf(f.bias[n], sn, a);
+    }
+  }
+}
 }  // namespace
 
 size_t tn_workspace_bytes(int M, int N, int K) {
@@ -457,6 +514,16 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   if (a.M <= 0) return SEPR_OK;
   if (!a.A || !a.B || !a.G || a.N <= 0 || a.K <= 0 || (a.N % 4) || (a.K % 4) || (a.lda % 4) || (a.ldb % 4)) return SEPR_EINVAL;
   if (a.B2 && ((a.ksplit % 4) || (a.ldb2 % 4))) return SEPR_EINVAL;
+  if (a.fin.kind != 0) {      // the fused finisher needs the plain outputs it stands in for, and its own operands
+    const TnFinish& f = a.fin;
+    if ((f.kind != 1 && f.kind != 2) || !a.colsum || a.accumulate || a.colsum_accumulate || f.seg_rows <= 0 || a.N % f.seg_rows ||
+        a.N / f.seg_rows > 3 || !f.dW[0])
+      return SEPR_EINVAL;
+    if (f.kind == 1 && (!f.g || !f.b)) return SEPR_EINVAL;
+    if (f.kind == 2 && (!f.W || !f.bias || !f.ls || !f.dbias[0] || !f.dls || f.seg_rows != a.N)) return SEPR_EINVAL;
+    for (int i = 1; i < a.N / f.seg_rows; ++i)
+      if (!f.dW[i]) return SEPR_EINVAL;
+  }
   const TnPlan p = tn_plan(a.M, a.N, a.K);
   const size_t need = tn_workspace_bytes(a.M, a.N, a.K);
   if (!ws || ws_bytes < need) return SEPR_EWORKSPACE;
@@ -525,10 +592,16 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
     // both operands once (bf16 sources: 2 bytes per element) + the statistics: what a contraction over M rows has to read
     prof_bytes((double)a.M * ((double)a.N * (a.a16 ? 2.0 : 4.0) + (double)a.K * (a.b16 ? 2.0 : 4.0) + (a.stats ? 8.0 : 0.0)));
   }
-  const long long total = (long long)a.N * a.K + a.N;
-  const int rgrid = (int)((total + 63) / 64);
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
-                     a.colsum, a.colsum_accumulate);
+  if (a.fin.kind == 1) {
+    hipLaunchKernelGGL(tn_reduce_rows_kernel<1>, dim3(a.N), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.colsum, a.fin);
+  } else if (a.fin.kind == 2) {
+    hipLaunchKernelGGL(tn_reduce_rows_kernel<2>, dim3(a.N), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.colsum, a.fin);
+  } else {
+    const long long total = (long long)a.N * a.K + a.N;
+    const int rgrid = (int)((total + 63) / 64);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
+                       a.colsum, a.colsum_accumulate);
+  }
   SEPR_CHECK_LAUNCH("gemm_tn_kernel");
   return SEPR_OK;
 }

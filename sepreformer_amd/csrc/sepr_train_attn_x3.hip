@@ -578,7 +578,10 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_x3_kernel(const AxArgs a) 
 // table gradient: band[grp][rel + Tp - 1][d] = sum over the group's (sequence, head) pairs and queries of
 // dS[nh][i][i - rel] * q[nh][i][d]   (rel = i - j in (-Tp, Tp)); consecutive threads = consecutive rel = consecutive j
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int AXB_GROUP = 4;
+#ifndef SEPR_AXB_GROUP
+#define SEPR_AXB_GROUP 4        // (sequence, head) pairs per workgroup of the table-gradient kernel (tools/variants.mk: 2, 1)
+#endif
+constexpr int AXB_GROUP = SEPR_AXB_GROUP;
 #ifndef SEPR_AXB_ROWS
 #define SEPR_AXB_ROWS 8         // (tools/variants.mk builds the 16-row form for the A/B)
 #define SEPR_AXB_BPC 4

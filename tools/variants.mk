@@ -38,3 +38,5 @@ VARIANT_gfold32 = -DSEPR_GF_ABL=32
 VARIANT_gfold64 = -DSEPR_GF_ABL=64
 # table-gradient kernel of the EGA attention backward: 16-row load batches (round 4 A/B)
 VARIANT_band16 = -DSEPR_AXB_ROWS=16 -DSEPR_AXB_BPC=2
+VARIANT_bandg2 = -DSEPR_AXB_GROUP=2
+VARIANT_bandg1 = -DSEPR_AXB_GROUP=1
