@@ -52,20 +52,15 @@ inline float sepr_drop_scale16(float p) { return (float)(65536.0 / (65536.0 - (d
 //   colsum[N] (+)= sum_m A[m][n]              (bias gradient, optional)
 // Deterministic: the M range is split over workgroups, partial tiles go to the workspace and are summed in a fixed order.
 // ---------------------------------------------------------------------------------------------------------------------
-// Per-row part of a parameter-gradient finisher, run by the split-M reduction itself (round 4: tn_reduce_rows_kernel owns whole rows of G,
-// so the row is finished where it is produced: one launch instead of reduction + finisher).  kind 1 = the row part of
-// launch_finish_norm_linear (G and colsum are still written: the column part reads them), kind 2 = launch_finish_linear_ls.
+// Per-row part of launch_finish_norm_linear run by the split-M reduction itself (round 4: one launch less per contraction; G and colsum
+// are still written - the column part reads them).  Needs K % 64 == 0.
 struct TnFinish {
-  int kind;
-  const float* W;              // kind 2: [N][K]
-  const float* g;              // kind 1: the folded normalisation's gamma / beta [K]
+  int kind;                    // 0 none, 1 = dW[seg][r][k] += G[n][k] * g[k] + s[n] * b[k];  dbias[seg][r] += s[n]   (n = seg * seg_rows + r)
+  const float* g;              // the folded normalisation's gamma / beta [K]
   const float* b;
-  const float* bias;           // kind 2: [N]
-  const float* ls;             // kind 2: [N]
   float* dW[3];                // gradient tensors of up to 3 row segments (the q / k / v stack), [seg_rows][K] each
-  float* dbias[3];             // [seg_rows] each (kind 1: may be null)
+  float* dbias[3];             // [seg_rows] each, may be null
   int seg_rows;                // rows per segment (N: one segment)
-  float* dls;                  // kind 2: [N]
 };
 struct TnArgs {
   int M, N, K;

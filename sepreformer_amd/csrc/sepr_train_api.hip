@@ -99,7 +99,7 @@ TnArgs wgrad_args(const float* A, int lda, const float* B, int ldb, const float*
   return t;
 }
 // Contraction + parameter-gradient finisher.  Round 4: the per-row part of the finisher runs inside the split-M reduction
-// (TnFinish; one launch less per contraction, same bits); SEPR_TRAIN_FUSEFIN=0 keeps the separate launches (read per call: the A/B
+// (TnFinish kind 1; one launch less per contraction, same bits); SEPR_TRAIN_FUSEFIN=0 keeps the separate launches (read per call: the A/B
 // test flips it inside one process).
 bool fin_fused() {
   const char* e = getenv("SEPR_TRAIN_FUSEFIN");
@@ -108,7 +108,7 @@ bool fin_fused() {
 // projection behind a folded normalisation (launch_finish_norm_linear's algebra); t.G / t.colsum are the dWh / s temporaries
 int tn_norm_fin(TnArgs t, int x3, void* tnw, size_t tnb, const float* W, const float* g, const float* b, float* dW_g, float* dbias_g,
                 float* dg_g, float* db_g, hipStream_t st) {
-  if (!fin_fused()) {
+  if (!fin_fused() || (t.K % 64)) {
     SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
     return launch_finish_norm_linear(t.G, t.colsum, W, g, b, dW_g, dbias_g, dg_g, db_g, t.N, t.K, st);
   }
@@ -116,16 +116,11 @@ int tn_norm_fin(TnArgs t, int x3, void* tnw, size_t tnb, const float* W, const f
   SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
   return launch_finish_norm_cols(t.G, t.colsum, W, dg_g, db_g, t.N, t.K, st);
 }
-// projection followed by LayerScale (launch_finish_linear_ls's algebra)
+// projection followed by LayerScale (launch_finish_linear_ls's algebra; its dls needs a row-long fmaf chain: a launch of its own)
 int tn_ls_fin(TnArgs t, int x3, void* tnw, size_t tnb, const float* W, const float* bias, const float* ls, float* dW_g, float* dbias_g,
               float* dls_g, hipStream_t st) {
-  if (!fin_fused()) {
-    SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
-    return launch_finish_linear_ls(t.G, t.colsum, W, bias, ls, dW_g, dbias_g, dls_g, t.N, t.K, st);
-  }
-  t.fin.kind = 2; t.fin.W = W; t.fin.bias = bias; t.fin.ls = ls; t.fin.dW[0] = dW_g; t.fin.dbias[0] = dbias_g; t.fin.dls = dls_g;
-  t.fin.seg_rows = t.N;
-  return launch_gemm_tn(t, x3, tnw, tnb, st);
+  SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
+  return launch_finish_linear_ls(t.G, t.colsum, W, bias, ls, dW_g, dbias_g, dls_g, t.N, t.K, st);
 }
 // arithmetic of the weight-gradient contraction that goes with a projection: 0 exact f32, 1 bf16x3, 2 plain bf16
 int tn_mode(const sepr_lin& l) { return !l.wp ? 0 : (l.planes == 1 ? 2 : 1); }
@@ -456,13 +451,14 @@ int mha_qkv_bwd(const float* dqkv, const float* xin, const float* stats, float* 
   float* gw[3] = {g->wq, g->wk, g->wv};
   float* gb[3] = {g->bq, g->bk, g->bv};
   TnArgs t = wgrad_args(dqkv, 3 * F, xin, F, stats, dWh, s, M, 3 * F, F);
-  if (fin_fused()) {   // the three stacked projections are three row segments of one reduction; the column parts stay three launches
+  const bool fq = fin_fused() && F % 64 == 0;
+  if (fq) {   // the three stacked projections are three row segments of one reduction; the column parts stay three launches
     t.fin.kind = 1; t.fin.g = w->ln_g; t.fin.b = w->ln_b; t.fin.seg_rows = F;                // (their dgamma / dbeta sums keep their order)
     for (int i = 0; i < 3; ++i) { t.fin.dW[i] = gw[i]; t.fin.dbias[i] = gb[i]; }
   }
   SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
   for (int i = 0; i < 3; ++i) {
-    if (fin_fused())
+    if (fq)
       SEPR_TRY(launch_finish_norm_cols(dWh + (long long)i * F * F, s + i * F, w->wqkv + (long long)i * F * F, g->ln_g, g->ln_b, F, F, st));
     else
       SEPR_TRY(launch_finish_norm_linear(dWh + (long long)i * F * F, s + i * F, w->wqkv + (long long)i * F * F, w->ln_g, w->ln_b, gw[i],

@@ -1709,8 +1709,8 @@ def test_captured_step_with_flat_adamw_follows_torch_adamw():
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("variant,n,T", [("SepReformer_Base_WSJ0", 4, 2040), ("tiny", 2, 300)])
 def test_finishers_inside_the_reduction_equal_separate_launches(variant, n, T, precision, monkeypatch):
-    """The per-row part of the parameter-gradient finishers (LayerNorm-folded projections, LayerScale projections) runs inside the
-    contraction's reduction kernel (tn_reduce_rows_kernel, SEPR_TRAIN_FUSEFIN default) vs the reduction + finisher launches of before
+    """The per-row part of the parameter-gradient finisher of every LayerNorm-folded projection runs inside the contraction's
+    reduction kernel (tn_reduce_fin1_kernel, SEPR_TRAIN_FUSEFIN default; K % 64 == 0) vs the reduction + finisher launches of before
     (SEPR_TRAIN_FUSEFIN=0): same summation order, same expressions - all four block kinds' input gradients and EVERY parameter
     gradient (incl. the q / k / v stack's three segments, the gate projection, LayerScales, biases) are bitwise equal; several split-M
     slices (8 160 rows) and a single one (600 rows)."""
