@@ -445,44 +445,6 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     colsum[n] = colsum_acc ? colsum[n] + s : s;
   }
 }
-// The same reduction with the per-row part of launch_finish_norm_linear applied in place (TnFinish kind 1; K % 64 == 0, so the 64
-// elements of a block lie in ONE row n): identical summation order for G and the column sums, and finish_norm_rows_kernel's expression
-// for dW - the fused and the two-launch forms produce the same bits.  Every block of a row re-derives the row's column sum s_n (nsplit
-// loads over 4 lanes); the row's first block also publishes it.  (A one-block-per-row form that also finished the LayerScale
-// projections - their dls needs a row-long fmaf chain - was measured first: 13 / 25 us per launch against 6.7 + 5 for the two launches,
-// too little parallelism at N = 128 rows; the LayerScale finisher stays a launch of its own.)
-__global__ __launch_bounds__(256) void tn_reduce_fin1_kernel(const float* __restrict__ part, const float* __restrict__ cpart, int nsplit,
-                                                            int N, int K, float* __restrict__ G, int ldg, float* __restrict__ colsum,
-                                                            const TnFinish f) {
-  __shared__ float sh[4][64];
-  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const long long total = (long long)N * K;
-  const long long i0 = (long long)blockIdx.x * 64;
-  const int n = (int)(i0 / K), k = (int)(i0 - (long long)n * K) + el;
-  float s = 0.f;
-  if (el == 0) {
-#pragma unroll 4
-    for (int sp = sl; sp < nsplit; sp += 4) s += cpart[(long long)sp * N + n];
-  }
-  sh[sl][el] = s;
-  __syncthreads();
-  const float sn = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
-  __syncthreads();
-  s = 0.f;
-#pragma unroll 4
-  for (int sp = sl; sp < nsplit; sp += 4) s += part[(long long)sp * total + i0 + el];
-  sh[sl][el] = s;
-  __syncthreads();
-  if (sl != 0) return;
-  const float gr = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
-  const int seg = n / f.seg_rows, r = n - seg * f.seg_rows;
-  G[(long long)n * ldg + k] = gr;
-  f.dW[seg][(long long)r * K + k] += fmaf(gr, f.g[k], sn * f.b[k]);
-  if (k == 0) {
-    colsum[n] = sn;
-    if (f.dbias[seg]) f.dbias[seg][r] += sn;
-  }
-}
 }  // namespace
 
 size_t tn_workspace_bytes(int M, int N, int K) {
@@ -495,14 +457,6 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   if (a.M <= 0) return SEPR_OK;
   if (!a.A || !a.B || !a.G || a.N <= 0 || a.K <= 0 || (a.N % 4) || (a.K % 4) || (a.lda % 4) || (a.ldb % 4)) return SEPR_EINVAL;
   if (a.B2 && ((a.ksplit % 4) || (a.ldb2 % 4))) return SEPR_EINVAL;
-  if (a.fin.kind != 0) {      // the fused finisher needs the plain outputs it stands in for, and its own operands
-    const TnFinish& f = a.fin;
-    if (f.kind != 1 || !a.colsum || a.accumulate || a.colsum_accumulate || f.seg_rows <= 0 || a.N % f.seg_rows || a.N / f.seg_rows > 3 ||
-        (a.K % 64) || !f.g || !f.b)
-      return SEPR_EINVAL;
-    for (int i = 0; i < a.N / f.seg_rows; ++i)
-      if (!f.dW[i]) return SEPR_EINVAL;
-  }
   const TnPlan p = tn_plan(a.M, a.N, a.K);
   const size_t need = tn_workspace_bytes(a.M, a.N, a.K);
   if (!ws || ws_bytes < need) return SEPR_EWORKSPACE;
@@ -571,15 +525,10 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
     // both operands once (bf16 sources: 2 bytes per element) + the statistics: what a contraction over M rows has to read
     prof_bytes((double)a.M * ((double)a.N * (a.a16 ? 2.0 : 4.0) + (double)a.K * (a.b16 ? 2.0 : 4.0) + (a.stats ? 8.0 : 0.0)));
   }
-  if (a.fin.kind == 1) {
-    hipLaunchKernelGGL(tn_reduce_fin1_kernel, dim3((int)((long long)a.N * a.K / 64)), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg,
-                       a.colsum, a.fin);
-  } else {
-    const long long total = (long long)a.N * a.K + a.N;
-    const int rgrid = (int)((total + 63) / 64);
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
-                       a.colsum, a.colsum_accumulate);
-  }
+  const long long total = (long long)a.N * a.K + a.N;
+  const int rgrid = (int)((total + 63) / 64);
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
+                     a.colsum, a.colsum_accumulate);
   SEPR_CHECK_LAUNCH("gemm_tn_kernel");
   return SEPR_OK;
 }

@@ -52,16 +52,6 @@ inline float sepr_drop_scale16(float p) { return (float)(65536.0 / (65536.0 - (d
 //   colsum[N] (+)= sum_m A[m][n]              (bias gradient, optional)
 // Deterministic: the M range is split over workgroups, partial tiles go to the workspace and are summed in a fixed order.
 // ---------------------------------------------------------------------------------------------------------------------
-// Per-row part of launch_finish_norm_linear run by the split-M reduction itself (round 4: one launch less per contraction; G and colsum
-// are still written - the column part reads them).  Needs K % 64 == 0.
-struct TnFinish {
-  int kind;                    // 0 none, 1 = dW[seg][r][k] += G[n][k] * g[k] + s[n] * b[k];  dbias[seg][r] += s[n]   (n = seg * seg_rows + r)
-  const float* g;              // the folded normalisation's gamma / beta [K]
-  const float* b;
-  float* dW[3];                // gradient tensors of up to 3 row segments (the q / k / v stack), [seg_rows][K] each
-  float* dbias[3];             // [seg_rows] each, may be null
-  int seg_rows;                // rows per segment (N: one segment)
-};
 struct TnArgs {
   int M, N, K;
   const float* A;
@@ -84,7 +74,6 @@ struct TnArgs {
   int accumulate;       // 1: G += result, 0: G = result
   float* colsum;        // [N] or null
   int colsum_accumulate;
-  TnFinish fin;         // fin.kind != 0: the reduction finishes its rows (needs G, colsum, accumulate == 0)
 };
 inline TnArgs tn_args_zero() {
   TnArgs a;
@@ -203,8 +192,6 @@ int launch_enc_bwd_pre(float* de, const float* add, const float* wav, const floa
 //   dg_k += sum_n W[n][k] dWh[n][k];  db_k += sum_n s[n] W[n][k]
 int launch_finish_norm_linear(const float* dWh, const float* s, const float* W, const float* g, const float* b, float* dW_g,
                               float* dbias_g, float* dg_g, float* db_g, int N, int K, hipStream_t st);
-// its column part alone (dg, db): the row part ran inside the reduction (TnFinish kind 1)
-int launch_finish_norm_cols(const float* dWh, const float* s, const float* W, float* dg_g, float* db_g, int N, int K, hipStream_t st);
 // projection followed by LayerScale:  y = ls * (v . W^T + bias)
 //   Gr [N][K] = sum dy v, s [N] = sum dy  ->  dW += ls_n Gr;  dbias += ls_n s_n;  dls_n += sum_k W[n][k] Gr[n][k] + bias_n s_n
 int launch_finish_linear_ls(const float* Gr, const float* s, const float* W, const float* bias, const float* ls, float* dW_g,

@@ -91,37 +91,6 @@ int wgrad(const float* A, int lda, const float* B, int ldb, const float* stats, 
   t.colsum = colsum; t.colsum_accumulate = accumulate;
   return launch_gemm_tn(t, x3, ws, wsb, st);
 }
-TnArgs wgrad_args(const float* A, int lda, const float* B, int ldb, const float* stats, float* G, float* colsum, long long M, int N, int K) {
-  TnArgs t = tn_args_zero();
-  t.M = (int)M; t.N = N; t.K = K;
-  t.A = A; t.lda = lda; t.B = B; t.ldb = ldb; t.stats = stats;
-  t.G = G; t.ldg = K; t.colsum = colsum;
-  return t;
-}
-// Contraction + parameter-gradient finisher.  Round 4: the per-row part of the finisher runs inside the split-M reduction
-// (TnFinish kind 1; one launch less per contraction, same bits); SEPR_TRAIN_FUSEFIN=0 keeps the separate launches (read per call: the A/B
-// test flips it inside one process).
-bool fin_fused() {
-  const char* e = getenv("SEPR_TRAIN_FUSEFIN");
-  return !(e && e[0] == '0');
-}
-// projection behind a folded normalisation (launch_finish_norm_linear's algebra); t.G / t.colsum are the dWh / s temporaries
-int tn_norm_fin(TnArgs t, int x3, void* tnw, size_t tnb, const float* W, const float* g, const float* b, float* dW_g, float* dbias_g,
-                float* dg_g, float* db_g, hipStream_t st) {
-  if (!fin_fused() || (t.K % 64)) {
-    SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
-    return launch_finish_norm_linear(t.G, t.colsum, W, g, b, dW_g, dbias_g, dg_g, db_g, t.N, t.K, st);
-  }
-  t.fin.kind = 1; t.fin.g = g; t.fin.b = b; t.fin.dW[0] = dW_g; t.fin.dbias[0] = dbias_g; t.fin.seg_rows = t.N;
-  SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
-  return launch_finish_norm_cols(t.G, t.colsum, W, dg_g, db_g, t.N, t.K, st);
-}
-// projection followed by LayerScale (launch_finish_linear_ls's algebra; its dls needs a row-long fmaf chain: a launch of its own)
-int tn_ls_fin(TnArgs t, int x3, void* tnw, size_t tnb, const float* W, const float* bias, const float* ls, float* dW_g, float* dbias_g,
-              float* dls_g, hipStream_t st) {
-  SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
-  return launch_finish_linear_ls(t.G, t.colsum, W, bias, ls, dW_g, dbias_g, dls_g, t.N, t.K, st);
-}
 // arithmetic of the weight-gradient contraction that goes with a projection: 0 exact f32, 1 bf16x3, 2 plain bf16
 int tn_mode(const sepr_lin& l) { return !l.wp ? 0 : (l.planes == 1 ? 2 : 1); }
 bool rows_ok(long long M) { return M > 0 && M <= 0x7fffffffLL / 8; }
@@ -217,8 +186,9 @@ int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int
     t.A = pl ? static_cast<const float*>(dy16) : dyq; t.lda = F; t.a16 = pl ? 1 : 0;
     t.B = static_cast<const float*>(gd); t.ldb = 3 * F; t.b16 = o16 ? 1 : 0;
     t.G = Gr; t.ldg = 3 * F; t.colsum = s2;
-    SEPR_TRY(tn_ls_fin(t, x3, tnw, tnb, w->w2, w->b2, w->ls, g->w2, g->b2, g->ls, st));
+    SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
   }
+  SEPR_TRY(launch_finish_linear_ls(Gr, s2, w->w2, w->b2, w->ls, g->w2, g->b2, g->ls, F, 3 * F, st));
   // net1 behind the LayerNorm
   {
     TnArgs t = tn_args_zero();
@@ -227,8 +197,9 @@ int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int
     if (pl) { t.B = static_cast<const float*>(xh16); t.ldb = F; t.b16 = 1; }     // the saved bf16 rows: no statistics prologue, half the bytes
     else { t.B = x; t.ldb = F; t.stats = stats; }
     t.G = dWh; t.ldg = F; t.colsum = s1;
-    SEPR_TRY(tn_norm_fin(t, x3, tnw, tnb, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, st));
+    SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
   }
+  SEPR_TRY(launch_finish_norm_linear(dWh, s1, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 6 * F, F, st));
   return dgrad_ln(static_cast<const float*>(dh1), 6 * F, 6 * F, w->up_t, o16 ? 1 : 0, x, stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
 int gcfn_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, Carve& cx, Carve& ws, float p, sepr_u64 seed,
@@ -280,13 +251,14 @@ int gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, co
     dyq = dyp;
   }
   // net2.2 + LayerScale: raw contraction, then dW2 / db2 / dls
-  SEPR_TRY(tn_ls_fin(wgrad_args(dyq, F, k.g, 3 * F, nullptr, Gr, s2, M, F, 3 * F), x3, tnw, tnb, w->w2, w->b2, w->ls, g->w2, g->b2, g->ls, st));
+  SEPR_TRY(wgrad(dyq, F, k.g, 3 * F, nullptr, Gr, s2, M, F, 3 * F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_linear_ls(Gr, s2, w->w2, w->b2, w->ls, g->w2, g->b2, g->ls, F, 3 * F, st));
   SEPR_TRY(plain(dyq, F, dg, 3 * F, M, 3 * F, F, w->down_t, nullptr, st));
   // GLU + depthwise conv (the dropout mask of the gated tensor is applied while dg is read)
   SEPR_TRY(launch_gcfn_mid_bwd(k.h1, dg, dh1, n, T, 3 * F, w->dw_w, w->dw_b, g->dw_w, g->dw_b, p, seed, site_off(0), midw, midb, st));
   // net1: LayerNorm-folded projection
-  SEPR_TRY(tn_norm_fin(wgrad_args(dh1, 6 * F, x, F, k.stats, dWh, s1, M, 6 * F, F), x3, tnw, tnb, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g,
-                       g->ln_b, st));
+  SEPR_TRY(wgrad(dh1, 6 * F, x, F, k.stats, dWh, s1, M, 6 * F, F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_norm_linear(dWh, s1, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 6 * F, F, st));
   return dgrad_ln(dh1, 6 * F, 6 * F, w->up_t, 0, x, k.stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
 
@@ -391,8 +363,9 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
       t.M = (int)M; t.N = F; t.K = 2 * F;
       t.A = dyq; t.lda = F; t.B = k.d; t.ldb = 2 * F; t.b16 = 1;
       t.G = Gr; t.ldg = 2 * F; t.colsum = s;
-      SEPR_TRY(tn_ls_fin(t, x3, tnw, tnb, w->w3, w->b3, w->ls, g->w3, g->b3, g->ls, st));
+      SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
     }
+    SEPR_TRY(launch_finish_linear_ls(Gr, s, w->w3, w->b3, w->ls, g->w3, g->b3, g->ls, F, 2 * F, st));
     SEPR_TRY(plain(dyq, F, dd, 2 * F, M, 2 * F, F, w->l3_t, nullptr, st));
     SEPR_TRY(launch_bn_gelu_bwd(dd, k.z, k.bn, w->bn_g, w->bn_b, dz16, g->bn_g, g->bn_b, M, 2 * F, csw, csb, st, 1));
     {
@@ -415,11 +388,13 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
       t.M = (int)M; t.N = 2 * F; t.K = F;
       t.A = da16; t.lda = 2 * F; t.a16 = 1; t.B = x; t.ldb = F; t.stats = k.stats;
       t.G = Gr; t.ldg = F; t.colsum = s;
-      SEPR_TRY(tn_norm_fin(t, x3, tnw, tnb, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, st));
+      SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
     }
+    SEPR_TRY(launch_finish_norm_linear(Gr, s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, st));
     return dgrad_ln(da16, 2 * F, 2 * F, w->l1_t, 1, x, k.stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
   }
-  SEPR_TRY(tn_ls_fin(wgrad_args(dyq, F, k.d, 2 * F, nullptr, Gr, s, M, F, 2 * F), x3, tnw, tnb, w->w3, w->b3, w->ls, g->w3, g->b3, g->ls, st));
+  SEPR_TRY(wgrad(dyq, F, k.d, 2 * F, nullptr, Gr, s, M, F, 2 * F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_linear_ls(Gr, s, w->w3, w->b3, w->ls, g->w3, g->b3, g->ls, F, 2 * F, st));
   SEPR_TRY(plain(dyq, F, dd, 2 * F, M, 2 * F, F, w->l3_t, nullptr, st));
   SEPR_TRY(launch_bn_gelu_bwd(dd, k.z, k.bn, w->bn_g, w->bn_b, dd, g->bn_g, g->bn_b, M, 2 * F, csw, csb, st));   // dd := dz
   SEPR_TRY(wgrad(dd, 2 * F, k.c, F, nullptr, g->w2, g->b2, M, 2 * F, F, 1, x3, tnw, tnb, st));                   // linear2 (direct)
@@ -431,8 +406,8 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
     SEPR_TRY(launch_dwconv_same(dc, du, n, T, F, K, w->dw_wf, w->zeros, st));                 // correlation with reversed taps
     SEPR_TRY(launch_glu_bwd(du, k.a, dd, M, F, st));                                           // dd := da [M][2F]
   }
-  SEPR_TRY(tn_norm_fin(wgrad_args(dd, 2 * F, x, F, k.stats, Gr, s, M, 2 * F, F), x3, tnw, tnb, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g,
-                       g->ln_b, st));
+  SEPR_TRY(wgrad(dd, 2 * F, x, F, k.stats, Gr, s, M, 2 * F, F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_norm_linear(Gr, s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, st));
   return dgrad_ln(dd, 2 * F, 2 * F, w->l1_t, 0, x, k.stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
 
@@ -442,28 +417,19 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
 // d(linear_out * LayerScale): Graw / finish / dO = dy' . (ls * Wo)
 int mha_out_bwd(const float* dyq, const float* o, float* dO, long long M, int F, const sepr_mha_tw* w, const sepr_mha_grad* g, float* Gr,
                 float* s, int x3, void* tnw, size_t tnb, hipStream_t st) {
-  SEPR_TRY(tn_ls_fin(wgrad_args(dyq, F, o, F, nullptr, Gr, s, M, F, F), x3, tnw, tnb, w->wo, w->bo, w->ls, g->wo, g->bo, g->ls, st));
+  SEPR_TRY(wgrad(dyq, F, o, F, nullptr, Gr, s, M, F, F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_linear_ls(Gr, s, w->wo, w->bo, w->ls, g->wo, g->bo, g->ls, F, F, st));
   return plain(dyq, F, dO, F, M, F, F, w->out_t, nullptr, st);
 }
 // d(q/k/v projection behind the LayerNorm): dWh [3F][F] -> three finishers (shared dgamma / dbeta), dxh = dqkv . (Wqkv * gamma)
 int mha_qkv_bwd(const float* dqkv, const float* xin, const float* stats, float* dxh, long long M, int F, const sepr_mha_tw* w,
                 const sepr_mha_grad* g, float* dWh, float* s, int x3, void* tnw, size_t tnb, const float* dres, float* dx, hipStream_t st) {
+  SEPR_TRY(wgrad(dqkv, 3 * F, xin, F, stats, dWh, s, M, 3 * F, F, 0, x3, tnw, tnb, st));
   float* gw[3] = {g->wq, g->wk, g->wv};
   float* gb[3] = {g->bq, g->bk, g->bv};
-  TnArgs t = wgrad_args(dqkv, 3 * F, xin, F, stats, dWh, s, M, 3 * F, F);
-  const bool fq = fin_fused() && F % 64 == 0;
-  if (fq) {   // the three stacked projections are three row segments of one reduction; the column parts stay three launches
-    t.fin.kind = 1; t.fin.g = w->ln_g; t.fin.b = w->ln_b; t.fin.seg_rows = F;                // (their dgamma / dbeta sums keep their order)
-    for (int i = 0; i < 3; ++i) { t.fin.dW[i] = gw[i]; t.fin.dbias[i] = gb[i]; }
-  }
-  SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
-  for (int i = 0; i < 3; ++i) {
-    if (fq)
-      SEPR_TRY(launch_finish_norm_cols(dWh + (long long)i * F * F, s + i * F, w->wqkv + (long long)i * F * F, g->ln_g, g->ln_b, F, F, st));
-    else
-      SEPR_TRY(launch_finish_norm_linear(dWh + (long long)i * F * F, s + i * F, w->wqkv + (long long)i * F * F, w->ln_g, w->ln_b, gw[i],
-                                         gb[i], g->ln_g, g->ln_b, F, F, st));
-  }
+  for (int i = 0; i < 3; ++i)
+    SEPR_TRY(launch_finish_norm_linear(dWh + (long long)i * F * F, s + i * F, w->wqkv + (long long)i * F * F, w->ln_g, w->ln_b, gw[i],
+                                       gb[i], g->ln_g, g->ln_b, F, F, st));
   // dx = dres + LayerNorm'(dqkv . (Wqkv gamma))   (dxh: scratch of the two-launch form for F > 128)
   return dgrad_ln(dqkv, 3 * F, 3 * F, w->qkv_t, 0, xin, stats, dres, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
@@ -562,8 +528,9 @@ int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, in
   else SEPR_TRY(launch_relattn_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), atw, atb, st));
   SEPR_TRY(mha_qkv_bwd(dqkv, xp, k.stats_p, dxh_p, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, nullptr, dxd, st));
   // gate projection behind its own LayerNorm
-  SEPR_TRY(tn_norm_fin(wgrad_args(dzg, F, x, F, k.stats, dWh, s, M, F, F), x3, tnw, tnb, w->gate_w, w->gate_ln_g, w->gate_ln_b, g->gate_w,
-                       g->gate_b, g->gate_ln_g, g->gate_ln_b, st));
+  SEPR_TRY(wgrad(dzg, F, x, F, k.stats, dWh, s, M, F, F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_norm_linear(dWh, s, w->gate_w, w->gate_ln_g, w->gate_ln_b, g->gate_w, g->gate_b, g->gate_ln_g, g->gate_ln_b, F, F,
+                                     st));
   // dx = dy + LN'(dzg . (Wgate gamma)) + avg-pool backward of dxd
   return dgrad_ln(dzg, F, F, w->gate_t, 0, x, k.stats, dy, dxd, T, Tp, fac, dx, dxh, M, F, st);
 }
@@ -991,8 +958,9 @@ int front_bwd(const float* wav, const float* enc, const float* dout, float* denc
     t.B = enc; t.ldb = N; t.rows_out = Lp; t.rows_valid = L; t.seq_stride = (long long)L * N;
     t.stats = stats; t.stat_seq = 1;
     t.G = dWh; t.ldg = N; t.colsum = s;
-    SEPR_TRY(tn_norm_fin(t, tn_mode(w->proj_t), tnw, tnb, w->proj_w, w->gn_g, w->gn_b, g->proj_w, nullptr, g->gn_g, g->gn_b, st));
+    SEPR_TRY(launch_gemm_tn(t, tn_mode(w->proj_t), tnw, tnb, st));
   }
+  SEPR_TRY(launch_finish_norm_linear(dWh, s, w->proj_w, w->gn_g, w->gn_b, g->proj_w, nullptr, g->gn_g, g->gn_b, F, N, st));
   {  // d enc_hat [B*L][N] = dout(valid rows) . (W * gamma)
     GemmArgs a = gemm_args_zero();
     a.M = (int)ML; a.N = N; a.K = F;

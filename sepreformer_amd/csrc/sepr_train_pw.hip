@@ -1494,12 +1494,6 @@ int launch_finish_norm_linear(const float* dWh, const float* s, const float* W, 
   SEPR_CHECK_LAUNCH("finish_norm_linear kernels");
   return SEPR_OK;
 }
-int launch_finish_norm_cols(const float* dWh, const float* s, const float* W, float* dg_g, float* db_g, int N, int K, hipStream_t st) {
-  if (!dWh || !s || !W || !dg_g || !db_g || N <= 0 || K <= 0) return SEPR_EINVAL;
-  hipLaunchKernelGGL(finish_norm_cols_kernel, dim3((K + 63) / 64), dim3(1024), 0, st, dWh, s, W, dg_g, db_g, N, K);
-  SEPR_CHECK_LAUNCH("finish_norm_cols_kernel");
-  return SEPR_OK;
-}
 int launch_finish_linear_ls(const float* Gr, const float* s, const float* W, const float* bias, const float* ls, float* dW_g,
                             float* dbias_g, float* dls_g, int N, int K, hipStream_t st) {
   if (!Gr || !s || !W || !bias || !ls || !dW_g || !dbias_g || !dls_g || N <= 0 || K <= 0) return SEPR_EINVAL;

@@ -1701,60 +1701,3 @@ def test_captured_step_with_flat_adamw_follows_torch_adamw():
         assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (a, b)
         assert abs(ga - gb_) <= 1e-5 * gb_, (a, b)
     assert a[-1][0] < a[0][0]
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# finishers inside the split-M reduction (round 4)
-# ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
-@pytest.mark.parametrize("variant,n,T", [("SepReformer_Base_WSJ0", 4, 2040), ("tiny", 2, 300)])
-def test_finishers_inside_the_reduction_equal_separate_launches(variant, n, T, precision, monkeypatch):
-    """The per-row part of the parameter-gradient finisher of every LayerNorm-folded projection runs inside the contraction's
-    reduction kernel (tn_reduce_fin1_kernel, SEPR_TRAIN_FUSEFIN default; K % 64 == 0) vs the reduction + finisher launches of before
-    (SEPR_TRAIN_FUSEFIN=0): same summation order, same expressions - all four block kinds' input gradients and EVERY parameter
-    gradient (incl. the q / k / v stack's three segments, the gate projection, LayerScales, biases) are bitwise equal; several split-M
-    slices (8 160 rows) and a single one (600 rows)."""
-    from sepreformer_amd.train_engine import TrainEngine
-    from sepreformer_amd.train_pack import GradBuffer, TrainPack
-    cfg = dataclasses.replace(VARIANTS[variant], dropout=0.2)
-    sd = synth_state_dict(cfg, 0)
-    dev = torch.device("cuda:0")
-    sdd = {k: v.to(dev) for k, v in sd.items()}
-    F = cfg.feat
-    n = n // 2 * cfg.num_spks if n // 2 * cfg.num_spks else cfg.num_spks
-    x, dy = rnd(n, T, F, seed=5).cuda(), rnd(n, T, F, seed=6).cuda()
-    outs = []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("SEPR_TRAIN_FUSEFIN", mode)
-        sdm = {k: v.clone() for k, v in sdd.items()}
-        gb = GradBuffer(cfg, dev)
-        tp = TrainPack(cfg, sdm, gb, precision)
-        eng = TrainEngine(cfg, dev)
-        res = []
-        for kind, w, Tp in (("gcfn", tp.gcfn[0], 0), ("cla", tp.cla[0], 0), ("ega", tp.ega[0], T // 4), ("spk", tp.spk[0], 0)):
-            y, rec = eng.block_fwd(kind, x, w, n, T, Tp, 0.2, 31)
-            dx = eng.block_bwd(rec, dy)
-            res += [dx.clone()]
-        torch.cuda.synchronize()
-        outs.append(res + [gb.flat.clone()])
-    for i, (a_, b_) in enumerate(zip(outs[0], outs[1])):
-        assert torch.isfinite(a_).all() and torch.equal(a_, b_), (i, int((a_ != b_).sum()), float((a_ - b_).abs().max()))
-    assert float(outs[0][-1].abs().max()) > 0
-
-
-def test_finishers_inside_the_reduction_whole_step(monkeypatch):
-    """The same switch over a whole tiny training step (front projector's GroupNorm-folded projection through the general loader, heads,
-    splits, every block): all gradients bitwise equal."""
-    from sepreformer_amd.model import Model
-    cfg = dataclasses.replace(VARIANTS["tiny"], dropout=0.0)
-    dev = torch.device("cuda:0")
-    x = torch.from_numpy(synth_sources(2, 1500, seed=21).sum(1) * 4.0).to(dev)
-    grads = []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("SEPR_TRAIN_FUSEFIN", mode)
-        m = Model.from_config(cfg, init_seed=0).load_synthetic_(0).to(dev).train()
-        audio, aux = m(x)
-        (torch.stack(audio).pow(2).mean() + 0.1 * sum(torch.stack(a).abs().mean() for a in aux)).backward()
-        grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone())
-    assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0
-    assert torch.equal(grads[0], grads[1]), int((grads[0] != grads[1]).sum())
