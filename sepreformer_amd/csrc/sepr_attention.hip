@@ -389,20 +389,12 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
 #pragma unroll
           for (int r = 0; r < 4; ++r) bias[r] = (SEPR_AT_ABL & 1) ? 0.f : psk[b0 - r];       // unconditional: the reads issue back to back
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sv[p][s][r] = sc[s][r] + bias[r];
+          for (int r = 0; r < 4; ++r) sv[p][s][r] = (j0 + 32 * p + 16 * s + 4 * g + r < Tp) ? sc[s][r] + bias[r] : -1e30f;
         }
       }
-      // only a tile that reaches past Tp pays the 16 key-bound selects: a wave-uniform branch (as selects inside the loop above they cost
-      // 48 VALU per tile and the compiler turned four of the bias reads into exec-masked blocks with their own LDS waits)
-      if (j0 + KT > Tp) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (j0 + 32 * p + 16 * s + 4 * g + r >= Tp) sv[p][s][r] = -1e30f;
-      }
+      // (Round 4 tried the key-bound selects as ONE wave-uniform pass taken only by the tile that crosses Tp: -29 % VALU per full tile, -4 %
+      //  kernel time - and run-to-run DIFFERENT outputs at B = 32 (tools/det_infer.py; the same pass executed on every tile, or these selects,
+      //  are deterministic; cause not established - the generated code reads correctly).  The selects stay where they are.)
       float mx = -1e30f;
 #pragma unroll
       for (int p = 0; p < 2; ++p)
