@@ -32,6 +32,9 @@ class FlatAdamW(torch.optim.Optimizer):
         params = [p for p in model.parameters() if p.requires_grad]
         if not params:
             raise ValueError("no trainable parameters")
+        if len(params) != sum(1 for _ in model.parameters()):
+            # the norm pass runs over the WHOLE flat gradient buffer, which holds the gradient of every parameter of the model
+            raise ValueError("FlatAdamW clips over the model's whole flat gradient buffer: every parameter must be trainable")
         if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or lr < 0.0 or eps < 0.0 or weight_decay < 0.0:
             raise ValueError("invalid AdamW hyper-parameters")
         dev = params[0].device
@@ -116,6 +119,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 g = p.grad
                 if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not (lo <= g.data_ptr() and g.data_ptr() + 4 * g.numel() <= hi):
                     raise RuntimeError("FlatAdamW: a parameter's .grad is not a slice of the model's flat gradient buffer")
+                if (g.data_ptr() - lo) % 16:
+                    raise RuntimeError("FlatAdamW: a gradient slice of the flat buffer is not 16-byte aligned")
                 offs.append((g.data_ptr() - lo) // 4)
             self._goff_host = offs
             self._t_goff = torch.tensor(offs, dtype=torch.int64, device=self._dev)

@@ -555,3 +555,18 @@ def test_captured_train_step_refuses_what_it_cannot_capture():
     with pytest.raises(RuntimeError, match="HIP device"):
         CapturedTrainStep(m, lambda a, b, *t: a[0].sum(), opt, x, [x, x])
     assert m.dropout_salt is None and m.train_graphs in (False, True)
+
+
+def test_flat_adamw_has_no_cpu_path():
+    """optim.FlatAdamW (include/sepr.h sepr_adamw_step) refuses parameters that are not on the HIP device - like every other entry
+    of the product path, there is no CPU fallback - and validates its hyper-parameters before touching the library."""
+    import torch
+    from sepreformer_amd.config import VARIANTS
+    from sepreformer_amd.model import Model
+    from sepreformer_amd.optim import FlatAdamW
+    m = Model.from_config(VARIANTS["tiny"], init_seed=0)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FlatAdamW(m, lr=1e-3)
+    with pytest.raises(ValueError):
+        FlatAdamW(m, lr=1e-3, betas=(1.0, 0.999))
+    assert FlatAdamW.fused_clip is True and issubclass(FlatAdamW, torch.optim.Optimizer)
