@@ -40,3 +40,4 @@ VARIANT_gfold64 = -DSEPR_GF_ABL=64
 VARIANT_band16 = -DSEPR_AXB_ROWS=16 -DSEPR_AXB_BPC=2
 VARIANT_bandg2 = -DSEPR_AXB_GROUP=2
 VARIANT_bandg1 = -DSEPR_AXB_GROUP=1
+VARIANT_noslp = -fno-slp-vectorize
