@@ -224,6 +224,9 @@ def measure_pmc_traffic(budget_s=90.0, kernel_re=None, sub_args=None):
             "traffic_over_algorithmic": round((fetch + write) / algo, 3) if algo else None}, None
 
 
+TRAIN_SUBS = (("bf16x3", "bf16x3", 16), ("bf16", "bf16", 16), ("bf16_b32", "bf16", 32))      # training sub-records: (name, precision, batch)
+SUB_STEPS_LARGE = 10       # timed steps of the Large sub-record (round 4: 3) and of every training sub-record (round 4: 2): the default run
+SUB_STEPS_TRAIN = 8        # uses a few minutes of its budget, and 2-step records could not be told from box-to-box noise
 PARITY_MIN_DB = 80.0        # agreement with the golden waveform (SURVEY.md section 8d gate i)
 PIT_GATE_DB = 1e-3          # |PIT SI-SNR(hip) - PIT SI-SNR(reference)| per utterance (north_star; gate ii)
 GOLDEN_4S = {"SepReformer_Base_WSJ0": "e2e_base_4s.npz", "SepReformer_Large_DM_WHAMR": "e2e_large_whamr_4s.npz"}
@@ -520,6 +523,41 @@ def gate_failures(rec) -> list:
     return bad
 
 
+def make_summary(rec) -> dict:
+    """Every headline number of the line in <= 1500 characters, emitted as the LAST key: a consumer that keeps only the tail of the
+    ~15 KB line still sees all of them (value / ms per step / fraction of the relevant peak / parity of each record)."""
+    def g(d, *ks):
+        for k in ks:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+    roof = rec.get("roofline") or {}
+    out = {"utt_s": rec.get("value"), "ms": rec.get("ms_per_step"), "parity_ok": rec.get("parity_ok"), "db": rec.get("parity_db_vs_golden"),
+           "pit_d": rec.get("pit_si_snr_max_abs_delta_db"), "roof": [roof.get("frac"), roof.get("avg_launch_ms"), roof.get("traffic_over_algorithmic")],
+           "one_pipe": g(rec, "single_pipeline", "value"), "fp32": [g(rec, "alt_precision", "value"), g(rec, "alt_precision", "parity_db_vs_golden")],
+           "lat_b1_ms": [g(rec, "latency_b1", "eager"), g(rec, "latency_b1", "hipgraph"), g(rec, "latency_b1", "launches")],
+           "cpu": [g(rec, "cpu_baseline", "value"), g(rec, "cpu_baseline", "cores"), rec.get("speedup_vs_cpu")]}
+    lg = rec.get("large")
+    if isinstance(lg, dict):
+        out["large"] = ({"err": lg["error"][:80]} if "error" in lg else
+                        {"utt_s": lg.get("value"), "ms": lg.get("ms_per_step"), "steps": lg.get("steps"), "ok": lg.get("parity_ok"), "db": lg.get("parity_db_vs_golden"),
+                         "pit_d": lg.get("pit_si_snr_max_abs_delta_db"), "roof": [g(lg, "roofline", "frac"), g(lg, "roofline", "traffic_over_algorithmic")],
+                         "cpu": g(lg, "cpu_baseline", "value")})
+    tr = rec.get("train")
+    if isinstance(tr, dict):
+        out["train"] = {}
+        for name, t in tr.items():
+            if not isinstance(t, dict):
+                continue
+            out["train"][name] = ({"err": t["error"][:80]} if "error" in t else
+                                  {"utt_s": t.get("value"), "ms": t.get("ms_per_step"), "steps": t.get("steps"), "frac_alg": t.get("model_frac_algorithmic"),
+                                   "tn_hbm": [g(t, "roofline", "frac"), g(t, "roofline", "traffic_over_algorithmic")],
+                                   "mid": [g(t, "roofline_gcfn_bwd", "avg_launch_ms"), g(t, "roofline_gcfn_bwd", "frac")],
+                                   "loss": t.get("loss"), "gn": t.get("grad_norm"), "att": t.get("attempts", 1)})
+    if rec.get("gate_failures"):
+        out["gate_failures"] = len(rec["gate_failures"])
+    return out
+
+
 def protect_stdout():
     """The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a five-line version banner from C
     when a communicator is created), so file descriptor 1 is pointed at stderr for the rest of the process and the JSON line
@@ -549,6 +587,7 @@ def main():
     from sepreformer_amd import lib as L
     from sepreformer_amd.config import VARIANTS
 
+    torch.manual_seed(0)        # every seed a model derives from torch.initial_seed() (dropout) is then the same on every box
     # a process group also at world size 1: the metric reduction then really runs through RCCL on a 1-GPU box
     dist_err = None
     try:
@@ -579,7 +618,7 @@ def main():
             # configs[3] (Large_DM_WHAMR inference, with its own parity gate) and configs[4] (the training step).
             t_sub = time.perf_counter()
             try:
-                sub = measure_infer(args, "SepReformer_Large_DM_WHAMR", 3, 1, rank, world, dev, lib, full=False)
+                sub = measure_infer(args, "SepReformer_Large_DM_WHAMR", SUB_STEPS_LARGE, 2, rank, world, dev, lib, full=False)
                 rec["large"] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "parity_db_vs_golden",
                                                      "pit_si_snr_max_abs_delta_db", "parity_ok", "model_tflops", "model_frac_algorithmic",
                                                      "model_mfma_frac", "roofline")}
@@ -622,15 +661,15 @@ def main():
             rec["train"] = {}
             keys = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "capture_fallback", "host_enqueue_ms_per_step",
                     "host_loop_ms_per_step", "loss", "grad_norm", "collective_backend", "allreduce_bytes_per_step", "model_tflops",
-                    "model_frac_algorithmic", "dp8_prediction", "roofline")
+                    "model_frac_algorithmic", "dp8_prediction", "roofline", "roofline_gcfn_bwd")
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-            for name, prec, tb in (("bf16x3", "bf16x3", 16), ("bf16", "bf16", 16), ("bf16_b32", "bf16", 32)):
+            for name, prec, tb in TRAIN_SUBS:
                 try:
                     # (one retry: a sub-run has died in the RCCL watchdog thread about once in 15 runs on the 1-GPU boxes - rc -6 before its
                     #  first step, never reproduced in isolation; the stderr of a failed attempt is kept, `attempts` says what happened)
                     for attempt in (1, 2):
-                        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "train", "--batch", str(tb), "--steps", "2", "--warmup", "1",
-                                              "--precision", prec], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+                        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "train", "--batch", str(tb), "--steps", str(SUB_STEPS_TRAIN), "--warmup", "2",
+                                              "--precision", prec], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, text=True)
                         lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
                         if out.returncode == 0 and lines:
                             break
@@ -655,25 +694,30 @@ def main():
                         rec["train"][name]["attempts"] = attempt
                 except Exception as e:          # noqa: BLE001
                     rec["train"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            # the training roofline's HBM traffic measured in THIS run as well (the contraction kernels of two eager bf16 steps at batch 16)
-            tb16 = rec["train"].get("bf16") or {}
-            if args.pmc != "off" and isinstance(tb16.get("roofline"), dict) and tb16["roofline"].get("algorithmic_bytes_per_launch"):
+            # the training rooflines' HBM traffic measured in THIS run as well, for every training record (the contraction kernels of one eager
+            # step at the record's own batch and arithmetic)
+            if args.pmc != "off":
                 t_pmc = time.perf_counter()
-                try:
-                    pm, why = measure_pmc_traffic(120.0, TN_KERNEL_RE, ["--mode", "train", "--batch", "16", "--steps", "1", "--warmup", "0", "--precision", "bf16",
-                                                                       "--train-graphs", "off"])
-                except Exception as e:          # noqa: BLE001
-                    pm, why = None, f"{type(e).__name__}: {e}"[:200]
-                roof = tb16["roofline"]
-                if pm and pm.get("traffic_over_algorithmic"):
-                    roof["traffic"] = round(pm["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"])
-                    roof["traffic_over_algorithmic"] = pm["traffic_over_algorithmic"]
-                    roof["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) over the "
-                                              f"{pm['launches']} gemm_tn launches of an eager 2-step sub-run at the same batch; FETCH_SIZE x2 (gfx950 correction of "
-                                              f"MI355X_MICROARCH.md), KiB units; fetch {pm['fetch_bytes_per_launch']} + write {pm['write_bytes_per_launch']} B per launch "
-                                              f"there = {pm['traffic_over_algorithmic']} x the algorithmic operand bytes (the write side is the split-M partial tiles)")
-                else:
-                    roof["traffic_source"] = (roof.get("traffic_source") or "") + f" (live PMC passes failed: {why})"
+                for name, prec, tb in TRAIN_SUBS:
+                    trn = rec["train"].get(name) or {}
+                    roof = trn.get("roofline")
+                    if not (isinstance(roof, dict) and roof.get("algorithmic_bytes_per_launch")):
+                        continue
+                    try:
+                        pm, why = measure_pmc_traffic(150.0, TN_KERNEL_RE, ["--mode", "train", "--batch", str(tb), "--steps", "1", "--warmup", "0", "--precision", prec,
+                                                                           "--train-graphs", "off"])
+                    except Exception as e:      # noqa: BLE001
+                        pm, why = None, f"{type(e).__name__}: {e}"[:200]
+                    if pm and pm.get("traffic_over_algorithmic"):
+                        roof["traffic"] = round(pm["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"])
+                        roof["traffic_over_algorithmic"] = pm["traffic_over_algorithmic"]
+                        roof["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) over the "
+                                                  f"{pm['launches']} gemm_tn launches of an eager sub-run at the same batch and arithmetic; FETCH_SIZE x2 (gfx950 correction of "
+                                                  f"MI355X_MICROARCH.md), KiB units; fetch {pm['fetch_bytes_per_launch']} + write {pm['write_bytes_per_launch']} B per launch "
+                                                  f"there = {pm['traffic_over_algorithmic']} x the algorithmic operand bytes (the write side is the split-M partial tiles)")
+                    else:
+                        roof["traffic"] = None
+                        roof["traffic_source"] = f"live PMC passes failed: {why}"
                 rec["train_pmc_s"] = round(time.perf_counter() - t_pmc, 1)
             rec["sub_records_s"] = round(time.perf_counter() - t_sub, 1)
         if world == 1 and (args.pmc == "on" or (args.pmc == "auto" and default_run)) and rec["roofline"].get("algorithmic_bytes_per_launch"):
@@ -705,6 +749,7 @@ def main():
         failed = gate_failures(rec)
         if failed:
             rec["gate_failures"] = failed
+        rec["summary"] = make_summary(rec)      # last key on purpose (see make_summary)
         emit(rec)
     else:
         failed = []

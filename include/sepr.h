@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define SEPR_VERSION 303 /* major*10000 + minor*100 + patch */
+#define SEPR_VERSION 400 /* minor*100 + patch ("ABI 4.00").  Any struct-layout or context-size change bumps the MINOR number
+                            (3.01 -> 3.03 grew sepr_ega_w under a patch bump: a caller built against 3.01 would have passed a short
+                            struct).  A binding must compare sepr_version() with the SEPR_VERSION it was written against before its
+                            first call: sepreformer_amd/lib.py refuses to load a library whose version differs. */
 
 #define SEPR_OK 0
 #define SEPR_EINVAL (-1)     /* bad shape / unsupported size / null pointer */
@@ -175,6 +178,14 @@ typedef struct {
 
 int sepr_version(void);
 const char* sepr_build_info(void);
+/* A/B switches of the launch path (environment variables of the same names with the SEPR_ prefix).  They are read ONCE per process,
+ * on first use - no entry point calls getenv on its launch path - and the host-side mirrors (sepreformer_amd/train_engine.py) ask the
+ * library instead of parsing the environment themselves, so both sides always agree on a context layout.  sepr_knobs_reload() re-reads
+ * the environment (tests that flip a switch inside one process call it between whole forward + backward runs, never inside one). */
+enum { SEPR_KNOB_X3_WIDE = 0 /* 0 / 1 (default) / 2: sepr_gemm_x3.hip */, SEPR_KNOB_TRAIN_GCFN_PLANES /* default 1 */,
+       SEPR_KNOB_TRAIN_ATTN_ONE /* default 1 */, SEPR_KNOB_TRAIN_CLA16 /* default 1 */, SEPR_KNOB_COUNT };
+int sepr_knob(int id);
+void sepr_knobs_reload(void);
 /* text of the last HIP error seen by the calling thread ("" if none) */
 const char* sepr_last_hip_error(void);
 
@@ -488,7 +499,10 @@ size_t sepr_pit_sisnr_mag_bwd_workspace(int S, int B, int T, int frame_len, int 
  * step: device double, incremented by the call; lr: device float (a scheduler refreshes it without re-capturing a graph);
  * max_norm <= 0: no clipping (no norm pass).  scal (device, 8 floats) receives [0] the total gradient norm BEFORE clipping,
  * [1] the clip coefficient min(1, max_norm / (norm + 1e-6)), [2..4] the step's derived scalars.  The gradients are NOT scaled in
- * place: the coefficient is applied inside the update.  Arithmetic: torch's AdamW (decoupled weight decay), fp32 per element. */
+ * place: the coefficient is applied inside the update.  Arithmetic: torch's AdamW (decoupled weight decay), fp32 per element.
+ * A non-finite total norm yields a NaN coefficient that reaches every element (clip_grad_norm_'s torch.clamp semantics).  The norm
+ * pass reads grads[0 .. grads_numel): the 64-element alignment padding between slices must be zero (the training path's buffer is
+ * allocated zeroed and only slices are ever written). */
 typedef struct {
   float* const* params;
   const long long* grad_off;

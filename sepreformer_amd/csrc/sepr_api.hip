@@ -1,6 +1,8 @@
 // extern "C" entry points of libsepr_hip.so (declared in include/sepr.h): each fused block of the
 // separator is a short, fixed sequence of launches on the caller's stream.
 #include <string.h>
+#include <atomic>
+#include <mutex>
 
 #include "sepr_gemm_epi.h"
 #include "sepr_gcfn_fused.h"
@@ -79,6 +81,39 @@ static size_t ws_enc(int B, int L) { return align_up((size_t)B * encoder_tiles(L
 }  // namespace sepr
 
 using namespace sepr;
+
+namespace sepr {
+namespace {
+std::atomic<int> g_knobs_loaded{0};
+int g_knobs[SEPR_KNOB_COUNT];
+std::mutex g_knobs_mu;
+void knobs_read() {
+  static const struct { const char* name; int dflt; } tab[SEPR_KNOB_COUNT] = {
+      {"SEPR_X3_WIDE", 1}, {"SEPR_TRAIN_GCFN_PLANES", 1}, {"SEPR_TRAIN_ATTN_ONE", 1}, {"SEPR_TRAIN_CLA16", 1}};
+  for (int i = 0; i < SEPR_KNOB_COUNT; ++i) {
+    const char* e = getenv(tab[i].name);
+    g_knobs[i] = (e && e[0]) ? atoi(e) : tab[i].dflt;
+  }
+}
+}  // namespace
+int knob(int id) {
+  if (id < 0 || id >= SEPR_KNOB_COUNT) return 0;
+  if (!g_knobs_loaded.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lk(g_knobs_mu);
+    if (!g_knobs_loaded.load(std::memory_order_relaxed)) {
+      knobs_read();
+      g_knobs_loaded.store(1, std::memory_order_release);
+    }
+  }
+  return g_knobs[id];
+}
+}  // namespace sepr
+extern "C" int sepr_knob(int id) { return sepr::knob(id); }
+extern "C" void sepr_knobs_reload(void) {
+  std::lock_guard<std::mutex> lk(sepr::g_knobs_mu);
+  sepr::knobs_read();
+  sepr::g_knobs_loaded.store(1, std::memory_order_release);
+}
 
 extern "C" int sepr_version(void) { return SEPR_VERSION; }
 extern "C" const char* sepr_build_info(void) {

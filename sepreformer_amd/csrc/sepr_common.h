@@ -115,6 +115,9 @@ void set_hip_error(hipError_t e, const char* where);
     if (rc__ != SEPR_OK) return rc__; \
   } while (0)
 
+// latched A/B switches (include/sepr.h SEPR_KNOB_*): one getenv per switch per process, not per launch (sepr_api.hip)
+int knob(int id);
+
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // sequential carve-out of the caller's workspace

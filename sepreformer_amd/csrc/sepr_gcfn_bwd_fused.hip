@@ -52,6 +52,31 @@ __device__ __forceinline__ void gb_wait_vm2(gb_u32x4& a, gb_u32x4& b) {
 }
 
 namespace {
+// Compile-time replay of the PL form's VMEM issue order (gcfn_bwd_mid_kernel below): per wave  D0 W0 D1 W1 D2 .. D(NQ-1)  in the prologue,
+// then W(s+2) right after the MFMAs of step s.  D = `dma` LDS-DMA copies of a slab, W = 4 fragment loads for an up-projection step
+// (q < nsl), 2 for a dgd step.  Returns how many VMEM operations have been issued AFTER the last one step q depends on (its slab D_q and
+// its fragments W_q) when step q waits - vmcnt retires in order, so that is exactly the s_waitcnt vmcnt(N) of the step.  The hand-counted
+// constants C0..C2 in the kernel are static_assert-ed against this replay: a change of DMA_PER_WAVE, NSL or the issue order that is not
+// carried into the waits stops the build instead of becoming a data race.
+constexpr int gb_pl_outstanding(int q, int nsl, int dma) {
+  const int nq = 2 * nsl;
+  int pos = 0, last_d[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < nq; ++i) {
+    pos += dma;
+    last_d[i] = pos;
+    if (i < 2) {
+      pos += i < nsl ? 4 : 2;
+      last_w[i] = pos;
+    }
+  }
+  for (int s = 0; s < q; ++s)
+    if (s + 2 < nq) {
+      pos += (s + 2) < nsl ? 4 : 2;
+      last_w[s + 2] = pos;
+    }
+  const int need = last_d[q] > last_w[q] ? last_d[q] : last_w[q];
+  return pos - need;
+}
 constexpr int GB_BM = 64;            // rows per tile (incl. halo)
 constexpr int GB_OUT = GB_BM - 4;    // rows a tile outputs
 constexpr int GB_BKS = 64;           // K extent of one LDS slab
@@ -286,6 +311,10 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
         constexpr int C0 = DMA_PER_WAVE * (NQ - 1) + (NQ > 1 ? (1 < NSL ? 4 : 2) : 0);      // behind W0: D1 W1 D2 ..
         constexpr int C1 = DMA_PER_WAVE * (NQ - 2) + (NQ > 2 ? (2 < NSL ? 4 : 2) : 0);      // behind W1: D2 .. and W2 (issued after step 0)
         constexpr int C2 = (NQ > 3) ? (3 < NSL ? 4 : 2) : 0;                                // behind W2: W3 (issued after step 1)
+        static_assert(NQ <= 8 && C0 == gb_pl_outstanding(0, NSL, DMA_PER_WAVE), "vmcnt of step 0 does not match the issue order");
+        static_assert(NQ < 2 || C1 == gb_pl_outstanding(1, NSL, DMA_PER_WAVE), "vmcnt of step 1 does not match the issue order");
+        static_assert(NQ < 3 || C2 == gb_pl_outstanding(2, NSL, DMA_PER_WAVE), "vmcnt of step 2 does not match the issue order");
+        static_assert(NQ < 4 || gb_pl_outstanding(3, NSL, DMA_PER_WAVE) == 0, "steps >= 3 wait vmcnt(0): nothing may be issued behind W3");
         if (up) {
           if (q == 0) gb_wait_vm4<C0>(wa[0][0], wa[1][0], wb[0][0], wb[1][0]);
           else if (q == 1) gb_wait_vm4<C1>(wa[0][0], wa[1][0], wb[0][0], wb[1][0]);

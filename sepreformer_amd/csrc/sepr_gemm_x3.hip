@@ -19,11 +19,9 @@ static int x3_grid_cap() {
 
 // SEPR_X3_WIDE: 0 = the 128 x 128 core only, 1 (default) = the 128 x 256 core (sepr_gemm_x3w.h) for launches with an even number of
 // 128-column tiles and at least two wide tiles per CU, 2 = for every launch with an even number of column tiles (A/B)
-// (read per launch, not cached: the parity tests flip it inside one process to compare the two cores bit for bit)
-static int x3_wide_mode() {
-  const char* e = getenv("SEPR_X3_WIDE");
-  return e && e[0] ? atoi(e) : 1;
-}
+// (latched once per process - include/sepr.h SEPR_KNOB_X3_WIDE; the parity tests that compare the two cores bit for bit inside one process
+//  call sepr_knobs_reload() after changing the variable)
+static int x3_wide_mode() { return knob(SEPR_KNOB_X3_WIDE); }
 
 template <int PRO, int EPI, int TAG = 0>
 static void launch_x3_inst(const GemmArgs& a, hipStream_t stream) {

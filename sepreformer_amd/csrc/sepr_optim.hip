@@ -56,7 +56,9 @@ __global__ __launch_bounds__(OPT_TPB) void opt_prep_kernel(const double* __restr
   float clip = 1.0f;
   if (with_norm && max_norm > 0.f) {
     clip = max_norm / (norm + 1e-6f);
-    clip = clip < 1.0f ? clip : 1.0f;
+    // torch.clamp(max = 1) semantics of clip_grad_norm_: a non-finite norm gives a NaN coefficient that reaches EVERY gradient element
+    // (the step then poisons the weights visibly, as with torch, instead of applying the finite elements unclipped)
+    clip = !(clip >= 1.0f) ? clip : 1.0f;
   }
   const double t = *step + 1.0;
   *step = t;

@@ -118,16 +118,14 @@ bool gcfn_is_fused(const sepr_gcfn_tw* w, int F) { return w && w->fused_w1p && w
 // pre-pass) by LDS-DMA with no VALU, and both weight-gradient contractions read bf16 operands only (round 4).  pl_dry: sizing runs.
 bool gcfn_pl16(const sepr_gcfn_tw* w, int pl_dry) {
   if (pl_dry >= 0) return pl_dry != 0;
-  const char* e = getenv("SEPR_TRAIN_GCFN_PLANES");      // (read per call: the A/B test flips it inside one process)
-  const bool off = e && e[0] == '0';
-  return !off && w && w->up.planes == 1;
+  // (SEPR_TRAIN_GCFN_PLANES=0 selects the register-staged form; latched once per process: the forward, the backward and the Python
+  //  mirror train_engine._gcfn_op all read the SAME value - the A/B test calls sepr_knobs_reload() between whole runs)
+  return knob(SEPR_KNOB_TRAIN_GCFN_PLANES) != 0 && w && w->up.planes == 1;
 }
 // EGA attention of the plain-bf16 precision (sepr_lin.planes == 1): ONE bf16 MFMA per product in the forward and both backward
 // kernels instead of the bf16x3 triple (round 4; SEPR_TRAIN_ATTN_ONE=0 keeps the triple - the A/B test flips it inside one process)
 int attn_one(const sepr_lin& qkv) {
-  const char* e = getenv("SEPR_TRAIN_ATTN_ONE");
-  const bool off = e && e[0] == '0';
-  return (!off && qkv.planes == 1) ? 1 : 0;
+  return (knob(SEPR_KNOB_TRAIN_ATTN_ONE) != 0 && qkv.planes == 1) ? 1 : 0;
 }
 int gcfn_fused_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_tw* w, Carve& cx, float p, sepr_u64 seed,
                    hipStream_t st, int pl_dry = -1) {
@@ -270,8 +268,7 @@ int gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, co
 // anyway (linear2 / linear3 and their weight gradients, the two input-gradient projections), so results are bit-identical to the
 // fp32-stored form (tested) while ~5.4 KB of the block's ~27 KB of HBM traffic per row disappear.  SEPR_TRAIN_CLA16=0: fp32 (A/B, test).
 bool cla_h16(const sepr_cla_tw* w, int F, int K) {
-  const char* e = getenv("SEPR_TRAIN_CLA16");
-  return !(e && e[0] == '0') && w && w->l1.wp && w->l1.planes == 1 && F % 128 == 0 && K == 65;
+  return knob(SEPR_KNOB_TRAIN_CLA16) != 0 && w && w->l1.wp && w->l1.planes == 1 && F % 128 == 0 && K == 65;
 }
 constexpr unsigned CLA_DROP_SITE = 3u;   // 16-bit generator site of the CLA output dropout (0, 1: fused GCFN; 2: attention probabilities)
 struct ClaCtx { float *stats, *a, *u, *c, *z, *bn, *d; };

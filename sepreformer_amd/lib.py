@@ -118,10 +118,14 @@ FrontGrad = _tstruct("FrontGrad", ["w_enc", "gn_g", "gn_b", "proj_w"])
 (TOP_GCFN, TOP_CLA, TOP_EGA, TOP_SPKATTN, TOP_DOWN, TOP_SPLIT, TOP_FUSE, TOP_OUT, TOP_FRONT, TOP_GCFN_FUSED, TOP_EGA_X3,
  TOP_GCFN_FUSED16) = range(12)
 
+KNOB_X3_WIDE, KNOB_TRAIN_GCFN_PLANES, KNOB_TRAIN_ATTN_ONE, KNOB_TRAIN_CLA16 = range(4)
+
 # name -> (restype, argtypes); must list every symbol include/sepr.h declares (tests check this)
 SIGNATURES = {
     "sepr_version": (_i, []),
     "sepr_build_info": (C.c_char_p, []),
+    "sepr_knob": (_i, [_i]),
+    "sepr_knobs_reload": (None, []),
     "sepr_last_hip_error": (C.c_char_p, []),
     "sepr_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "sepr_encoder_fwd": (_i, [_fp, _i, _i, _fp, _i, _i, _i, _f, _fp, _fp, _fp, _sz, _fp]),
@@ -179,6 +183,9 @@ _lib: Optional[C.CDLL] = None
 _lock = threading.Lock()
 
 
+ABI_VERSION = 400          # include/sepr.h SEPR_VERSION this binding mirrors (tests/test_boundary_cpu.py keeps the two equal)
+
+
 class SeprLibraryError(RuntimeError):
     pass
 
@@ -206,6 +213,10 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError -> a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        got = int(lib.sepr_version())
+        if got != ABI_VERSION:      # the ctypes struct mirrors below are written against ONE header version: a stale .so would read short structs
+            raise SeprLibraryError(f"{LIB_PATH} reports ABI {got}, this binding is written against include/sepr.h SEPR_VERSION {ABI_VERSION}: "
+                                   "rebuild the library (`make -C sepreformer_amd/csrc`)")
         _lib = lib
         return lib
 

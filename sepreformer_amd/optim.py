@@ -82,7 +82,11 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         """Accepts a ``torch.optim.AdamW`` / ``FlatAdamW`` state dict: the moments are copied INTO the flat buffers."""
+        if len(state_dict.get("param_groups", [])) != 1:
+            raise ValueError("FlatAdamW has ONE parameter group (one set of hyper-parameters for the whole flat buffer)")
         super().load_state_dict(state_dict)
+        for grp in self.param_groups:           # a torch.optim.AdamW checkpoint carries capturable=False: the step here is always capturable
+            grp["capturable"] = True
         steps = []
         for p, so in zip(self._params, self._soff):
             st = self.state.get(p, {})
@@ -97,6 +101,12 @@ class FlatAdamW(torch.optim.Optimizer):
             self._step.fill_(steps[0])
         self._lr_host = None
         self._expose_state()
+
+    def add_param_group(self, param_group):
+        """One group only: the update reads ``param_groups[0]``'s hyper-parameters for every tensor of the flat buffer."""
+        if getattr(self, "param_groups", None):
+            raise ValueError("FlatAdamW supports a single parameter group (per-group lr / weight decay would be silently ignored)")
+        super().add_param_group(param_group)
 
     def refresh(self):
         """Mirror the (scheduler-updated) learning rate into the device scalar.  Called by ``step`` outside a capture and by

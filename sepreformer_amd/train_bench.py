@@ -176,6 +176,17 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
         model.train_graphs = mode == "split"
     L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
     algo_bytes = float(lib.sepr_prof_last_bytes())
+    # the LARGEST kernel of the step - the GCFN backward's middle kernel - timed the same way on one more eager step (its own site)
+    n_m, ms_m, fl_m, bytes_m = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0), 0.0
+    if getattr(model, "fused_gcfn_train", True):
+        prev_graphs = model.train_graphs
+        model.train_graphs = False
+        L.check(lib.sepr_prof_start(L.SITE_GCFN_BWD, 128), "sepr_prof_start")
+        host_step()
+        torch.cuda.synchronize(dev)
+        model.train_graphs = prev_graphs
+        L.check(lib.sepr_prof_stop(C.byref(n_m), C.byref(ms_m), C.byref(fl_m)), "sepr_prof_stop")
+        bytes_m = float(lib.sepr_prof_last_bytes())
     elapsed = sdist.max_over_ranks(elapsed, dev)
     # the gradient all-reduce on its own (the collective of this path): wall time of one synchronised call on the flat buffer,
     # median of 5 - at world size 1 the floor RCCL adds to a step, at N > 1 the real exchange
@@ -238,6 +249,19 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
                          "avg_launch_ms": round(ms.value / max(n_l.value, 1), 4),
                          "measured_on": "one eager step after the timed region (a replayed hipGraph has no per-launch events)" if graphs else "the timed steps"},
         }
+        if n_m.value > 0 and ms_m.value > 0:
+            sec_m = ms_m.value / 1e3
+            tf_m = fl_m.value / 1e12 / sec_m
+            # recomputed up-projection + input gradient of net2.2 (+ the conv / GLU forward and backward on the VALU): matrix-pipe bound in
+            # principle (18 F^2 FLOP per row against ~2.8 KB per row), so the fraction is quoted against the dense bf16 MFMA peak; the HBM view rides along
+            rec["roofline_gcfn_bwd"] = {
+                "kernel": "gcfn_bwd_mid_kernel (GCFN backward middle: recomputes LN(x) W1, dgd = dy (ls W2), conv / GLU / dropout forward + backward; the largest kernel of the step)",
+                "bound": "mfma", "achieved": round(tf_m, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf_m / peak, 4),
+                "mfma_pipe_frac": round(mult * tf_m / peak, 4), "ceiling": round(1.0 / mult, 4),
+                "launches": int(n_m.value), "avg_launch_ms": round(ms_m.value / n_m.value, 4),
+                "algorithmic_bytes_per_launch": round(bytes_m / n_m.value), "hbm_gbs": round(bytes_m / 1e9 / sec_m, 1),
+                "hbm_frac": round(bytes_m / 1e9 / sec_m / HBM_PEAK_GBS, 4), "traffic": None,
+                "measured_on": "one more eager step after the timed region (hipEvents on the launch stream)"}
     model.grad_sync = None
     del opt, model
     torch.cuda.empty_cache()
@@ -247,6 +271,7 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
 def main(args):
     from . import dist as sdist
 
+    torch.manual_seed(0)        # the dropout seeds derive from torch.initial_seed(): `loss` / `grad_norm` are box-independent fingerprints
     share = bool(getattr(args, "share_gpu", False))   # DEBUG: all ranks on GPU 0, gloo collectives (exercises the N > 1 code path on one GPU)
     # a process group also at world size 1: the gradient all-reduce then really runs through RCCL on a 1-GPU box
     rank, world, local = sdist.init_from_env("gloo" if share else None, single_rank_group=not share)

@@ -39,6 +39,7 @@ class TrainEngine:
         self._ws: Optional[torch.Tensor] = None
         self._idx: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
         self._sizes: Dict[tuple, int] = {}      # sepr_train_ctx_bytes / sepr_train_ws_bytes per (kind, op, shape): one C call each, ever
+        self._attn_valu = os.environ.get("SEPR_TRAIN_ATTN_VALU", "0") == "1"     # (the library latches it at its first EGA call as well)
 
     # ---- plumbing -------------------------------------------------------------------------------------------------------
     def _workspace(self, nbytes: int):
@@ -77,14 +78,14 @@ class TrainEngine:
         """Sizing op of a GCFN block; mirrors ``gcfn_is_fused`` / ``gcfn_pl16`` of csrc/sepr_train_api.hip."""
         if not (tw.fused_w1p and self.cfg.feat in (64, 128)):
             return L.TOP_GCFN
-        planes16 = tw.up.planes == 1 and os.environ.get("SEPR_TRAIN_GCFN_PLANES", "1") != "0"
+        planes16 = tw.up.planes == 1 and self.lib.sepr_knob(L.KNOB_TRAIN_GCFN_PLANES) != 0     # the library's own (latched) reading
         return L.TOP_GCFN_FUSED16 if planes16 else L.TOP_GCFN_FUSED
 
     def _ega_op(self, tw) -> int:
         """Sizing op of an EGA block: the packed-bf16 precisions run the attention flash-style on the bf16 MFMA (context = one
         log-sum-exp per query row instead of the [Tp, Tp] probabilities); mirrors ``ega_mfma`` of csrc/sepr_train_api.hip."""
         dk = self.cfg.feat // self.cfg.heads
-        mfma = bool(tw.attn.qkv.wp) and dk in (16, 32) and os.environ.get("SEPR_TRAIN_ATTN_VALU", "0") != "1"
+        mfma = bool(tw.attn.qkv.wp) and dk in (16, 32) and not self._attn_valu
         return L.TOP_EGA_X3 if mfma else L.TOP_EGA
 
     # ---- single blocks (also what the unit tests drive) --------------------------------------------------------------------

@@ -34,3 +34,32 @@ def golden():
         return cache[name]
 
     return load
+
+
+# A/B switches the library latches once per process (include/sepr.h SEPR_KNOB_*): a test that flips one with monkeypatch.setenv gets the
+# library's copy refreshed right away, and restored together with the environment when the test ends.
+_KNOBS = {"SEPR_X3_WIDE", "SEPR_TRAIN_GCFN_PLANES", "SEPR_TRAIN_ATTN_ONE", "SEPR_TRAIN_CLA16"}
+
+
+def _knobs_reload():
+    from sepreformer_amd import lib as L
+    if os.path.exists(L.LIB_PATH):
+        L.load().sepr_knobs_reload()
+
+
+@pytest.fixture(autouse=True)
+def _knob_env(monkeypatch):
+    touched = []
+    plain_setenv = monkeypatch.setenv
+
+    def setenv(name, value, prepend=None):
+        plain_setenv(name, value, prepend)
+        if name in _KNOBS:
+            touched.append(name)
+            _knobs_reload()
+
+    monkeypatch.setenv = setenv
+    yield
+    if touched:
+        monkeypatch.undo()
+        _knobs_reload()

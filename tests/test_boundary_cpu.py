@@ -149,7 +149,9 @@ def test_abi_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.sepr_version() == int(re.search(r"#define SEPR_VERSION (\d+)", hdr).group(1))
+    assert lib.sepr_version() == int(re.search(r"#define SEPR_VERSION (\d+)", hdr).group(1)) == L.ABI_VERSION
+    # the latched A/B switches: defaults, and a reload picks up the environment (what the knob fixture of conftest.py relies on)
+    assert [lib.sepr_knob(i) for i in range(4)] == [1, 1, 1, 1] and lib.sepr_knob(99) == 0
     assert b"gfx950" in lib.sepr_build_info()
     # argument validation happens before any HIP call, so it is checkable without a device
     assert lib.sepr_workspace_bytes(L.OP_GCFN, 0, 8, 0, 128, 256, 2) == 0

@@ -26,7 +26,9 @@ REPORT = {}
 
 
 def record(name, db):
-    REPORT[name] = round(float(db), 2)
+    v = float(db)
+    # dB figures keep two decimals; small magnitudes (PIT SI-SNR deltas, ~1e-4 dB against a 1e-3 gate) keep three significant digits
+    REPORT[name] = round(v, 2) if abs(v) >= 1.0 or v == 0.0 else float(f"{v:.3e}")
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     path = os.path.join(out, "parity_report.json")

@@ -32,7 +32,9 @@ BF16_DB = 35.0
 
 
 def record(name, db):
-    REPORT[name] = round(float(db), 2)
+    v = float(db)
+    # dB figures keep two decimals; small magnitudes (PIT SI-SNR deltas, ~1e-4 dB against a 1e-3 gate) keep three significant digits
+    REPORT[name] = round(v, 2) if abs(v) >= 1.0 or v == 0.0 else float(f"{v:.3e}")
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     path = os.path.join(out, "train_parity_report.json")
