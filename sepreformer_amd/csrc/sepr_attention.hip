@@ -173,6 +173,9 @@ __global__ __launch_bounds__(256) void relattn_kernel(const float* __restrict__ 
 #define SEPR_AT_ABL 0   // timing ablations of relattn_x3_kernel (WRONG results): 1 no relative-position product, 2 no exp,
                        // 4 K / V / band staged once (first key tile only), 8 no PV product, 16 no q.k product
 #endif
+#ifndef SEPR_AT_MASKPASS
+#define SEPR_AT_MASKPASS 0
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -389,9 +392,23 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
 #pragma unroll
           for (int r = 0; r < 4; ++r) bias[r] = (SEPR_AT_ABL & 1) ? 0.f : psk[b0 - r];       // unconditional: the reads issue back to back
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sv[p][s][r] = (j0 + 32 * p + 16 * s + 4 * g + r < Tp) ? sc[s][r] + bias[r] : -1e30f;
+          for (int r = 0; r < 4; ++r)
+            sv[p][s][r] = (SEPR_AT_MASKPASS || j0 + 32 * p + 16 * s + 4 * g + r < Tp) ? sc[s][r] + bias[r] : -1e30f;
         }
       }
+#if SEPR_AT_MASKPASS
+      // EXPERIMENT (withdrawn in round 4, kept as a build switch for the fault probe tools/probe/attn_maskpass.md): the key-bound selects as
+      // ONE wave-uniform pass taken only by the tile that crosses Tp.  1 = branch form, 2 = the same pass on every tile (no branch)
+      if (SEPR_AT_MASKPASS == 2 || j0 + KT > Tp) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (j0 + 32 * p + 16 * s + 4 * g + r >= Tp) sv[p][s][r] = -1e30f;
+      }
+#endif
       // (Round 4 tried the key-bound selects as ONE wave-uniform pass taken only by the tile that crosses Tp: -29 % VALU per full tile, -4 %
       //  kernel time - and run-to-run DIFFERENT outputs at B = 32 (tools/det_infer.py; the same pass executed on every tile, or these selects,
       //  are deterministic; cause not established - the generated code reads correctly).  The selects stay where they are.)

@@ -463,7 +463,11 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   float* part = static_cast<float*>(ws);
   float* cpart = part + (size_t)p.nsplit * a.N * a.K;
   const int grid = p.tn * p.tk * p.nsplit;
-  const bool gen = a.rows_out > 0 || a.B2 != nullptr || a.idx != nullptr || a.mask_a != 0 || a.stat_seq != 0;
+  // fault-probe switches (tools/probe/tn_fault.py; read once, never set in the product): SEPR_TN_FORCE_GEN=1 routes every launch through
+  // the general loader, SEPR_TN_GEN_PAD=<bytes> replaces the 16 KB LDS pad that keeps the general loader at one workgroup per CU
+  static const bool force_gen = [] { const char* e = getenv("SEPR_TN_FORCE_GEN"); return e && e[0] == '1'; }();
+  static const int gen_pad = [] { const char* e = getenv("SEPR_TN_GEN_PAD"); return (e && e[0]) ? atoi(e) : 16384; }();
+  const bool gen = force_gen || a.rows_out > 0 || a.B2 != nullptr || a.idx != nullptr || a.mask_a != 0 || a.stat_seq != 0;
   if (gen && (a.a16 || a.b16)) return SEPR_EINVAL;      // (checked before the profiling slot opens)
   long long slot = -1;
   const bool timed = prof_begin(SEPR_SITE_WGRAD, s, &slot);
@@ -492,8 +496,8 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   // round 3, reproduced by tools/det_tn.py, root cause not established).  Round 4: ALL general-loader launches take the pad (not
   // only those with statistics: a handful of launches per step), and the occupancy it is meant to produce is verified once per
   // instantiation instead of assumed - if a toolchain / driver ever fits two such workgroups on a CU the launch fails loudly.
-  const int dyn = gen ? 16384 : 0;
-  if (gen) {
+  const int dyn = gen ? gen_pad : 0;
+  if (gen && gen_pad == 16384) {
     static const bool one_per_cu = [] {
       int n0 = 0, n1 = 0, n2 = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, gemm_tn_kernel<0, true, false>, TN_THREADS, 16384) != hipSuccess) return false;
