@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void relattn_kernel(const float* __restrict__ 
                        // 4 K / V / band staged once (first key tile only), 8 no PV product, 16 no q.k product
 #endif
 #ifndef SEPR_AT_MASKPASS
-#define SEPR_AT_MASKPASS 0
+#define SEPR_AT_MASKPASS 1   // key-bound mask as one wave-uniform pass (0: selects inside the score loop - rounds 1-4; 2: pass on every tile)
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -373,7 +373,8 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
         const int bb = 16 * w - 32 * p + 32;
 #pragma unroll
         for (int tb = 0; tb < ((SEPR_AT_ABL & 1) ? 0 : 3); ++tb) {
-          const int row = bb + 16 * tb + ii;                    // <= 126 except unused rows of the last tile
+          const int row = bb + 16 * tb + (15 - ii);             // <= 126 except unused rows of the last tile; REVERSED inside the 16-row tile:
+                                                                // the lane's four results are then band rows in DESCENDING order (see the store)
           const int rc = row < NBAND ? row : NBAND - 1;
           const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bh + rc * KSB + go);
           const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + rc * KSB + go);
@@ -383,22 +384,29 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ql, a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, qh, a, 0, 0, 0);
           }
-          st4(psk + 16 * tb + 4 * g, make_float4(a[0], a[1], a[2], a[3]));   // rows b = 16 tb + 4g + r of this query
+          // a[r] = band row b = 16 tb + 15 - 4g - r of this query, stored MIRRORED (row b at float 47 - b = 32 - 16 tb + 4g + r): the four
+          // bias values of a key group are then read in ASCENDING address order, i.e. as register pairs in the order of the score pairs they
+          // are added to.  With the rows in natural order hipcc packed that add as v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (pair swap) -
+          // the gfx950-faulty form of sepr_common.h norm4_pinned: THAT was round 4's "nondeterministic mask pass" (tools/isa_lint.py now
+          // rejects the form; reversing the band rows in the A fragment costs nothing, reversing the results would cost v_pk_mov's)
+          st4(psk + 32 - 16 * tb + 4 * g, make_float4(a[0], a[1], a[2], a[3]));
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const int b0 = ii + 31 - 16 * s - 4 * g;              // b of key 16 s + 4g + 0; r steps down
           float bias[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) bias[r] = (SEPR_AT_ABL & 1) ? 0.f : psk[b0 - r];       // unconditional: the reads issue back to back
+          for (int r = 0; r < 4; ++r) bias[r] = (SEPR_AT_ABL & 1) ? 0.f : psk[47 - b0 + r];  // unconditional: the reads issue back to back
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             sv[p][s][r] = (SEPR_AT_MASKPASS || j0 + 32 * p + 16 * s + 4 * g + r < Tp) ? sc[s][r] + bias[r] : -1e30f;
         }
       }
 #if SEPR_AT_MASKPASS
-      // EXPERIMENT (withdrawn in round 4, kept as a build switch for the fault probe tools/probe/attn_maskpass.md): the key-bound selects as
-      // ONE wave-uniform pass taken only by the tile that crosses Tp.  1 = branch form, 2 = the same pass on every tile (no branch)
+      // only a tile that reaches past Tp pays the 16 key-bound selects: ONE wave-uniform pass (as selects inside the loop above they cost 48
+      // VALU per tile and hipcc turned four of the bias reads into exec-masked blocks with their own LDS waits: 300 -> 212 VALU per full
+      // tile).  Round 4 withdrew this form as "run-to-run nondeterministic, cause not established"; round 5 established it - not the pass
+      // but the packed bias add the compiler formed around it (see the mirrored store above).  2 = the pass on every tile (bisecting aid)
       if (SEPR_AT_MASKPASS == 2 || j0 + KT > Tp) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
@@ -409,9 +417,6 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
               if (j0 + 32 * p + 16 * s + 4 * g + r >= Tp) sv[p][s][r] = -1e30f;
       }
 #endif
-      // (Round 4 tried the key-bound selects as ONE wave-uniform pass taken only by the tile that crosses Tp: -29 % VALU per full tile, -4 %
-      //  kernel time - and run-to-run DIFFERENT outputs at B = 32 (tools/det_infer.py; the same pass executed on every tile, or these selects,
-      //  are deterministic; cause not established - the generated code reads correctly).  The selects stay where they are.)
       float mx = -1e30f;
 #pragma unroll
       for (int p = 0; p < 2; ++p)

@@ -62,6 +62,21 @@ __device__ __forceinline__ void st4_bf16(float* base, long long idx, float4 v) {
   *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(base) + idx) = h;
 }
 
+// gfx950 fault (tools/probe/pk_opsel.hip): a packed-f32 VALU instruction whose LOW result half selects the HIGH dword
+// of src1 (VOP3P op_sel:[x,1]) returns wrong low halves in lanes 16-31 / 48-63 while another wave of the SIMD executes bf16 MFMAs.  hipcc's
+// SLP vectoriser emits that form whenever it splats an ODD register into a packed operand - e.g. rstd, the high dword of a loaded
+// (mean, rstd) pair - or builds a horizontal add.  tools/isa_lint.py stops the build on any such instruction; these helpers pin the
+// safe forms where the natural source would produce it.
+//   (v - mean) * rstd on four values: broadcast pairs built with moves, packed instructions WITHOUT operand selects
+__device__ __forceinline__ float4 norm4_pinned(float4 v, float mean, float rstd) {
+  typedef float sepr_f2 __attribute__((ext_vector_type(2)));
+  sepr_f2 xy = {v.x, v.y}, zw = {v.z, v.w};
+  const sepr_f2 mm = {mean, mean}, rr = {rstd, rstd};
+  asm volatile("v_pk_add_f32 %0, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+               "v_pk_mul_f32 %0, %0, %3\n\tv_pk_mul_f32 %1, %1, %3" : "+v"(xy), "+v"(zw) : "v"(mm), "v"(rr));
+  return make_float4(xy[0], xy[1], zw[0], zw[1]);
+}
+
 // butterfly sums over the lanes of a wave64
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

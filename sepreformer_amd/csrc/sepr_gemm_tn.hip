@@ -172,7 +172,9 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
           if (a.stats) {                               // kernel-uniform
             const long long si = a.stat_seq ? srow : m;
             const float2 st = *reinterpret_cast<const float2*>(a.stats + 2 * si);
-            v.x = (v.x - st.x) * st.y; v.y = (v.y - st.x) * st.y; v.z = (v.z - st.x) * st.y; v.w = (v.w - st.x) * st.y;
+            // (form pinned: the compiler's own packing of this expression splats st.y with op_sel:[0,1] - the gfx950 fault of
+            //  sepr_common.h norm4_pinned; found as wrong weight gradients in round 3, root-caused in round 5)
+            v = norm4_pinned(v, st.x, st.y);
           }
           r[e] = valid ? v : zero4();
         }
@@ -463,10 +465,9 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   float* part = static_cast<float*>(ws);
   float* cpart = part + (size_t)p.nsplit * a.N * a.K;
   const int grid = p.tn * p.tk * p.nsplit;
-  // fault-probe switches (tools/probe/tn_fault.py; read once, never set in the product): SEPR_TN_FORCE_GEN=1 routes every launch through
-  // the general loader, SEPR_TN_GEN_PAD=<bytes> replaces the 16 KB LDS pad that keeps the general loader at one workgroup per CU
+  // test switch (tools/probe/tn_fault.py, tests; read once, never set in the product): SEPR_TN_FORCE_GEN=1 routes every launch through the
+  // general loader, so the public sepr_linear_wgrad_norm entry exercises it with per-row statistics at any size
   static const bool force_gen = [] { const char* e = getenv("SEPR_TN_FORCE_GEN"); return e && e[0] == '1'; }();
-  static const int gen_pad = [] { const char* e = getenv("SEPR_TN_GEN_PAD"); return (e && e[0]) ? atoi(e) : 16384; }();
   const bool gen = force_gen || a.rows_out > 0 || a.B2 != nullptr || a.idx != nullptr || a.mask_a != 0 || a.stat_seq != 0;
   if (gen && (a.a16 || a.b16)) return SEPR_EINVAL;      // (checked before the profiling slot opens)
   long long slot = -1;
@@ -490,30 +491,14 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
     return SEPR_OK;
   }
   float* cp = a.colsum ? cpart : nullptr;
-  // The general loader runs ONE workgroup per CU (16 KB of dynamic LDS on top of the static 74 KB make a second one not fit): with
-  // two co-resident workgroups and statistics its bf16 instantiations returned wrong, run-to-run different values in the even
-  // components of lanes 16-31 / 48-63 of the B staging waves (M >= ~20 000 rows; found by the full-size determinism test of
-  // round 3, reproduced by tools/det_tn.py, root cause not established).  Round 4: ALL general-loader launches take the pad (not
-  // only those with statistics: a handful of launches per step), and the occupancy it is meant to produce is verified once per
-  // instantiation instead of assumed - if a toolchain / driver ever fits two such workgroups on a CU the launch fails loudly.
-  const int dyn = gen ? gen_pad : 0;
-  if (gen && gen_pad == 16384) {
-    static const bool one_per_cu = [] {
-      int n0 = 0, n1 = 0, n2 = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, gemm_tn_kernel<0, true, false>, TN_THREADS, 16384) != hipSuccess) return false;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, gemm_tn_kernel<1, true, false>, TN_THREADS, 16384) != hipSuccess) return false;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, gemm_tn_kernel<2, true, false>, TN_THREADS, 16384) != hipSuccess) return false;
-      return n0 == 1 && n1 == 1 && n2 == 1;
-    }();
-    if (!one_per_cu) {
-      if (timed) prof_end(slot, 0.0, s);
-      fprintf(stderr, "sepr: gemm_tn general loader: expected exactly one workgroup per CU with the LDS pad\n");
-      return SEPR_EHIP;
-    }
-  }
+  // (Rounds 3-4 ran the general loader at ONE workgroup per CU behind a 16 KB LDS pad: with two co-resident workgroups its bf16
+  //  instantiations returned wrong, run-to-run different values in the even columns of the upper half of every B tile.  Round 5 found the
+  //  cause - the packed-f32 op_sel fault described in sepr_common.h, triggered by the normalisation's v_pk_mul_f32 op_sel:[0,1] while the
+  //  other workgroup's bf16 MFMAs run - pinned the instruction form and removed the pad: tools/probe/tn_fault.py, tests/test_train_gpu.py
+  //  test_general_loader_two_workgroups_per_cu.)
 #define SEPR_TN_LAUNCH(MD)                                                                                                   \
   do {                                                                                                                       \
-    if (gen) hipLaunchKernelGGL((gemm_tn_kernel<MD, true, false>), dim3(grid), dim3(TN_THREADS), dyn, s, a, p, part, cp);    \
+    if (gen) hipLaunchKernelGGL((gemm_tn_kernel<MD, true, false>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp);      \
     else if (a.stats) hipLaunchKernelGGL((gemm_tn_kernel<MD, false, true>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp); \
     else hipLaunchKernelGGL((gemm_tn_kernel<MD, false, false>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp);         \
   } while (0)

@@ -572,3 +572,23 @@ def test_flat_adamw_has_no_cpu_path():
     with pytest.raises(ValueError):
         FlatAdamW(m, lr=1e-3, betas=(1.0, 0.999))
     assert FlatAdamW.fused_clip is True and issubclass(FlatAdamW, torch.optim.Optimizer)
+
+
+def test_isa_lint_guards_the_gfx950_packed_f32_fault():
+    """tools/isa_lint.py: the shipped library contains no packed-f32 instruction whose low half selects the high
+    dword of src1 / src2 - the form that is wrong on gfx950 beside bf16 MFMAs (tools/probe/pk_opsel.hip) - and the lint recognises it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    bad = ["v_pk_mul_f32 v[2:3], v[2:3], v[6:7] op_sel:[0,1]", "v_pk_add_f32 v[8:9], v[12:13], v[12:13] op_sel:[0,1] op_sel_hi:[1,0]",
+           "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,0,1]", "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[1,1,0]"]
+    good = ["v_pk_mul_f32 v[2:3], v[2:3], v[6:7]", "v_pk_mul_f32 v[2:3], v[2:3], v[6:7] op_sel_hi:[0,1]", "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[1,0,0]",
+            "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel_hi:[0,1,1]", "v_pk_add_f32 v[2:3], v[2:3], v[6:7] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]"]
+    for ins in bad:
+        assert lint.PK_F32.search(ins) and (lint.BAD_SEL.search(ins) or lint.BAD_SEL2.search(ins)), ins
+    for ins in good:
+        assert lint.PK_F32.search(ins) and not (lint.BAD_SEL.search(ins) or lint.BAD_SEL2.search(ins)), ins
+    n_pk, found = lint.lint(L.LIB_PATH)
+    assert n_pk > 5000, n_pk           # the disassembly really saw the device code (the library holds ~21 000 packed-f32 instructions)
+    assert not found, found[:3]

@@ -8,6 +8,7 @@ to gpurun_out/train_parity_report.json.
 import dataclasses
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -1703,3 +1704,23 @@ def test_captured_step_with_flat_adamw_follows_torch_adamw():
         assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (a, b)
         assert abs(ga - gb_) <= 1e-5 * gb_, (a, b)
     assert a[-1][0] < a[0][0]
+
+
+@pytest.mark.gpu
+def test_general_loader_two_workgroups_per_cu():
+    """Round 3's fault shape class: the weight-gradient contraction's GENERAL loader normalising its B rows with two
+    workgroups per CU - wrong, run-to-run different even columns of the upper tile half until round 5 pinned the packed-f32 form and
+    removed the LDS pad that had kept the loader at one workgroup per CU.  SEPR_TN_FORCE_GEN=1 (latched per process: a subprocess) routes
+    the public wgrad entry through that loader at 20 000 - 128 000 rows; every arithmetic must repeat bitwise and agree with fp64."""
+    import subprocess
+    env = dict(os.environ, SEPR_TN_FORCE_GEN="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe", "tn_fault.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if "wgrad_norm" in ln]
+    assert len(lines) == 9, out.stdout
+    bar = {"x3=0": 1e-5, "x3=1": 1e-4, "x3=2": 2e-2}
+    for ln in lines:
+        assert "[gen=1" in ln and "repeats_equal=True" in ln, ln
+        err = float(ln.split("max_rel_err=")[1].split()[0])
+        assert err <= next(v for k, v in bar.items() if k + ":" in ln), ln
