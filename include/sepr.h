@@ -478,6 +478,25 @@ int sepr_linear_wgrad(const float* A, const float* B, float* G, float* colsum, i
 int sepr_linear_wgrad_norm(const float* A, const float* B, const float* stats, float* G, float* colsum, int M, int N, int K,
                            int accumulate, int x3, void* ws, size_t ws_bytes, sepr_stream_t stream);
 
+/* ---- per-step weight re-pack on the device (ABI 4.00) -----------------------------------------------------------------
+ * What the reference's modules do implicitly - read the CURRENT value of every nn.Parameter on each forward (network.py:60-66 etc.) - costs
+ * this path a re-layout of every projection after each optimizer step (sepreformer_amd/train_pack.py).  One call handles a STACK of G
+ * same-shaped projections and reads the parameters where they live:
+ *   src    device table of G * panels pointers; block g's [SN][SK] fp32 source matrix is the row-wise concatenation of its `panels`
+ *          tensors (panels = 3: linear_q / linear_k / linear_v stacked, network.py:76-78), each [SN / panels][SK] row-major
+ *   scale  device table of G pointers (or NULL with scale_kind 0): scale_kind 1 = per source COLUMN [SK] (LayerNorm / GroupNorm gamma
+ *          folded into the weight), 2 = per source ROW [SN] (LayerScale folded in)
+ *   transpose 0: out[n][k] = src[n][k] * s;  1: out[n][k] = src[k][n] * s  (the input-gradient form), N x K = SK x SN
+ *   planes 1: out = G x pack_x3 fragments (bf16 hi / lo planes, [N/16][K/32][2][64][8], as sepr_x3_w.wp); 0: G x fp32 [N][K]
+ * N % 16 == 0 and K % 32 == 0.  Bit-identical to the torch formulation fl32((double)w * (double)s) -> bf16 split. */
+int sepr_train_pack_lin(const void* const* src, const void* const* scale, int G, int SN, int SK, int panels, int scale_kind, int transpose,
+                        int planes, void* out, sepr_stream_t stream);
+/* out[g][n] = (float)((double)bias[g][n] + sum_k (double)W[g][n][k] (double)beta[g][k]): the bias with the LayerNorm beta folded in.
+ * w / bias: tables of G * panels pointers ([N / panels][K] and [N / panels] each), beta: G pointers [K].  bias NULL: 0; w and beta NULL: a
+ * plain gather of the biases into one [G][N] buffer. */
+int sepr_train_fold_bias(const void* const* w, const void* const* bias, const void* const* beta, int G, int N, int K, int panels, float* out,
+                         sepr_stream_t stream);
+
 /* PIT_SISNR_time backward (criterions.py:191-217): d(sum_b loss[b] * gl[b]) / d est.  est, tgt, dest [S,B,T]; perm from the forward. */
 int sepr_pit_sisnr_bwd(const float* est, const float* tgt, const int* perm, const float* gl, int S, int B, int T, double eps,
                        double clamp_min, float* dest, void* ws, size_t ws_bytes, sepr_stream_t stream);

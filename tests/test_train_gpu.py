@@ -1724,3 +1724,53 @@ def test_general_loader_two_workgroups_per_cu():
         assert "[gen=1" in ln and "repeats_equal=True" in ln, ln
         err = float(ln.split("max_rel_err=")[1].split()[0])
         assert err <= next(v for k, v in bar.items() if k + ":" in ln), ln
+
+
+@pytest.mark.gpu
+def test_device_repack_equals_torch_formulation():
+    """Round 5: the per-step weight re-pack runs on the device (sepr_train_pack_lin / sepr_train_fold_bias, one launch per stack of projections,
+    parameters read in place through pointer tables).  Against the batched torch formulation rounds 2-4 used - fold in fp64, transpose,
+    bf16 hi / lo split, fragment permutation - the packed bytes must be IDENTICAL and the folded biases equal to one fp32 ulp."""
+    from sepreformer_amd.train_pack import _Stack
+    dev = torch.device("cuda:0")
+
+    def pack_x3_batched(w):
+        G, N, K = w.shape
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+
+        def frag(p):
+            return p.view(G, N // 16, 16, K // 32, 4, 8).permute(0, 1, 3, 4, 2, 5)
+
+        return torch.stack([frag(hi), frag(lo)], dim=3).contiguous()
+
+    G, F = 5, 128
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *s: (torch.randn(*s, generator=g) * 0.3).to(dev)          # noqa: E731
+    for name, SN, SK, panels in (("up", 6 * F, F, 1), ("qkv", 3 * F, F, 3), ("down", F, 3 * F, 1), ("proj", 64, 256, 1)):
+        w = [[rn(SN // panels, SK) for _ in range(panels)] for _ in range(G)]
+        b = [[rn(SN // panels) for _ in range(panels)] for _ in range(G)]
+        col, row, beta = [1.0 + rn(SK) for _ in range(G)], [1.0 + rn(SN) for _ in range(G)], [rn(SK) for _ in range(G)]
+        W = torch.stack([torch.cat(ws, 0) for ws in w], 0)                                      # [G,SN,SK]
+        B = torch.stack([torch.cat(bs, 0) for bs in b], 0)
+        C, R_, BE = torch.stack(col, 0), torch.stack(row, 0), torch.stack(beta, 0)
+        keep = []
+        # forward form: gamma folded per column, beta folded into the bias
+        s = _Stack(keep, w, (SN, SK), "bf16x3", b=b, scale=col, scale_kind=1, beta=beta)
+        wf = (W.double() * C.double()[:, None, :]).float()
+        assert torch.equal(s.wp.view(torch.int16), pack_x3_batched(wf).reshape(G, -1).view(torch.int16)), name
+        bf = (B.double() + torch.einsum("gnk,gk->gn", W.double(), BE.double())).float()
+        assert float((s.b - bf).abs().max()) <= 2.0 * float(torch.finfo(torch.float32).eps * bf.abs().max()), name
+        # input-gradient forms: transposed, gamma per source column / LayerScale per source row
+        st_ = _Stack(keep, w, (SN, SK), "bf16", scale=col, scale_kind=1, transpose=True)
+        assert st_.planes == 1 and torch.equal(st_.wp.view(torch.int16), pack_x3_batched(wf.transpose(1, 2).contiguous()).reshape(G, -1).view(torch.int16)), name
+        sr = _Stack(keep, w, (SN, SK), "bf16x3", scale=row, scale_kind=2, transpose=True)
+        assert torch.equal(sr.wp.view(torch.int16), pack_x3_batched((W * R_[:, :, None]).transpose(1, 2).contiguous()).reshape(G, -1).view(torch.int16)), name
+        # plain forms: no fold; exact-f32 layout; bias gather without a fold
+        sp = _Stack(keep, w, (SN, SK), "bf16x3", b=b)
+        assert torch.equal(sp.wp.view(torch.int16), pack_x3_batched(W).reshape(G, -1).view(torch.int16)) and torch.equal(sp.b, B), name
+        s32 = _Stack(keep, w, (SN, SK), "fp32", scale=col, scale_kind=1, transpose=True)
+        assert s32.wp is None and torch.equal(s32.w, wf.transpose(1, 2).contiguous()), name
+        assert s.lin(2).wp == s.wp.data_ptr() + 2 * 2 * 2 * SN * SK and s.lin(2).b == s.b.data_ptr() + 4 * 2 * SN
+    with pytest.raises(ValueError):
+        _Stack([], [[rn(24, 32)]], (24, 32), "bf16x3")                   # not whole MFMA fragments
