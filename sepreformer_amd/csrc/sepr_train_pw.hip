@@ -1432,22 +1432,22 @@ int launch_enc_bwd_pre(float* de, const float* add, const float* wav, const floa
 // parameter-gradient finishers (weight-sized tensors; see sepr_train.h for the algebra)
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-// block = one weight row n (dW, dbias); second phase: block = one input channel k (dg, db).  Two launches.
-__global__ __launch_bounds__(TPB) void finish_norm_rows_kernel(const float* __restrict__ dWh, const float* __restrict__ s,
-                                                              const float* __restrict__ g, const float* __restrict__ b,
-                                                              float* __restrict__ dW_g, float* __restrict__ dbias_g, int N, int K) {
-  const int n = blockIdx.x;
-  const float sn = s[n];
-  for (int k = threadIdx.x; k < K; k += TPB) dW_g[(long long)n * K + k] += fmaf(dWh[(long long)n * K + k], g[k], sn * b[k]);
-  if (threadIdx.x == 0 && dbias_g) dbias_g[n] += sn;
-}
-// block = 64 input channels k x 16 row lanes: rows n = lane, lane + 16, ... are read as coalesced 256-byte segments
-__global__ __launch_bounds__(1024) void finish_norm_cols_kernel(const float* __restrict__ dWh, const float* __restrict__ s,
-                                                               const float* __restrict__ W, float* __restrict__ dg_g,
-                                                               float* __restrict__ db_g, int N, int K) {
+// ONE launch (round 5; two before - ~200 of each per step, 5-6 us apiece, i.e. launch-latency bound): blocks [0, N) each own one weight
+// row n (dW, dbias), blocks [N, N + ceil(K / 64)) each own 64 input channels k x 16 row lanes (dg, db: rows n = lane, lane + 16, ... are
+// read as coalesced 256-byte segments).  Both parts only READ dWh / s and write disjoint gradient tensors, so they need no ordering.
+__global__ __launch_bounds__(1024) void finish_norm_kernel(const float* __restrict__ dWh, const float* __restrict__ s, const float* __restrict__ W,
+                                                          const float* __restrict__ g, const float* __restrict__ b, float* __restrict__ dW_g,
+                                                          float* __restrict__ dbias_g, float* __restrict__ dg_g, float* __restrict__ db_g, int N, int K) {
   __shared__ float sh[16][64][2];
+  if ((int)blockIdx.x < N) {
+    const int n = blockIdx.x;
+    const float sn = s[n];
+    for (int k = threadIdx.x; k < K; k += 1024) dW_g[(long long)n * K + k] += fmaf(dWh[(long long)n * K + k], g[k], sn * b[k]);
+    if (threadIdx.x == 0 && dbias_g) dbias_g[n] += sn;
+    return;
+  }
   const int kl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + kl;
+  const int k = ((int)blockIdx.x - N) * 64 + kl;
   float a = 0.f, c = 0.f;
   if (k < K) {
 #pragma unroll 4
@@ -1489,8 +1489,7 @@ __global__ __launch_bounds__(64) void finish_ls_kernel(const float* __restrict__
 int launch_finish_norm_linear(const float* dWh, const float* s, const float* W, const float* g, const float* b, float* dW_g,
                               float* dbias_g, float* dg_g, float* db_g, int N, int K, hipStream_t st) {
   if (!dWh || !s || !W || !g || !b || !dW_g || !dg_g || !db_g || N <= 0 || K <= 0) return SEPR_EINVAL;
-  hipLaunchKernelGGL(finish_norm_rows_kernel, dim3(N), dim3(TPB), 0, st, dWh, s, g, b, dW_g, dbias_g, N, K);
-  hipLaunchKernelGGL(finish_norm_cols_kernel, dim3((K + 63) / 64), dim3(1024), 0, st, dWh, s, W, dg_g, db_g, N, K);
+  hipLaunchKernelGGL(finish_norm_kernel, dim3(N + (K + 63) / 64), dim3(1024), 0, st, dWh, s, W, g, b, dW_g, dbias_g, dg_g, db_g, N, K);
   SEPR_CHECK_LAUNCH("finish_norm_linear kernels");
   return SEPR_OK;
 }

@@ -64,6 +64,13 @@ class CapturedTrainStep:
                 self._clip_and_step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        if self.sync is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            # The warm-up steps ran gradient all-reduces.  The process group's watchdog thread polls the events of those collectives
+            # (hipEventQuery, every 100 ms) until it has retired them; about one bench sub-run in 15 died in that thread (SIGABRT before
+            # the first replay) when a capture started while it was still polling.  Everything is complete after the synchronize above, so
+            # two polling periods later the watchdog's work list is empty and it issues no HIP call during the capture.
+            import time
+            time.sleep(0.25)
 
         self.g_main, self.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         pool = torch.cuda.graph_pool_handle()
