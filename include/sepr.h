@@ -497,6 +497,14 @@ int sepr_train_pack_lin(const void* const* src, const void* const* scale, int G,
 int sepr_train_fold_bias(const void* const* w, const void* const* bias, const void* const* beta, int G, int N, int K, int panels, float* out,
                          sepr_stream_t stream);
 
+/* The fused GCFN kernel's weight forms (sepr_gcfn_tw.fused_w1p / fused_w2p, i.e. sepr_gcfn_w's) for a stack of G blocks in one launch:
+ * seven device tables of G pointers to the blocks' parameters (net1.1.weight [6F,F], net1.1.bias, net1.0.weight / bias [F], net2.2.weight
+ * [F,3F], depthwise.weight [6F,1,3], depthwise.bias [6F]).  w1p: G x (3F/32) x (4 * (F/32) * 2 KiB + 4 KiB) bytes, w2p: G x (3F/32) x
+ * (F/16) x 2 KiB bytes; layouts as documented on sepr_gcfn_w.  F in {64, 128}. */
+int sepr_train_pack_gcfn_fused(const void* const* w1, const void* const* b1, const void* const* ln_g, const void* const* ln_b,
+                               const void* const* w2, const void* const* dw_w, const void* const* dw_b, int G, int F, void* w1p, void* w2p,
+                               sepr_stream_t stream);
+
 /* PIT_SISNR_time backward (criterions.py:191-217): d(sum_b loss[b] * gl[b]) / d est.  est, tgt, dest [S,B,T]; perm from the forward. */
 int sepr_pit_sisnr_bwd(const float* est, const float* tgt, const int* perm, const float* gl, int S, int B, int T, double eps,
                        double clamp_min, float* dest, void* ws, size_t ws_bytes, sepr_stream_t stream);

@@ -52,6 +52,8 @@ __device__ __forceinline__ void gb_wait_vm2(gb_u32x4& a, gb_u32x4& b) {
 }
 
 namespace {
+template <bool V>
+struct gb_bool { static constexpr bool value = V; };
 // Compile-time replay of the PL form's VMEM issue order (gcfn_bwd_mid_kernel below): per wave  D0 W0 D1 W1 D2 .. D(NQ-1)  in the prologue,
 // then W(s+2) right after the MFMAs of step s.  D = `dma` LDS-DMA copies of a slab, W = 4 fragment loads for an up-projection step
 // (q < nsl), 2 for a dgd step.  Returns how many VMEM operations have been issued AFTER the last one step q depends on (its slab D_q and
@@ -415,6 +417,13 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc8[e][k] = 0.f;
+    // Interior tiles (every row this tile touches - m0 - 2 .. m0 + 61 - lies strictly inside ONE sequence: all but ~1 tile in 130 at T = 8000)
+    // run the instantiation WITHOUT the conv's zero-padding flags: 24 multiplies per row and thread out of both passes (round 5; the fused
+    // forward has done the same since round 1).  Wave-uniform choice, bit-identical results (a flag of 1.0 multiplies exactly).
+    const int lo_t = (m0 >= 1) ? (m0 - 1) % a.T : 0;
+    const bool edge_tile = !(m0 >= 2 && lo_t >= 1 && lo_t + 62 <= a.T - 2 && m0 + GB_BM - 2 <= a.M);
+    auto passes = [&](auto edge_c) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     float4 dcv[4], dcg[4];
     {
 #pragma clang fp contract(off)
@@ -425,15 +434,17 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
         dcv[i] = zero4();
         dcg[i] = zero4();
         if (r < 1 || r > GB_BM - 2 || m < 0 || m >= a.M) continue;
-        const int t = m % a.T;
-        const float f0 = t > 0 ? 1.f : 0.f, f2 = t < a.T - 1 ? 1.f : 0.f;    // zero padding at the sequence ends
         const float* hr = Hs + r * GB_HS + c4;
         const float4 hvc = ld4(hr), hgc = ld4(hr + 64);
         float4 hvm = ld4(hr - GB_HS), hgm = ld4(hr - GB_HS + 64), hvp = ld4(hr + GB_HS), hgp = ld4(hr + GB_HS + 64);
-        hvm.x *= f0; hvm.y *= f0; hvm.z *= f0; hvm.w *= f0;
-        hgm.x *= f0; hgm.y *= f0; hgm.z *= f0; hgm.w *= f0;
-        hvp.x *= f2; hvp.y *= f2; hvp.z *= f2; hvp.w *= f2;
-        hgp.x *= f2; hgp.y *= f2; hgp.z *= f2; hgp.w *= f2;
+        if constexpr (EDGE) {                                  // zero padding at the sequence ends (tiles that touch one: ~1 in 130)
+          const int t = m % a.T;
+          const float f0 = t > 0 ? 1.f : 0.f, f2 = t < a.T - 1 ? 1.f : 0.f;
+          hvm.x *= f0; hvm.y *= f0; hvm.z *= f0; hvm.w *= f0;
+          hgm.x *= f0; hgm.y *= f0; hgm.z *= f0; hgm.w *= f0;
+          hvp.x *= f2; hvp.y *= f2; hvp.z *= f2; hvp.w *= f2;
+          hgp.x *= f2; hgp.y *= f2; hgp.z *= f2; hgp.w *= f2;
+        }
         float4 keep = make_float4(1.f, 1.f, 1.f, 1.f);
         if (drop) {                                            // network.py:55: mask of the gated tensor, element (m, hc + e)
           const unsigned d0 = sepr_drop_word(dk0, (unsigned)m, (unsigned)(hc >> 1)), d1 = sepr_drop_word(dk0, (unsigned)m, (unsigned)(hc >> 1) + 1u);
@@ -504,8 +515,12 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
         const int r = 4 * strip + i;
         const int m = m0 - 2 + r;
         if (r < 2 || r >= 2 + GB_OUT || m >= a.M) continue;
-        const int t = m % a.T;
-        const float f0 = t > 0 ? 1.f : 0.f, f2 = t < a.T - 1 ? 1.f : 0.f;
+        float f0 = 1.f, f2 = 1.f;
+        if constexpr (EDGE) {
+          const int t = m % a.T;
+          f0 = t > 0 ? 1.f : 0.f;
+          f2 = t < a.T - 1 ? 1.f : 0.f;
+        }
         const float* hr = Hs + r * GB_HS + c4;
         const float4 pv = ld4(hr - GB_HS), pg = ld4(hr - GB_HS + 64), nv = ld4(hr + GB_HS), ng = ld4(hr + GB_HS + 64);
         // dh[t] = w0 dc[t+1] + w1 dc[t] + w2 dc[t-1]   (frames of OTHER sequences do not contribute: f0 / f2)
@@ -522,6 +537,8 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
         gb_store4(a.dh1, (long long)m * C6 + C3 + hc, og, a.out16 != 0);
       }
     }
+    };
+    if (edge_tile) passes(gb_bool<true>{}); else passes(gb_bool<false>{});
     // per-tile depthwise partials: part[mb][pair][8], the 64 pairs of this column block are 512 consecutive floats
     {
       float* po = a.part + ((long long)mb * C3 + 64 * nb) * 8;

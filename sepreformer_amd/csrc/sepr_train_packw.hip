@@ -100,10 +100,112 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* const* __re
   }
   if (lane == 0) out[(long long)g * N + n] = (float)((bias ? (double)bias[g * panels + p][r] : 0.0) + s);
 }
+
+// The fused GCFN kernel's weight forms (sepr_gcfn_fused.h GcfnFusedArgs w1p / w2p; pack.py pack_gcfn_fused) for all G blocks: grid (chunk, block).
+//   w1p  per chunk: [4 tiles v0 v1 g0 g1][KS][plane][64][8] bf16 of W1 * gamma, then 4 KB of constants [2 tile pairs][10][16] fp32 =
+//        b1 + W1 . beta (fp64), the value taps, the gate taps and gate bias scaled by -log2(e) (fp64 products), zero padding
+//   w2p  per chunk: [F/16][plane][64][8] bf16 of W2 in the down-projection's row / k-slot order
+struct PackGcfnArgs {
+  const float* const* w1; const float* const* b1; const float* const* ln_g; const float* const* ln_b;
+  const float* const* w2; const float* const* dw_w; const float* const* dw_b;
+  int F;
+  unsigned char* w1p; unsigned char* w2p;
+};
+__global__ __launch_bounds__(256) void pack_gcfn_fused_kernel(const PackGcfnArgs a) {
+#pragma clang fp contract(off)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = blockIdx.x, g = blockIdx.y;
+  const int F = a.F, H3 = 3 * F, KS = F / 32, FT = F / 16, nch = H3 / 32;
+  const int i = lane & 15, g4 = lane >> 4;
+  const float* W1 = a.w1[g];
+  const float* gam = a.ln_g[g];
+  const size_t w1_chunk = (size_t)4 * KS * 2 * 1024 + 4096;
+  unsigned char* o1 = a.w1p + ((size_t)g * nch + c) * w1_chunk;
+  // ---- up-projection fragments ----
+  for (int b = w; b < 4 * KS; b += 4) {
+    const int t = b / KS, ks = b - t * KS;
+    const int n = (t < 2 ? 0 : H3) + 32 * c + 16 * (t & 1) + i, k0 = 32 * ks + 8 * g4;
+    const float* s = W1 + (long long)n * F + k0;
+    const float4 p = ld4(s), q = ld4(s + 4), gp = ld4(gam + k0), gq = ld4(gam + k0 + 4);
+    const float v[8] = {p.x * gp.x, p.y * gp.y, p.z * gp.z, p.w * gp.w, q.x * gq.x, q.y * gq.y, q.z * gq.z, q.w * gq.w};
+    pw_bf16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 hh = (__bf16)v[e];
+      h[e] = hh;
+      l[e] = (__bf16)(v[e] - (float)hh);
+    }
+    unsigned char* o = o1 + ((size_t)(t * KS + ks) * 2) * 1024 + lane * 16;
+    *reinterpret_cast<pw_bf16x8*>(o) = h;
+    *reinterpret_cast<pw_bf16x8*>(o + 1024) = l;
+  }
+  // ---- constants ----
+  float* cst = reinterpret_cast<float*>(o1 + (size_t)4 * KS * 2 * 1024);
+  for (int e = 320 + tid; e < 1024; e += 256) cst[e] = 0.f;
+  {
+    const float* b1 = a.b1[g];
+    const float* be = a.ln_b[g];
+    for (int u = w; u < 64; u += 4) {                       // folded biases: u = (j, value | gate, i)
+      const int j = u >> 5, kind = (u >> 4) & 1, ii = u & 15;
+      const int n = (kind ? H3 : 0) + 32 * c + 16 * j + ii;
+      double sum = 0.0;
+      for (int k = lane; k < F; k += 64) sum += (double)W1[(long long)n * F + k] * (double)be[k];
+      sum = wave_sum_d(sum);
+      if (lane == 0) cst[j * 160 + kind * 16 + ii] = (float)((double)b1[n] + sum);
+    }
+    const float* dw = a.dw_w[g];
+    const float* db = a.dw_b[g];
+    if (tid < 256) {                                         // taps (q = 2..7) and conv biases (q = 8, 9): 2 x 8 x 16 values
+      const int j = tid >> 7, q = 2 + ((tid >> 4) & 7), ii = tid & 15;
+      const int v = 32 * c + 16 * j + ii;
+      double val;
+      if (q < 5) val = (double)dw[(long long)v * 3 + (q - 2)];
+      else if (q < 8) val = (double)dw[(long long)(H3 + v) * 3 + (q - 5)] * -1.4426950408889634;
+      else if (q == 8) val = (double)db[v];
+      else val = (double)db[H3 + v] * -1.4426950408889634;
+      cst[j * 160 + q * 16 + ii] = (float)val;
+    }
+  }
+  // ---- down-projection fragments: row 16 ft + (4 q + r) -> output channel 32 (ft / 2) + 8 q + 4 (ft % 2) + r; k slot 8 g4 + e -> hidden
+  //      channel 32 c + (e < 4 ? 4 g4 + e : 16 + 4 g4 + e - 4) ----
+  const float* W2 = a.w2[g];
+  unsigned char* o2 = a.w2p + ((size_t)g * nch + c) * FT * 2 * 1024;
+  for (int ft = w; ft < FT; ft += 4) {
+    const int row = 32 * (ft >> 1) + 8 * (i >> 2) + 4 * (ft & 1) + (i & 3);
+    const float* s = W2 + (long long)row * H3 + 32 * c + 4 * g4;
+    const float4 p = ld4(s), q = ld4(s + 16);
+    const float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+    pw_bf16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 hh = (__bf16)v[e];
+      h[e] = hh;
+      l[e] = (__bf16)(v[e] - (float)hh);
+    }
+    unsigned char* o = o2 + ((size_t)ft * 2) * 1024 + lane * 16;
+    *reinterpret_cast<pw_bf16x8*>(o) = h;
+    *reinterpret_cast<pw_bf16x8*>(o + 1024) = l;
+  }
+}
 }  // namespace
 }  // namespace sepr
 
 using namespace sepr;
+
+extern "C" int sepr_train_pack_gcfn_fused(const void* const* w1, const void* const* b1, const void* const* ln_g, const void* const* ln_b,
+                                          const void* const* w2, const void* const* dw_w, const void* const* dw_b, int G, int F, void* w1p,
+                                          void* w2p, sepr_stream_t stream) {
+  if (!w1 || !b1 || !ln_g || !ln_b || !w2 || !dw_w || !dw_b || !w1p || !w2p || G <= 0 || (F != 64 && F != 128)) return SEPR_EINVAL;
+  PackGcfnArgs a;
+  a.w1 = reinterpret_cast<const float* const*>(w1); a.b1 = reinterpret_cast<const float* const*>(b1);
+  a.ln_g = reinterpret_cast<const float* const*>(ln_g); a.ln_b = reinterpret_cast<const float* const*>(ln_b);
+  a.w2 = reinterpret_cast<const float* const*>(w2); a.dw_w = reinterpret_cast<const float* const*>(dw_w);
+  a.dw_b = reinterpret_cast<const float* const*>(dw_b);
+  a.F = F; a.w1p = static_cast<unsigned char*>(w1p); a.w2p = static_cast<unsigned char*>(w2p);
+  hipLaunchKernelGGL(pack_gcfn_fused_kernel, dim3(3 * F / 32, G), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  SEPR_CHECK_LAUNCH("pack_gcfn_fused_kernel");
+  return SEPR_OK;
+}
 
 extern "C" int sepr_train_pack_lin(const void* const* src, const void* const* scale, int G, int SN, int SK, int panels, int scale_kind, int transpose,
                                    int planes, void* out, sepr_stream_t stream) {

@@ -225,10 +225,15 @@ class TrainPack:
         self.fused_gcfn = (P in ("bf16x3", "bf16") and F in (64, 128) and os.environ.get("SEPR_TRAIN_FUSE_GCFN", "1") != "0")
         fw1 = fw2 = None
         if self.fused_gcfn:
-            from .pack import pack_gcfn_fused_batched
-            fw1, fw2 = pack_gcfn_fused_batched(st(gcfn_p, ".net1.1.weight"), st(gcfn_p, ".net1.1.bias"), st(gcfn_p, ".net1.0.weight"),
-                                               st(gcfn_p, ".net1.0.bias"), st(gcfn_p, ".net2.2.weight"),
-                                               st(gcfn_p, ".depthwise.weight", view=(6 * F, 3)), st(gcfn_p, ".depthwise.bias"))
+            # the fused kernel's forms of all blocks in ONE launch, from the parameters in place (sepr_train_pack_gcfn_fused; the batched torch
+            # formulation pack.pack_gcfn_fused_batched remains the inference packer's and the device test's reference)
+            G_, KS_, nch_ = len(gcfn_p), F // 32, 3 * F // 32
+            fw1 = torch.empty(G_, nch_ * (4 * KS_ * 2048 + 4096), dtype=torch.uint8, device=dev)
+            fw2 = torch.empty(G_, nch_, F // 16, 2, 64, 8, dtype=torch.bfloat16, device=dev)
+            L.check(L.load().sepr_train_pack_gcfn_fused(_table(g_w1).data_ptr(), _table(g_b1).data_ptr(), _table(g_lg).data_ptr(), _table(g_lb).data_ptr(),
+                                                        _table(g_w2).data_ptr(), _table(ps(gcfn_p, ".depthwise.weight")).data_ptr(),
+                                                        _table(ps(gcfn_p, ".depthwise.bias")).data_ptr(), G_, F, fw1.data_ptr(), fw2.data_ptr(),
+                                                        torch.cuda.current_stream(dev).cuda_stream), "sepr_train_pack_gcfn_fused")
             self.keep += [fw1, fw2]
         self.gcfn = []
         for i, p in enumerate(gcfn_p):

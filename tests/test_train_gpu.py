@@ -1401,6 +1401,51 @@ def test_training_loop_learns_bf16():
     assert l1[0] - l1[-1] >= 0.8 * (ref[0] - ref[-1]) and l1[-1] < l1[0] - 1.0, (l1, ref)
 
 
+def test_training_loop_base_width_60_steps_bf16_follows_bf16x3():
+    """Round-4 review item 8: longer evidence that a plain-bf16 model TRAINS at Base width.  SepReformer_Base_WSJ0, 0.5 s, batch 4, 60 AdamW
+    steps (clip 5, dropout live, FlatAdamW) in precision "bf16" and in "bf16x3" on the same data and seeds: the bf16 trajectory goes down
+    (every 10-step mean below the one before), ends within 5 % of the bf16x3 final loss (relative to the total decrease), and is
+    bitwise reproducible."""
+    from sepreformer_amd.criterion import PIT_SISNR_mag, PIT_SISNR_time
+    from sepreformer_amd.model import Model
+    from sepreformer_amd.optim import FlatAdamW
+    cfg = VARIANTS["SepReformer_Base_WSJ0"]
+    dev = torch.device("cuda:0")
+    B, T = 4, 4000
+    srcn = synth_sources(B, T, seed=7) * 4.0
+    src = [torch.from_numpy(srcn[:, s].copy()).to(dev) for s in range(2)]
+    x = (src[0] + src[1]).contiguous()
+    sizes = torch.full((B,), T)
+
+    def run(precision, steps=60):
+        torch.manual_seed(4321)
+        m = Model.from_config(cfg, init_seed=0, precision=precision).to(dev)
+        m.train()
+        opt = FlatAdamW(m, lr=2.0e-4, weight_decay=1.0e-2)
+        crit_t = PIT_SISNR_time(dev, 2, True)
+        crit_m = PIT_SISNR_mag(dev, 512, 128, "hann", cfg.num_stages, 2, True, False)
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            audio, aux = m(x)
+            l_mag = [crit_m(estims=a, idx=i, input_sizes=sizes, target_attr=src) for i, a in enumerate(aux)]
+            loss = (0.6 * crit_t(estims=audio, input_sizes=sizes, target_attr=src) + 0.4 * sum(l_mag) / len(l_mag)) / 2
+            loss.backward()
+            opt.step(max_norm=5.0)
+            losses.append(loss.detach())
+        return [float(v) for v in torch.stack(losses).cpu()]
+
+    ref = run("bf16x3")
+    l1, l2 = run("bf16"), run("bf16")
+    for k, v in (("first", l1[0]), ("last", l1[-1]), ("x3_last", ref[-1])):
+        record(f"train_loop.base_0p5s.bf16.loss_{k}", v)
+    assert all(np.isfinite(l1)) and l1 == l2, "bf16 trajectory not reproducible"
+    means = [sum(l1[i:i + 10]) / 10 for i in range(0, 60, 10)]
+    assert all(b < a for a, b in zip(means, means[1:])), means
+    drop_ref, drop = ref[0] - sum(ref[-5:]) / 5, l1[0] - sum(l1[-5:]) / 5
+    assert drop_ref > 1.0 and abs(drop - drop_ref) <= 0.05 * drop_ref + 0.1, (drop, drop_ref, l1[-5:], ref[-5:])
+
+
 def test_train_graphs_survive_a_larger_shape():
     """captured training graphs bake the engine's scratch-workspace pointer in.  Shape A, then a LARGER shape B
     (the engine allocates a bigger workspace), then A again: the replayed A step must still equal the eager A step bitwise (the
@@ -1774,3 +1819,36 @@ def test_device_repack_equals_torch_formulation():
         assert s.lin(2).wp == s.wp.data_ptr() + 2 * 2 * 2 * SN * SK and s.lin(2).b == s.b.data_ptr() + 4 * 2 * SN
     with pytest.raises(ValueError):
         _Stack([], [[rn(24, 32)]], (24, 32), "bf16x3")                   # not whole MFMA fragments
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F", [64, 128])
+def test_device_gcfn_fused_pack_equals_torch_packer(F):
+    """sepr_train_pack_gcfn_fused (one launch for a stack of GCFN blocks, parameters read in place) against pack.pack_gcfn_fused_batched - the
+    torch formulation whose per-block equality with the inference packer a CPU test pins: fragments and conv constants bit-identical, the
+    fp64-folded biases to one fp32 ulp."""
+    from sepreformer_amd.pack import pack_gcfn_fused_batched
+    from sepreformer_amd.train_pack import _table
+    dev = torch.device("cuda:0")
+    G = 3
+    g = torch.Generator().manual_seed(F)
+    rn = lambda *s: (torch.randn(*s, generator=g) * 0.4).to(dev)          # noqa: E731
+    w1, b1, lg, lb = [rn(6 * F, F) for _ in range(G)], [rn(6 * F) for _ in range(G)], [1.0 + rn(F) for _ in range(G)], [rn(F) for _ in range(G)]
+    w2, dw, db = [rn(F, 3 * F) for _ in range(G)], [rn(6 * F, 1, 3) for _ in range(G)], [rn(6 * F) for _ in range(G)]
+    st = lambda ts: torch.stack(ts, 0)                                     # noqa: E731
+    want1, want2 = pack_gcfn_fused_batched(st(w1), st(b1), st(lg), st(lb), st(w2), st(dw).reshape(G, 6 * F, 3), st(db))
+    KS, nch = F // 32, 3 * F // 32
+    got1 = torch.full((G, nch * (4 * KS * 2048 + 4096)), 0xAB, dtype=torch.uint8, device=dev)
+    got2 = torch.empty(G, nch, F // 16, 2, 64, 8, dtype=torch.bfloat16, device=dev)
+    L.check(L.load().sepr_train_pack_gcfn_fused(*[_table(t).data_ptr() for t in (w1, b1, lg, lb, w2, dw, db)], G, F, got1.data_ptr(), got2.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), "sepr_train_pack_gcfn_fused")
+    torch.cuda.synchronize()
+    assert want1.shape == got1.shape and torch.equal(got2.view(torch.int16), want2.view(torch.int16))
+    chunk = 4 * KS * 2048 + 4096
+    a, b = got1.view(G, nch, chunk), want1.view(G, nch, chunk)
+    assert torch.equal(a[:, :, :4 * KS * 2048], b[:, :, :4 * KS * 2048])                      # up-projection fragments
+    ca, cb = a[:, :, 4 * KS * 2048:].contiguous().view(torch.float32).view(G, nch, 1024), b[:, :, 4 * KS * 2048:].contiguous().view(torch.float32).view(G, nch, 1024)
+    assert torch.equal(ca[:, :, 320:], cb[:, :, 320:]) and float(ca[:, :, 320:].abs().max()) == 0.0
+    cav, cbv = ca[:, :, :320].view(G, nch, 2, 10, 16), cb[:, :, :320].view(G, nch, 2, 10, 16)
+    assert torch.equal(cav[:, :, :, 2:], cbv[:, :, :, 2:])                                      # taps and conv biases (fp64 products)
+    assert float((cav[:, :, :, :2] - cbv[:, :, :, :2]).abs().max()) <= 2.0 * float(torch.finfo(torch.float32).eps * cbv[:, :, :, :2].abs().max())
