@@ -69,8 +69,9 @@ class CapturedTrainStep:
             # (hipEventQuery, every 100 ms) until it has retired them; about one bench sub-run in 15 died in that thread (SIGABRT before
             # the first replay) when a capture started while it was still polling.  Everything is complete after the synchronize above, so
             # two polling periods later the watchdog's work list is empty and it issues no HIP call during the capture.
+            import os
             import time
-            time.sleep(0.25)
+            time.sleep(float(os.environ.get("SEPR_CAPTURE_DRAIN_S", "0.25") or 0.0))       # (0 = the round-4 behaviour, for tools/rccl_watchdog_loop.sh)
 
         self.g_main, self.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         pool = torch.cuda.graph_pool_handle()
