@@ -72,23 +72,43 @@ def collectives_active(group=None) -> bool:
     return dist.is_initialized() and (dist.get_world_size(group) > 1 or _SINGLE_RANK_COLLECTIVES)
 
 
+def all_reduce_off_stream(t: torch.Tensor, op=dist.ReduceOp.SUM, group=None) -> None:
+    """``dist.all_reduce`` whose completion event lives on the backend's INTERNAL stream, with the caller's stream ordered behind it.
+
+    torch runs a synchronous collective (``async_op=False``) on the caller's CURRENT stream and records the work's completion event there;
+    the process group's watchdog thread then polls that event (``hipEventQuery``, every 100 ms) until it has retired the work.  If the same
+    stream starts - or is pulled into - a hipGraph capture before that, HIP refuses the query ("operation not permitted on an event last
+    recorded in a capturing stream", even for an event recorded BEFORE the capture began), the watchdog thread throws and the process
+    aborts: the ~1-in-15 SIGABRT of round 4's training sub-runs (backtrace: profiles/r05_fault_rccl_watchdog_backtrace.txt; DESIGN.md
+    section 10c).  ``async_op=True`` + ``wait()`` keeps the event on the backend's own stream, which never captures; ``wait()`` is a
+    stream-level dependency, not a host block.  gloo (CPU tests) completes inside ``wait()`` as well."""
+    work = dist.all_reduce(t, op=op, group=group, async_op=True)
+    if work is not None:
+        work.wait()
+
+
 def reduce_metric_sums(values: torch.Tensor) -> torch.Tensor:
     """Sum a small vector of metric accumulators (e.g. [sum SI-SNR, sum SI-SNRi, count]) over ranks."""
     if collectives_active():
-        dist.all_reduce(values, op=dist.ReduceOp.SUM)
+        all_reduce_off_stream(values)
     return values
 
 
 def max_over_ranks(seconds: float, device: torch.device) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_off_stream(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":          # (RCCL's barrier is a synchronous all-reduce on the caller's stream: see all_reduce_off_stream)
+            t = torch.zeros(1, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+            all_reduce_off_stream(t)
+            torch.cuda.current_stream().synchronize()
+        else:
+            dist.barrier()
 
 
 def separate_sharded(separate: Callable[[torch.Tensor], torch.Tensor], mixtures: torch.Tensor,
@@ -115,7 +135,7 @@ def separate_sharded(separate: Callable[[torch.Tensor], torch.Tensor], mixtures:
     meta = torch.zeros(2, dtype=torch.long, device=mixtures.device)
     if local is not None:
         meta[0], meta[1] = local.shape[0], local.shape[2]
-    dist.all_reduce(meta, op=dist.ReduceOp.MAX)
+    all_reduce_off_stream(meta, op=dist.ReduceOp.MAX)
     S, Tout = int(meta[0]), int(meta[1])
     pad = torch.zeros(S, per, Tout, dtype=torch.float32, device=mixtures.device)
     if local is not None:
@@ -181,11 +201,11 @@ class GradSync:
             work, offset = self._pending
             self._pending = None
             head = flat[:offset]
-            dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce_off_stream(head, group=self.group)
             work.wait()
             self.bytes += head.numel() * head.element_size()
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce_off_stream(flat, group=self.group)          # (never on the caller's stream: see all_reduce_off_stream)
             self.bytes += flat.numel() * flat.element_size()
         if dist.get_world_size(self.group) > 1:
             flat.div_(dist.get_world_size(self.group))

@@ -65,10 +65,12 @@ class CapturedTrainStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         if self.sync is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
-            # The warm-up steps ran gradient all-reduces.  The process group's watchdog thread polls the events of those collectives
-            # (hipEventQuery, every 100 ms) until it has retired them; about one bench sub-run in 15 died in that thread (SIGABRT before
-            # the first replay) when a capture started while it was still polling.  Everything is complete after the synchronize above, so
-            # two polling periods later the watchdog's work list is empty and it issues no HIP call during the capture.
+            # The warm-up steps ran gradient all-reduces.  Their completion events are polled by the process group's watchdog thread
+            # (hipEventQuery, every 100 ms) until it has retired them, and HIP refuses such a query for an event whose stream is capturing -
+            # the watchdog then throws and the process aborts (round 4's ~1-in-15 SIGABRT; reproduced with a backtrace in round 5: DESIGN.md
+            # section 10c).  dist.all_reduce_off_stream keeps those events off every stream a capture can touch; this wait (two polling
+            # periods after everything has completed) additionally lets the watchdog empty its list before the capture starts, which also
+            # covers collectives issued by the caller's own code with plain dist.all_reduce.
             import os
             import time
             time.sleep(float(os.environ.get("SEPR_CAPTURE_DRAIN_S", "0.25") or 0.0))       # (0 = the round-4 behaviour, for tools/rccl_watchdog_loop.sh)
