@@ -12,7 +12,7 @@
  *   - every function returns an int status: SEPR_OK (0) or a negative SEPR_E* code; nothing throws;
  *   - no allocation inside: scratch is a caller-provided workspace (sepr_workspace_bytes tells how much);
  *   - the library never frees or retains caller memory, holds no global mutable state besides the
- *     opt-in profiler, and launches on the stream it is given (NULL = default stream): re-entrant
+ *     opt-in profiler, the latched A/B switches and the per-thread deferred-finisher window (both below), and launches on the stream it is given (NULL = default stream): re-entrant
  *     from several host threads, one per device, like torch.nn.parallel.data_parallel's replicas
  *     (reference engine.py:64,98,130,167);
  *   - all activations are fp32, *channel-last* rows: a tensor the reference holds as [b, C, T] is
@@ -504,6 +504,18 @@ int sepr_train_fold_bias(const void* const* w, const void* const* bias, const vo
 int sepr_train_pack_gcfn_fused(const void* const* w1, const void* const* b1, const void* const* ln_g, const void* const* ln_b,
                                const void* const* w2, const void* const* dw_w, const void* const* dw_b, int G, int F, void* w1p, void* w2p,
                                sepr_stream_t stream);
+
+/* ---- deferred gradient finishers (ABI 4.00) ---------------------------------------------------------------------------
+ * Every sepr_<block>_bwd ends the gradient of a projection behind a LayerNorm / in front of a LayerScale with a weight-sized "finisher"
+ * launch (csrc/sepr_train.h); a step has ~320 of them at 5-7 us each - launch latency, not work - and nothing in the backward reads
+ * their outputs.  Between sepr_train_defer_begin and sepr_train_defer_flush ON THE SAME HOST THREAD the finishers are queued and the
+ * flush runs them as a few batched launches on `stream` (bit-identical arithmetic).  `arena`: device scratch that receives the reduced
+ * contractions until the flush - the sum over the deferred projections of (N K + N) floats, i.e. about one model's worth of parameters
+ * (Base: 64 MB is plenty); a full arena simply falls back to immediate launches.  flush(close = 0) keeps the window open (a caller that
+ * needs the gradients of the blocks processed so far - an early all-reduce bucket - flushes there); flush(close = 1) ends it.  The window
+ * is per host thread (thread-local state); without one the entry points behave exactly as before. */
+int sepr_train_defer_begin(void* arena, size_t arena_bytes);
+int sepr_train_defer_flush(int close, sepr_stream_t stream);
 
 /* PIT_SISNR_time backward (criterions.py:191-217): d(sum_b loss[b] * gl[b]) / d est.  est, tgt, dest [S,B,T]; perm from the forward. */
 int sepr_pit_sisnr_bwd(const float* est, const float* tgt, const int* perm, const float* gl, int S, int B, int T, double eps,

@@ -197,6 +197,14 @@ int launch_finish_norm_linear(const float* dWh, const float* s, const float* W, 
 int launch_finish_linear_ls(const float* Gr, const float* s, const float* W, const float* bias, const float* ls, float* dW_g,
                             float* dbias_g, float* dls_g, int N, int K, hipStream_t st);
 
+// Deferred finishers (round 5; include/sepr.h sepr_train_defer_begin / _flush).  The ~320 finisher launches of a training step are 5-7 us
+// each - launch latency, not work (a weight-sized pass) - and nothing in the backward reads what they write (parameter gradients only).
+// While a deferral window is open on the calling thread, a finisher whose inputs (the reduced contraction G and its column sums s) live in
+// the window's ARENA is queued instead of launched, and the window's flush runs the queue as a few batched launches (8 jobs each, the job
+// table travels by value in the kernel arguments).  fin_alloc hands out arena slots for G / s; inputs anywhere else keep the immediate launch.
+float* fin_alloc(size_t count);      // nullptr: no window open on this thread, or the arena is full
+int fin_flush(hipStream_t st);       // launches and empties the queue (the window stays open)
+
 // ---- attention with stored probabilities (sepr_train_attn.hip) ----------------------------------------------------
 size_t relattn_train_ws(int n, int Tp, int F, int H);
 // QKV [n,Tp,3F] -> O [n,Tp,F]; P [n,H,Tp,Tp] = softmax probabilities (saved for the backward)

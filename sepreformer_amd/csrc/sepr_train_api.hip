@@ -39,6 +39,23 @@ struct Carve {
   size_t need() const { return align_up(off); }
 };
 
+// Scratch of ONE finished projection - the reduced contraction G [N][K] and its column sums s [N] (sepr_train.h finishers).  With a
+// deferred-finisher window open on this thread the pair lives in the window's arena until the flush (every projection its OWN slot: the
+// finisher runs later, so the buffers of a block cannot be shared between its projections as the workspace copies are); otherwise, and
+// in sizing runs, it is carved from the workspace like everything else (the carve itself is identical in both cases).
+struct FinBuf { float* G; float* s; };
+FinBuf fin_buf(Carve& ws, long long nk, int n) {
+  FinBuf b;
+  b.G = ws.f32((size_t)nk);
+  b.s = ws.f32((size_t)n);
+  if (!ws.dry) {
+    float* g = fin_alloc((size_t)nk);
+    float* s = g ? fin_alloc((size_t)n) : nullptr;
+    if (g && s) { b.G = g; b.s = s; }
+  }
+  return b;
+}
+
 int lin(int pro, int epi, GemmArgs& a, const sepr_lin& l, int site, hipStream_t st) {
   a.W = l.w;
   a.Wp = l.wp;
@@ -160,10 +177,12 @@ int gcfn_fused_bwd(const float* x, const float* dy, float* dx, int n, int T, int
   void* gd = ws.take((size_t)3 * F * M * sizeof(float));       // (sized for fp32 in both cases: one workspace plan)
   void* dh1 = ws.take((size_t)6 * F * M * sizeof(float));
   float* dyp = p > 0.f ? ws.f32((long long)F * M) : nullptr;
-  float* Gr = ws.f32(3LL * F * F);
-  float* s2 = ws.f32(F);
-  float* dWh = ws.f32(6LL * F * F);
-  float* s1 = ws.f32(6 * F);
+  const FinBuf fb2 = fin_buf(ws, 3LL * F * F, F);
+  float* Gr = fb2.G;
+  float* s2 = fb2.s;
+  const FinBuf fb1 = fin_buf(ws, 6LL * F * F, 6 * F);
+  float* dWh = fb1.G;
+  float* s1 = fb1.s;
   float* dxh = ws.f32((long long)F * M);
   const size_t tnb = tn_workspace_bytes((int)M, 6 * F, F) > tn_workspace_bytes((int)M, F, 3 * F) ? tn_workspace_bytes((int)M, 6 * F, F)
                                                                                                    : tn_workspace_bytes((int)M, F, 3 * F);
@@ -228,12 +247,14 @@ int gcfn_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, co
   const long long M = (long long)n * T;
   GcfnCtx k = gcfn_ctx(cx, M, F);
   float* dyp = p > 0.f ? ws.f32((long long)F * M) : nullptr;
-  float* Gr = ws.f32(3LL * F * F);
-  float* s2 = ws.f32(F);
+  const FinBuf fb2 = fin_buf(ws, 3LL * F * F, F);
+  float* Gr = fb2.G;
+  float* s2 = fb2.s;
   float* dg = ws.f32(3LL * F * M);
   float* dh1 = ws.f32(6LL * F * M);
-  float* dWh = ws.f32(6LL * F * F);
-  float* s1 = ws.f32(6 * F);
+  const FinBuf fb1 = fin_buf(ws, 6LL * F * F, 6 * F);
+  float* dWh = fb1.G;
+  float* s1 = fb1.s;
   float* dxh = ws.f32((long long)F * M);
   const size_t tnb = tn_workspace_bytes((int)M, 6 * F, F) > tn_workspace_bytes((int)M, F, 3 * F) ? tn_workspace_bytes((int)M, 6 * F, F)
                                                                                                    : tn_workspace_bytes((int)M, F, 3 * F);
@@ -331,8 +352,9 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
   const long long M = (long long)n * T;
   ClaCtx k = cla_ctx(cx, M, F);
   float* dyp = p > 0.f ? ws.f32((long long)F * M) : nullptr;
-  float* Gr = ws.f32(2LL * F * F);
-  float* s = ws.f32(2 * F);
+  const FinBuf fb3 = fin_buf(ws, 2LL * F * F, 2 * F), fb1 = fin_buf(ws, 2LL * F * F, 2 * F);      // linear3 (+ LayerScale), linear1 (behind the LayerNorm)
+  float* Gr = fb3.G;
+  float* s = fb3.s;
   float* dd = ws.f32(2LL * F * M);      // d(gelu out), later dz in place, later da
   float* dc = ws.f32((long long)F * M);
   float* du = ws.f32((long long)F * M);
@@ -384,10 +406,10 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
       TnArgs t = tn_args_zero();
       t.M = (int)M; t.N = 2 * F; t.K = F;
       t.A = da16; t.lda = 2 * F; t.a16 = 1; t.B = x; t.ldb = F; t.stats = k.stats;
-      t.G = Gr; t.ldg = F; t.colsum = s;
+      t.G = fb1.G; t.ldg = F; t.colsum = fb1.s;
       SEPR_TRY(launch_gemm_tn(t, x3, tnw, tnb, st));
     }
-    SEPR_TRY(launch_finish_norm_linear(Gr, s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, st));
+    SEPR_TRY(launch_finish_norm_linear(fb1.G, fb1.s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, st));
     return dgrad_ln(da16, 2 * F, 2 * F, w->l1_t, 1, x, k.stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
   }
   SEPR_TRY(wgrad(dyq, F, k.d, 2 * F, nullptr, Gr, s, M, F, 2 * F, 0, x3, tnw, tnb, st));
@@ -403,8 +425,8 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
     SEPR_TRY(launch_dwconv_same(dc, du, n, T, F, K, w->dw_wf, w->zeros, st));                 // correlation with reversed taps
     SEPR_TRY(launch_glu_bwd(du, k.a, dd, M, F, st));                                           // dd := da [M][2F]
   }
-  SEPR_TRY(wgrad(dd, 2 * F, x, F, k.stats, Gr, s, M, 2 * F, F, 0, x3, tnw, tnb, st));
-  SEPR_TRY(launch_finish_norm_linear(Gr, s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, st));
+  SEPR_TRY(wgrad(dd, 2 * F, x, F, k.stats, fb1.G, fb1.s, M, 2 * F, F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_norm_linear(fb1.G, fb1.s, w->w1, w->ln_g, w->ln_b, g->w1, g->b1, g->ln_g, g->ln_b, 2 * F, F, st));
   return dgrad_ln(dd, 2 * F, 2 * F, w->l1_t, 0, x, k.stats, dy, nullptr, 0, 0, 0, dx, dxh, M, F, st);
 }
 
@@ -503,8 +525,7 @@ int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, in
   float* dqkv = ws.f32(3LL * F * Mp);
   float* dxh_p = ws.f32((long long)F * Mp);
   float* dxd = ws.f32((long long)F * Mp);
-  float* dWh = ws.f32(3LL * F * F);
-  float* s = ws.f32(3 * F);
+  const FinBuf fbo = fin_buf(ws, (long long)F * F, F), fbq = fin_buf(ws, 3LL * F * F, 3 * F), fbg = fin_buf(ws, (long long)F * F, F);   // out, q/k/v, gate
   float* dxh = ws.f32((long long)F * M);
   size_t tnb = tn_workspace_bytes((int)M, F, F);
   if (tn_workspace_bytes((int)Mp, 3 * F, F) > tnb) tnb = tn_workspace_bytes((int)Mp, 3 * F, F);
@@ -519,14 +540,14 @@ int ega_bwd(const float* x, const float* dy, float* dx, int n, int T, int Tp, in
   SEPR_TRY(launch_gate_bwd(dy, k.zg, k.att, dzg, datt, n, T, Tp, F, st));
   if (p > 0.f) SEPR_TRY(launch_dropout(datt, datt, (long long)F * Mp, p, seed, site_off(1), st));   // attention-output dropout mask
   // attention branch first (its input gradient is added while the gate branch's LayerNorm backward writes dx)
-  SEPR_TRY(mha_out_bwd(datt, k.o, dO, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, st));
+  SEPR_TRY(mha_out_bwd(datt, k.o, dO, Mp, F, &w->attn, &g->attn, fbo.G, fbo.s, x3, tnw, tnb, st));
   if (mfma) SEPR_TRY(launch_relattn_x3_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, drop_salt(), atw, atb, st,
                                            w->attn.qkv.planes == 1 ? 1 : 0, attn_one(w->attn.qkv)));
   else SEPR_TRY(launch_relattn_bwd(k.qkv, k.P, k.o, dO, dqkv, g->pe_k, n, Tp, F, H, w->pe_k, w->maxlen, p, seed, site_off(0), atw, atb, st));
-  SEPR_TRY(mha_qkv_bwd(dqkv, xp, k.stats_p, dxh_p, Mp, F, &w->attn, &g->attn, dWh, s, x3, tnw, tnb, nullptr, dxd, st));
+  SEPR_TRY(mha_qkv_bwd(dqkv, xp, k.stats_p, dxh_p, Mp, F, &w->attn, &g->attn, fbq.G, fbq.s, x3, tnw, tnb, nullptr, dxd, st));
   // gate projection behind its own LayerNorm
-  SEPR_TRY(wgrad(dzg, F, x, F, k.stats, dWh, s, M, F, F, 0, x3, tnw, tnb, st));
-  SEPR_TRY(launch_finish_norm_linear(dWh, s, w->gate_w, w->gate_ln_g, w->gate_ln_b, g->gate_w, g->gate_b, g->gate_ln_g, g->gate_ln_b, F, F,
+  SEPR_TRY(wgrad(dzg, F, x, F, k.stats, fbg.G, fbg.s, M, F, F, 0, x3, tnw, tnb, st));
+  SEPR_TRY(launch_finish_norm_linear(fbg.G, fbg.s, w->gate_w, w->gate_ln_g, w->gate_ln_b, g->gate_w, g->gate_b, g->gate_ln_g, g->gate_ln_b, F, F,
                                      st));
   // dx = dy + LN'(dzg . (Wgate gamma)) + avg-pool backward of dxd
   return dgrad_ln(dzg, F, F, w->gate_t, 0, x, k.stats, dy, dxd, T, Tp, fac, dx, dxh, M, F, st);
@@ -569,8 +590,7 @@ int spk_bwd(const float* x, const float* dy, float* dx, int nS, int S, int T, in
   SpkCtx k = spk_ctx(cx, M, F);
   float* dO = ws.f32((long long)F * M);
   float* dqkv = ws.f32(3LL * F * M);
-  float* dWh = ws.f32(3LL * F * F);
-  float* s = ws.f32(3 * F);
+  const FinBuf fbo = fin_buf(ws, (long long)F * F, F), fbq = fin_buf(ws, 3LL * F * F, 3 * F);      // out, q/k/v
   float* dxh = dO;                      // dO is dead after the speaker-mix backward
   float* dyp = p > 0.f ? ws.f32((long long)F * M) : nullptr;
   const size_t tnb = tn_workspace_bytes((int)M, 3 * F, F);
@@ -583,9 +603,9 @@ int spk_bwd(const float* x, const float* dy, float* dx, int nS, int S, int T, in
     SEPR_TRY(launch_dropout(dy, dyp, (long long)F * M, p, seed, site_off(1), st));
     dyq = dyp;
   }
-  SEPR_TRY(mha_out_bwd(dyq, k.o, dO, M, F, w, g, dWh, s, x3, tnw, tnb, st));
+  SEPR_TRY(mha_out_bwd(dyq, k.o, dO, M, F, w, g, fbo.G, fbo.s, x3, tnw, tnb, st));
   SEPR_TRY(launch_spkmix_bwd(k.qkv, dO, dqkv, nS / S, S, T, F, H, p, seed, site_off(0), st));
-  return mha_qkv_bwd(dqkv, x, k.stats, dxh, M, F, w, g, dWh, s, x3, tnw, tnb, dy, dx, st);
+  return mha_qkv_bwd(dqkv, x, k.stats, dxh, M, F, w, g, fbq.G, fbq.s, x3, tnw, tnb, dy, dx, st);
 }
 
 // =====================================================================================================================

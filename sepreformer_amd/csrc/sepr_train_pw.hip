@@ -6,6 +6,7 @@
 // Reference semantics are those of torch.autograd applied to modules/network.py / modules/module.py; each kernel cites
 // the forward lines it differentiates.
 #include "sepr_train.h"
+#include <vector>
 
 namespace sepr {
 
@@ -1486,9 +1487,125 @@ __global__ __launch_bounds__(64) void finish_ls_kernel(const float* __restrict__
   }
 }
 }  // namespace
+// ---- deferred / batched form (sepr_train.h "Deferred finishers") --------------------------------------------------------------------
+namespace {
+struct FinJob {
+  int kind, N, K, pad;                 // kind 0: LayerNorm-folded (finish_norm_kernel), 1: LayerScale (finish_ls_kernel)
+  const float *G, *s, *W, *p0, *p1;    // kind 0: p0 = gamma, p1 = beta;  kind 1: p0 = bias, p1 = ls
+  float *o0, *o1, *o2, *o3;            // kind 0: dW, dbias, dgamma, dbeta;  kind 1: dW, dbias, dls, -
+};
+constexpr int FIN_BATCH = 8;
+struct FinBatch { FinJob j[FIN_BATCH]; };
+// grid (max blocks of any job in the batch, jobs): block (x, y) runs block x of job y's own kernel, bit for bit the immediate form
+__global__ __launch_bounds__(1024) void finish_batch_kernel(const FinBatch b) {
+  const FinJob& j = b.j[blockIdx.y];
+  if (j.kind == 0) {
+    __shared__ float sh[16][64][2];
+    if ((int)blockIdx.x >= j.N + (j.K + 63) / 64) return;
+    if ((int)blockIdx.x < j.N) {
+      const int n = blockIdx.x;
+      const float sn = j.s[n];
+      for (int k = threadIdx.x; k < j.K; k += 1024) j.o0[(long long)n * j.K + k] += fmaf(j.G[(long long)n * j.K + k], j.p0[k], sn * j.p1[k]);
+      if (threadIdx.x == 0 && j.o1) j.o1[n] += sn;
+      return;
+    }
+    const int kl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int k = ((int)blockIdx.x - j.N) * 64 + kl;
+    float a = 0.f, c = 0.f;
+    if (k < j.K) {
+#pragma unroll 4
+      for (int n = rl; n < j.N; n += 16) {
+        const float w = j.W[(long long)n * j.K + k];
+        a = fmaf(w, j.G[(long long)n * j.K + k], a);
+        c = fmaf(j.s[n], w, c);
+      }
+    }
+    sh[rl][kl][0] = a;
+    sh[rl][kl][1] = c;
+    __syncthreads();
+    if (rl == 0 && k < j.K) {
+      float ta = 0.f, tc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ta += sh[r][kl][0]; tc += sh[r][kl][1]; }
+      j.o2[k] += ta;
+      j.o3[k] += tc;
+    }
+  } else {
+    if ((int)blockIdx.x >= j.N || threadIdx.x >= 64) return;
+    const int n = blockIdx.x;
+    const float l = j.p1[n];
+    float a = 0.f;
+    for (int k = threadIdx.x; k < j.K; k += 64) {
+      const float gr = j.G[(long long)n * j.K + k];
+      j.o0[(long long)n * j.K + k] += l * gr;
+      a = fmaf(j.W[(long long)n * j.K + k], gr, a);
+    }
+    a = wave_sum(a);
+    if (threadIdx.x == 0) {
+      j.o1[n] += l * j.s[n];
+      j.o2[n] += fmaf(j.p0[n], j.s[n], a);
+    }
+  }
+}
+struct FinQueue {
+  bool open = false;
+  char* arena = nullptr;
+  size_t bytes = 0, off = 0;
+  std::vector<FinJob> jobs;
+};
+thread_local FinQueue g_fin;
+bool fin_in_arena(const void* p) {
+  const char* c = static_cast<const char*>(p);
+  return g_fin.open && c >= g_fin.arena && c < g_fin.arena + g_fin.bytes;
+}
+}  // namespace
+float* fin_alloc(size_t count) {
+  if (!g_fin.open) return nullptr;
+  const size_t o = align_up(g_fin.off), n = count * sizeof(float);
+  if (o + n > g_fin.bytes) return nullptr;
+  g_fin.off = o + n;
+  return reinterpret_cast<float*>(g_fin.arena + o);
+}
+int fin_flush(hipStream_t st) {
+  // Jobs of one launch run CONCURRENTLY, so two jobs that accumulate into the same tensor (the q / k / v finishers share the LayerNorm's
+  // dgamma / dbeta) never share a launch: a job that writes what an earlier job of the current batch writes starts the next batch.  Launches
+  // run in queue order, so every destination still sees its additions in the immediate form's order - bit-identical gradients.
+  const size_t nj = g_fin.jobs.size();
+  size_t i = 0;
+  while (i < nj) {
+    FinBatch b;
+    int cnt = 0, bx = 1;
+    while (i < nj && cnt < FIN_BATCH) {
+      const FinJob& c = g_fin.jobs[i];
+      bool clash = false;
+      for (int q = 0; q < cnt && !clash; ++q) {
+        const float* oq[4] = {b.j[q].o0, b.j[q].o1, b.j[q].o2, b.j[q].o3};
+        const float* oc[4] = {c.o0, c.o1, c.o2, c.o3};
+        for (int x = 0; x < 4 && !clash; ++x)
+          for (int y = 0; y < 4; ++y)
+            if (oq[x] && oq[x] == oc[y]) { clash = true; break; }
+      }
+      if (clash) break;
+      b.j[cnt++] = c;
+      const int need = c.kind == 0 ? c.N + (c.K + 63) / 64 : c.N;
+      if (need > bx) bx = need;
+      ++i;
+    }
+    for (int q = cnt; q < FIN_BATCH; ++q) b.j[q] = b.j[0];
+    hipLaunchKernelGGL(finish_batch_kernel, dim3(bx, cnt), dim3(1024), 0, st, b);
+  }
+  g_fin.jobs.clear();
+  g_fin.off = 0;                       // (everything queued has been consumed in stream order: the arena can be carved again)
+  SEPR_CHECK_LAUNCH("finish_batch_kernel");
+  return SEPR_OK;
+}
 int launch_finish_norm_linear(const float* dWh, const float* s, const float* W, const float* g, const float* b, float* dW_g,
                               float* dbias_g, float* dg_g, float* db_g, int N, int K, hipStream_t st) {
   if (!dWh || !s || !W || !g || !b || !dW_g || !dg_g || !db_g || N <= 0 || K <= 0) return SEPR_EINVAL;
+  if (fin_in_arena(dWh) && fin_in_arena(s)) {
+    g_fin.jobs.push_back(FinJob{0, N, K, 0, dWh, s, W, g, b, dW_g, dbias_g, dg_g, db_g});
+    return SEPR_OK;
+  }
   hipLaunchKernelGGL(finish_norm_kernel, dim3(N + (K + 63) / 64), dim3(1024), 0, st, dWh, s, W, g, b, dW_g, dbias_g, dg_g, db_g, N, K);
   SEPR_CHECK_LAUNCH("finish_norm_linear kernels");
   return SEPR_OK;
@@ -1496,9 +1613,32 @@ int launch_finish_norm_linear(const float* dWh, const float* s, const float* W, 
 int launch_finish_linear_ls(const float* Gr, const float* s, const float* W, const float* bias, const float* ls, float* dW_g,
                             float* dbias_g, float* dls_g, int N, int K, hipStream_t st) {
   if (!Gr || !s || !W || !bias || !ls || !dW_g || !dbias_g || !dls_g || N <= 0 || K <= 0) return SEPR_EINVAL;
+  if (fin_in_arena(Gr) && fin_in_arena(s)) {
+    g_fin.jobs.push_back(FinJob{1, N, K, 0, Gr, s, W, bias, ls, dW_g, dbias_g, dls_g, nullptr});
+    return SEPR_OK;
+  }
   hipLaunchKernelGGL(finish_ls_kernel, dim3(N), dim3(64), 0, st, Gr, s, W, bias, ls, dW_g, dbias_g, dls_g, N, K);
   SEPR_CHECK_LAUNCH("finish_ls_kernel");
   return SEPR_OK;
 }
 
 }  // namespace sepr
+
+extern "C" int sepr_train_defer_begin(void* arena, size_t arena_bytes) {
+  using namespace sepr;
+  if (!arena || arena_bytes < 4096) return SEPR_EINVAL;
+  if (g_fin.open && !g_fin.jobs.empty()) return SEPR_EINVAL;      // a window with queued work must be flushed first
+  g_fin.open = true;
+  g_fin.arena = static_cast<char*>(arena);
+  g_fin.bytes = arena_bytes;
+  g_fin.off = 0;
+  g_fin.jobs.clear();
+  return SEPR_OK;
+}
+extern "C" int sepr_train_defer_flush(int close, sepr_stream_t stream) {
+  using namespace sepr;
+  if (!g_fin.open) return SEPR_OK;
+  const int rc = fin_flush(static_cast<hipStream_t>(stream));
+  if (close) g_fin.open = false;
+  return rc;
+}

@@ -170,6 +170,8 @@ SIGNATURES = {
     "sepr_linear_wgrad_norm": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _sz, _fp]),
     "sepr_train_pack_lin": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _fp]),
     "sepr_train_fold_bias": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp]),
+    "sepr_train_defer_begin": (_i, [_fp, _sz]),
+    "sepr_train_defer_flush": (_i, [_i, _fp]),
     "sepr_train_pack_gcfn_fused": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _fp]),
     "sepr_pit_sisnr_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _d, _d, _fp, _fp, _sz, _fp]),
     "sepr_pit_sisnr_mag_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),

@@ -39,6 +39,7 @@ class TrainEngine:
         self._ws: Optional[torch.Tensor] = None
         self._idx: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
         self._sizes: Dict[tuple, int] = {}      # sepr_train_ctx_bytes / sepr_train_ws_bytes per (kind, op, shape): one C call each, ever
+        self._fin_arena: Optional[torch.Tensor] = None      # deferred-finisher arena (backward)
         self._attn_valu = os.environ.get("SEPR_TRAIN_ATTN_VALU", "0") == "1"     # (the library latches it at its first EGA call as well)
 
     # ---- plumbing -------------------------------------------------------------------------------------------------------
@@ -310,6 +311,25 @@ class TrainEngine:
         S, F, N = c.num_spks, c.feat, c.enc_channels
         nS = B * S
         Tout = (L_ - 1) * c.enc_stride + c.enc_kernel
+        # Deferred gradient finishers (include/sepr.h sepr_train_defer_begin): the ~320 weight-sized finisher launches of the walk below are
+        # queued by the library and run as ~45 batched launches - at the early all-reduce point (the decoder half's gradients must be final
+        # there) and at the end.  The arena holds the reduced contractions in between: about one model's worth of parameters.
+        if self._fin_arena is None:
+            n_par = sum(int(v.numel()) for v in tp.sd.values() if v.dtype == torch.float32)
+            self._fin_arena = torch.empty(int(1.25 * 4 * n_par) + (8 << 20), dtype=torch.uint8, device=self.device)
+        st_ = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.sepr_train_defer_begin(self._fin_arena.data_ptr(), self._fin_arena.numel()), "sepr_train_defer_begin")
+        try:
+            self._backward_walk(tape, dims, d_wav, d_aux, tp, p_drop, on_decoder_done)
+        finally:
+            L.check(self.lib.sepr_train_defer_flush(1, st_), "sepr_train_defer_flush")
+
+    def _backward_walk(self, tape: list, dims, d_wav, d_aux, tp: TrainPack, p_drop: float, on_decoder_done=None):
+        c = self.cfg
+        B, T, L_, Lp, Tp = dims
+        S, F, N = c.num_spks, c.feat, c.enc_channels
+        nS = B * S
+        Tout = (L_ - 1) * c.enc_stride + c.enc_kernel
         dcur: Optional[torch.Tensor] = None          # gradient w.r.t. the running activation
         dskips: Dict[int, torch.Tensor] = {}         # gradient w.r.t. the split skip tensors, by encoder level
         denc = torch.zeros(B, L_, N, dtype=torch.float32, device=self.device)
@@ -342,6 +362,8 @@ class TrainEngine:
             elif kind == "split":
                 _, xin, cx, w, Tc = rec
                 if on_decoder_done is not None:
+                    # (the decoder half's queued finishers run now: the early all-reduce bucket reads their gradients)
+                    L.check(self.lib.sepr_train_defer_flush(0, torch.cuda.current_stream(self.device).cuda_stream), "sepr_train_defer_flush")
                     on_decoder_done()
                 dx = torch.empty_like(xin)
                 self.split_bwd(xin, cx, w, dcur, dx, False, B, Tc)

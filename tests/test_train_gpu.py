@@ -1869,3 +1869,37 @@ def test_device_gcfn_fused_pack_equals_torch_packer(F):
     cav, cbv = ca[:, :, :320].view(G, nch, 2, 10, 16), cb[:, :, :320].view(G, nch, 2, 10, 16)
     assert torch.equal(cav[:, :, :, 2:], cbv[:, :, :, 2:])                                      # taps and conv biases (fp64 products)
     assert float((cav[:, :, :, :2] - cbv[:, :, :, :2]).abs().max()) <= 2.0 * float(torch.finfo(torch.float32).eps * cbv[:, :, :, :2].abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_deferred_finishers_equal_immediate(precision):
+    """Round 5: TrainEngine.backward queues the ~320 gradient-finisher launches of a step (sepr_train_defer_begin / _flush) and runs them as a
+    few batched launches.  The batched kernel is the immediate kernels' code per job, jobs that accumulate into the same tensor never share
+    a launch, launches keep queue order - so every gradient must be BIT-identical to the immediate form (forced here by an arena too small
+    for any slot).  Base width so that EGA (three finishers per block, q / k / v sharing dgamma) and every block kind take part."""
+    from sepreformer_amd.model import Model
+    cfg = VARIANTS["SepReformer_Base_WSJ0"]
+    dev = torch.device("cuda:0")
+    m = Model.from_config(cfg, init_seed=0, precision=precision).load_synthetic_(0).to(dev)
+    m.train()
+    m.dropout_p = 0.0
+    x = torch.from_numpy(synth_sources(2, 4000, seed=3).sum(1)).to(dev)
+
+    def grads():
+        m.zero_grad(set_to_none=True)
+        audio, aux = m(x)
+        (sum(a.square().mean() for a in audio) + sum(b.square().mean() for lvl in aux for b in lvl)).backward()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    g_def = grads()
+    eng = m.__dict__["_train_engine"]
+    assert eng._fin_arena is not None and eng._fin_arena.numel() > (32 << 20)
+    big = eng._fin_arena
+    eng._fin_arena = torch.empty(4096, dtype=torch.uint8, device=dev)          # no slot fits: every finisher launches immediately
+    g_imm = grads()
+    eng._fin_arena = big
+    g_def2 = grads()
+    bad = [k for k in g_def if not (torch.equal(g_def[k], g_imm[k]) and torch.equal(g_def[k], g_def2[k]))]
+    assert not bad, bad[:8]
+    assert all(torch.isfinite(v).all() for v in g_def.values())
