@@ -1568,28 +1568,39 @@ float* fin_alloc(size_t count) {
 }
 int fin_flush(hipStream_t st) {
   // Jobs of one launch run CONCURRENTLY, so two jobs that accumulate into the same tensor (the q / k / v finishers share the LayerNorm's
-  // dgamma / dbeta) never share a launch: a job that writes what an earlier job of the current batch writes starts the next batch.  Launches
-  // run in queue order, so every destination still sees its additions in the immediate form's order - bit-identical gradients.
+  // dgamma / dbeta) never share a launch, and launches run in order: a job goes into the first batch with room AFTER the batch of the last
+  // earlier job it clashes with.  Every destination therefore sees its additions in the immediate form's order - bit-identical gradients.
+  // (Clashes only occur between finishers of one block, i.e. within a few queue positions: the search looks back 16 jobs.)
   const size_t nj = g_fin.jobs.size();
-  size_t i = 0;
-  while (i < nj) {
+  auto clash = [](const FinJob& p, const FinJob& c) {
+    const float* op[4] = {p.o0, p.o1, p.o2, p.o3};
+    const float* oc[4] = {c.o0, c.o1, c.o2, c.o3};
+    for (int x = 0; x < 4; ++x)
+      for (int y = 0; y < 4; ++y)
+        if (op[x] && op[x] == oc[y]) return true;
+    return false;
+  };
+  std::vector<int> batch_of(nj, 0), fill;
+  for (size_t i = 0; i < nj; ++i) {
+    int b0 = 0;
+    for (size_t q = i > 16 ? i - 16 : 0; q < i; ++q)
+      if (batch_of[q] + 1 > b0 && clash(g_fin.jobs[q], g_fin.jobs[i])) b0 = batch_of[q] + 1;
+    int bsel = b0;
+    while (bsel < (int)fill.size() && fill[bsel] >= FIN_BATCH) ++bsel;
+    if (bsel >= (int)fill.size()) fill.resize(bsel + 1, 0);
+    batch_of[i] = bsel;
+    ++fill[bsel];
+  }
+  for (int bi = 0; bi < (int)fill.size(); ++bi) {
+    if (fill[bi] == 0) continue;
     FinBatch b;
     int cnt = 0, bx = 1;
-    while (i < nj && cnt < FIN_BATCH) {
+    for (size_t i = 0; i < nj; ++i) {
+      if (batch_of[i] != bi) continue;
       const FinJob& c = g_fin.jobs[i];
-      bool clash = false;
-      for (int q = 0; q < cnt && !clash; ++q) {
-        const float* oq[4] = {b.j[q].o0, b.j[q].o1, b.j[q].o2, b.j[q].o3};
-        const float* oc[4] = {c.o0, c.o1, c.o2, c.o3};
-        for (int x = 0; x < 4 && !clash; ++x)
-          for (int y = 0; y < 4; ++y)
-            if (oq[x] && oq[x] == oc[y]) { clash = true; break; }
-      }
-      if (clash) break;
       b.j[cnt++] = c;
       const int need = c.kind == 0 ? c.N + (c.K + 63) / 64 : c.N;
       if (need > bx) bx = need;
-      ++i;
     }
     for (int q = cnt; q < FIN_BATCH; ++q) b.j[q] = b.j[0];
     hipLaunchKernelGGL(finish_batch_kernel, dim3(bx, cnt), dim3(1024), 0, st, b);

@@ -40,6 +40,7 @@ class TrainEngine:
         self._idx: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
         self._sizes: Dict[tuple, int] = {}      # sepr_train_ctx_bytes / sepr_train_ws_bytes per (kind, op, shape): one C call each, ever
         self._fin_arena: Optional[torch.Tensor] = None      # deferred-finisher arena (backward)
+        self._defer = os.environ.get("SEPR_TRAIN_DEFER", "1") != "0"           # A/B switch of the deferred finishers
         self._attn_valu = os.environ.get("SEPR_TRAIN_ATTN_VALU", "0") == "1"     # (the library latches it at its first EGA call as well)
 
     # ---- plumbing -------------------------------------------------------------------------------------------------------
@@ -314,6 +315,8 @@ class TrainEngine:
         # Deferred gradient finishers (include/sepr.h sepr_train_defer_begin): the ~320 weight-sized finisher launches of the walk below are
         # queued by the library and run as ~45 batched launches - at the early all-reduce point (the decoder half's gradients must be final
         # there) and at the end.  The arena holds the reduced contractions in between: about one model's worth of parameters.
+        if not self._defer:
+            return self._backward_walk(tape, dims, d_wav, d_aux, tp, p_drop, on_decoder_done)
         if self._fin_arena is None:
             n_par = sum(int(v.numel()) for v in tp.sd.values() if v.dtype == torch.float32)
             self._fin_arena = torch.empty(int(1.25 * 4 * n_par) + (8 << 20), dtype=torch.uint8, device=self.device)
@@ -362,7 +365,7 @@ class TrainEngine:
             elif kind == "split":
                 _, xin, cx, w, Tc = rec
                 if on_decoder_done is not None:
-                    # (the decoder half's queued finishers run now: the early all-reduce bucket reads their gradients)
+                    # (the decoder half's queued finishers run now: the early all-reduce bucket reads their gradients; a no-op without a window)
                     L.check(self.lib.sepr_train_defer_flush(0, torch.cuda.current_stream(self.device).cuda_stream), "sepr_train_defer_flush")
                     on_decoder_done()
                 dx = torch.empty_like(xin)
