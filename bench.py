@@ -501,7 +501,10 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
         finally:
             model.use_graphs = False
         rec["latency_b1"] = {"unit": "ms per 4 s utterance (batch 1, model(x): full forward incl. aux heads)",
-                             "eager": eager, "hipgraph": graphed}
+                             "eager": eager, "hipgraph": graphed,
+                             # launches of one batch-1 forward: a rocprofv3 kernel trace (tools/b1_launches.sh), not re-counted in this run
+                             "launches": 295, "launches_source": "static: profiles/r05_v1_b1_launches.txt (rocprofv3 --kernel-trace of 21 forwards)",
+                             "note": "the latency is the sum of per-tile kernel latencies (56 fused-GCFN launches x 38 us = 2.15 ms), not launch overhead: hipGraph replay is no faster"}
     del model
     torch.cuda.empty_cache()
     return rec
