@@ -1278,6 +1278,9 @@ def test_general_loader_contraction_full_size(x3):
     soft.done()
 
 
+B4_STEP_MIN_DB = 80.0      # batch-4 whole-step bar = the batch-1 bar (measured, round 5: worst tensor 81.35 dB, median 92.9 dB; batch 1: 81.57 / 96.3)
+
+
 def _frozen_gate_step(precision, B, T, seed):
     """One train step of Base (dropout 0) on the device with the reference's FULL loss, and the same step through the oracle with
     the auxiliary heads' ReLU gates frozen to the gates the device forward took (see test_train_step_base_full_loss_frozen_gates).
@@ -1325,14 +1328,17 @@ def _frozen_gate_step(precision, B, T, seed):
     return cfg, m, audio, aux, loss, sdl, o_audio, o_aux, o_loss
 
 
-def test_train_step_base_4s_gradients_match_oracle():
-    """The reference loop's step (engine.py:60-77: forward, full loss, backward) at its REAL length - Base, 4 s, one utterance:
+@pytest.mark.parametrize("B,bar", [(1, MIN_DB), (4, B4_STEP_MIN_DB)])
+def test_train_step_base_4s_gradients_match_oracle(B, bar):
+    """The reference loop's step (engine.py:60-77: forward, full loss, backward) at its REAL length - Base, 4 s:
     8000-frame sequences at the top level, T' = 500 attention, every kernel of the bench's training step in its large-launch
     instantiation - with EVERY one of the 1312 gradient tensors checked against the oracle (auxiliary ReLU gates frozen to the device's,
-    which removes the loss's only discontinuity).  Default bf16x3 arithmetic, bar 80 dB per tensor like the 0.5 s test."""
-    B, T = 1, 32000
+    which removes the loss's only discontinuity).  Default bf16x3 arithmetic; one utterance at the 80 dB bar of the 0.5 s test, and (round 5,
+    review round 4 weak #1) a batch of FOUR - 32 000 rows per top-level contraction, four times longer fp32 sums on both sides, BatchNorm
+    statistics over four sequences - at the same bar (the margin did not shrink with the batch: 81.4 dB worst tensor against 81.6)."""
+    T = 32000
     cfg, m, audio, aux, loss, sdl, o_audio, o_aux, o_loss = _frozen_gate_step("bf16x3", B, T, seed=41)
-    soft = Soft("train_step.base_4s.bf16x3.full_frozen_gates")
+    soft = Soft("train_step.base_4s.bf16x3.full_frozen_gates" + ("" if B == 1 else f".b{B}"))
     soft.agree("main", torch.stack(list(audio), 0), torch.stack([a.detach() for a in o_audio], 0))
     soft.agree("aux", torch.stack([torch.stack(list(a), 0) for a in aux], 0),
                torch.stack([torch.stack([t_.detach()[..., :T] for t_ in a], 0) for a in o_aux], 0))
@@ -1340,7 +1346,7 @@ def test_train_step_base_4s_gradients_match_oracle():
     gscale = max(float(v.grad.abs().max()) for v in sdl.values() if v.requires_grad and v.grad is not None)
     dbs = []
     for k, p_ in m.named_parameters():
-        agree_grad(soft, "grad." + k, k, p_.grad, sdl[k].grad, gscale, MIN_DB)
+        agree_grad(soft, "grad." + k, k, p_.grad, sdl[k].grad, gscale, bar)
         if not k.endswith(STRUCTURAL_ZERO):
             dbs.append(REPORT.get(f"{soft.tag}.grad.{k}", 999.0))
     record(f"{soft.tag}.worst_grad_db", float(np.min(dbs)))
