@@ -88,6 +88,8 @@ constexpr int GB_BKS = 64;           // K extent of one LDS slab
 constexpr int GB_LDK = GB_BKS + SEPR_GB_LDK_PAD;  // bf16 per LDS row (160 B; 144 B with pad 8)
 constexpr int GB_HS = 128 + 4;       // fp32 row stride of the h1 / dc tile (64 value + 64 gate columns)
 constexpr int GB_DS = 64 + 4;        // fp32 row stride of the dgd tile
+constexpr int GB_RS = 36;            // fp32 row stride of the depthwise-partial scratch [4 waves][16 column quads][32 sums] that reuses the dgd tile
+static_assert(4 * 16 * GB_RS <= GB_BM * GB_DS, "the reduction scratch must fit the dgd tile");
 constexpr int GB_THREADS = 256;
 
 struct GcfnBwdArgs {
@@ -499,7 +501,9 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
       st4(hr + 64, dcg[i]);
     }
     if (lane < 16) {
-      float* rs = Ds + (wn * 16 + q4) * 32;
+      // (row stride 36 floats, not 32: the 16 lanes' 16-byte stores then hit 16 distinct bank groups instead of two - PMC, round 5: LDS bank
+      //  conflicts were 9.8 % of this kernel's CU cycles)
+      float* rs = Ds + (wn * 16 + q4) * GB_RS;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         st4(rs + 8 * e, make_float4(acc8[e][0], acc8[e][1], acc8[e][2], acc8[e][3]));
@@ -545,7 +549,8 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int o = tid + GB_THREADS * h;                    // (q, slot) = (o / 32, o % 32)
-        po[o] = (Ds[o] + Ds[512 + o]) + (Ds[1024 + o] + Ds[1536 + o]);
+        const float* d = Ds + (o >> 5) * GB_RS + (o & 31);
+        po[o] = (d[0] + d[16 * GB_RS]) + (d[32 * GB_RS] + d[48 * GB_RS]);
       }
     }
     tile = nxt;

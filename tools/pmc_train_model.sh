@@ -7,7 +7,7 @@ REGEX="$1"; shift
 ROOT=$PWD
 cd /tmp
 timeout 500 rocprofv3 --pmc "$@" --kernel-trace --kernel-include-regex "$REGEX" --output-format csv -d $OUT/pmc3 -o m -- \
-  python $ROOT/bench.py --mode train --precision bf16x3 --batch 16 --steps 1 --warmup 0 --train-graphs off > $OUT/pmc3.log 2>&1
+  python $ROOT/bench.py --mode train --precision ${PMC_PREC:-bf16x3} --batch 16 --steps 1 --warmup 0 --train-graphs off > $OUT/pmc3.log 2>&1
 echo "rc=$?"
 python3 - <<PY
 import csv, glob, collections
