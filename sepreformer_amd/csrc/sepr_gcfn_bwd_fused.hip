@@ -408,12 +408,7 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
     __syncthreads();
 
     // ---- pass A: conv, GLU, dropout, GLU backward for rows 1..62; thread = 4 hidden channel pairs x 4 consecutive rows ----
-    // Thread = 4 channel pairs (one float4 column q4 of the 16) x 4 consecutive rows (strip).  The column a lane owns is ROTATED by its strip:
-    // a wave's four strips start 4 rows = 4 x 132 (or 4 x 68) words apart, i.e. 16 banks, and the LDS serves a ds_read_b128 in fixed
-    // 16-lane groups made of lanes of TWO adjacent strips ({0-3, 12-15, 20-27}, ... - MI355X_MICROARCH.md, LDS table): with the same column in
-    // every strip a group touches 16 of the 64 banks twice (PMC, round 5: bank conflicts 9.8 % of this kernel's CU cycles, ~44 two-cycle-longer
-    // reads per thread and tile).  With column (lane - 4 strip) mod 16 every lane of a group lands on bank group 4 x (lane mod 16): conflict-free.
-    const int strip = tid >> 4, q4 = ((tid & 15) + 12 * (strip & 3)) & 15;
+    const int q4 = tid & 15, strip = tid >> 4;
     const int c4 = 4 * q4, hc = 64 * nb + c4;                    // hidden value channel of column 0 (gate: C3 + hc)
     const int C6 = 2 * C3;
     const float4 wv0 = ld4(a.dw_w + hc), wv1 = ld4(a.dw_w + C6 + hc), wv2 = ld4(a.dw_w + 2 * C6 + hc);
@@ -487,17 +482,14 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
 #undef SEPR_GB_ELEM
         if (own) gb_store4(a.g, (long long)m * C3 + hc, gd, a.out16 != 0);
       }
-      // depthwise gradient partials: sum over the 4 strips of this wave, then over the 4 waves through LDS.  The lane of strip s' that owns
-      // this lane's columns is 16 s' + (q4 + 4 s') mod 16 (the column rotation above); same pairing order as before: (s + s^1) + (s^2 + s^3)
-      const int sw = strip & 3;
-      const int p1 = 16 * (sw ^ 1) + ((q4 + 4 * (sw ^ 1)) & 15), p2 = 16 * (sw ^ 2) + ((q4 + 4 * (sw ^ 2)) & 15);
+      // depthwise gradient partials: sum over the 4 strips of this wave (lanes 16 apart), then over the 4 waves through LDS
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           float v = acc8[e][k];
-          v += __shfl(v, p1, 64);
-          v += __shfl(v, p2, 64);
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
           acc8[e][k] = v;
         }
     }
