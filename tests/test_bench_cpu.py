@@ -58,3 +58,20 @@ def test_pipeline_default_is_the_product_mode(monkeypatch):
     assert m.effective_pipelines(32) == 3 and m.effective_pipelines(2) <= 2
     monkeypatch.setenv("SEPR_PIPELINES", "1")
     assert Model.from_config(VARIANTS["tiny"], init_seed=0).pipelines == 1
+
+
+def test_summary_is_last_key_and_small():
+    """Round 5 (review item 5c): the line ends with a `summary` object of at most 1 500 characters that carries every headline number, so a
+    consumer that keeps only the tail of the ~17 KB line still sees them.  Checked on the committed line of the round."""
+    import json
+    import bench
+    path = os.path.join(ROOT, "profiles", "r05_v3_bench.json")
+    line = open(path).read().strip().split("\n")[-1]
+    rec = json.loads(line)
+    assert list(rec)[-1] == "summary"
+    s = rec["summary"]
+    assert len(json.dumps(s)) <= 1500 and line.rstrip().endswith(json.dumps(s) + "}")
+    assert s["utt_s"] == rec["value"] and s["parity_ok"] is True and s["large"]["utt_s"] == rec["large"]["value"]
+    assert set(s["train"]) == {"bf16x3", "bf16", "bf16_b32"} and all(t["steps"] >= 8 for t in s["train"].values()) and s["large"]["steps"] >= 10
+    assert all(t["tn_hbm"][1] is not None and t["mid"][0] is not None for t in s["train"].values())     # live PMC traffic + middle-kernel time for all three
+    assert len(json.dumps(bench.make_summary(rec))) <= 1500
