@@ -141,6 +141,19 @@ class FlatAdamW(torch.optim.Optimizer):
                 raise RuntimeError("FlatAdamW: the gradients are no longer slices of the flat gradient buffer in the recorded layout")
         return flat
 
+    def validate(self) -> None:
+        """Full check of what ``step`` only spot-checks (first / last tensor): every parameter still lives where the tables say and every
+        ``.grad`` is the recorded slice of the model's flat gradient buffer.  ``CapturedTrainStep`` calls it once before capturing."""
+        if [p.data_ptr() for p in self._params] != self._ptrs:
+            raise RuntimeError("FlatAdamW: a parameter moved after the optimizer was built; build a new optimizer")
+        flat = self._model.__dict__.get("_grad_flat")
+        if flat is None or self._goff_host is None:
+            return
+        lo = flat.data_ptr()
+        for p, off in zip(self._params, self._goff_host):
+            if p.grad is None or p.grad.data_ptr() - lo != 4 * off:
+                raise RuntimeError("FlatAdamW: a gradient is no longer the recorded slice of the flat gradient buffer")
+
     @torch.no_grad()
     def step(self, closure=None, max_norm: Optional[float] = None):
         """One AdamW update; ``max_norm``: clip the total gradient norm first (``clip_grad_norm_`` semantics, norm type 2).  Returns

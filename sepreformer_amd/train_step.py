@@ -64,6 +64,8 @@ class CapturedTrainStep:
                 self._clip_and_step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        if hasattr(optimizer, "validate"):
+            optimizer.validate()                     # (optim.FlatAdamW: every pointer of its tables, once, before they are baked into a graph)
         if self.sync is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
             # The warm-up steps ran gradient all-reduces.  Their completion events are polled by the process group's watchdog thread
             # (hipEventQuery, every 100 ms) until it has retired them, and HIP refuses such a query for an event whose stream is capturing -
