@@ -176,6 +176,9 @@ __global__ __launch_bounds__(256) void relattn_kernel(const float* __restrict__ 
 #ifndef SEPR_AT_MASKPASS
 #define SEPR_AT_MASKPASS 1   // key-bound mask as one wave-uniform pass (0: selects inside the score loop - rounds 1-4; 2: pass on every tile)
 #endif
+#ifndef SEPR_AT_NW
+#define SEPR_AT_NW 4         // 16-query waves per workgroup of the Base inference kernel (8: 128 queries per staged tile, round-5 experiment)
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -195,8 +198,8 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& l) {
 // backward keeps of the probabilities - and applies inverted dropout to the probabilities that multiply V (network.py:121;
 // the softmax denominator sums the undropped ones); mask of element (row = (seq*H + h)*Tp + i, key j) = 16-bit half j & 1 of
 // sepr_drop_word(dkey, row, j >> 1) >= thr (sepr_train.h).
-template <int DK, bool TRAIN = false, bool BP = false, bool ONE = false>
-__global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const float* __restrict__ QKV, float* __restrict__ O, int Tp, int F,
+template <int DK, bool TRAIN = false, bool BP = false, bool ONE = false, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, DK == 16 ? 4 : 2) void relattn_x3_kernel(const float* __restrict__ QKV, float* __restrict__ O, int Tp, int F,
                                                         const float* __restrict__ pe, int maxlen, float inv_sqrt_dk,
                                                         float* __restrict__ lse = nullptr, unsigned thr = 0u, float dscale = 1.0f,
                                                         unsigned long long seed = 0ull, const unsigned long long* __restrict__ salt = nullptr,
@@ -211,11 +214,13 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
   constexpr bool bp = BP;
   DropKey dkey = {0u, 0u};
   if (TRAIN && thr) dkey = sepr_drop_key(seed, salt, 2u);
-  constexpr int QB = 64, KT = 64;
+  static_assert(NWV == 4 || NWV == 8, "waves (16-query slices) per workgroup");
+  constexpr int NT = 64 * NWV;        // NWV = 8: 128 queries share every staged K / V / band tile (SEPR_AT_NW, inference only)
+  constexpr int QB = 16 * NWV, KT = 64;
   constexpr int KSB = DK + 8;         // K / band row stride in bf16 (DK used + 8 pad; DK = 16: the pad is the zero half of K = 32)
   constexpr int OT = DK / 16;         // 16-row tiles of O^T
-  constexpr int NU = KT * (DK / 4) / 256;                       // K / V float4 per thread per key tile
-  constexpr int NBU = (127 * (DK / 4) + 255) / 256;             // band float4 per thread
+  constexpr int NU = (KT * (DK / 4) + NT - 1) / NT;                       // K / V float4 per thread per key tile
+  constexpr int NBU = ((QB + KT - 1) * (DK / 4) + NT - 1) / NT;             // band float4 per thread
   constexpr int VSB = KT + 8;         // V^T row stride in bf16 (144 B)
   constexpr int NBAND = QB + KT - 1;
   constexpr int PSK = 52;             // skew scratch row stride in floats (48 used)
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
   __bf16* const Kl = ONE ? Kh : Kl_;          // ONE: dead aliases (the reads through them stay in bounds and feed nothing)
   __bf16* const Vl = ONE ? Vh : Vl_;
   __bf16* const Bl = ONE ? Bh : Bl_;
-  __shared__ __attribute__((aligned(16))) float Psk[4 * 16 * PSK];
+  __shared__ __attribute__((aligned(16))) float Psk[NWV * 16 * PSK];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ii = lane & 15, g = lane >> 4;
@@ -238,14 +243,14 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
   const bool lowk = DK == 32 || g < 2;            // DK = 16: lane groups 2,3 carry the zero half of the K = 32 fragments:
   const int gk = DK == 32 ? g : (g & 1);          // they read the (zeroed) 8-element pad at the end of every K / band row
   const int go = DK == 32 ? 8 * g : 8 * (g < 2 ? g : 2);
-  for (int r = tid; r < KT; r += 256) {
+  for (int r = tid; r < KT; r += NT) {
 #pragma unroll
     for (int e = DK; e < KSB; ++e) {
       Kh[r * KSB + e] = (__bf16)0.f;
       if constexpr (!ONE) Kl[r * KSB + e] = (__bf16)0.f;
     }
   }
-  for (int r = tid; r < NBAND; r += 256) {
+  for (int r = tid; r < NBAND; r += NT) {
 #pragma unroll
     for (int e = DK; e < KSB; ++e) {
       Bh[r * KSB + e] = (__bf16)0.f;
@@ -278,11 +283,11 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
   auto fetch = [&](int j0) {          // global -> registers for the key tile starting at j0
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int idx = tid + 256 * u;
+      const int idx = tid + NT * u;
       const int j = j0 + idx / (DK / 4), sc4 = idx % (DK / 4);
       rk[u] = zero4();
       rv[u] = zero4();
-      if (j < Tp) {
+      if (j < Tp && idx < KT * (DK / 4)) {
         const float* kp = base + (long long)j * ld + F + 4 * sc4;
         rk[u] = ld4(kp);
         rv[u] = ld4(kp + F);
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
     }
 #pragma unroll
     for (int u = 0; u < NBU; ++u) {
-      const int idx = tid + 256 * u;
+      const int idx = tid + NT * u;
       const int rr = idx / (DK / 4) < NBAND ? idx / (DK / 4) : NBAND - 1;
       int rel = i0 - j0 - (KT - 1) + rr;                      // i - j for band row rr
       rel = rel < -maxlen ? -maxlen : (rel > maxlen - 1 ? maxlen - 1 : rel);
@@ -312,8 +317,9 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
       bf16x4 hh, ll;
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        const int idx = tid + 256 * u;
+        const int idx = tid + NT * u;
         const int sjj = idx / (DK / 4), sc4 = idx % (DK / 4);
+        if (NT * NU > KT * (DK / 4) && idx >= KT * (DK / 4)) continue;
         split4(rk[u], hh, ll);
         *reinterpret_cast<bf16x4*>(Kh + sjj * KSB + 4 * sc4) = hh;
         if constexpr (!ONE) *reinterpret_cast<bf16x4*>(Kl + sjj * KSB + 4 * sc4) = ll;
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256, DK == 16 ? 4 : 2) void relattn_x3_kernel(const
       }
 #pragma unroll
       for (int u = 0; u < NBU; ++u) {
-        const int idx = tid + 256 * u;
+        const int idx = tid + NT * u;
         if (idx < NBAND * (DK / 4)) {
           if (bp) {
             *reinterpret_cast<uint2*>(Bh + (idx / (DK / 4)) * KSB + 4 * (idx % (DK / 4))) = make_uint2(__float_as_uint(rb[u].x), __float_as_uint(rb[u].y));
@@ -524,6 +530,10 @@ int launch_relattn(const float* QKV, float* O, int n, int Tp, int F, int H, cons
   const float isd = 1.0f / sqrtf((float)dk);
   if (dk == 16 && x3) {
     if (pe_planes)
+      if (SEPR_AT_NW == 8)
+        hipLaunchKernelGGL((relattn_x3_kernel<16, false, true, false, 8>), dim3((Tp + 127) / 128, H, n), dim3(512), 0, s, QKV, O, Tp, F, pe_k, maxlen,
+                           isd, (float*)nullptr, 0u, 1.0f, 0ull, (const unsigned long long*)nullptr, static_cast<const unsigned short*>(pe_planes));
+      else
       hipLaunchKernelGGL((relattn_x3_kernel<16, false, true>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, (float*)nullptr, 0u, 1.0f, 0ull,
                          (const unsigned long long*)nullptr, static_cast<const unsigned short*>(pe_planes));
     else

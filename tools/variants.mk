@@ -41,3 +41,5 @@ VARIANT_band16 = -DSEPR_AXB_ROWS=16 -DSEPR_AXB_BPC=2
 VARIANT_bandg2 = -DSEPR_AXB_GROUP=2
 VARIANT_bandg1 = -DSEPR_AXB_GROUP=1
 VARIANT_noslp = -fno-slp-vectorize
+# Base inference attention: 8 waves (128 queries) per workgroup (round 5 A/B)
+VARIANT_atnw8 = -DSEPR_AT_NW=8
