@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * NWV, DK == 16 ? 4 : 2) void relattn_x3_kernel(
       const int j = j0 + idx / (DK / 4), sc4 = idx % (DK / 4);
       rk[u] = zero4();
       rv[u] = zero4();
-      if (j < Tp && idx < KT * (DK / 4)) {
+      if (j < Tp && (NT * NU == KT * (DK / 4) || idx < KT * (DK / 4))) {
         const float* kp = base + (long long)j * ld + F + 4 * sc4;
         rk[u] = ld4(kp);
         rv[u] = ld4(kp + F);
@@ -530,12 +530,13 @@ int launch_relattn(const float* QKV, float* O, int n, int Tp, int F, int H, cons
   const float isd = 1.0f / sqrtf((float)dk);
   if (dk == 16 && x3) {
     if (pe_planes)
-      if (SEPR_AT_NW == 8)
+#if SEPR_AT_NW == 8
         hipLaunchKernelGGL((relattn_x3_kernel<16, false, true, false, 8>), dim3((Tp + 127) / 128, H, n), dim3(512), 0, s, QKV, O, Tp, F, pe_k, maxlen,
                            isd, (float*)nullptr, 0u, 1.0f, 0ull, (const unsigned long long*)nullptr, static_cast<const unsigned short*>(pe_planes));
-      else
+#else
       hipLaunchKernelGGL((relattn_x3_kernel<16, false, true>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, (float*)nullptr, 0u, 1.0f, 0ull,
                          (const unsigned long long*)nullptr, static_cast<const unsigned short*>(pe_planes));
+#endif
     else
       hipLaunchKernelGGL((relattn_x3_kernel<16, false, false>), grid, dim3(256), 0, s, QKV, O, Tp, F, pe_k, maxlen, isd, (float*)nullptr, 0u, 1.0f,
                          0ull, (const unsigned long long*)nullptr, (const unsigned short*)nullptr);
