@@ -68,12 +68,15 @@ inline TnPlan tn_plan(int M, int N, int K) {
 // The !GEN loader is straight-line: all 16 row loads of a thread are issued back to back from clamped (always valid)
 // addresses, validity is a select afterwards, and the per-row (mean, rstd) pairs of a slab are fetched ONCE by 64 threads
 // and handed out through LDS instead of 16 x 8-byte loads per staging thread.
+#ifndef SEPR_TN_ONE_WPE
+#define SEPR_TN_ONE_WPE 2   // waves per SIMD the plain-bf16 instantiations are compiled for (3: round-5 experiment, two LDS planes + 168 VGPRs)
+#endif
 template <int MD, bool GEN, bool STATS>
-__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part,
+__global__ __launch_bounds__(TN_THREADS, MD == 2 ? SEPR_TN_ONE_WPE : 2) void gemm_tn_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part,
                                                                float* __restrict__ cpart) {
   // x3: [A_hi, A_lo, B_hi, B_lo][128][72] bf16 = 73 728 B;  f32: [A, B][64][132] fp32 = 67 584 B
   constexpr bool X3 = MD != 0, ONE = MD == 2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[X3 ? 4 * TN_T * TN_LDM * 2 : 2 * TN_SLAB * TN_LDF * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[X3 ? (ONE ? 2 : 4) * TN_T * TN_LDM * 2 : 2 * TN_SLAB * TN_LDF * 4];   // ONE: hi planes only
   __shared__ float csum_s[4][TN_T];
   // DBUF: TWO slabs of operand rows in flight in registers (the loads of slab s+2 issued before the MFMAs of slab s, consumed two
   // barriers later).  Built in round 4 for the plain-bf16 instantiation and NOT enabled: next to the 64 accumulator and 32 fragment
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
       }
     }
     if (X3) {
-      unsigned short* hi = reinterpret_cast<unsigned short*>(smem) + (roleA ? 0 : 2) * TN_T * TN_LDM;
+      unsigned short* hi = reinterpret_cast<unsigned short*>(smem) + (roleA ? 0 : (ONE ? 1 : 2)) * TN_T * TN_LDM;
       unsigned short* lo = hi + TN_T * TN_LDM;
 #pragma unroll
       for (int nb = 0; nb < TN_NB; ++nb)
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const TnArgs a, 
     if (X3) {
       const unsigned short* Ahi = reinterpret_cast<const unsigned short*>(smem);
       const unsigned short* Alo = Ahi + TN_T * TN_LDM;
-      const unsigned short* Bhi = Alo + TN_T * TN_LDM;
+      const unsigned short* Bhi = Ahi + (ONE ? 1 : 2) * TN_T * TN_LDM;      // ONE: [A_hi][B_hi] only, the lo pointers are never dereferenced
       const unsigned short* Blo = Bhi + TN_T * TN_LDM;
 #pragma unroll
       for (int nb = 0; nb < TN_NB; ++nb) {

@@ -43,3 +43,5 @@ VARIANT_bandg1 = -DSEPR_AXB_GROUP=1
 VARIANT_noslp = -fno-slp-vectorize
 # Base inference attention: 8 waves (128 queries) per workgroup (round 5 A/B)
 VARIANT_atnw8 = -DSEPR_AT_NW=8
+# plain-bf16 weight-gradient contraction compiled for 3 waves per SIMD (round 5 A/B; pair with SEPR_TN_WGS=768)
+VARIANT_tn3w = -DSEPR_TN_ONE_WPE=3
