@@ -74,7 +74,8 @@ inline TnPlan tn_plan(int M, int N, int K) {
 template <int MD, bool GEN, bool STATS>
 __global__ __launch_bounds__(TN_THREADS, MD == 2 ? SEPR_TN_ONE_WPE : 2) void gemm_tn_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part,
                                                                float* __restrict__ cpart) {
-  // x3: [A_hi, A_lo, B_hi, B_lo][128][72] bf16 = 73 728 B;  f32: [A, B][64][132] fp32 = 67 584 B
+  // x3: [A_hi, A_lo, B_hi, B_lo][128][72] bf16 = 73 728 B;  plain bf16: [A_hi, B_hi] = 36 864 B;  f32: [A, B][64][132] fp32 = 67 584 B
+  // (the plain-bf16 form stays at two workgroups per CU all the same: 208 VGPRs - profiles/r05_v4_wgrad_3waves.txt)
   constexpr bool X3 = MD != 0, ONE = MD == 2;
   __shared__ __attribute__((aligned(16))) unsigned char smem[X3 ? (ONE ? 2 : 4) * TN_T * TN_LDM * 2 : 2 * TN_SLAB * TN_LDF * 4];   // ONE: hi planes only
   __shared__ float csum_s[4][TN_T];
