@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SEPR_VERSION 400 /* minor*100 + patch ("ABI 4.00").  Any struct-layout or context-size change bumps the MINOR number
+#define SEPR_VERSION 410 /* minor*100 + patch ("ABI 4.10").  Any struct-layout or context-size change bumps the MINOR number
                             (3.01 -> 3.03 grew sepr_ega_w under a patch bump: a caller built against 3.01 would have passed a short
                             struct).  A binding must compare sepr_version() with the SEPR_VERSION it was written against before its
                             first call: sepreformer_amd/lib.py refuses to load a library whose version differs. */
@@ -172,6 +172,13 @@ typedef struct {
   /* optional one-kernel form of end_conv1x1.0 + GLU + end_conv1x1.2 (bf16x3, F = 128, N % 128 == 0), as in sepr_split_w */
   const void* fused_w1p;
   const void* fused_w2p;
+  /* optional (ABI 4.10), heads WITHOUT a mask only (masking = False, model.py:28): end_conv1x1.2 (2F -> N, bias) and the
+   * ConvTranspose1d(N -> 1, K = 16, stride 4, no bias) have no nonlinearity between them, so they are ONE linear map:
+   * fold_w2p = bf16 hi/lo k-slot fragments [2F/32][1][2][64][8] of W_fold[K, 2F] = wdec^T . W2, fold_b [K] = wdec^T . b2 (both formed in
+   * fp64, pack.pack_glumlp_fold).  With fused_w1p set, sepr_outlayer_decoder_fwd(idx = NULL, enc = NULL) is then one launch: up-projection,
+   * GLU, 16-row down-projection, overlap-add into wav; no [rows, N] tensor, no workspace.  NULL = the two-step form. */
+  const void* fold_w2p;
+  const float* fold_b;
 } sepr_out_w;
 
 /* ---- library ---------------------------------------------------------------------------------- */
@@ -183,7 +190,8 @@ const char* sepr_build_info(void);
  * library instead of parsing the environment themselves, so both sides always agree on a context layout.  sepr_knobs_reload() re-reads
  * the environment (tests that flip a switch inside one process call it between whole forward + backward runs, never inside one). */
 enum { SEPR_KNOB_X3_WIDE = 0 /* 0 / 1 (default) / 2: sepr_gemm_x3.hip */, SEPR_KNOB_TRAIN_GCFN_PLANES /* default 1 */,
-       SEPR_KNOB_TRAIN_ATTN_ONE /* default 1 */, SEPR_KNOB_TRAIN_CLA16 /* default 1 */, SEPR_KNOB_COUNT };
+       SEPR_KNOB_TRAIN_ATTN_ONE /* default 1 */, SEPR_KNOB_TRAIN_CLA16 /* default 1 */,
+       SEPR_KNOB_FOLD_HEAD /* default 1: main OutputLayer + AudioDecoder as one launch when sepr_out_w.fold_* are set */, SEPR_KNOB_COUNT };
 int sepr_knob(int id);
 void sepr_knobs_reload(void);
 /* text of the last HIP error seen by the calling thread ("" if none) */

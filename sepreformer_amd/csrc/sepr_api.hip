@@ -89,7 +89,7 @@ int g_knobs[SEPR_KNOB_COUNT];
 std::mutex g_knobs_mu;
 void knobs_read() {
   static const struct { const char* name; int dflt; } tab[SEPR_KNOB_COUNT] = {
-      {"SEPR_X3_WIDE", 1}, {"SEPR_TRAIN_GCFN_PLANES", 1}, {"SEPR_TRAIN_ATTN_ONE", 1}, {"SEPR_TRAIN_CLA16", 1}};
+      {"SEPR_X3_WIDE", 1}, {"SEPR_TRAIN_GCFN_PLANES", 1}, {"SEPR_TRAIN_ATTN_ONE", 1}, {"SEPR_TRAIN_CLA16", 1}, {"SEPR_FOLD_HEAD", 1}};
   for (int i = 0; i < SEPR_KNOB_COUNT; ++i) {
     const char* e = getenv(tab[i].name);
     g_knobs[i] = (e && e[0]) ? atoi(e) : tab[i].dflt;
@@ -435,6 +435,15 @@ extern "C" int sepr_outlayer_decoder_fwd(const float* x, int nS, int S, int Tsrc
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long M = (long long)nS * L;
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
+  if (w->fold_w2p && w->fold_b && w->fused_w1p && F == 128 && !idx && !enc && K == 16 && stride == 4 && knob(SEPR_KNOB_FOLD_HEAD)) {
+    // main head (masking = False, model.py:28): end_conv1x1.2 and the ConvTranspose1d are one linear map - one launch, no [rows, N]
+    // basis tensor, no workspace (launch_glumlp_fold)
+    GcfnFusedArgs f = {};
+    f.x = x; f.y = wav; f.T = L; f.in_src = Tsrc;
+    f.w1p = w->fused_w1p; f.w2p = w->fold_w2p; f.b2 = w->fold_b;
+    f.nch = 2 * F / 32; f.out_S = S; f.fold_nseq = nS; f.fold_N = N;
+    return launch_glumlp_fold(f, F, SEPR_SITE_OUT, st);
+  }
   Arena ar(ws, ws_bytes);
   float* o1 = ar.f32(2LL * F * M);
   float* o2 = ar.f32((long long)N * M);

@@ -24,6 +24,8 @@ struct GcfnFusedArgs {
   int ldy, col_off;   // output row stride in floats and first output column (one launch writes F columns of a wider tensor)
   int in_rows, in_src;          // in_rows > 0: input row of frame m is (m / in_rows) * in_src + m % in_rows (crop of every sequence)
   int out_T, out_S, out_s;      // out_S > 0: output row of frame m is ((m / out_T) * out_S + out_s) * out_T + m % out_T (speaker split)
+  // MODE 2 (launch_glumlp_fold: OutputLayer + folded AudioDecoder): sequences, tiles per sequence and wav samples per sequence
+  int fold_nseq, fold_tps, fold_Tout, fold_N;   // fold_N: basis size N (FLOP accounting only)
   // TRAIN instantiation (sepr_gcfn_train_fwd, fused form): the LayerNorm statistics of every output frame go to `stats`
   // ([M][2] = mean, rstd: all the backward keeps of this block), and both dropout sites of network.py:55,57 are live when
   // drop_thr > 0 (sepr_train.h sepr_drop_word: site 0 = gated tensor [M][3F], site 1 = block output [M][F]; the keep scale
@@ -41,5 +43,6 @@ struct GcfnFusedArgs {
 
 int launch_gcfn_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream);
 int launch_glumlp_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream);
+int launch_glumlp_fold(const GcfnFusedArgs& a, int F, int site, hipStream_t stream);
 
 }  // namespace sepr

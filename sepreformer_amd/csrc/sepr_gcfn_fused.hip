@@ -100,9 +100,10 @@ struct bool_c { static constexpr bool value = V; };
 // ONE (training precision "bf16" only): plain bf16 operands - the normalised frames, the weights and the gated tensor are used
 // as their bf16 hi plane alone, ONE MFMA per product instead of three, no lo-plane split on the VALU, and only the hi-plane
 // blocks of every packed weight chunk are copied to LDS (half the L2 -> LDS stream).  Same packed weights, same LDS layout.
-template <int F, int MT, int NW, int MODE = 0, bool TRAIN = false, bool ONE = false>
-__global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
-  constexpr bool PLAIN = MODE == 1;   // frames are independent: no halo, no seam exchange, no conv
+template <int F, int MT, int NW, int MODE = 0, bool TRAIN = false, bool ONE = false, int LAT = 0>
+__global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
+  constexpr bool PLAIN = MODE >= 1;   // frames are independent: no halo, no seam exchange, no conv
+  constexpr bool FOLD = MODE == 2;    // OutputLayer with the AudioDecoder folded into its second projection (see launch_glumlp_fold)
   static_assert(!(TRAIN && PLAIN), "the train instantiation is the GCFN block");
   static_assert(!ONE || TRAIN, "plain bf16 operands do not pass the inference parity gate: a training arithmetic only");
   const bool drop = TRAIN && a.drop_thr > 0u;
@@ -123,27 +124,35 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
   constexpr bool XCH = (SEPR_GF3_XCH != 0) && MT == 2 && UF && !PLAIN;
   constexpr int HALO = PLAIN ? 0 : 1;
   constexpr int WSTR = (XCH || PLAIN) ? 16 * MT : 16 * MT - 2;            // frames a wave advances
-  constexpr int GF_TILE = XCH ? NW * 16 * MT - 2 : NW * WSTR;   // output frames per workgroup tile
+  constexpr int FOLD_HB = 3;                                       // (K - 1) / stride of the folded ConvTranspose1d(k = 16, stride 4)
+  constexpr int GF_TILE = FOLD ? NW * 16 * MT - FOLD_HB : (XCH ? NW * 16 * MT - 2 : NW * WSTR);   // output frames per workgroup tile
   constexpr int EH = (16 * MT * NW + 63) / 64;   // epilogue passes of up to 64 frames
   constexpr int KS = F / 32;
   const int NCH = PLAIN ? a.nch : 3 * F / 32;
-  constexpr int FT = F / 16;
+  constexpr int FT = FOLD ? 1 : F / 16;   // 16-row output tiles of the down-projection (FOLD: the 16 decoder taps)
   constexpr int W1F_U4 = 4 * KS * 2 * 64;
   constexpr int CS_U4 = 256;
   constexpr int W1_U4 = W1F_U4 + CS_U4;
   constexpr int W2_U4 = FT * 2 * 64;
   constexpr int OS = F + 4;
-  __shared__ __attribute__((aligned(16))) uint4 wl[W1F_U4 + W2_U4 + 2 * CS_U4];
+  // LAT > 0 (latency form, launches with fewer tiles than CUs): a ring of LAT whole-chunk images [W1 fragments | constants | W2 fragments]
+  // (52 KB each at F = 128; one workgroup per CU, so the LDS the second workgroup would use is free), chunk c + LAT - 1 requested
+  // while chunk c multiplies, ONE raw barrier per chunk and counted vmcnt waits.  The copies are inline asm: hipcc (ROCm 7.2) drains
+  // vmcnt to 0 in front of the first LDS read behind any LDS-DMA it knows about, which is what serialised copy and multiply before.
+  constexpr int NST = LAT > 0 ? LAT : 1;
+  constexpr int STG_U4 = W1_U4 + W2_U4;
+  static_assert(LAT == 0 || (!XCH && !TRAIN && !FOLD && F == 128), "latency form: the small-launch inference instantiations");
+  __shared__ __attribute__((aligned(16))) uint4 wl[LAT > 0 ? NST * STG_U4 : W1F_U4 + W2_U4 + 2 * CS_U4];
   __shared__ __attribute__((aligned(16))) float xch[XCH ? NW * 2 * 2 * 2 * 16 : 4];   // [wave][first|last frame][j][v|g][16 ch]
-  static_assert(sizeof(uint4) * (W1F_U4 + W2_U4) >= sizeof(float) * 64 * OS, "epilogue staging must fit");
+  static_assert(FOLD || sizeof(uint4) * (W1F_U4 + W2_U4) >= sizeof(float) * 64 * OS, "epilogue staging must fit");
   static_assert(W1F_U4 / 64 <= 16 * NW, "copy partition");
-  const uint4* const w1s = wl;
-  const uint4* const w2s = wl + W1F_U4;
-  uint4* const csl = wl + W1F_U4 + W2_U4;
+  const uint4* w1s = wl;                      // (LAT: re-pointed at the chunk's ring stage)
+  const uint4* w2s = wl + (LAT > 0 ? W1_U4 : W1F_U4);
+  uint4* csl = wl + (LAT > 0 ? W1F_U4 : W1F_U4 + W2_U4);
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fi = lane & 15, fg = lane >> 4;
-  const int ntiles = (a.M + GF_TILE - 1) / GF_TILE;
+  const int ntiles = FOLD ? a.fold_nseq * a.fold_tps : (a.M + GF_TILE - 1) / GF_TILE;
   const uint4* const W1g = static_cast<const uint4*>(a.w1p);
   const uint4* const W2g = static_cast<const uint4*>(a.w2p);
 
@@ -193,6 +202,45 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!(SEPR_GF_ABL & 4)) __syncthreads();
   };
+  // LAT: one chunk image into ring stage c % NST.  Every wave issues exactly LAT_NI copies (block index wraps, so a few blocks are
+  // copied twice with the same bytes): the counted waits below are compile-time constants.
+  constexpr int LAT_N1 = (W1_U4 / 64 + NW - 1) / NW, LAT_N2 = (W2_U4 / 64 + NW - 1) / NW, LAT_NI = LAT_N1 + LAT_N2;
+  [[maybe_unused]] const unsigned wl_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)wl;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 (the LDS-DMA destination register) is "reserved": hipcc re-materialises it before each of its own uses
+  [[maybe_unused]] auto lat_dma = [&](int c) {
+    const unsigned stage = wl_lds + (unsigned)((c % NST) * STG_U4 * 16);
+    const char* g1 = reinterpret_cast<const char*>(W1g + (long long)c * W1_U4) + lane * 16;
+    const char* g2 = reinterpret_cast<const char*>(W2g + (long long)c * W2_U4) + lane * 16;
+#pragma unroll
+    for (int i = 0; i < LAT_N1; ++i) {
+      const int blk = (i * NW + w) % (W1_U4 / 64);
+      const unsigned dst = __builtin_amdgcn_readfirstlane(stage + (unsigned)blk * 1024u);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g1 + blk * 1024), "s"(dst) : "memory", "m0");
+    }
+#pragma unroll
+    for (int i = 0; i < LAT_N2; ++i) {
+      const int blk = (i * NW + w) % (W2_U4 / 64);
+      const unsigned dst = __builtin_amdgcn_readfirstlane(stage + (unsigned)(W1_U4 * 16) + (unsigned)blk * 1024u);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g2 + blk * 1024), "s"(dst) : "memory", "m0");
+    }
+  };
+#pragma clang diagnostic pop
+  // LAT, top of chunk c: this wave's share of chunk c has landed (later chunks may stay in flight), then the barrier that (a) publishes
+  // every wave's share and (b) says every wave is done reading chunk c - 1, whose stage the next request overwrites
+  [[maybe_unused]] auto lat_enter = [&](int c) {
+    const int ahead = NCH - 1 - c < NST - 2 ? NCH - 1 - c : NST - 2;
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LAT_NI) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LAT_NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (c + NST - 1 < NCH) lat_dma(c + NST - 1);
+    w1s = wl + (c % NST) * STG_U4;
+    csl = wl + (c % NST) * STG_U4 + W1F_U4;
+    w2s = wl + (c % NST) * STG_U4 + W1_U4;
+  };
+  static_assert(LAT <= 4 && 2 * LAT_NI < 64, "vmcnt immediates");
   // fragment pair (bf16 hi plane, lo plane) of one 16-channel tile at one K step
   auto ld_up = [&](int j, int g, uint4 (&d)[2]) {   // g = 2*ks + (0 value tile | 1 gate tile)
     const uint4* p = w1s + ((((g & 1) * 2 + j) * KS + (g >> 1)) * 2) * 64 + lane;
@@ -227,8 +275,14 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // chunk 0 of the weights is requested first: it lands under the frame loads and the LayerNorm below
     __syncthreads();   // the previous tile's epilogue staging is fully consumed
-    dma_w1(0);
-    dma_w2(0);
+    if constexpr (LAT > 0) {
+#pragma unroll
+      for (int c0 = 0; c0 < NST - 1; ++c0)
+        if (c0 < NCH) lat_dma(c0);
+    } else {
+      dma_w1(0);
+      dma_w2(0);
+    }
     // ---- this wave's 32 frames (lane fi holds frames 2*fi and 2*fi+1): load, LayerNorm, split --------------
     const int mw0 = tile * GF_TILE + w * WSTR - HALO;           // wave frame 0 (GCFN: tile frame 0 is halo)
     bf16x8 xh[MT][KS], xl[MT][KS];
@@ -239,14 +293,19 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     bool edge_lane = false;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int m = mw0 + MT * fi + mt;
-      const bool valid = (m >= 0 && m < a.M);
+      int m = mw0 + MT * fi + mt;
+      bool valid = (m >= 0 && m < a.M);
+      if constexpr (FOLD) {   // tiles walk ONE sequence: frame l of sequence seq, the first FOLD_HB frames of a tile are recomputed halo
+        const int seq = tile / a.fold_tps, l = (tile - seq * a.fold_tps) * GF_TILE - FOLD_HB + w * 16 * MT + MT * fi + mt;
+        valid = l >= 0 && l < a.T;
+        m = seq * a.in_src + l;       // the crop of module.py:250: rows l >= T of the source sequence are never read
+      }
       const int trow = (valid && !PLAIN) ? m % a.T : -2;
       f0[mt] = (trow == 0) ? 0.f : 1.f;
       f2[mt] = (trow == a.T - 1) ? 0.f : 1.f;
       edge_lane = edge_lane || trow == 0 || trow == a.T - 1;
       long long mi = valid ? m : 0;
-      if (PLAIN && a.in_rows > 0) mi = (long long)(mi / a.in_rows) * a.in_src + mi % a.in_rows;
+      if (PLAIN && !FOLD && a.in_rows > 0) mi = (long long)(mi / a.in_rows) * a.in_src + mi % a.in_rows;
       const float* xp = a.x + mi * F + 8 * fg;
       float v[KS][8];
       float s = 0.f;
@@ -310,6 +369,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
     auto chunks = [&](auto edge_c) {
       constexpr bool EDGE = decltype(edge_c)::value;
       for (int c = 0; c < ((SEPR_GF_ABL & 1) ? 0 : NCH); ++c) {
+        if constexpr (LAT > 0) lat_enter(c);
         bf16x8 gh[MT], gw[MT];          // gated values (bf16 hi / lo) in down-projection k-slot order
         uint4 fb[RD + 1][2];            // fragment ring: RD MFMA groups in flight ahead of the one being multiplied
 #pragma unroll
@@ -321,7 +381,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
           // fragments is then issued one conv earlier and has conv + conv + down-projection to land
           const int j = UF ? (jj & 1) : jj;
           const bool do_up = !UF || jj < 2, do_conv = !UF || jj >= 2;
-          const float* cs = reinterpret_cast<const float*>(csl + (c & 1) * CS_U4) + j * 160 + 4 * fg;
+          const float* cs = reinterpret_cast<const float*>(csl + (LAT > 0 ? 0 : (c & 1) * CS_U4)) + j * 160 + 4 * fg;
           f32x4 (&hv)[MT] = hvA[UF ? j : 0];
           f32x4 (&hg)[MT] = hgA[UF ? j : 0];
           if (do_up) {
@@ -386,11 +446,14 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
                 }
               }
             }
+            if constexpr (LAT == 0) {
             dma_barrier();                         // every wave has read its up-projection fragments of chunk c;
                                                    // this chunk's down-projection fragments have landed
             if (c + 1 < NCH && !(SEPR_GF_ABL & 2)) dma_w1(c + 1);        // lands under the conv + down-projection below
+            }
 #pragma unroll
-            for (int g = 0; g < RD; ++g) ld_dn(g, fb[g]);
+            for (int g = 0; g < RD; ++g)
+              if (g < FT) ld_dn(g, fb[g]);
           }
           }
           if (!do_conv) continue;
@@ -502,13 +565,45 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
           __builtin_amdgcn_sched_barrier(0);
         }
         if (SEPR_GF3_PRIO) __builtin_amdgcn_s_setprio(0);
+        if constexpr (LAT == 0) {
         dma_barrier();                             // down-projection fragments consumed; chunk c+1's up-projection
         if (c + 1 < NCH && !(SEPR_GF_ABL & 2)) dma_w2(c + 1);            // fragments have landed
+        }
       }
     };
-    dma_barrier();     // chunk 0 landed
+    if constexpr (LAT == 0) dma_barrier();     // chunk 0 landed
     if (edge) chunks(bool_c<true>{}); else chunks(bool_c<false>{});
+    if constexpr (LAT > 0) __syncthreads();    // every wave is done with the last chunk's stage (nothing is in flight: the last wait was
+                                               // vmcnt(0)); the epilogue staging below overwrites the ring
 
+    if constexpr (FOLD) {
+      // ---- folded decoder epilogue: acc = the 16 ConvTranspose1d taps of every frame; overlap-add (stride 4) inside the tile,
+      //      summed newest frame first like decoder_kernel, so a sample's value does not depend on the tiling ----------------
+      constexpr int DS = 20;   // staging row stride in floats (16-byte aligned, spreads the gather over the banks)
+      float* const Ds = reinterpret_cast<float*>(wl);
+      const int seq = tile / a.fold_tps, jt = tile - seq * a.fold_tps;
+      const float4 bf = ld4(a.b2 + 4 * fg);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int lr = w * 16 * MT + MT * fi + mt, l = jt * GF_TILE - FOLD_HB + lr;
+        const f32x4 v = acc[0][mt];
+        const bool ok = l >= 0 && l < a.T;
+        st4(Ds + lr * DS + 4 * fg, ok ? make_float4(v[0] + bf.x, v[1] + bf.y, v[2] + bf.z, v[3] + bf.w) : zero4());
+      }
+      __syncthreads();
+      const int sp = seq % a.out_S, bb = seq / a.out_S;
+      float* const dst = a.y + ((long long)sp * (a.fold_nseq / a.out_S) + bb) * a.fold_Tout;
+      for (int tl = tid; tl < 4 * GF_TILE; tl += NT) {
+        const int tau = 4 * jt * GF_TILE + tl;
+        if (tau >= a.fold_Tout) break;
+        const int lr = (tl >> 2) + FOLD_HB, ph = tl & 3;
+        float yv = 0.f;
+#pragma unroll
+        for (int jj = 0; jj <= FOLD_HB; ++jj) yv += Ds[(lr - jj) * DS + ph + 4 * jj];
+        dst[tau] = yv;
+      }
+      continue;   // (the next tile starts on a barrier: the staging is consumed before the weight copies overwrite it)
+    }
     // ---- epilogue: y = x + ls * (acc + b2), two waves at a time through LDS ---------------------------------
     float* const Os = reinterpret_cast<float*>(wl);
     constexpr int WPP = 64 / (16 * MT);   // waves per 64-frame epilogue pass
@@ -604,6 +699,25 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void gcfn_fused3_kernel(cons
 #endif
 [[maybe_unused]] constexpr int GF3_MT = SEPR_GF3_MT, GF3_NW = (SEPR_GF3_MT == 1) ? 6 : 4;
 
+// Latency form of the small-launch instantiations (template parameter LAT): taken when a launch has at most one tile per CU, i.e. when its
+// duration IS one workgroup's chunk walk (batch 1, Engine._inference_sample): SEPR_GF_LAT = ring depth (3 default, 2, 0 = off).
+static int lat_ring() {
+  static const int v = [] {
+    const char* e = getenv("SEPR_GF_LAT");
+    const int r = e && e[0] ? atoi(e) : 3;
+    return (r == 2 || r == 3) ? r : 0;
+  }();
+  return v;
+}
+static int lat_max_tiles() {
+  static const int v = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+  }();
+  return v;
+}
+
 // Plain GLU-MLP (MODE 1): one launch computes F = 128 output columns; a wider output takes one launch per 128 columns
 // (the up-projection is recomputed: 1.5x the MFMAs of a single pass, still ~2.5x faster than two generic projections with the
 // [rows, hidden] tensor through HBM).
@@ -615,13 +729,42 @@ int launch_glumlp_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t str
   const int cap = persistent_grid();
   if (a.M < 12000) {
     const int ntiles = (a.M + 95) / 96;
-    hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 1>), dim3(ntiles < cap ? ntiles : cap), dim3(384), 0, stream, a);
+    const int lat = ntiles <= lat_max_tiles() ? lat_ring() : 0;   // one tile per CU at most: the latency form (3-stage weight ring, one workgroup per CU)
+    if (lat == 3) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 1, false, false, 3>), dim3(ntiles), dim3(384), 0, stream, a);
+    else if (lat == 2) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 1, false, false, 2>), dim3(ntiles), dim3(384), 0, stream, a);
+    else hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 1>), dim3(ntiles < cap ? ntiles : cap), dim3(384), 0, stream, a);
   } else {
     const int ntiles = (a.M + 127) / 128;
     hipLaunchKernelGGL((gcfn_fused3_kernel<128, 2, 4, 1>), dim3(ntiles < cap ? ntiles : cap), dim3(256), 0, stream, a);
   }
   if (timed) prof_end(slot, (double)a.M * (2.0 * F * 64.0 * a.nch + 2.0 * 32.0 * a.nch * F), stream);
   SEPR_CHECK_LAUNCH("glumlp_fused_kernel");
+  return SEPR_OK;
+}
+
+// OutputLayer (no mask) + AudioDecoder in ONE launch (modules/module.py:249-256 + :278-283 with masking = False, model.py:28,42-44):
+// there is no nonlinearity between end_conv1x1.2 (2F -> N, bias) and ConvTranspose1d(N -> 1, k = 16, stride 4), so the packers fold them
+// (fp64): W_fold[16, 2F] = wdec^T W2, b_fold[16] = wdec^T b2.  The down-projection is then ONE 16-row tile (the 16 taps of a frame) and
+// the epilogue is the transposed convolution's overlap-add.  Tiles walk one sequence each (125 output frame slots + 3 recomputed halo
+// frames), the [rows, N] basis tensor and the separate decoder launch are gone.  a: x [nseq, in_src, F], y = wav [out_S, nseq / out_S,
+// fold_Tout], T = frames per sequence L, fold_nseq sequences, b2 = b_fold, w2p = [nch][1][2][64][8] bf16 k-slot fragments of W_fold.
+int launch_glumlp_fold(const GcfnFusedArgs& a_in, int F, int site, hipStream_t stream) {
+  if (a_in.fold_nseq <= 0 || a_in.T <= 0) return SEPR_OK;
+  GcfnFusedArgs a = a_in;
+  if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || a.nch <= 0 || F != 128 || a.out_S <= 0 || a.fold_nseq % a.out_S != 0 || a.in_src < a.T)
+    return SEPR_EINVAL;
+  constexpr int tile_slots = 4 * 16 * 2 - 3;
+  a.fold_tps = (a.T + 3 + tile_slots - 1) / tile_slots;
+  a.fold_Tout = 4 * (a.T - 1) + 16;
+  a.M = a.fold_nseq * a.in_src;
+  long long slot = -1;
+  const bool timed = prof_begin(site, stream, &slot);
+  const int cap = persistent_grid();
+  const long long ntiles = (long long)a.fold_nseq * a.fold_tps;
+  hipLaunchKernelGGL((gcfn_fused3_kernel<128, 2, 4, 2>), dim3((int)(ntiles < cap ? ntiles : cap)), dim3(256), 0, stream, a);
+  // algorithmic FLOPs of what the launch replaces: both projections + the transposed convolution
+  if (timed) prof_end(slot, (double)a.fold_nseq * a.T * (2.0 * F * 64.0 * a.nch + 2.0 * 32.0 * a.nch * a.fold_N + 2.0 * a.fold_N * 16.0), stream);
+  SEPR_CHECK_LAUNCH("glumlp_fold_kernel");
   return SEPR_OK;
 }
 
@@ -657,7 +800,10 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
       if (F == 128) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 0, true>), dim3(grid), dim3(384), 0, stream, a);
       else hipLaunchKernelGGL((gcfn_fused3_kernel<64, 1, 6, 0, true>), dim3(grid), dim3(384), 0, stream, a);
     } else if (F == 128) {
-      hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6>), dim3(grid), dim3(384), 0, stream, a);
+      const int lat = ntiles <= lat_max_tiles() ? lat_ring() : 0;
+      if (lat == 3) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 0, false, false, 3>), dim3(grid), dim3(384), 0, stream, a);
+      else if (lat == 2) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 0, false, false, 2>), dim3(grid), dim3(384), 0, stream, a);
+      else hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6>), dim3(grid), dim3(384), 0, stream, a);
     } else if (F == 64) {
       hipLaunchKernelGGL((gcfn_fused3_kernel<64, 1, 6>), dim3(grid), dim3(384), 0, stream, a);
     } else {

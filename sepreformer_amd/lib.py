@@ -54,7 +54,7 @@ class EgaW(C.Structure):
 DownW = _struct("DownW", ["w", "scale", "shift"])
 SplitW = _struct("SplitW", ["w1", "b1", "w2", "b2", "gn_g", "gn_b"], ["x3_1", "x3_2"], ["fused_w1p", "fused_w2p"])
 FuseW = _struct("FuseW", ["w", "b"], ["x3"])
-OutW = _struct("OutW", ["w1", "b1", "w2", "b2", "wdec"], ["x3_1", "x3_2"], ["fused_w1p", "fused_w2p"])
+OutW = _struct("OutW", ["w1", "b1", "w2", "b2", "wdec"], ["x3_1", "x3_2"], ["fused_w1p", "fused_w2p", "fold_w2p", "fold_b"])
 
 _i, _f, _sz, _ll = C.c_int, C.c_float, C.c_size_t, C.c_longlong
 _u64, _d = C.c_ulonglong, C.c_double
@@ -118,7 +118,7 @@ FrontGrad = _tstruct("FrontGrad", ["w_enc", "gn_g", "gn_b", "proj_w"])
 (TOP_GCFN, TOP_CLA, TOP_EGA, TOP_SPKATTN, TOP_DOWN, TOP_SPLIT, TOP_FUSE, TOP_OUT, TOP_FRONT, TOP_GCFN_FUSED, TOP_EGA_X3,
  TOP_GCFN_FUSED16) = range(12)
 
-KNOB_X3_WIDE, KNOB_TRAIN_GCFN_PLANES, KNOB_TRAIN_ATTN_ONE, KNOB_TRAIN_CLA16 = range(4)
+KNOB_X3_WIDE, KNOB_TRAIN_GCFN_PLANES, KNOB_TRAIN_ATTN_ONE, KNOB_TRAIN_CLA16, KNOB_FOLD_HEAD = range(5)
 
 # name -> (restype, argtypes); must list every symbol include/sepr.h declares (tests check this)
 SIGNATURES = {
@@ -188,7 +188,7 @@ _lib: Optional[C.CDLL] = None
 _lock = threading.Lock()
 
 
-ABI_VERSION = 400          # include/sepr.h SEPR_VERSION this binding mirrors (tests/test_boundary_cpu.py keeps the two equal)
+ABI_VERSION = 410          # include/sepr.h SEPR_VERSION this binding mirrors (tests/test_boundary_cpu.py keeps the two equal)
 
 
 class SeprLibraryError(RuntimeError):

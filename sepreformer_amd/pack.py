@@ -89,6 +89,16 @@ class Packed:
         self.keep += [w1p, w2p]
         return {"fused_w1p": w1p.data_ptr(), "fused_w2p": w2p.data_ptr()}
 
+    def glumlp_fold(self, w1, w2, b2, dec_weight) -> dict:
+        """OutputLayer's second projection with the AudioDecoder folded in (heads without a mask; bf16x3, F = 128, k = 16)."""
+        F, H = w1.shape[1], w1.shape[0] // 2
+        if (self.precision != "bf16x3" or F != 128 or H % 32 or w2.shape[0] % 128 or not self.fuse_mlp or dec_weight.shape[2] != 16
+                or os.environ.get("SEPR_FOLD_HEAD", "1") == "0"):
+            return {}
+        w2p, bf = pack_glumlp_fold(w2, b2, dec_weight)
+        self.keep += [w2p, bf]
+        return {"fold_w2p": w2p.data_ptr(), "fold_b": bf.data_ptr()}
+
     def gcfn_fused(self, sd, p: str) -> dict:
         """Fused-GCFN weight forms (bf16x3 mode, F in {64, 128}); empty dict otherwise."""
         F = sd[p + ".net1.0.weight"].shape[0]
@@ -285,6 +295,19 @@ def pack_glumlp_fused(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor):
     return w1p, w2p
 
 
+def pack_glumlp_fold(w2: torch.Tensor, b2: torch.Tensor, dec_weight: torch.Tensor):
+    """``end_conv1x1.2`` (``w2 [N,H]``, ``b2 [N]``) followed by ``ConvTranspose1d(N -> 1, K, stride)`` (``dec_weight [N,1,K]``, no bias) with
+    nothing in between (reference ``modules/module.py:252-256,278-283`` with ``masking=False``, ``model.py:28``) is one linear map from the
+    gated tensor to the K taps a frame adds to the waveform: ``W_fold [K,H] = wdec^T . w2``, ``b_fold [K] = wdec^T . b2``, formed in fp64
+    and rounded once.  Returns (``[H/32][1][2][64][8]`` bf16 hi/lo k-slot fragments for ``gcfn_fused3_kernel<..., MODE = 2>``, ``b_fold`` fp32)."""
+    wd = dec_weight.detach().double()[:, 0, :]                                # [N, K]
+    wf = (wd.t() @ w2.detach().double()).float()                              # [K, H]
+    bf = (wd.t() @ b2.detach().double()).float().contiguous()
+    if wf.shape[0] != 16 or wf.shape[1] % 32:
+        raise ValueError(f"folded head needs K = 16 taps and H % 32 == 0, got {tuple(wf.shape)}")
+    return _kslot_frags(wf, wf.shape[1] // 32), bf
+
+
 def _kslot_frags(w2: torch.Tensor, nch: int) -> torch.Tensor:
     """``w2`` ``[F, 32*nch]`` -> ``[nch][F/16][2][64][8]`` bf16: per 32-wide K chunk, the fragments with the k-slot
     order the fused kernels' registers provide (lane group g, slot e -> channel ``e<4 ? 4g+e : 16+4g+e-4``)."""
@@ -442,14 +465,16 @@ def pack_fuse(pk: Packed, sd, p: str) -> L.FuseW:
     return L.FuseW(w=pk.t(w), b=pk.t(b), x3=pk.x3(w, b))
 
 
-def pack_out(pk: Packed, sd, p: str, dec_weight: torch.Tensor) -> L.OutW:
+def pack_out(pk: Packed, sd, p: str, dec_weight: torch.Tensor, fold: bool = False) -> L.OutW:
     return L.OutW(
         w1=pk.t(sd[p + ".end_conv1x1.0.weight"]), b1=pk.t(sd[p + ".end_conv1x1.0.bias"]),
         w2=pk.t(sd[p + ".end_conv1x1.2.weight"]), b2=pk.t(sd[p + ".end_conv1x1.2.bias"]),
         wdec=pk.t(_tapmajor(dec_weight)),
         x3_1=pk.x3(sd[p + ".end_conv1x1.0.weight"], sd[p + ".end_conv1x1.0.bias"]),
         x3_2=pk.x3(sd[p + ".end_conv1x1.2.weight"], sd[p + ".end_conv1x1.2.bias"]),
-        **pk.glumlp_fused(sd[p + ".end_conv1x1.0.weight"], sd[p + ".end_conv1x1.0.bias"], sd[p + ".end_conv1x1.2.weight"]))
+        **pk.glumlp_fused(sd[p + ".end_conv1x1.0.weight"], sd[p + ".end_conv1x1.0.bias"], sd[p + ".end_conv1x1.2.weight"]),
+        **(pk.glumlp_fold(sd[p + ".end_conv1x1.0.weight"], sd[p + ".end_conv1x1.2.weight"], sd[p + ".end_conv1x1.2.bias"], dec_weight)
+           if fold else {}))
 
 
 class PackedModel(Packed):
@@ -502,5 +527,5 @@ class PackedModel(Packed):
                                   self.spk_fused(sd, f"{p}.spk_attn_{j}.self_attn", cfg.heads, cfg.num_spks)),
                          pack_gcfn(self, sd, f"{p}.spk_attn_{j}.feed_forward")) for j in (1, 2, 3)],
             })
-        self.out_main = pack_out(self, sd, "out_layer", sd["audio_decoder.weight"])
+        self.out_main = pack_out(self, sd, "out_layer", sd["audio_decoder.weight"], fold=True)   # no mask on the main head (model.py:28)
         self.out_aux = [pack_out(self, sd, f"out_layer_bn.{i}", sd[f"decoder_bn.{i}.weight"]) for i in range(R)]

@@ -151,7 +151,7 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.sepr_version() == int(re.search(r"#define SEPR_VERSION (\d+)", hdr).group(1)) == L.ABI_VERSION
     # the latched A/B switches: defaults, and a reload picks up the environment (what the knob fixture of conftest.py relies on)
-    assert [lib.sepr_knob(i) for i in range(4)] == [1, 1, 1, 1] and lib.sepr_knob(99) == 0
+    assert [lib.sepr_knob(i) for i in range(5)] == [1, 1, 1, 1, 1] and lib.sepr_knob(99) == 0
     assert b"gfx950" in lib.sepr_build_info()
     # argument validation happens before any HIP call, so it is checkable without a device
     assert lib.sepr_workspace_bytes(L.OP_GCFN, 0, 8, 0, 128, 256, 2) == 0
@@ -220,6 +220,35 @@ def test_pack_glumlp_fused_layout():
     href = x @ w1.double().t() + b1.double()
     yref = (href[:, :H] * torch.sigmoid(href[:, H:])) @ w2.double().t()
     assert float((y - yref).abs().max() / yref.abs().max()) < 1e-4
+
+
+def test_pack_glumlp_fold_is_the_decoder_behind_the_second_projection():
+    """Folded main head (csrc gcfn_fused3_kernel MODE 2, reference modules/module.py:252-256 + :278-283 with masking = False): the decoded
+    k-slot fragments of ``W_fold = wdec^T . W2`` with ``b_fold``, overlap-added at stride 4, must equal ConvTranspose1d(Linear(g))."""
+    from sepreformer_amd.pack import pack_glumlp_fold
+    g = torch.Generator().manual_seed(11)
+    N, H, K, Lf = 256, 256, 16, 9
+    w2, b2 = torch.randn(N, H, generator=g) * 0.1, torch.randn(N, generator=g) * 0.1
+    wdec = torch.randn(N, 1, K, generator=g) * 0.1
+    w2p, bf = pack_glumlp_fold(w2, b2, wdec)
+    nch = H // 32
+    assert tuple(w2p.shape) == (nch, 1, 2, 64, 8) and w2p.dtype == torch.bfloat16 and tuple(bf.shape) == (K,)
+    ws = w2p[:, 0, 0].double() + w2p[:, 0, 1].double()                       # [c, lane, 8]
+    Wf = torch.zeros(K, H, dtype=torch.float64)
+    for c in range(nch):
+        for gq in range(4):
+            for i in range(16):
+                for e in range(8):
+                    n = 4 * gq + e if e < 4 else 16 + 4 * gq + e - 4
+                    Wf[i, 32 * c + n] = ws[c, gq * 16 + i, e]
+    gated = torch.randn(Lf, H, generator=g).double()
+    taps = gated @ Wf.t() + bf.double()                                      # [L, K]
+    wav = torch.zeros((Lf - 1) * 4 + K, dtype=torch.float64)
+    for l in range(Lf):
+        wav[4 * l:4 * l + K] += taps[l]
+    basis = gated @ w2.double().t() + b2.double()                            # [L, N]
+    ref = torch.nn.functional.conv_transpose1d(basis.t()[None], wdec.double(), stride=4)[0, 0]
+    assert float((wav - ref).abs().max() / ref.abs().max()) < 1e-4
 
 
 def test_pack_x3_layout_and_split():
