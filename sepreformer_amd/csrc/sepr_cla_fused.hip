@@ -98,17 +98,25 @@ __device__ __forceinline__ void load_frames(const float* __restrict__ X, int m0,
   }
 }
 
+#ifndef SEPR_CF_ASMDMA
+#define SEPR_CF_ASMDMA 1   // inline-asm LDS-DMA (sepr_common.h glds16_asm): the copies are waited for at the chunk barriers only
+#endif
 __device__ __forceinline__ void dma_blocks(const uint4* gbase, uint4* lbase, int nblk, int lane, int w) {
   // 1 KiB per wave instruction; per-lane byte offset laundered so the addresses are not hoisted and spilled
   unsigned loff = (unsigned)lane * 16u;
   asm volatile("" : "+v"(loff));
+  [[maybe_unused]] const int ws = __builtin_amdgcn_readfirstlane(w);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     if (i >= nblk) break;
+#if SEPR_CF_ASMDMA
+    glds16_asm(gbase + (i * CF_NW + ws) * 64, loff, __builtin_amdgcn_readfirstlane(lds_addr(lbase + (i * CF_NW + ws) * 64)));
+#else
     const int blk = i * CF_NW + w;
     const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+#endif
   }
 }
 __device__ __forceinline__ void dma_barrier() {

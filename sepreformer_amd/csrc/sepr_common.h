@@ -77,6 +77,22 @@ __device__ __forceinline__ float4 norm4_pinned(float4 v, float mean, float rstd)
   return make_float4(xy[0], xy[1], zw[0], zw[1]);
 }
 
+// ---- LDS-DMA as inline asm ------------------------------------------------------------------------------------------------------------
+// hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the first LDS read behind any LDS-DMA it knows about (it cannot tell the copy's
+// destination from the other LDS reads of the array), which serialises "request the next weight chunk, multiply the current one" - the whole
+// point of the copy (tools/isa_trace.py shows the waits).  Issued from inline asm the copy is invisible to the waitcnt pass and the caller
+// owns the ordering: s_waitcnt vmcnt(N) + a barrier before the first read of the destination.
+// one wave-wide copy: 64 lanes x 16 bytes -> 1 KiB at the wave-uniform LDS address
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 is "reserved": hipcc re-materialises it before each of its own uses
+// (scalar-base form: wave-uniform 64-bit source base in an SGPR pair + one 32-bit per-lane byte offset - no 64-bit per-lane addresses to
+//  keep alive or spill; a spilled address would be re-loaded by a scratch_load, and the wait for THAT drains every copy in flight)
+__device__ __forceinline__ void glds16_asm(const void* src_wave, unsigned lane_off, unsigned lds_wave) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(src_wave), "s"(lds_wave) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
+#pragma clang diagnostic pop
+
 // butterfly sums over the lanes of a wave64
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -91,6 +91,11 @@ struct bool_c { static constexpr bool value = V; };
 #ifndef SEPR_GF3_WGPRIO
 #define SEPR_GF3_WGPRIO 0
 #endif
+#ifndef SEPR_GF3_ASMDMA
+#define SEPR_GF3_ASMDMA 1   // 1: the weight-chunk copies are inline-asm LDS-DMA (invisible to hipcc's waitcnt pass, which otherwise puts an
+                            // s_waitcnt vmcnt(0) in front of the first LDS read behind a copy it knows about - tools/isa_trace.py shows one in
+                            // the middle of the up-projection of the 4-wave kernel); the copies are then waited for at the two chunk barriers only
+#endif
 #ifndef SEPR_GF3_RESX
 #define SEPR_GF3_RESX 0   // EXPERIMENT (round-3 review item 6): 1 = the residual x is rebuilt from the bf16 hi + lo planes the wave
                           // already holds ((hi + lo) / rstd + mean, 2^-17 relative) instead of being re-read from HBM in the
@@ -114,6 +119,10 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fuse
   }
   static_assert(MT == 1 || MT == 2, "frame tiles per wave");
   constexpr int RD = SEPR_GF3_RING;      // LDS fragment read-ahead, in MFMA groups
+  // (Round 6, measured no: with MT = 1 the three MFMAs of a group run back to back on ONE accumulator; issuing the value and the gate tile of a
+  //  K step - and two output tiles of the down-projection - interleaved, from a 6-slot fragment ring, changed nothing: 24.8 vs 23.5 us per
+  //  batch-1 launch, profiles/r06_b1_latency.txt.  Back-to-back accumulation into one tile is forwarded at the issue rate.)
+  constexpr int RDX = RD, FBN = RD + 1;
   constexpr bool UF = SEPR_GF3_UPFIRST != 0;
   constexpr int NT = 64 * NW;
   // XCH: the waves of a workgroup cover 16*MT*NW CONTIGUOUS frames and hand each other the conv's neighbour frame at
@@ -157,6 +166,7 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fuse
   const uint4* const W2g = static_cast<const uint4*>(a.w2p);
 
   // ---- weight chunks: global -> LDS by LDS-DMA, 1 KiB per wave instruction ---------------------------
+  [[maybe_unused]] const int ws = __builtin_amdgcn_readfirstlane(w);   // the wave index as a scalar
   auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {   // nblk 1 KiB blocks, dealt round-robin to the waves
     unsigned loff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(loff));
@@ -166,8 +176,13 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fuse
       const int blk = i * NW + w;
       if (blk < nblk) {
         const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
+#if SEPR_GF3_ASMDMA
+        (void)src;
+        glds16_asm(gbase + (i * NW + ws) * 64, loff, __builtin_amdgcn_readfirstlane(lds_addr(lbase + (i * NW + ws) * 64)));
+#else
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+#endif
       }
     }
   };
@@ -180,8 +195,13 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fuse
       const int blk = 2 * (i * NW + w);
       if (blk < nblk) {
         const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
+#if SEPR_GF3_ASMDMA
+        (void)src;
+        glds16_asm(gbase + 2 * (i * NW + ws) * 64, loff, __builtin_amdgcn_readfirstlane(lds_addr(lbase + 2 * (i * NW + ws) * 64)));
+#else
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+#endif
       }
     }
   };
@@ -205,27 +225,24 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fuse
   // LAT: one chunk image into ring stage c % NST.  Every wave issues exactly LAT_NI copies (block index wraps, so a few blocks are
   // copied twice with the same bytes): the counted waits below are compile-time constants.
   constexpr int LAT_N1 = (W1_U4 / 64 + NW - 1) / NW, LAT_N2 = (W2_U4 / 64 + NW - 1) / NW, LAT_NI = LAT_N1 + LAT_N2;
-  [[maybe_unused]] const unsigned wl_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)wl;
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"   // m0 (the LDS-DMA destination register) is "reserved": hipcc re-materialises it before each of its own uses
+  [[maybe_unused]] const unsigned wl_lds = lds_addr(wl);
   [[maybe_unused]] auto lat_dma = [&](int c) {
     const unsigned stage = wl_lds + (unsigned)((c % NST) * STG_U4 * 16);
-    const char* g1 = reinterpret_cast<const char*>(W1g + (long long)c * W1_U4) + lane * 16;
-    const char* g2 = reinterpret_cast<const char*>(W2g + (long long)c * W2_U4) + lane * 16;
+    const uint4* g1 = W1g + (long long)c * W1_U4;
+    const uint4* g2 = W2g + (long long)c * W2_U4;
+    unsigned loff = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(loff));
 #pragma unroll
     for (int i = 0; i < LAT_N1; ++i) {
-      const int blk = (i * NW + w) % (W1_U4 / 64);
-      const unsigned dst = __builtin_amdgcn_readfirstlane(stage + (unsigned)blk * 1024u);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g1 + blk * 1024), "s"(dst) : "memory", "m0");
+      const int blk = (i * NW + ws) % (W1_U4 / 64);
+      glds16_asm(g1 + blk * 64, loff, __builtin_amdgcn_readfirstlane(stage + (unsigned)blk * 1024u));
     }
 #pragma unroll
     for (int i = 0; i < LAT_N2; ++i) {
-      const int blk = (i * NW + w) % (W2_U4 / 64);
-      const unsigned dst = __builtin_amdgcn_readfirstlane(stage + (unsigned)(W1_U4 * 16) + (unsigned)blk * 1024u);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g2 + blk * 1024), "s"(dst) : "memory", "m0");
+      const int blk = (i * NW + ws) % (W2_U4 / 64);
+      glds16_asm(g2 + blk * 64, loff, __builtin_amdgcn_readfirstlane(stage + (unsigned)(W1_U4 * 16) + (unsigned)blk * 1024u));
     }
   };
-#pragma clang diagnostic pop
   // LAT, top of chunk c: this wave's share of chunk c has landed (later chunks may stay in flight), then the barrier that (a) publishes
   // every wave's share and (b) says every wave is done reading chunk c - 1, whose stage the next request overwrites
   [[maybe_unused]] auto lat_enter = [&](int c) {
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fuse
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (c + NST - 1 < NCH) lat_dma(c + NST - 1);
+    if (c + NST - 1 < NCH && !(SEPR_GF_ABL & 2)) lat_dma(c + NST - 1);
     w1s = wl + (c % NST) * STG_U4;
     csl = wl + (c % NST) * STG_U4 + W1F_U4;
     w2s = wl + (c % NST) * STG_U4 + W1_U4;
@@ -371,9 +388,9 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fuse
       for (int c = 0; c < ((SEPR_GF_ABL & 1) ? 0 : NCH); ++c) {
         if constexpr (LAT > 0) lat_enter(c);
         bf16x8 gh[MT], gw[MT];          // gated values (bf16 hi / lo) in down-projection k-slot order
-        uint4 fb[RD + 1][2];            // fragment ring: RD MFMA groups in flight ahead of the one being multiplied
+        uint4 fb[FBN][2];               // fragment ring: RDX MFMA groups in flight ahead of the one being multiplied
 #pragma unroll
-        for (int g = 0; g < RD; ++g) ld_up(0, g, fb[g]);
+        for (int g = 0; g < RDX; ++g) ld_up(0, g, fb[g]);
         f32x4 hvA[UF ? 2 : 1][MT], hgA[UF ? 2 : 1][MT];
 #pragma unroll
         for (int jj = 0; jj < (UF ? 4 : 2); ++jj) {
@@ -429,7 +446,7 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fuse
           if (SEPR_GF3_PRIO) __builtin_amdgcn_s_setprio(0);
           if (j == 0) {                            // the second tile pair's first fragments arrive under the conv
 #pragma unroll
-            for (int g = 0; g < RD; ++g) ld_up(1, g, fb[g]);
+            for (int g = 0; g < RDX; ++g) ld_up(1, g, fb[g]);
           } else {
             if (XCH) {   // this wave's first / last frame of both tile pairs for the neighbouring waves' conv
 #pragma unroll
@@ -452,7 +469,7 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fuse
             if (c + 1 < NCH && !(SEPR_GF_ABL & 2)) dma_w1(c + 1);        // lands under the conv + down-projection below
             }
 #pragma unroll
-            for (int g = 0; g < RD; ++g)
+            for (int g = 0; g < RDX; ++g)
               if (g < FT) ld_dn(g, fb[g]);
           }
           }
@@ -700,12 +717,18 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fuse
 [[maybe_unused]] constexpr int GF3_MT = SEPR_GF3_MT, GF3_NW = (SEPR_GF3_MT == 1) ? 6 : 4;
 
 // Latency form of the small-launch instantiations (template parameter LAT): taken when a launch has at most one tile per CU, i.e. when its
-// duration IS one workgroup's chunk walk (batch 1, Engine._inference_sample): SEPR_GF_LAT = ring depth (3 default, 2, 0 = off).
+// duration IS one workgroup's chunk walk (batch 1, Engine._inference_sample): SEPR_GF_LAT=0 switches it off.
 static int lat_ring() {
   static const int v = [] {
     const char* e = getenv("SEPR_GF_LAT");
-    const int r = e && e[0] ? atoi(e) : 3;
-    return (r == 2 || r == 3) ? r : 0;
+    return (e && e[0] ? atoi(e) : 3) != 0 ? 3 : 0;
+  }();
+  return v;
+}
+static int lat_nw() {   // A/B: SEPR_GF_LAT_NW=6 keeps the 6-wave tiles for every latency-form launch
+  static const int v = [] {
+    const char* e = getenv("SEPR_GF_LAT_NW");
+    return e && e[0] ? atoi(e) : 4;
   }();
   return v;
 }
@@ -729,9 +752,12 @@ int launch_glumlp_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t str
   const int cap = persistent_grid();
   if (a.M < 12000) {
     const int ntiles = (a.M + 95) / 96;
-    const int lat = ntiles <= lat_max_tiles() ? lat_ring() : 0;   // one tile per CU at most: the latency form (3-stage weight ring, one workgroup per CU)
-    if (lat == 3) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 1, false, false, 3>), dim3(ntiles), dim3(384), 0, stream, a);
-    else if (lat == 2) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 1, false, false, 2>), dim3(ntiles), dim3(384), 0, stream, a);
+    // one tile per CU at most: the latency form (3-stage weight ring, one workgroup per CU), 4 waves (one per SIMD) when that still fits
+    const int lat = ntiles <= lat_max_tiles() ? lat_ring() : 0;
+    const int nt4 = (a.M + 63) / 64;
+    if (lat && nt4 <= lat_max_tiles() && lat_nw() != 6)
+      hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 4, 1, false, false, 3>), dim3(nt4), dim3(256), 0, stream, a);
+    else if (lat) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 1, false, false, 3>), dim3(ntiles), dim3(384), 0, stream, a);
     else hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 1>), dim3(ntiles < cap ? ntiles : cap), dim3(384), 0, stream, a);
   } else {
     const int ntiles = (a.M + 127) / 128;
@@ -801,8 +827,10 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
       else hipLaunchKernelGGL((gcfn_fused3_kernel<64, 1, 6, 0, true>), dim3(grid), dim3(384), 0, stream, a);
     } else if (F == 128) {
       const int lat = ntiles <= lat_max_tiles() ? lat_ring() : 0;
-      if (lat == 3) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 0, false, false, 3>), dim3(grid), dim3(384), 0, stream, a);
-      else if (lat == 2) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 0, false, false, 2>), dim3(grid), dim3(384), 0, stream, a);
+      const int nt4 = (a.M + 4 * 14 - 1) / (4 * 14);
+      if (lat && nt4 <= lat_max_tiles() && lat_nw() != 6)
+        hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 4, 0, false, false, 3>), dim3(nt4), dim3(256), 0, stream, a);
+      else if (lat) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 0, false, false, 3>), dim3(grid), dim3(384), 0, stream, a);
       else hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6>), dim3(grid), dim3(384), 0, stream, a);
     } else if (F == 64) {
       hipLaunchKernelGGL((gcfn_fused3_kernel<64, 1, 6>), dim3(grid), dim3(384), 0, stream, a);

@@ -119,16 +119,24 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const 
       for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- weight chunks: global -> LDS by LDS-DMA (protocol of gcfn_fused3_kernel) ------------------------------
+#ifndef SEPR_SPK_ASMDMA
+#define SEPR_SPK_ASMDMA 1   // inline-asm LDS-DMA (sepr_common.h glds16_asm): the copies are waited for at the chunk barriers only
+#endif
+    [[maybe_unused]] const int ws = __builtin_amdgcn_readfirstlane(w);
     auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {
       unsigned loff = (unsigned)lane * 16u;
       asm volatile("" : "+v"(loff));
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if (i >= nblk) break;
+#if SEPR_SPK_ASMDMA
+        glds16_asm(gbase + (i * NW + ws) * 64, loff, __builtin_amdgcn_readfirstlane(lds_addr(lbase + (i * NW + ws) * 64)));
+#else
         const int blk = i * NW + w;
         const char* src = reinterpret_cast<const char*>(gbase + blk * 64) + loff;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lbase + blk * 64), 16, 0, 0);
+#endif
       }
     };
     auto dma_w1 = [&](int c) {

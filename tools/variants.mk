@@ -45,3 +45,13 @@ VARIANT_noslp = -fno-slp-vectorize
 VARIANT_atnw8 = -DSEPR_AT_NW=8
 # plain-bf16 weight-gradient contraction compiled for 3 waves per SIMD (round 5 A/B; pair with SEPR_TN_WGS=768)
 VARIANT_tn3w = -DSEPR_TN_ONE_WPE=3
+# round 6: timing ablations of the latency-form fused GCFN (batch 1): no chunk loop / no copies after the ring prologue / one fragment read per chunk / no exp+rcp
+VARIANT_gfa1 = -DSEPR_GF_ABL=1
+VARIANT_gfa2 = -DSEPR_GF_ABL=2
+VARIANT_gfa8 = -DSEPR_GF_ABL=8
+VARIANT_gfa16 = -DSEPR_GF_ABL=16
+VARIANT_gfa10 = -DSEPR_GF_ABL=10
+# round 6: inline-asm LDS-DMA in the (non-latency) fused GCFN kernels
+VARIANT_gfasm = -DSEPR_GF3_ASMDMA=1
+VARIANT_noasm = -DSEPR_GF3_ASMDMA=0 -DSEPR_CF_ASMDMA=0 -DSEPR_SPK_ASMDMA=0
+VARIANT_noasmcf = -DSEPR_CF_ASMDMA=0 -DSEPR_SPK_ASMDMA=0
