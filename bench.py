@@ -170,7 +170,7 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-PMC_KERNEL_RE = "gcfn_fused3_kernel<[0-9]+, [0-9], [0-9], 0, false, false>"     # the GCFN instantiations of the fused kernel (not the plain GLU-MLP mode)
+PMC_KERNEL_RE = "gcfn_fused3_kernel<[0-9]+, [0-9], [0-9], 0, false, false, [0-9]>"     # the GCFN instantiations of the fused kernel (not the plain GLU-MLP mode)
 
 
 LARGE_KERNEL_RE = "gemm_x3w?_kernel<1, 7, 1>"       # Large's GCFN up-projection (wide or narrow core), TAG 1
@@ -312,6 +312,8 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
         L.check(lib.sepr_prof_stop(C.byref(n_l), C.byref(ms), C.byref(fl)), "sepr_prof_stop")
         single = {"value": round(world * B * steps / e1, 3), "unit": "utt/s", "ms_per_step": round(1e3 * e1 / max(steps, 1), 3), "steps": steps}
         model.pipelines = pl_setting
+    # per-rank spread of the timed region BEFORE the max: the first multi-GPU run shows its launch jitter directly (min == max on one rank)
+    rank_min_s, rank_max_s = sdist.min_max_over_ranks(elapsed, dev)
     elapsed = sdist.max_over_ranks(elapsed, dev)
     # the path's collective on its own, EVERY rank takes part: wall time of one synchronised 3-scalar all-reduce, median of 10
     ar_ms = None
@@ -440,6 +442,10 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
         "model_frac_algorithmic": round(utt_per_s * gflop / 1e3 / world / peak, 4),
         "model_mfma_frac": round(utt_per_s * gflop / 1e3 / world * mult / peak, 4),
         "roofline": roof,
+        # measured, every run: the ranks' own wall times of the timed region (ms per step, before the max-over-ranks) and the metric
+        # all-reduce on its own - on N > 1 GPUs the min/max spread is the host-side launch jitter dp8_prediction does not model
+        "per_rank_ms_per_step": {"min": round(1e3 * rank_min_s / max(steps, 1), 3), "max": round(1e3 * rank_max_s / max(steps, 1), 3), "ranks": world},
+        "metric_allreduce_ms": None if ar_ms is None else round(ar_ms, 4),
     }
     if single is not None:
         rec["single_pipeline"] = single
@@ -502,9 +508,9 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
             model.use_graphs = False
         rec["latency_b1"] = {"unit": "ms per 4 s utterance (batch 1, model(x): full forward incl. aux heads)",
                              "eager": eager, "hipgraph": graphed,
-                             # launches of one batch-1 forward: a rocprofv3 kernel trace (tools/b1_launches.sh), not re-counted in this run
-                             "launches": 295, "launches_source": "static: profiles/r05_v1_b1_launches.txt (rocprofv3 --kernel-trace of 21 forwards)",
-                             "note": "the latency is the sum of per-tile kernel latencies (56 fused-GCFN launches x 38 us = 2.15 ms), not launch overhead: hipGraph replay is no faster"}
+                             # (the launch count of a batch-1 forward is a rocprofv3 kernel trace, not re-counted here: profiles/r06_b1_launches.txt)
+                             "note": "round 6: launches with at most one tile per CU run the latency form of the fused GCFN / GLU-MLP kernels (3-stage LDS weight "
+                                     "ring, inline-asm LDS-DMA, one barrier per chunk, 4 waves); the latency is still the SUM of per-kernel latencies (hipGraph replay is no faster)"}
     del model
     torch.cuda.empty_cache()
     return rec
@@ -537,7 +543,7 @@ def make_summary(rec) -> dict:
     out = {"utt_s": rec.get("value"), "ms": rec.get("ms_per_step"), "parity_ok": rec.get("parity_ok"), "db": rec.get("parity_db_vs_golden"),
            "pit_d": rec.get("pit_si_snr_max_abs_delta_db"), "roof": [roof.get("frac"), roof.get("avg_launch_ms"), roof.get("traffic_over_algorithmic")],
            "one_pipe": g(rec, "single_pipeline", "value"), "fp32": [g(rec, "alt_precision", "value"), g(rec, "alt_precision", "parity_db_vs_golden")],
-           "lat_b1_ms": [g(rec, "latency_b1", "eager"), g(rec, "latency_b1", "hipgraph"), g(rec, "latency_b1", "launches")],
+           "lat_b1_ms": [g(rec, "latency_b1", "eager"), g(rec, "latency_b1", "hipgraph")],
            "cpu": [g(rec, "cpu_baseline", "value"), g(rec, "cpu_baseline", "cores"), rec.get("speedup_vs_cpu")]}
     lg = rec.get("large")
     if isinstance(lg, dict):

@@ -250,6 +250,21 @@ int sepr_downconv_fwd(const float* x, float* y, int n, int T, int F, int K, cons
 int sepr_spksplit_fwd(const float* x, float* y, int B, int S, int T, int F, float gn_eps,
                       const sepr_split_w* w, void* ws, size_t ws_bytes, sepr_stream_t stream);
 
+/* Statistics-threaded forms of the four residual blocks (ABI 4.10).  Every block of the residual stream starts with a LayerNorm over the F
+ * channels of each frame (network.py:50,81,133,162) and ends by writing that stream; x_stats / y_stats [rows][2] = (mean, rstd) of the rows
+ * of x / y in the library's LayerNorm arithmetic (eps 1e-5).  x_stats (or NULL): as returned through y_stats by the call that produced x -
+ * the block's own statistics pass over x is skipped.  y_stats (or NULL): receives the statistics of y; they come out of the last
+ * projection's tile tail where a workgroup tile holds whole rows (F = 256: the generic bf16x3 path of the Large variants), else from one
+ * extra pass over y.  Results are identical to the plain entry points.  Everything else as in the function without the suffix. */
+int sepr_gcfn_fwd_st(const float* x, const float* x_stats, float* y, float* y_stats, int n, int T, int F, const sepr_gcfn_w* w, void* ws,
+                     size_t ws_bytes, sepr_stream_t stream);
+int sepr_cla_fwd_st(const float* x, const float* x_stats, float* y, float* y_stats, int n, int T, int F, int K, const sepr_cla_w* w,
+                    void* ws, size_t ws_bytes, sepr_stream_t stream);
+int sepr_ega_fwd_st(const float* x, const float* x_stats, float* y, float* y_stats, int n, int T, int Tp, int F, int H,
+                    const sepr_ega_w* w, void* ws, size_t ws_bytes, sepr_stream_t stream);
+int sepr_spkattn_fwd_st(const float* x, const float* x_stats, float* y, float* y_stats, int nS, int S, int T, int F, int H,
+                        const sepr_mha_w* w, void* ws, size_t ws_bytes, sepr_stream_t stream);
+
 /* Decoder-side fusion, modules/module.py:212-214: nearest x2 upsample of lo [n,T/2,F], concat with
  * skip [n,T,F] along channels, Conv1d(2F->F,k=1) -> y [n,T,F]. */
 int sepr_fuse_fwd(const float* lo, const float* skip, float* y, int n, int T, int F, const sepr_fuse_w* w,

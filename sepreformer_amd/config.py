@@ -139,6 +139,8 @@ VARIANTS: Dict[str, SepConfig] = {
     "SepReformer_Large_DM_WHAM": SepConfig(feat=256, dropout=0.1, per_level_split=True),
     # small configuration used by the parity tests (not a reference variant)
     "tiny": SepConfig(num_stages=2, enc_channels=64, feat=64, heads=4, maxlen=40),
+    # the same with THREE speakers: the reference is generic in num_spks (modules/module.py:111-118, network.py:241-247)
+    "tiny3": SepConfig(num_stages=2, num_spks=3, enc_channels=64, feat=64, heads=4, maxlen=40),
 }
 
 

@@ -57,6 +57,18 @@ static int project(int pro, int epi, GemmArgs& a, const sepr_x3_w& x3, int site,
   return launch_gemm(pro, epi, a, site, st);
 }
 
+// the same, with the LayerNorm statistics of the output rows delivered to y_stats (optional): the bf16x3 core takes them from its tile tail
+// or launches rowstats itself (GemmArgs.stats_out); the exact-f32 core is followed by a rowstats launch here
+static int project_stats(int pro, int epi, GemmArgs& a, const sepr_x3_w& x3, int site, hipStream_t st, float* y_stats) {
+  if (y_stats && x3.wp) {
+    a.stats_out = y_stats;
+    a.stats_eps = LN_EPS;
+    return project(pro, epi, a, x3, site, st);
+  }
+  SEPR_TRY(project(pro, epi, a, x3, site, st));
+  return y_stats ? launch_rowstats(a.Y, y_stats, a.M, a.N, LN_EPS, st) : SEPR_OK;
+}
+
 // ---- workspace plans (floats unless noted) --------------------------------------------------------
 static size_t ws_gcfn(long long M, int F) {
   return align_up(2 * M * 4) + align_up(3LL * F * M * 4) + 1024;
@@ -165,8 +177,12 @@ extern "C" int sepr_projector_fwd(const float* enc, int B, int L, int Lp, int N,
   return launch_gemm(PRO_NORM, EPI_STORE, a, SEPR_SITE_PROJECTOR, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int sepr_gcfn_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_w* w, void* ws, size_t ws_bytes,
-                             sepr_stream_t stream) {
+// The *_st entry points (ABI 4.10) thread the LayerNorm row statistics along the residual stream: x_stats (optional) = (mean, rstd) of x's rows
+// as the previous block's *_st call returned them - the block's own statistics pass is skipped; y_stats (optional) = where the statistics of
+// y's rows go (taken from the last projection's tile tail when that tile holds whole rows, else by one rowstats launch).  The values are
+// those of rowstats_kernel either way (sepr_common.h rowstats_one), so a chained walk and an unchained one give identical results.
+static int gcfn_fwd_impl(const float* x, const float* x_stats, float* y, float* y_stats, int n, int T, int F, const sepr_gcfn_w* w, void* ws,
+                         size_t ws_bytes, sepr_stream_t stream) {
   if (!x || !y || !w || n <= 0 || T <= 0 || F <= 0 || F % 32 != 0) return SEPR_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long M = (long long)n * T;
@@ -177,13 +193,15 @@ extern "C" int sepr_gcfn_fwd(const float* x, float* y, int n, int T, int F, cons
     f.x = x; f.y = y; f.M = (int)M; f.T = T;
     f.w1p = w->fused_w1p; f.w2p = w->fused_w2p;
     f.b2 = w->b2; f.ls = w->ls; f.eps = LN_EPS; f.stagger = 0;
-    return launch_gcfn_fused(f, F, SEPR_SITE_GCFN_UP, st);
+    SEPR_TRY(launch_gcfn_fused(f, F, SEPR_SITE_GCFN_UP, st));
+    return y_stats ? launch_rowstats(y, y_stats, M, F, LN_EPS, st) : SEPR_OK;
   }
   Arena ar(ws, ws_bytes);
-  float* stats = ar.f32(2 * M);
+  float* stats_ws = ar.f32(2 * M);
   float* g = ar.f32(3LL * F * M);
   if (!ar.ok()) return SEPR_EWORKSPACE;
-  SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
+  const float* stats = x_stats ? x_stats : stats_ws;
+  if (!x_stats) SEPR_TRY(launch_rowstats(x, stats_ws, M, F, LN_EPS, st));
   {  // net1: LayerNorm -> Linear F->6F, then depthwise k=3 + GLU on the tile while it is still in LDS:
      // the [rows, 6F] hidden tensor (3 KB per row) never goes to HBM      (network.py:61-65)
     GemmArgs a = gemm_args_zero();
@@ -198,19 +216,27 @@ extern "C" int sepr_gcfn_fwd(const float* x, float* y, int n, int T, int F, cons
     a.M = (int)M; a.N = F; a.K = 3 * F;
     a.A = g; a.lda = 3 * F; a.W = w->w2; a.bias = w->b2;
     a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
-    SEPR_TRY(project(PRO_PLAIN, EPI_RES, a, w->x3_down, SEPR_SITE_GCFN_DOWN, st));
+    SEPR_TRY(project_stats(PRO_PLAIN, EPI_RES, a, w->x3_down, SEPR_SITE_GCFN_DOWN, st, y_stats));
   }
   return SEPR_OK;
 }
+extern "C" int sepr_gcfn_fwd(const float* x, float* y, int n, int T, int F, const sepr_gcfn_w* w, void* ws, size_t ws_bytes,
+                             sepr_stream_t stream) {
+  return gcfn_fwd_impl(x, nullptr, y, nullptr, n, T, F, w, ws, ws_bytes, stream);
+}
+extern "C" int sepr_gcfn_fwd_st(const float* x, const float* x_stats, float* y, float* y_stats, int n, int T, int F, const sepr_gcfn_w* w,
+                                void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  return gcfn_fwd_impl(x, x_stats, y, y_stats, n, T, F, w, ws, ws_bytes, stream);
+}
 
-extern "C" int sepr_cla_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_cla_w* w, void* ws,
-                            size_t ws_bytes, sepr_stream_t stream) {
+static int cla_fwd_impl(const float* x, const float* x_stats, float* y, float* y_stats, int n, int T, int F, int K, const sepr_cla_w* w, void* ws,
+                        size_t ws_bytes, sepr_stream_t stream) {
   if (!x || !y || !w || n <= 0 || T <= 0 || F <= 0 || F % 64 != 0) return SEPR_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long M = (long long)n * T;
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
   Arena ar(ws, ws_bytes);
-  float* stats = ar.f32(2 * M);
+  float* stats_ws = ar.f32(2 * M);
   float* u = ar.f32((long long)F * M);
   float* c = ar.f32((long long)F * M);
   float* d = ar.f32(2LL * F * M);
@@ -227,9 +253,11 @@ extern "C" int sepr_cla_fwd(const float* x, float* y, int n, int T, int F, int K
     t.x = c; t.res = x; t.y = y; t.M = (int)M;
     t.w1p = w->fused_w2p; t.w2p = w->fused_w3p; t.b3 = w->b3; t.ls = w->ls; t.eps = 0.f;
     t.att = nullptr; t.T = 0; t.Tp = 0; t.fac = 0;
-    return launch_cla_tail(t, F, SEPR_SITE_CLA, st);
+    SEPR_TRY(launch_cla_tail(t, F, SEPR_SITE_CLA, st));
+    return y_stats ? launch_rowstats(y, y_stats, M, F, LN_EPS, st) : SEPR_OK;
   }
-  SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
+  const float* stats = x_stats ? x_stats : stats_ws;
+  if (!x_stats) SEPR_TRY(launch_rowstats(x, stats_ws, M, F, LN_EPS, st));
   {  // LayerNorm -> linear1 F->2F -> GLU                                  (network.py:175-177)
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = 2 * F; a.K = F;
@@ -249,9 +277,17 @@ extern "C" int sepr_cla_fwd(const float* x, float* y, int n, int T, int F, int K
     a.M = (int)M; a.N = F; a.K = 2 * F;
     a.A = d; a.lda = 2 * F; a.W = w->w3; a.bias = w->b3;
     a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
-    SEPR_TRY(project(PRO_PLAIN, EPI_RES, a, w->x3_3, SEPR_SITE_CLA, st));
+    SEPR_TRY(project_stats(PRO_PLAIN, EPI_RES, a, w->x3_3, SEPR_SITE_CLA, st, y_stats));
   }
   return SEPR_OK;
+}
+extern "C" int sepr_cla_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_cla_w* w, void* ws,
+                            size_t ws_bytes, sepr_stream_t stream) {
+  return cla_fwd_impl(x, nullptr, y, nullptr, n, T, F, K, w, ws, ws_bytes, stream);
+}
+extern "C" int sepr_cla_fwd_st(const float* x, const float* x_stats, float* y, float* y_stats, int n, int T, int F, int K, const sepr_cla_w* w,
+                               void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  return cla_fwd_impl(x, x_stats, y, y_stats, n, T, F, K, w, ws, ws_bytes, stream);
 }
 
 // the bf16x3 attention kernel serves the bf16x3 arithmetic mode (packed q/k/v present); SEPR_ATTN_F32=1 keeps the f32 one
@@ -263,27 +299,30 @@ static int relattn_x3(const sepr_ega_w* w) {
   return (w->attn.x3_qkv.wp != nullptr && !f32) ? 1 : 0;
 }
 
-extern "C" int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const sepr_ega_w* w, void* ws,
-                            size_t ws_bytes, sepr_stream_t stream) {
+static int ega_fwd_impl(const float* x, const float* x_stats, float* y, float* y_stats, int n, int T, int Tp, int F, int H, const sepr_ega_w* w,
+                        void* ws, size_t ws_bytes, sepr_stream_t stream) {
   if (!x || !y || !w || x == y || n <= 0 || T <= 0 || Tp <= 0 || F <= 0 || F % 32 != 0 || T % Tp != 0) return SEPR_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int fac = T / Tp;
   const long long M = (long long)n * T, Mp = (long long)n * Tp;
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
   Arena ar(ws, ws_bytes);
-  float* stats = ar.f32(2 * M);
-  float* stats_p = ar.f32(2 * Mp);
+  float* stats_ws = ar.f32(2 * M);
+  float* stats_pws = ar.f32(2 * Mp);
   float* xd = ar.f32((long long)F * Mp);
   float* qkv = ar.f32(3LL * F * Mp);
   float* o = ar.f32((long long)F * Mp);
   float* att = ar.f32((long long)F * Mp);
   if (!ar.ok()) return SEPR_EWORKSPACE;
   const float* xpool = x;
+  const float* stats_p = stats_pws;
   if (fac > 1) {  // adaptive_avg_pool1d + the LayerNorm statistics of the pooled rows  (network.py:146, :99)
-    SEPR_TRY(launch_pool_stats(x, xd, stats_p, n, Tp, fac, F, LN_EPS, st));
+    SEPR_TRY(launch_pool_stats(x, xd, stats_pws, n, Tp, fac, F, LN_EPS, st));
     xpool = xd;
+  } else if (x_stats) {
+    stats_p = x_stats;          // no pooling: the attention's LayerNorm sees x's own rows
   } else {
-    SEPR_TRY(launch_rowstats(xpool, stats_p, Mp, F, LN_EPS, st));
+    SEPR_TRY(launch_rowstats(xpool, stats_pws, Mp, F, LN_EPS, st));
   }
   {  // MHA: LayerNorm -> q,k,v                                             (network.py:99-102)
     GemmArgs a = gemm_args_zero();
@@ -305,22 +344,32 @@ extern "C" int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int 
     g.x = x; g.res = x; g.y = y; g.M = (int)M;
     g.w1p = w->fused_gate_p; g.w2p = nullptr; g.b3 = nullptr; g.ls = nullptr; g.eps = LN_EPS;
     g.att = att; g.T = T; g.Tp = Tp; g.fac = fac;
-    return launch_ega_gate(g, F, SEPR_SITE_EGA_GATE, st);
+    SEPR_TRY(launch_ega_gate(g, F, SEPR_SITE_EGA_GATE, st));
+    return y_stats ? launch_rowstats(y, y_stats, M, F, LN_EPS, st) : SEPR_OK;
   }
-  SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
+  const float* stats = x_stats ? x_stats : stats_ws;
+  if (!x_stats) SEPR_TRY(launch_rowstats(x, stats_ws, M, F, LN_EPS, st));
   {  // x + sigmoid(Linear(LayerNorm(x))) * upsample(att)                   (network.py:132-135,151-153)
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = F; a.K = F;
     a.A = x; a.lda = F; a.stats = stats; a.gamma = w->gate_ln_g; a.beta = w->gate_ln_b;
     a.W = w->gate_w; a.bias = w->gate_b;
     a.Y = y; a.ldc = F; a.R = x; a.aux = att; a.T = T; a.Tp = Tp; a.fac = fac;
-    SEPR_TRY(project(PRO_NORM, EPI_GATE, a, w->x3_gate, SEPR_SITE_EGA_GATE, st));
+    SEPR_TRY(project_stats(PRO_NORM, EPI_GATE, a, w->x3_gate, SEPR_SITE_EGA_GATE, st, y_stats));
   }
   return SEPR_OK;
 }
+extern "C" int sepr_ega_fwd(const float* x, float* y, int n, int T, int Tp, int F, int H, const sepr_ega_w* w, void* ws,
+                            size_t ws_bytes, sepr_stream_t stream) {
+  return ega_fwd_impl(x, nullptr, y, nullptr, n, T, Tp, F, H, w, ws, ws_bytes, stream);
+}
+extern "C" int sepr_ega_fwd_st(const float* x, const float* x_stats, float* y, float* y_stats, int n, int T, int Tp, int F, int H,
+                               const sepr_ega_w* w, void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  return ega_fwd_impl(x, x_stats, y, y_stats, n, T, Tp, F, H, w, ws, ws_bytes, stream);
+}
 
-extern "C" int sepr_spkattn_fwd(const float* x, float* y, int nS, int S, int T, int F, int H, const sepr_mha_w* w, void* ws,
-                                size_t ws_bytes, sepr_stream_t stream) {
+static int spkattn_fwd_impl(const float* x, const float* x_stats, float* y, float* y_stats, int nS, int S, int T, int F, int H, const sepr_mha_w* w,
+                            void* ws, size_t ws_bytes, sepr_stream_t stream) {
   if (!x || !y || !w || nS <= 0 || S <= 0 || nS % S != 0 || T <= 0 || F <= 0 || F % 32 != 0) return SEPR_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long M = (long long)nS * T;
@@ -331,14 +380,17 @@ extern "C" int sepr_spkattn_fwd(const float* x, float* y, int nS, int S, int T, 
     f.x = x; f.y = y; f.NF = (int)(M / 2); f.T = T;
     f.w1p = w->fused_qkv_p; f.w2p = w->fused_out_p;
     f.bo = w->bo; f.ls = w->ls; f.eps = LN_EPS; f.inv_sqrt_dk = 1.0f / sqrtf((float)(F / H));
-    return launch_spk_fused(f, F, SEPR_SITE_ATTN_PROJ, st);
+    SEPR_TRY(launch_spk_fused(f, F, SEPR_SITE_ATTN_PROJ, st));
+    return y_stats ? launch_rowstats(y, y_stats, M, F, LN_EPS, st) : SEPR_OK;
   }
   Arena ar(ws, ws_bytes);
-  float* stats = ar.f32(2 * M);
+  float* stats_ws = ar.f32(2 * M);
   float* qkv = ar.f32(3LL * F * M);
   float* o = ar.f32((long long)F * M);
   if (!ar.ok()) return SEPR_EWORKSPACE;
-  SEPR_TRY(launch_rowstats(x, stats, M, F, LN_EPS, st));
+  if (x == y && x_stats && y_stats == x_stats) return SEPR_EINVAL;   // (in-place call: the input statistics are still read while the output's are written)
+  const float* stats = x_stats ? x_stats : stats_ws;
+  if (!x_stats) SEPR_TRY(launch_rowstats(x, stats_ws, M, F, LN_EPS, st));
   {
     GemmArgs a = gemm_args_zero();
     a.M = (int)M; a.N = 3 * F; a.K = F;
@@ -352,9 +404,17 @@ extern "C" int sepr_spkattn_fwd(const float* x, float* y, int nS, int S, int T, 
     a.M = (int)M; a.N = F; a.K = F;
     a.A = o; a.lda = F; a.W = w->wo; a.bias = w->bo;
     a.Y = y; a.ldc = F; a.R = x; a.ls = w->ls;
-    SEPR_TRY(project(PRO_PLAIN, EPI_RES, a, w->x3_out, SEPR_SITE_ATTN_PROJ, st));
+    SEPR_TRY(project_stats(PRO_PLAIN, EPI_RES, a, w->x3_out, SEPR_SITE_ATTN_PROJ, st, y_stats));
   }
   return SEPR_OK;
+}
+extern "C" int sepr_spkattn_fwd(const float* x, float* y, int nS, int S, int T, int F, int H, const sepr_mha_w* w, void* ws,
+                                size_t ws_bytes, sepr_stream_t stream) {
+  return spkattn_fwd_impl(x, nullptr, y, nullptr, nS, S, T, F, H, w, ws, ws_bytes, stream);
+}
+extern "C" int sepr_spkattn_fwd_st(const float* x, const float* x_stats, float* y, float* y_stats, int nS, int S, int T, int F, int H,
+                                   const sepr_mha_w* w, void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  return spkattn_fwd_impl(x, x_stats, y, y_stats, nS, S, T, F, H, w, ws, ws_bytes, stream);
 }
 
 extern "C" int sepr_downconv_fwd(const float* x, float* y, int n, int T, int F, int K, const sepr_down_w* w,

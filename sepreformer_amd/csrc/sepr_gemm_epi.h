@@ -62,6 +62,12 @@ struct GemmArgs {
   float drop_scale;
   unsigned long long drop_seed;
   const unsigned long long* drop_salt;
+  // bf16x3 core (round 6): when non-null, (mean, rstd) of every OUTPUT row (LayerNorm statistics over the N = ldc columns, eps stats_eps)
+  // land in stats_out [M][2] - the next block's LayerNorm needs them.  A launch whose workgroup tile holds whole rows (the wide core at
+  // N = 256) computes them at the end of the tile, from the rows it has just written (L2-hot), with the arithmetic of rowstats_kernel;
+  // any other launch is followed by a rowstats launch.  Either way the values are identical.
+  float* stats_out;
+  float stats_eps;
 };
 
 

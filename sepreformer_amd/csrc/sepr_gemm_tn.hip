@@ -212,7 +212,9 @@ __global__ __launch_bounds__(TN_THREADS, MD == 2 ? SEPR_TN_ONE_WPE : 2) void gem
       for (int e = 0; e < 8 * TN_NB; ++e) {
         // (columns past K hold (0 - mean) * rstd garbage: they only ever reach accumulator columns that are never stored)
         const float2 st = st_s[sbuf][32 * (e >> 3) + 8 * mg + (e & 7)];
-        r[e].x = (r[e].x - st.x) * st.y; r[e].y = (r[e].y - st.x) * st.y; r[e].z = (r[e].z - st.x) * st.y; r[e].w = (r[e].w - st.x) * st.y;
+        // pinned like the general loader (round 6): the natural source - st an 8-byte pair, rstd its high dword - is what hipcc's SLP
+        // vectoriser turns into v_pk_mul_f32 op_sel:[0,1], the gfx950-faulty form (sepr_common.h norm4_pinned; tools/isa_lint.py)
+        r[e] = norm4_pinned(r[e], st.x, st.y);
       }
     }
     if (X3) {

@@ -1,5 +1,6 @@
 // Instantiations + host launcher of the bf16x3 projection core.
 #include "sepr_gemm_x3w.h"
+#include "sepr_pointwise.h"
 #include <stdlib.h>
 
 namespace sepr {
@@ -34,12 +35,15 @@ static void launch_x3_inst(const GemmArgs& a, hipStream_t stream) {
     if (wmode > 0 && NB >= 2 && (NB % 2) == 0 && (wmode == 2 || wtiles >= persistent_grid())) {
       const int grid = (cap <= 0 || wtiles < cap) ? wtiles : cap;
       hipLaunchKernelGGL((gemm_x3w_kernel<PRO, EPI, TAG>), dim3(grid), dim3(GEMM_THREADS), 0, stream, a);
+      // output-row statistics: in the kernel's tile tail when a wide tile holds whole rows, else by the row-statistics kernel
+      if (a.stats_out && !(NB == 2 && EPI == EPI_RES)) (void)launch_rowstats(a.Y, a.stats_out, a.M, a.N, a.stats_eps, stream);
       return;
     }
   }
   const int tiles = gemm_tiles(a, EPI);
   const int grid = (cap <= 0 || tiles < cap) ? tiles : cap;
   hipLaunchKernelGGL((gemm_x3_kernel<PRO, EPI, TAG>), dim3(grid), dim3(GEMM_THREADS), 0, stream, a);
+  if (a.stats_out) (void)launch_rowstats(a.Y, a.stats_out, a.M, a.N, a.stats_eps, stream);
 }
 
 int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t stream) {
@@ -51,6 +55,7 @@ int launch_gemm_x3(int pro, int epi, const GemmArgs& a, int site, hipStream_t st
   if (glu && (((a.N / 2) % 16) != 0 || !a.bias)) return SEPR_EINVAL;
   if (!a.A || !a.Wp || !a.Y) return SEPR_EINVAL;
   if ((a.lda % 4) != 0 || (a.ldc % 4) != 0) return SEPR_EINVAL;
+  if (a.stats_out && (a.ldc != a.N || a.N > 512)) return SEPR_EINVAL;   // row statistics: contiguous output rows of at most 512 columns
   if (pro == PRO_CAT2 && (!a.A2 || (a.ksplit % 32) != 0 || (a.lda2 % 4) != 0)) return SEPR_EINVAL;
   if (pro == PRO_NORM && !a.stats) return SEPR_EINVAL;
   if (epi == EPI_DWGLU && (!a.dw_w || !a.dw_b || a.T <= 0)) return SEPR_EINVAL;

@@ -257,6 +257,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_kernel(const GemmArg
       load_slab(0);
     }
     epilogue(m0c, nbc);
+    if constexpr (EPI == EPI_RES) {   // (the gate epilogue's instantiation has no registers to spare: its launcher adds a rowstats launch)
+      if (a.stats_out && NB == 2) {   // (workgroup-uniform) the tile holds whole output rows: their LayerNorm statistics for the next block
+        __syncthreads();              // every wave's rows of the tile are written (workgroup-scope visibility of the global stores)
+        const int sub = tid & 15, nf4 = a.N >> 2;
+        const float invF = 1.0f / (float)a.N;
+#pragma unroll 1
+        for (int r = tid >> 4; r < GEMM_BM; r += GEMM_THREADS / 16) {
+          const int m = m0c + r;
+          if (m < a.M) {
+            float mean, rstd;
+            rowstats_one<4>(a.Y + (long long)m * a.ldc, nf4, invF, a.stats_eps, sub, mean, rstd);   // (NB == 2: at most 256 columns)
+            if (sub == 0) *reinterpret_cast<float2*>(a.stats_out + 2LL * m) = make_float2(mean, rstd);
+          }
+        }
+      }
+    }
     if (!more) break;
     tile = nxt;
     __syncthreads();   // the epilogue staged the tile through the slab buffers

@@ -6,6 +6,7 @@
 // Reference semantics are those of torch.autograd applied to modules/network.py / modules/module.py; each kernel cites
 // the forward lines it differentiates.
 #include "sepr_train.h"
+#include <unordered_map>
 #include <vector>
 
 namespace sepr {
@@ -19,14 +20,7 @@ DropSaltScope::~DropSaltScope() { tl_drop_salt = prev; }
 namespace {
 constexpr int TPB = 256;
 
-__device__ __forceinline__ float reduce16(float v) {
-  v += __shfl_xor(v, 8, 16);
-  v += __shfl_xor(v, 4, 16);
-  v += __shfl_xor(v, 2, 16);
-  v += __shfl_xor(v, 1, 16);
-  return v;
-}
-__device__ __forceinline__ float sum4(float4 v) { return (v.x + v.y) + (v.z + v.w); }
+// (reduce16 / sum4: sepr_common.h)
 // d/dx of the exact-erf GELU: Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_grad(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
@@ -1570,26 +1564,27 @@ int fin_flush(hipStream_t st) {
   // Jobs of one launch run CONCURRENTLY, so two jobs that accumulate into the same tensor (the q / k / v finishers share the LayerNorm's
   // dgamma / dbeta) never share a launch, and launches run in order: a job goes into the first batch with room AFTER the batch of the last
   // earlier job it clashes with.  Every destination therefore sees its additions in the immediate form's order - bit-identical gradients.
-  // (Clashes only occur between finishers of one block, i.e. within a few queue positions: the search looks back 16 jobs.)
+  // The last batch that writes each destination is tracked over the WHOLE queue (round 6; rounds 5's 16-job look-back would have let two
+  // accumulations into one tensor more than 16 jobs apart - a tied weight, a block reused across levels - share a launch).
   const size_t nj = g_fin.jobs.size();
-  auto clash = [](const FinJob& p, const FinJob& c) {
-    const float* op[4] = {p.o0, p.o1, p.o2, p.o3};
-    const float* oc[4] = {c.o0, c.o1, c.o2, c.o3};
-    for (int x = 0; x < 4; ++x)
-      for (int y = 0; y < 4; ++y)
-        if (op[x] && op[x] == oc[y]) return true;
-    return false;
-  };
+  std::unordered_map<const float*, int> last_batch;      // destination -> batch of the last queued job that accumulates into it
   std::vector<int> batch_of(nj, 0), fill;
   for (size_t i = 0; i < nj; ++i) {
+    const FinJob& c = g_fin.jobs[i];
+    const float* oc[4] = {c.o0, c.o1, c.o2, c.o3};
     int b0 = 0;
-    for (size_t q = i > 16 ? i - 16 : 0; q < i; ++q)
-      if (batch_of[q] + 1 > b0 && clash(g_fin.jobs[q], g_fin.jobs[i])) b0 = batch_of[q] + 1;
+    for (int y = 0; y < 4; ++y) {
+      if (!oc[y]) continue;
+      const auto it = last_batch.find(oc[y]);
+      if (it != last_batch.end() && it->second + 1 > b0) b0 = it->second + 1;
+    }
     int bsel = b0;
     while (bsel < (int)fill.size() && fill[bsel] >= FIN_BATCH) ++bsel;
     if (bsel >= (int)fill.size()) fill.resize(bsel + 1, 0);
     batch_of[i] = bsel;
     ++fill[bsel];
+    for (int y = 0; y < 4; ++y)
+      if (oc[y]) last_batch[oc[y]] = bsel;
   }
   for (int bi = 0; bi < (int)fill.size(); ++bi) {
     if (fill[bi] == 0) continue;

@@ -101,6 +101,16 @@ def max_over_ranks(seconds: float, device: torch.device) -> float:
     return float(t.item())
 
 
+def min_max_over_ranks(seconds: float, device: torch.device) -> Tuple[float, float]:
+    """(min, max) of a per-rank wall time: the spread IS the host-side launch jitter between ranks (the one thing a model of the
+    collective cannot predict); one 2-element MAX all-reduce of (-t, t)."""
+    t = torch.tensor([-seconds, seconds], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        all_reduce_off_stream(t, op=dist.ReduceOp.MAX)
+    lo, hi = t.tolist()
+    return -lo, hi
+
+
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         if dist.get_backend() == "nccl":          # (RCCL's barrier is a synchronous all-reduce on the caller's stream: see all_reduce_off_stream)

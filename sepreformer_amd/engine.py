@@ -55,6 +55,11 @@ class SeparatorEngine:
         self._held: list = []
         self._peers: list = []
         self._peer_streams: list = []
+        # SEPR_CHAIN_STATS=1 (round 6 experiment, OFF by default): LayerNorm statistics travel with the residual stream where no fused kernel
+        # owns the LayerNorm (the generic bf16x3 projection path: F = 256) - identical results, and MEASURED NOT FASTER: the wide core's
+        # statistics tail costs what the 92 removed rowstats launches saved (357 utt/s either way; profiles/r06_large_statschain_*.csv)
+        self.chain_stats = (packed.precision == "bf16x3" and cfg.feat not in (64, 128) and os.environ.get("SEPR_CHAIN_STATS", "0") == "1")
+        self._ys: Optional[torch.Tensor] = None       # statistics of the rows the last chained block wrote
 
     # ---- plumbing ---------------------------------------------------------------------------------
     def _stream(self) -> int:
@@ -106,31 +111,64 @@ class SeparatorEngine:
         return t
 
     # ---- blocks (each = one C-ABI call) --------------------------------------------------------------
-    def gcfn(self, x, w, n, T):
+    # Statistics threading (round 6, include/sepr.h "*_st"): on the generic projection path (F = 256, the Large variants) every block
+    # needs the LayerNorm statistics of its input rows, which used to cost a pass over the tensor per block.  A block now hands the
+    # statistics of its OUTPUT rows (computed where the last projection's tile holds whole rows) to the next block: ``xs`` in, ``ys`` out.
+    # Base (fused kernels: LayerNorm inside) keeps the plain entry points.
+    def _stats(self, x):
+        return torch.empty(x.numel() // x.shape[-1], 2, dtype=torch.float32, device=x.device) if self.chain_stats else None
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else t.data_ptr()
+
+    def gcfn(self, x, w, n, T, xs=None):
         y = torch.empty_like(x)
-        L.check(self.lib.sepr_gcfn_fwd(x.data_ptr(), y.data_ptr(), n, T, self.cfg.feat, C.byref(w), *self._wsargs, self._st), "sepr_gcfn_fwd")
+        if not self.chain_stats:
+            L.check(self.lib.sepr_gcfn_fwd(x.data_ptr(), y.data_ptr(), n, T, self.cfg.feat, C.byref(w), *self._wsargs, self._st), "sepr_gcfn_fwd")
+            return y
+        ys = self._stats(y)
+        L.check(self.lib.sepr_gcfn_fwd_st(x.data_ptr(), self._p(xs), y.data_ptr(), ys.data_ptr(), n, T, self.cfg.feat, C.byref(w), *self._wsargs, self._st), "sepr_gcfn_fwd_st")
+        self._ys = ys
         return y
 
-    def cla(self, x, w, n, T):
+    def cla(self, x, w, n, T, xs=None):
         y = torch.empty_like(x)
-        L.check(self.lib.sepr_cla_fwd(x.data_ptr(), y.data_ptr(), n, T, self.cfg.feat, self.cfg.cla_kernel, C.byref(w), *self._wsargs, self._st), "sepr_cla_fwd")
+        if not self.chain_stats:
+            L.check(self.lib.sepr_cla_fwd(x.data_ptr(), y.data_ptr(), n, T, self.cfg.feat, self.cfg.cla_kernel, C.byref(w), *self._wsargs, self._st), "sepr_cla_fwd")
+            return y
+        ys = self._stats(y)
+        L.check(self.lib.sepr_cla_fwd_st(x.data_ptr(), self._p(xs), y.data_ptr(), ys.data_ptr(), n, T, self.cfg.feat, self.cfg.cla_kernel, C.byref(w), *self._wsargs, self._st), "sepr_cla_fwd_st")
+        self._ys = ys
         return y
 
-    def ega(self, x, w, n, T, Tp):
+    def ega(self, x, w, n, T, Tp, xs=None):
         y = torch.empty_like(x)
-        L.check(self.lib.sepr_ega_fwd(x.data_ptr(), y.data_ptr(), n, T, Tp, self.cfg.feat, self.cfg.heads, C.byref(w), *self._wsargs, self._st), "sepr_ega_fwd")
+        if not self.chain_stats:
+            L.check(self.lib.sepr_ega_fwd(x.data_ptr(), y.data_ptr(), n, T, Tp, self.cfg.feat, self.cfg.heads, C.byref(w), *self._wsargs, self._st), "sepr_ega_fwd")
+            return y
+        ys = self._stats(y)
+        L.check(self.lib.sepr_ega_fwd_st(x.data_ptr(), self._p(xs), y.data_ptr(), ys.data_ptr(), n, T, Tp, self.cfg.feat, self.cfg.heads, C.byref(w), *self._wsargs, self._st), "sepr_ega_fwd_st")
+        self._ys = ys
         return y
 
-    def spkattn(self, x, w, n, T):
+    def spkattn(self, x, w, n, T, xs=None):
         y = torch.empty_like(x)
-        L.check(self.lib.sepr_spkattn_fwd(x.data_ptr(), y.data_ptr(), n, self.cfg.num_spks, T, self.cfg.feat, self.cfg.heads, C.byref(w), *self._wsargs, self._st), "sepr_spkattn_fwd")
+        if not self.chain_stats:
+            L.check(self.lib.sepr_spkattn_fwd(x.data_ptr(), y.data_ptr(), n, self.cfg.num_spks, T, self.cfg.feat, self.cfg.heads, C.byref(w), *self._wsargs, self._st), "sepr_spkattn_fwd")
+            return y
+        ys = self._stats(y)
+        L.check(self.lib.sepr_spkattn_fwd_st(x.data_ptr(), self._p(xs), y.data_ptr(), ys.data_ptr(), n, self.cfg.num_spks, T, self.cfg.feat, self.cfg.heads, C.byref(w), *self._wsargs, self._st), "sepr_spkattn_fwd_st")
+        self._ys = ys
         return y
 
-    def global_block(self, x, gw, n, T, Tp):       # reference modules/network.py:198-209
-        return self.gcfn(self.ega(x, gw[0], n, T, Tp), gw[1], n, T)
+    def global_block(self, x, gw, n, T, Tp, xs=None):       # reference modules/network.py:198-209
+        h = self.ega(x, gw[0], n, T, Tp, xs)
+        return self.gcfn(h, gw[1], n, T, self._ys if self.chain_stats else None)
 
-    def local_block(self, x, lw, n, T):            # reference modules/network.py:220-224
-        return self.gcfn(self.cla(x, lw[0], n, T), lw[1], n, T)
+    def local_block(self, x, lw, n, T, xs=None):            # reference modules/network.py:220-224
+        h = self.cla(x, lw[0], n, T, xs)
+        return self.gcfn(h, lw[1], n, T, self._ys if self.chain_stats else None)
 
     def downconv(self, x, w, n, T):
         K = self.cfg.down_kernel
@@ -306,18 +344,22 @@ class SeparatorEngine:
         Tc = Lp
         for i in range(R):
             st = pk.enc_stages[i]
+            cs = None                                                 # (the stage input comes from the projector / a DownConv: no statistics yet)
             for j in range(2):
-                cur = self.global_block(cur, st["g"][j], B, Tc, Tp)
-                cur = self.local_block(cur, st["l"][j], B, Tc)
+                cur = self.global_block(cur, st["g"][j], B, Tc, Tp, cs)
+                cur = self.local_block(cur, st["l"][j], B, Tc, self._ys)
+                cs = self._ys
             if taps is not None:
                 taps[f"enc{i}.skip_pre_split"] = cur
             skips.append((self._aside(lambda ws, sh, x_=cur, i_=i, T_=Tc: self.spksplit(x_, pk.splits[i_], B, T_, ws, sh), cur), Tc))
             cur, Tc = self.downconv(cur, st["down"], B, Tc)
         if Tc != Tp:
             raise RuntimeError(f"internal: bottleneck length {Tc} != pooled length {Tp}")
+        cs = None
         for j in range(2):
-            cur = self.global_block(cur, pk.bottleneck["g"][j], B, Tc, Tp)
-            cur = self.local_block(cur, pk.bottleneck["l"][j], B, Tc)
+            cur = self.global_block(cur, pk.bottleneck["g"][j], B, Tc, Tp, cs)
+            cur = self.local_block(cur, pk.bottleneck["l"][j], B, Tc, self._ys)
+            cs = self._ys
         if taps is not None:
             taps["bottleneck"] = cur
         cur = self.spksplit(cur, pk.splits[R], B, Tc)
@@ -335,11 +377,13 @@ class SeparatorEngine:
             cur = self.fuse(cur, skip, pk.fuse[i], nS, Ts)
             Tc = Ts
             st = pk.dec_stages[i]
+            cs = None                                                 # (fusion conv output)
             for j in range(3):
-                cur = self.global_block(cur, st["g"][j], nS, Tc, Tp)
-                cur = self.local_block(cur, st["l"][j], nS, Tc)
-                cur = self.spkattn(cur, st["spk"][j][0], nS, Tc)
-                cur = self.gcfn(cur, st["spk"][j][1], nS, Tc)
+                cur = self.global_block(cur, st["g"][j], nS, Tc, Tp, cs)
+                cur = self.local_block(cur, st["l"][j], nS, Tc, self._ys)
+                cur = self.spkattn(cur, st["spk"][j][0], nS, Tc, self._ys)
+                cur = self.gcfn(cur, st["spk"][j][1], nS, Tc, self._ys)
+                cs = self._ys
             if taps is not None:
                 taps[f"dec{i}"] = cur
         skips.clear()

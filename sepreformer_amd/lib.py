@@ -134,6 +134,10 @@ SIGNATURES = {
     "sepr_cla_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, C.POINTER(ClaW), _fp, _sz, _fp]),
     "sepr_ega_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _i, C.POINTER(EgaW), _fp, _sz, _fp]),
     "sepr_spkattn_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _i, C.POINTER(MhaW), _fp, _sz, _fp]),
+    "sepr_gcfn_fwd_st": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, C.POINTER(GcfnW), _fp, _sz, _fp]),
+    "sepr_cla_fwd_st": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, C.POINTER(ClaW), _fp, _sz, _fp]),
+    "sepr_ega_fwd_st": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(EgaW), _fp, _sz, _fp]),
+    "sepr_spkattn_fwd_st": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(MhaW), _fp, _sz, _fp]),
     "sepr_downconv_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, C.POINTER(DownW), _fp]),
     "sepr_spksplit_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _f, C.POINTER(SplitW), _fp, _sz, _fp]),
     "sepr_fuse_fwd": (_i, [_fp, _fp, _fp, _i, _i, _i, C.POINTER(FuseW), _fp]),

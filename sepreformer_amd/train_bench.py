@@ -187,6 +187,7 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
         model.train_graphs = prev_graphs
         L.check(lib.sepr_prof_stop(C.byref(n_m), C.byref(ms_m), C.byref(fl_m)), "sepr_prof_stop")
         bytes_m = float(lib.sepr_prof_last_bytes())
+    rank_min_s, rank_max_s = sdist.min_max_over_ranks(elapsed, dev)     # per-rank spread before the max: launch jitter between ranks
     elapsed = sdist.max_over_ranks(elapsed, dev)
     # the gradient all-reduce on its own (the collective of this path): wall time of one synchronised call on the flat buffer,
     # median of 5 - at world size 1 the floor RCCL adds to a step, at N > 1 the real exchange
@@ -233,6 +234,8 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
             "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
             "collective_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
             "allreduce_bytes_per_step": (sync.bytes // max(sync.calls, 1)) if sync.calls else 0,
+            "per_rank_ms_per_step": {"min": round(1e3 * rank_min_s / max(steps, 1), 3), "max": round(1e3 * rank_max_s / max(steps, 1), 3), "ranks": world},
+            "grad_allreduce_ms": None if ar_ms is None else round(ar_ms, 4),
             "model_tflops": round(utt_per_s * gflop / 1e3 / world, 2),
             "model_frac_algorithmic": round(utt_per_s * gflop / 1e3 / world / peak, 4),
             "dp8_prediction": dp8_prediction(1e3 * elapsed / max(steps, 1), B, (sync.bytes // max(sync.calls, 1)) if sync.calls else 0, ar_ms, world,

@@ -324,8 +324,10 @@ class TrainEngine:
         L.check(self.lib.sepr_train_defer_begin(self._fin_arena.data_ptr(), self._fin_arena.numel()), "sepr_train_defer_begin")
         try:
             self._backward_walk(tape, dims, d_wav, d_aux, tp, p_drop, on_decoder_done)
-        finally:
-            L.check(self.lib.sepr_train_defer_flush(1, st_), "sepr_train_defer_flush")
+        except BaseException:
+            self.lib.sepr_train_defer_flush(1, st_)       # close the window, but let the walk's own exception through
+            raise
+        L.check(self.lib.sepr_train_defer_flush(1, st_), "sepr_train_defer_flush")
 
     def _backward_walk(self, tape: list, dims, d_wav, d_aux, tp: TrainPack, p_drop: float, on_decoder_done=None):
         c = self.cfg

@@ -22,6 +22,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional, Tuple
 
 import os
+import sys
 
 import torch
 
@@ -63,9 +64,12 @@ class GradBuffer:
 _TABLES: Dict[tuple, torch.Tensor] = {}      # device pointer tables, keyed by (device index, the pointers): built once per weight placement
 
 
-def _table(tensors: List[torch.Tensor]) -> torch.Tensor:
+def _table(tensors: List[torch.Tensor], keep: Optional[list] = None) -> torch.Tensor:
     """Device table of the tensors' addresses (int64).  Cached: the parameters of a model do not move between steps, so the
-    per-step re-pack issues no host-to-device copy (a captured step could not contain one); ``model.to()`` changes the key."""
+    per-step re-pack issues no host-to-device copy (a captured step could not contain one); ``model.to()`` changes the key.
+    The table's ADDRESS is baked into captured hipGraphs (the pack launches' arguments), so the pack that uses a table holds it
+    (``keep``), and the cache only ever evicts tables nobody else references (round 6: a global clear could free a table a live
+    ``CapturedTrainStep`` replays against)."""
     dev = tensors[0].device
     key = (dev.index, tuple(t.data_ptr() for t in tensors))
     tab = _TABLES.get(key)
@@ -76,8 +80,11 @@ def _table(tensors: List[torch.Tensor]) -> torch.Tensor:
             if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev or t.data_ptr() % 16:
                 raise ValueError("TrainPack reads the parameters in place: every tensor must be contiguous, 16-byte aligned fp32 on one device")
         if len(_TABLES) > 4096:
-            _TABLES.clear()
+            for k in [k for k, v in _TABLES.items() if sys.getrefcount(v) <= 3]:      # the dict, the loop variable, getrefcount's argument
+                del _TABLES[k]
         tab = _TABLES[key] = torch.tensor(key[1], dtype=torch.int64, device=dev)
+    if keep is not None:
+        keep.append(tab)
     return tab
 
 
@@ -104,7 +111,7 @@ class _Stack:
         dev = w[0][0].device
         st = torch.cuda.current_stream(dev).cuda_stream
         flat_w = [t for ws in w for t in ws]
-        wt = _table(flat_w)
+        wt = _table(flat_w, keep)
         self.planes = 1 if precision == "bf16" else 0
         packed = precision in ("bf16x3", "bf16")
         if packed:
@@ -116,7 +123,7 @@ class _Stack:
             self.wp = None
             out = self.w
         keep.append(out)
-        sct = _table(scale).data_ptr() if scale_kind else None
+        sct = _table(scale, keep).data_ptr() if scale_kind else None
         L.check(lib.sepr_train_pack_lin(wt.data_ptr(), sct, G, SN, SK, panels, scale_kind, 1 if transpose else 0, 1 if packed else 0,
                                         out.data_ptr(), st), "sepr_train_pack_lin")
         self.b = None
@@ -125,8 +132,8 @@ class _Stack:
                 raise ValueError("a transposed (input-gradient) form carries no bias")
             self.b = torch.empty(G, self.N, dtype=torch.float32, device=dev)
             keep.append(self.b)
-            bt = _table([t for bs in b for t in bs]).data_ptr() if b is not None else None
-            L.check(lib.sepr_train_fold_bias(wt.data_ptr() if beta is not None else None, bt, _table(beta).data_ptr() if beta is not None else None,
+            bt = _table([t for bs in b for t in bs], keep).data_ptr() if b is not None else None
+            L.check(lib.sepr_train_fold_bias(wt.data_ptr() if beta is not None else None, bt, _table(beta, keep).data_ptr() if beta is not None else None,
                                              G, self.N, self.K, panels, self.b.data_ptr(), st), "sepr_train_fold_bias")
 
     def lin(self, i: int) -> L.Lin:
@@ -230,9 +237,9 @@ class TrainPack:
             G_, KS_, nch_ = len(gcfn_p), F // 32, 3 * F // 32
             fw1 = torch.empty(G_, nch_ * (4 * KS_ * 2048 + 4096), dtype=torch.uint8, device=dev)
             fw2 = torch.empty(G_, nch_, F // 16, 2, 64, 8, dtype=torch.bfloat16, device=dev)
-            L.check(L.load().sepr_train_pack_gcfn_fused(_table(g_w1).data_ptr(), _table(g_b1).data_ptr(), _table(g_lg).data_ptr(), _table(g_lb).data_ptr(),
-                                                        _table(g_w2).data_ptr(), _table(ps(gcfn_p, ".depthwise.weight")).data_ptr(),
-                                                        _table(ps(gcfn_p, ".depthwise.bias")).data_ptr(), G_, F, fw1.data_ptr(), fw2.data_ptr(),
+            tb = lambda ts: _table(ts, self.keep).data_ptr()                                    # noqa: E731
+            L.check(L.load().sepr_train_pack_gcfn_fused(tb(g_w1), tb(g_b1), tb(g_lg), tb(g_lb), tb(g_w2), tb(ps(gcfn_p, ".depthwise.weight")),
+                                                        tb(ps(gcfn_p, ".depthwise.bias")), G_, F, fw1.data_ptr(), fw2.data_ptr(),
                                                         torch.cuda.current_stream(dev).cuda_stream), "sepr_train_pack_gcfn_fused")
             self.keep += [fw1, fw2]
         self.gcfn = []

@@ -273,6 +273,43 @@ def test_blocks(variant, precision):
     agree(f"{tag}.head_aux", got, want)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_ega_base_width_crosses_maxlen(precision):
+    """EGA at Base width with T' = 2100 pooled frames > maxlen = 2000 (more than 16 s of audio at the bottleneck rate): the relative
+    positions |i - j| >= maxlen are clamped (reference modules/module.py:53); until round 6 the clamp was only exercised at tiny
+    width with maxlen 40.  One sequence, pool factor 1 and 2."""
+    m, sd = gpu_model("SepReformer_Base_WSJ0", precision)
+    cfg = m.cfg
+    assert cfg.maxlen == 2000
+    eng = m.engine()
+    eng.prepare(8, 2400, 2400)
+    tag = "Base" + ("" if precision == "fp32" else ".x3")
+    for fac, Tp in ((1, 2100), (2, 2050)):
+        x = rnd(1, cfg.feat, Tp * fac, seed=90 + fac)
+        y = eng.ega(cl(x), eng.pk.enc_stages[0]["g"][0][0], 1, Tp * fac, Tp)
+        want = orc.ega(sd, "separator.enc_stages.0.g_block_1.block.ega", x, orc.rel_pos_k(sd, Tp, cfg.maxlen), cfg.heads)
+        agree(f"{tag}.ega.fac{fac}.Tp{Tp}.clamped", y, want)
+
+
+def test_large_statistics_chain_is_bit_identical():
+    """Round 6 (include/sepr.h ``*_st``): on the generic projection path (F = 256) every block hands the LayerNorm statistics of its output
+    rows - taken from the wide core's tile tail where a tile holds whole rows, else from a rowstats launch - to the next block.  The walk
+    with the chain must equal the walk with one statistics pass per block bit for bit, at a size whose top level runs the wide core
+    (>= 65 536 rows) and whose deeper levels run the narrow one."""
+    m, _ = gpu_model("SepReformer_Large_DM_WHAMR", "bf16x3")
+    eng = m.engine()
+    assert not eng.chain_stats                           # (off by default: measured not faster, profiles/r06_large_statschain_*.csv)
+    x = synth_mixture(9, 32000, seed=77).cuda()          # 9 x 8000 = 72 000 rows at the top level
+    try:
+        b = eng.forward(x)
+        eng.chain_stats = True
+        a = eng.forward(x)
+    finally:
+        eng.chain_stats = False
+    assert torch.isfinite(a[0]).all() and torch.equal(a[0], b[0])
+    assert all(torch.equal(p_, q_) for p_, q_ in zip(a[1], b[1]))
+
+
 def test_groupnorm_stats_entry():
     lib = L.load()
     x = rnd(5, 40000, seed=3) * 2 + 0.7
@@ -290,7 +327,8 @@ def test_groupnorm_stats_entry():
 # ---------------------------------------------------------------------------------------------------
 # end to end against the golden vectors produced by the imported reference
 # ---------------------------------------------------------------------------------------------------
-E2E = [("tiny", "tiny"), ("tiny", "tiny_b1"), ("SepReformer_Base_WSJ0", "base_0p5s"),
+E2E = [("tiny", "tiny"), ("tiny", "tiny_b1"), ("tiny3", "tiny_s3"),            # tiny_s3: THREE speakers (the generic S != 2 paths of the C ABI)
+       ("SepReformer_Base_WSJ0", "base_0p5s"),
        ("SepReformer_Base_WSJ0", "base_4s"), ("SepReformer_Base_WSJ0", "base_sample_wav"),
        ("SepReformer_Large_DM_WHAMR", "large_whamr_0p5s"), ("SepReformer_Large_DM_WHAM", "large_wham_0p5s"),
        ("SepReformer_Large_DM_WHAMR", "large_whamr_4s")]

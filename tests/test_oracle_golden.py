@@ -17,7 +17,7 @@ from sepreformer_amd.config import VARIANTS
 from sepreformer_amd.synth import synth_state_dict
 
 MIN_DB = 100.0
-E2E = [("tiny", "tiny"), ("tiny", "tiny_b1"), ("SepReformer_Base_WSJ0", "base_0p5s"),
+E2E = [("tiny", "tiny"), ("tiny", "tiny_b1"), ("tiny3", "tiny_s3"), ("SepReformer_Base_WSJ0", "base_0p5s"),
        ("SepReformer_Base_WSJ0", "base_4s"), ("SepReformer_Large_DM_WHAMR", "large_whamr_0p5s"),
        ("SepReformer_Large_DM_WHAM", "large_wham_0p5s")]
 

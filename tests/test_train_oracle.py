@@ -3,6 +3,7 @@ made by tests/golden/make_train_golden.py from the IMPORTED reference Model in t
 import dataclasses
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import sepreformer_oracle as orc
@@ -11,9 +12,10 @@ from sepreformer_amd.config import VARIANTS
 from sepreformer_amd.synth import _gen, synth_state_dict
 
 
-def test_train_oracle_reproduces_reference_step(golden):
-    g = golden("train_tiny")
-    cfg = dataclasses.replace(VARIANTS["tiny"], dropout=0.0)
+@pytest.mark.parametrize("variant,tag", [("tiny", "train_tiny"), ("tiny3", "train_tiny_s3")])      # two and THREE speakers
+def test_train_oracle_reproduces_reference_step(golden, variant, tag):
+    g = golden(tag)
+    cfg = dataclasses.replace(VARIANTS[variant], dropout=0.0)
     x = torch.from_numpy(g["x"])
     src = [torch.from_numpy(g["src"][:, s].copy()) for s in range(cfg.num_spks)]
     sd = tor.leaf_state(synth_state_dict(cfg, 0))
