@@ -106,7 +106,7 @@ struct bool_c { static constexpr bool value = V; };
 // as their bf16 hi plane alone, ONE MFMA per product instead of three, no lo-plane split on the VALU, and only the hi-plane
 // blocks of every packed weight chunk are copied to LDS (half the L2 -> LDS stream).  Same packed weights, same LDS layout.
 template <int F, int MT, int NW, int MODE = 0, bool TRAIN = false, bool ONE = false, int LAT = 0>
-__global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
+__global__ __launch_bounds__(64 * NW, LAT > 0 ? (NW > 4 ? 2 : 1) : (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
   constexpr bool PLAIN = MODE >= 1;   // frames are independent: no halo, no seam exchange, no conv
   constexpr bool FOLD = MODE == 2;    // OutputLayer with the AudioDecoder folded into its second projection (see launch_glumlp_fold)
   static_assert(!(TRAIN && PLAIN), "the train instantiation is the GCFN block");
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fuse
   // two frames at the workgroup's ends are recomputed halo: 126 outputs per 128 frames instead of 120, and - what
   // matters more - 64000 x 2^k rows are then just under 512 x 2^k tiles, i.e. full launch rounds instead of
   // "one round + a 4 % tail" (534 tiles on 512 slots).  Without XCH every wave carries its own two halo frames.
-  constexpr bool XCH = (SEPR_GF3_XCH != 0) && MT == 2 && UF && !PLAIN;
+  constexpr bool XCH = (SEPR_GF3_XCH != 0) && MT == 2 && UF && !PLAIN && LAT == 0;   // (ring form: ONE barrier per chunk - with a second, LDS-only
+                                                                                    //  barrier for the seam exchange it measured 2 % slower: r06_gcfn_ring.txt)
   constexpr int HALO = PLAIN ? 0 : 1;
   constexpr int WSTR = (XCH || PLAIN) ? 16 * MT : 16 * MT - 2;            // frames a wave advances
   constexpr int FOLD_HB = 3;                                       // (K - 1) / stride of the folded ConvTranspose1d(k = 16, stride 4)
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? 1 : (2 * NW) / 4) void gcfn_fuse
   // vmcnt to 0 in front of the first LDS read behind any LDS-DMA it knows about, which is what serialised copy and multiply before.
   constexpr int NST = LAT > 0 ? LAT : 1;
   constexpr int STG_U4 = W1_U4 + W2_U4;
-  static_assert(LAT == 0 || (!XCH && !TRAIN && !FOLD && F == 128), "latency form: the small-launch inference instantiations");
+  static_assert(LAT == 0 || (!TRAIN && !FOLD && F == 128), "ring form: inference instantiations");
   __shared__ __attribute__((aligned(16))) uint4 wl[LAT > 0 ? NST * STG_U4 : W1F_U4 + W2_U4 + 2 * CS_U4];
   __shared__ __attribute__((aligned(16))) float xch[XCH ? NW * 2 * 2 * 2 * 16 : 4];   // [wave][first|last frame][j][v|g][16 ch]
   static_assert(FOLD || sizeof(uint4) * (W1F_U4 + W2_U4) >= sizeof(float) * 64 * OS, "epilogue staging must fit");
@@ -843,6 +844,15 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
       const int ntiles = (a.M + tile_rows - 1) / tile_rows;
       const int cap = persistent_grid();
       const int grid = ntiles < cap ? ntiles : cap;
+      static const int big_ring = [] {   // EXPERIMENT (round 6): the ring form for LARGE launches - one 8-wave workgroup per CU, 30-frame waves
+        const char* e = getenv("SEPR_GF_BIG_RING");
+        return e && e[0] ? atoi(e) : 0;
+      }();
+      if (big_ring && !a.train && F == 128) {
+        const int nt8 = (a.M + 8 * 30 - 1) / (8 * 30);
+        const int cus = lat_max_tiles();
+        hipLaunchKernelGGL((gcfn_fused3_kernel<128, 2, 8, 0, false, false, 3>), dim3(nt8 < cus ? nt8 : cus), dim3(512), 0, stream, a);
+      } else
       if (a.train && a.planes == 1) {
         if (F == 128) hipLaunchKernelGGL((gcfn_fused3_kernel<128, GF3_MT, GF3_NW, 0, true, true>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
         else hipLaunchKernelGGL((gcfn_fused3_kernel<64, GF3_MT, GF3_NW, 0, true, true>), dim3(grid), dim3(64 * GF3_NW), 0, stream, a);
