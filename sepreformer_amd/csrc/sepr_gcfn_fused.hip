@@ -649,7 +649,11 @@ __global__ __launch_bounds__(64 * NW, LAT > 0 ? (NW > 4 ? 2 : 1) : (2 * NW) / 4)
         const bool ok = row < 64 && ww < NW && m < a.M &&
                         (PLAIN ? true : (XCH ? (bf >= 1 && bf <= GF_TILE) : (lr >= 1 && lr <= 16 * MT - 2)));
         mrow[p] = ok ? m : -1;
-        xr[p] = (PLAIN || (SEPR_GF3_RESX && !TRAIN)) ? zero4() : ld4(a.x + (long long)(ok ? m : 0) * F + 4 * q4);
+        // (timing ablations, wrong results: SEPR_GF_ABL & 128 = no residual re-read at all - the upper bound of what removing the second read of x
+        //  could buy; & 256 = the re-read comes from a COLD address range (the output tensor of the launch) instead of the rows the tile loaded
+        //  ~20 us earlier - if that costs nothing either, the re-read is off the critical path wherever it is served from)
+        xr[p] = (PLAIN || (SEPR_GF3_RESX && !TRAIN) || (SEPR_GF_ABL & 128)) ? zero4()
+                : ld4(((SEPR_GF_ABL & 256) ? a.y : a.x) + (long long)(ok ? m : 0) * F + 4 * q4);
       }
       if (w / WPP == half) {
         float* base = Os + (w % WPP) * (16 * MT) * OS;

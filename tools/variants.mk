@@ -55,3 +55,6 @@ VARIANT_gfa10 = -DSEPR_GF_ABL=10
 VARIANT_gfasm = -DSEPR_GF3_ASMDMA=1
 VARIANT_noasm = -DSEPR_GF3_ASMDMA=0 -DSEPR_CF_ASMDMA=0 -DSEPR_SPK_ASMDMA=0
 VARIANT_noasmcf = -DSEPR_CF_ASMDMA=0 -DSEPR_SPK_ASMDMA=0
+# round 6, review item 4: what does the epilogue's second read of x cost?  gfa128 = no residual read (wrong results), gfa256 = residual read from a cold range
+VARIANT_gfa128 = -DSEPR_GF_ABL=128
+VARIANT_gfa256 = -DSEPR_GF_ABL=256
