@@ -882,21 +882,31 @@ __global__ __launch_bounds__(TPB) void decoder_kernel(const float* __restrict__ 
   const float* xrow = O2 + ((long long)seq * (idx ? Tsrc : L) + src) * N + 4 * fg;
   const float* erow = enc ? enc + ((long long)(seq / S) * L + lc) * N + 4 * fg : nullptr;
   const float* wrow = wdec + (long long)fi * N + 4 * fg;     // tap fi
-  f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // Four K steps per trip: their 12 loads are issued back to back BEFORE the first product (a trip pays one memory latency, not four), and the
+  // products alternate between two accumulators (the f32 MFMA's dependent-accumulator latency is 40 cycles against a 32-cycle issue).
+  // (N % 64 == 0 is checked by the launcher; round 6: 168 -> see profiles/r06_*kernel_stats.csv per launch for the four auxiliary heads)
+  f32x4 d0 = (f32x4){0.f, 0.f, 0.f, 0.f}, d1 = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int steps = N / 16;
-  for (int cc = 0; cc < steps; ++cc) {
-    float4 x = ld4(xrow + 16 * cc);
-    const float4 wv = ld4(wrow + 16 * cc);
-    if (erow) {
-      const float4 e = ld4(erow + 16 * cc);
-      x = make_float4(fmaxf(x.x, 0.f) * e.x, fmaxf(x.y, 0.f) * e.y, fmaxf(x.z, 0.f) * e.z, fmaxf(x.w, 0.f) * e.w);
+#pragma unroll 1
+  for (int cb = 0; cb < steps; cb += 4) {
+    float4 x[4], wv[4], e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      x[u] = ld4(xrow + 16 * (cb + u));
+      wv[u] = ld4(wrow + 16 * (cb + u));
+      e[u] = erow ? ld4(erow + 16 * (cb + u)) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
-    if (!valid) x = zero4();
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, x.x, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, x.y, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, x.z, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, x.w, d, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (erow) x[u] = make_float4(fmaxf(x[u].x, 0.f) * e[u].x, fmaxf(x[u].y, 0.f) * e[u].y, fmaxf(x[u].z, 0.f) * e[u].z, fmaxf(x[u].w, 0.f) * e[u].w);
+      if (!valid) x[u] = zero4();
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].x, x[u].x, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].y, x[u].y, d1, 0, 0, 0);
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].z, x[u].z, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].w, x[u].w, d1, 0, 0, 0);
+    }
   }
+  const f32x4 d = d0 + d1;
   // lane holds D[frame = 16w + fi][tap = 4fg + r]
   st4(Ds + (16 * w + fi) * K + 4 * fg, make_float4(d[0], d[1], d[2], d[3]));
   __syncthreads();
@@ -918,7 +928,7 @@ __global__ __launch_bounds__(TPB) void decoder_kernel(const float* __restrict__ 
 int launch_decoder(const float* O2, int nS, int S, int L, int N, int K, int stride, const float* wdec, float* wav,
                    int Tout, const int* idx, int Tsrc, const float* enc, hipStream_t s) {
   if (nS <= 0 || L <= 0) return SEPR_EINVAL;
-  if (K != 16 || stride < 4 || stride > 16 || N > 4096 || N % 16 != 0 || S <= 0 || nS % S != 0) return SEPR_EINVAL;
+  if (K != 16 || stride < 4 || stride > 16 || N > 4096 || N % 64 != 0 || S <= 0 || nS % S != 0) return SEPR_EINVAL;
   if ((K - 1) / stride > DEC_HB) return SEPR_EINVAL;
   const int hb = (K - 1) / stride;
   const int tiles = (L + hb + DEC_FT - 1) / DEC_FT;
