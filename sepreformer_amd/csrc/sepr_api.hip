@@ -187,7 +187,7 @@ static int gcfn_fwd_impl(const float* x, const float* x_stats, float* y, float* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long M = (long long)n * T;
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
-  if (w->fused_w1p && w->fused_w2p && x != y && (F == 64 || F == 128)) {
+  if (w->fused_w1p && w->fused_w2p && x != y && (F == 64 || F == 128 || F == 256)) {
     // one kernel: LayerNorm + both projections + depthwise conv + GLU + LayerScale + residual
     GcfnFusedArgs f = {};
     f.x = x; f.y = y; f.M = (int)M; f.T = T;

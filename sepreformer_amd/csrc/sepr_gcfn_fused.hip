@@ -106,7 +106,7 @@ struct bool_c { static constexpr bool value = V; };
 // as their bf16 hi plane alone, ONE MFMA per product instead of three, no lo-plane split on the VALU, and only the hi-plane
 // blocks of every packed weight chunk are copied to LDS (half the L2 -> LDS stream).  Same packed weights, same LDS layout.
 template <int F, int MT, int NW, int MODE = 0, bool TRAIN = false, bool ONE = false, int LAT = 0>
-__global__ __launch_bounds__(64 * NW, LAT > 0 ? (NW > 4 ? 2 : 1) : (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
+__global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128) ? (NW > 4 ? 2 : 1) : (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
   constexpr bool PLAIN = MODE >= 1;   // frames are independent: no halo, no seam exchange, no conv
   constexpr bool FOLD = MODE == 2;    // OutputLayer with the AudioDecoder folded into its second projection (see launch_glumlp_fold)
   static_assert(!(TRAIN && PLAIN), "the train instantiation is the GCFN block");
@@ -807,8 +807,22 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
   }();
   GcfnFusedArgs a = a_in;
   a.stagger = stagger;
-  if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || !a.ls || a.T <= 0 || (F != 64 && F != 128)) return SEPR_EINVAL;
+  if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || !a.ls || a.T <= 0 || (F != 64 && F != 128 && F != 256)) return SEPR_EINVAL;
   if (a.x == a.y) return SEPR_EINVAL;   // halo frames of a tile are outputs of its neighbours
+  if (F == 256) {
+    // Large (round 6): the row-stationary form at F = 256 needs 128 registers of frame planes + 128 of down-projection accumulators per
+    // wave - it exists in the ONE-wave-per-SIMD regime (512 registers per wave: four 30-frame waves, one 106 KB workgroup per CU), which the
+    // inline-asm weight copies make viable (they fly under the multiplies instead of being waited for).  Inference only.
+    if (a.train) return SEPR_EINVAL;
+    long long slot256 = -1;
+    const bool timed256 = prof_begin(site, stream, &slot256);
+    const int cus = lat_max_tiles();
+    const int nt = (a.M + 4 * 32 - 2 - 1) / (4 * 32 - 2);
+    hipLaunchKernelGGL((gcfn_fused3_kernel<256, 2, 4>), dim3(nt < cus ? nt : cus), dim3(256), 0, stream, a);
+    if (timed256) prof_end(slot256, (double)a.M * (2.0 * F * 6 * F + 2.0 * 3 * 6 * F + 2.0 * 3 * F * F), stream);
+    SEPR_CHECK_LAUNCH("gcfn_fused_kernel<256>");
+    return SEPR_OK;
+  }
   if (a.planes == 1 && !a.train) return SEPR_EINVAL;   // plain bf16 operands: a training arithmetic only
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);

@@ -102,7 +102,7 @@ class Packed:
     def gcfn_fused(self, sd, p: str) -> dict:
         """Fused-GCFN weight forms (bf16x3 mode, F in {64, 128}); empty dict otherwise."""
         F = sd[p + ".net1.0.weight"].shape[0]
-        if self.precision != "bf16x3" or F not in (64, 128) or not self.fuse_gcfn:
+        if self.precision != "bf16x3" or F not in (64, 128, 256) or not self.fuse_gcfn or (F == 256 and os.environ.get("SEPR_FUSE_GCFN256", "1") == "0"):
             return {}
         w1p, w2p = pack_gcfn_fused(sd[p + ".net1.1.weight"], sd[p + ".net1.1.bias"], sd[p + ".net1.0.weight"],
                                    sd[p + ".net1.0.bias"], sd[p + ".net2.2.weight"], sd[p + ".depthwise.weight"],
