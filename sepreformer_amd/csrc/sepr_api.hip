@@ -241,7 +241,7 @@ static int cla_fwd_impl(const float* x, const float* x_stats, float* y, float* y
   float* c = ar.f32((long long)F * M);
   float* d = ar.f32(2LL * F * M);
   if (!ar.ok()) return SEPR_EWORKSPACE;
-  if (w->fused_w1p && w->fused_w2p && w->fused_w3p && F == 128 && x != y) {
+  if (w->fused_w1p && w->fused_w2p && w->fused_w3p && (F == 128 || F == 256) && x != y) {
     // three launches: LayerNorm+linear1+GLU | depthwise conv | linear2+BN+GELU+linear3+LayerScale+residual
     ClaFusedArgs h;
     h.x = x; h.res = nullptr; h.y = u; h.M = (int)M;
@@ -339,7 +339,7 @@ static int ega_fwd_impl(const float* x, const float* x_stats, float* y, float* y
     a.Y = att; a.ldc = F; a.R = nullptr; a.ls = w->attn.ls;
     SEPR_TRY(project(PRO_PLAIN, EPI_RES, a, w->attn.x3_out, SEPR_SITE_ATTN_PROJ, st));
   }
-  if (w->fused_gate_p && F == 128) {
+  if (w->fused_gate_p && (F == 128 || F == 256)) {
     ClaFusedArgs g;
     g.x = x; g.res = x; g.y = y; g.M = (int)M;
     g.w1p = w->fused_gate_p; g.w2p = nullptr; g.b3 = nullptr; g.ls = nullptr; g.eps = LN_EPS;

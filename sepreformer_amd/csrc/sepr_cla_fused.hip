@@ -107,7 +107,7 @@ __device__ __forceinline__ void dma_blocks(const uint4* gbase, uint4* lbase, int
   asm volatile("" : "+v"(loff));
   [[maybe_unused]] const int ws = __builtin_amdgcn_readfirstlane(w);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < 17; ++i) {       // (17: the head's chunk at F = 256 is 64 KB of fragments + the 4 KB constants block)
     if (i >= nblk) break;
 #if SEPR_CF_ASMDMA
     glds16_asm(gbase + (i * CF_NW + ws) * 64, loff, __builtin_amdgcn_readfirstlane(lds_addr(lbase + (i * CF_NW + ws) * 64)));
@@ -198,8 +198,9 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[F / 16][CF_MT], fl
 // GATE = false: the CLA head.  GATE = true: the EGA gate  y = x + sigmoid(Linear_F->F(LayerNorm(x))) * upsample(att)
 // (network.py:132-135,151-153): the same chunk walk with the four tiles of a chunk as four plain output tiles
 // (64 output channels per chunk) and the gate applied in the store pass.
+// F = 256 (Large, round 6): 128 registers of frame planes + 128 of output tile - the ONE-wave-per-SIMD regime (one 139 KB workgroup per CU)
 template <int F, bool GATE>
-__global__ __launch_bounds__(CF_NT, 2) void cla_head_kernel(const ClaFusedArgs a) {
+__global__ __launch_bounds__(CF_NT, F > 128 ? 1 : 2) void cla_head_kernel(const ClaFusedArgs a) {
   constexpr int MT = CF_MT, NW = CF_NW, NT = CF_NT;
   constexpr int TILE = 32 * NW;
   constexpr int KS = F / 32;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(CF_NT, 2) void cla_head_kernel(const ClaFusedArgs a
   // two (fragments + constants) buffers: chunk c+1 is copied while chunk c is multiplied
   __shared__ __attribute__((aligned(16))) uint4 wl[2 * W1_U4];
   static_assert(sizeof(uint4) * 2 * W1_U4 >= sizeof(float) * 64 * OS, "epilogue staging must fit");
-  static_assert(W1_U4 % NT == 0 && W1_U4 / NT <= 16, "copy partition");
+  static_assert(W1_U4 % NT == 0 && W1_U4 / NT <= 17, "copy partition");
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fi = lane & 15, fg = lane >> 4;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(CF_NT, 2) void cla_head_kernel(const ClaFusedArgs a
 // tail: y = x + ls * Linear3(GELU(Linear2'(c)))      (eval BatchNorm folded into Linear2')
 // ---------------------------------------------------------------------------------------------------------------------
 template <int F>
-__global__ __launch_bounds__(CF_NT, 2) void cla_tail_kernel(const ClaFusedArgs a) {
+__global__ __launch_bounds__(CF_NT, F > 128 ? 1 : 2) void cla_tail_kernel(const ClaFusedArgs a) {
   constexpr int MT = CF_MT, NW = CF_NW, NT = CF_NT;
   constexpr int TILE = 32 * NW;
   constexpr int KS = F / 32;
@@ -425,12 +426,13 @@ __global__ __launch_bounds__(CF_NT, 2) void cla_tail_kernel(const ClaFusedArgs a
 
 int launch_cla_head(const ClaFusedArgs& a, int F, int site, hipStream_t stream) {
   if (a.M <= 0) return SEPR_OK;
-  if (!a.x || !a.y || !a.w1p || a.x == a.y || F != 128) return SEPR_EINVAL;
+  if (!a.x || !a.y || !a.w1p || a.x == a.y || (F != 128 && F != 256)) return SEPR_EINVAL;
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
   const int ntiles = (a.M + 127) / 128;
   const int cap = persistent_grid();
-  hipLaunchKernelGGL((cla_head_kernel<128, false>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
+  if (F == 256) hipLaunchKernelGGL((cla_head_kernel<256, false>), dim3(ntiles < cap / 2 ? ntiles : cap / 2), dim3(CF_NT), 0, stream, a);   // one workgroup per CU
+  else hipLaunchKernelGGL((cla_head_kernel<128, false>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
   if (timed) prof_end(slot, (double)a.M * 2.0 * F * 2 * F, stream);
   SEPR_CHECK_LAUNCH("cla_head_kernel");
   return SEPR_OK;
@@ -438,13 +440,14 @@ int launch_cla_head(const ClaFusedArgs& a, int F, int site, hipStream_t stream) 
 
 int launch_ega_gate(const ClaFusedArgs& a, int F, int site, hipStream_t stream) {
   if (a.M <= 0) return SEPR_OK;
-  if (!a.x || !a.res || !a.att || !a.y || !a.w1p || a.x == a.y || F != 128 || a.T <= 0 || a.Tp <= 0 || a.fac <= 0)
+  if (!a.x || !a.res || !a.att || !a.y || !a.w1p || a.x == a.y || (F != 128 && F != 256) || a.T <= 0 || a.Tp <= 0 || a.fac <= 0)
     return SEPR_EINVAL;
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
   const int ntiles = (a.M + 127) / 128;
   const int cap = persistent_grid();
-  hipLaunchKernelGGL((cla_head_kernel<128, true>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
+  if (F == 256) hipLaunchKernelGGL((cla_head_kernel<256, true>), dim3(ntiles < cap / 2 ? ntiles : cap / 2), dim3(CF_NT), 0, stream, a);
+  else hipLaunchKernelGGL((cla_head_kernel<128, true>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
   if (timed) prof_end(slot, (double)a.M * 2.0 * F * F, stream);
   SEPR_CHECK_LAUNCH("ega_gate_kernel");
   return SEPR_OK;
@@ -452,12 +455,13 @@ int launch_ega_gate(const ClaFusedArgs& a, int F, int site, hipStream_t stream) 
 
 int launch_cla_tail(const ClaFusedArgs& a, int F, int site, hipStream_t stream) {
   if (a.M <= 0) return SEPR_OK;
-  if (!a.x || !a.res || !a.y || !a.w1p || !a.w2p || !a.b3 || !a.ls || a.x == a.y || F != 128) return SEPR_EINVAL;
+  if (!a.x || !a.res || !a.y || !a.w1p || !a.w2p || !a.b3 || !a.ls || a.x == a.y || (F != 128 && F != 256)) return SEPR_EINVAL;
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
   const int ntiles = (a.M + 127) / 128;
   const int cap = persistent_grid();
-  hipLaunchKernelGGL((cla_tail_kernel<128>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
+  if (F == 256) hipLaunchKernelGGL((cla_tail_kernel<256>), dim3(ntiles < cap / 2 ? ntiles : cap / 2), dim3(CF_NT), 0, stream, a);
+  else hipLaunchKernelGGL((cla_tail_kernel<128>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
   if (timed) prof_end(slot, (double)a.M * (2.0 * F * 2 * F + 2.0 * 2 * F * F), stream);
   SEPR_CHECK_LAUNCH("cla_tail_kernel");
   return SEPR_OK;

@@ -114,7 +114,7 @@ class Packed:
     def cla_fused(self, sd, p: str, w2: torch.Tensor, b2: torch.Tensor) -> dict:
         """Fused CLA head / tail weight forms (bf16x3, F = 128); ``w2`` / ``b2`` = linear2 with BatchNorm folded."""
         F = sd[p + ".layer_norm.weight"].shape[0]
-        if self.precision != "bf16x3" or F != 128 or not self.fuse_cla:
+        if self.precision != "bf16x3" or F not in (128, 256) or not self.fuse_cla or (F == 256 and os.environ.get("SEPR_FUSE_CLA256", "1") == "0"):
             return {}
         w1p, w2p, w3p = pack_cla_fused(sd[p + ".linear1.weight"], sd[p + ".linear1.bias"], sd[p + ".layer_norm.weight"],
                                        sd[p + ".layer_norm.bias"], w2, b2, sd[p + ".linear3.1.weight"])
@@ -124,7 +124,7 @@ class Packed:
     def gate_fused(self, sd, p: str) -> dict:
         """Fused EGA-gate weight form (bf16x3, F = 128)."""
         F = sd[p + ".block.linear.0.weight"].shape[0]
-        if self.precision != "bf16x3" or F != 128 or not self.fuse_gate:
+        if self.precision != "bf16x3" or F not in (128, 256) or not self.fuse_gate or (F == 256 and os.environ.get("SEPR_FUSE_GATE256", "1") == "0"):
             return {}
         wp = pack_gate_fused(sd[p + ".block.linear.1.weight"], sd[p + ".block.linear.1.bias"],
                              sd[p + ".block.linear.0.weight"], sd[p + ".block.linear.0.bias"])
