@@ -439,7 +439,7 @@ extern "C" int sepr_spksplit_fwd(const float* x, float* y, int B, int S, int T, 
   double* part = ar.f64((size_t)n_out * nchunk * 2);
   float* stats = ar.f32((size_t)n_out * 2);
   if (!ar.ok()) return SEPR_EWORKSPACE;
-  if (w->fused_w1p && w->fused_w2p && F == 128 && x != y) {
+  if (w->fused_w1p && w->fused_w2p && (F == 128 || F == 256) && x != y) {
     // one kernel per speaker: Conv1d F->4FS + GLU + the speaker's F rows of Conv1d 2FS->FS, written straight to sequence
     // b*S+s (module.py:114-116,123); the [rows, 2FS] gated tensor stays in registers
     const int nch = 2 * F * S / 32;
@@ -495,7 +495,7 @@ extern "C" int sepr_outlayer_decoder_fwd(const float* x, int nS, int S, int Tsrc
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long M = (long long)nS * L;
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
-  if (w->fold_w2p && w->fold_b && w->fused_w1p && F == 128 && !idx && !enc && K == 16 && stride == 4 && knob(SEPR_KNOB_FOLD_HEAD)) {
+  if (w->fold_w2p && w->fold_b && w->fused_w1p && (F == 128 || F == 256) && !idx && !enc && K == 16 && stride == 4 && knob(SEPR_KNOB_FOLD_HEAD)) {
     // main head (masking = False, model.py:28): end_conv1x1.2 and the ConvTranspose1d are one linear map - one launch, no [rows, N]
     // basis tensor, no workspace (launch_glumlp_fold)
     GcfnFusedArgs f = {};
@@ -513,16 +513,16 @@ extern "C" int sepr_outlayer_decoder_fwd(const float* x, int nS, int S, int Tsrc
   // while it reads the rows.  Without idx the row map is the crop of module.py:250.
   const bool unique = idx != nullptr && Tsrc <= L;   // (a down-sampling map keeps the gather in the first projection)
   const long long Mp = unique ? (long long)nS * Tsrc : M;
-  if (w->fused_w1p && w->fused_w2p && F == 128 && N % 128 == 0 && (unique || !idx)) {
-    // one kernel per 128 basis columns: Linear F->4F + GLU + Linear 2F->N; the crop of module.py:250 is the kernel's row map
+  if (w->fused_w1p && w->fused_w2p && (F == 128 || F == 256) && N % F == 0 && (unique || !idx)) {
+    // one kernel per F basis columns: Linear F->4F + GLU + Linear 2F->N; the crop of module.py:250 is the kernel's row map
     const int nch = 2 * F / 32;
     const size_t half_bytes = (size_t)nch * (F / 16) * 2 * 64 * 16;
-    for (int h = 0; h < N / 128; ++h) {
+    for (int h = 0; h < N / F; ++h) {
       GcfnFusedArgs f = {};
       f.x = x; f.y = o2; f.M = (int)Mp; f.T = L;
       f.w1p = w->fused_w1p; f.w2p = static_cast<const char*>(w->fused_w2p) + h * half_bytes;
-      f.b2 = w->b2 + 128 * h; f.ls = nullptr; f.eps = 0.f;
-      f.nch = nch; f.ldy = N; f.col_off = 128 * h;
+      f.b2 = w->b2 + F * h; f.ls = nullptr; f.eps = 0.f;
+      f.nch = nch; f.ldy = N; f.col_off = F * h;
       if (!unique) { f.in_rows = L; f.in_src = Tsrc; }
       SEPR_TRY(launch_glumlp_fused(f, F, SEPR_SITE_OUT, st));
     }

@@ -106,7 +106,7 @@ struct bool_c { static constexpr bool value = V; };
 // as their bf16 hi plane alone, ONE MFMA per product instead of three, no lo-plane split on the VALU, and only the hi-plane
 // blocks of every packed weight chunk are copied to LDS (half the L2 -> LDS stream).  Same packed weights, same LDS layout.
 template <int F, int MT, int NW, int MODE = 0, bool TRAIN = false, bool ONE = false, int LAT = 0>
-__global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128) ? (NW > 4 ? 2 : 1) : (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
+__global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128 || MT > 2) ? (NW > 4 ? 2 : 1) : (2 * NW) / 4) void gcfn_fused3_kernel(const GcfnFusedArgs a) {
   constexpr bool PLAIN = MODE >= 1;   // frames are independent: no halo, no seam exchange, no conv
   constexpr bool FOLD = MODE == 2;    // OutputLayer with the AudioDecoder folded into its second projection (see launch_glumlp_fold)
   static_assert(!(TRAIN && PLAIN), "the train instantiation is the GCFN block");
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128) ? (NW > 4 ? 2 : 1) : 
     dk0 = sepr_drop_key(a.seed, a.salt, 0u);
     dk1 = sepr_drop_key(a.seed, a.salt, 1u);
   }
-  static_assert(MT == 1 || MT == 2, "frame tiles per wave");
+  static_assert(MT == 1 || MT == 2 || MT == 4, "frame tiles per wave");
   constexpr int RD = SEPR_GF3_RING;      // LDS fragment read-ahead, in MFMA groups
   // (Round 6, measured no: with MT = 1 the three MFMAs of a group run back to back on ONE accumulator; issuing the value and the gate tile of a
   //  K step - and two output tiles of the down-projection - interleaved, from a 6-slot fragment ring, changed nothing: 24.8 vs 23.5 us per
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128) ? (NW > 4 ? 2 : 1) : 
   // two frames at the workgroup's ends are recomputed halo: 126 outputs per 128 frames instead of 120, and - what
   // matters more - 64000 x 2^k rows are then just under 512 x 2^k tiles, i.e. full launch rounds instead of
   // "one round + a 4 % tail" (534 tiles on 512 slots).  Without XCH every wave carries its own two halo frames.
-  constexpr bool XCH = (SEPR_GF3_XCH != 0) && MT == 2 && UF && !PLAIN && LAT == 0;   // (ring form: ONE barrier per chunk - with a second, LDS-only
+  constexpr bool XCH = (SEPR_GF3_XCH != 0) && MT >= 2 && UF && !PLAIN && LAT == 0;   // (ring form: ONE barrier per chunk - with a second, LDS-only
                                                                                     //  barrier for the seam exchange it measured 2 % slower: r06_gcfn_ring.txt)
   constexpr int HALO = PLAIN ? 0 : 1;
   constexpr int WSTR = (XCH || PLAIN) ? 16 * MT : 16 * MT - 2;            // frames a wave advances
@@ -751,10 +751,17 @@ static int lat_max_tiles() {
 // [rows, hidden] tensor through HBM).
 int launch_glumlp_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t stream) {
   if (a.M <= 0) return SEPR_OK;
-  if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || a.nch <= 0 || a.ldy < F || a.x == a.y || F != 128) return SEPR_EINVAL;
+  if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || a.nch <= 0 || a.ldy < F || a.x == a.y || (F != 128 && F != 256)) return SEPR_EINVAL;
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
   const int cap = persistent_grid();
+  if (F == 256) {   // Large (round 6): F output columns per launch in the one-wave-per-SIMD regime, as launch_gcfn_fused does at F = 256
+    const int ntiles = (a.M + 127) / 128, cus = lat_max_tiles();
+    hipLaunchKernelGGL((gcfn_fused3_kernel<256, 2, 4, 1>), dim3(ntiles < cus ? ntiles : cus), dim3(256), 0, stream, a);
+    if (timed) prof_end(slot, (double)a.M * (2.0 * F * 64.0 * a.nch + 2.0 * 32.0 * a.nch * F), stream);
+    SEPR_CHECK_LAUNCH("glumlp_fused_kernel<256>");
+    return SEPR_OK;
+  }
   if (a.M < 12000) {
     const int ntiles = (a.M + 95) / 96;
     // one tile per CU at most: the latency form (3-stage weight ring, one workgroup per CU), 4 waves (one per SIMD) when that still fits
@@ -782,7 +789,7 @@ int launch_glumlp_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t str
 int launch_glumlp_fold(const GcfnFusedArgs& a_in, int F, int site, hipStream_t stream) {
   if (a_in.fold_nseq <= 0 || a_in.T <= 0) return SEPR_OK;
   GcfnFusedArgs a = a_in;
-  if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || a.nch <= 0 || F != 128 || a.out_S <= 0 || a.fold_nseq % a.out_S != 0 || a.in_src < a.T)
+  if (!a.x || !a.y || !a.w1p || !a.w2p || !a.b2 || a.nch <= 0 || (F != 128 && F != 256) || a.out_S <= 0 || a.fold_nseq % a.out_S != 0 || a.in_src < a.T)
     return SEPR_EINVAL;
   constexpr int tile_slots = 4 * 16 * 2 - 3;
   a.fold_tps = (a.T + 3 + tile_slots - 1) / tile_slots;
@@ -792,7 +799,12 @@ int launch_glumlp_fold(const GcfnFusedArgs& a_in, int F, int site, hipStream_t s
   const bool timed = prof_begin(site, stream, &slot);
   const int cap = persistent_grid();
   const long long ntiles = (long long)a.fold_nseq * a.fold_tps;
-  hipLaunchKernelGGL((gcfn_fused3_kernel<128, 2, 4, 2>), dim3((int)(ntiles < cap ? ntiles : cap)), dim3(256), 0, stream, a);
+  if (F == 256) {
+    const int cus = lat_max_tiles();
+    hipLaunchKernelGGL((gcfn_fused3_kernel<256, 2, 4, 2>), dim3((int)(ntiles < cus ? ntiles : cus)), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((gcfn_fused3_kernel<128, 2, 4, 2>), dim3((int)(ntiles < cap ? ntiles : cap)), dim3(256), 0, stream, a);
+  }
   // algorithmic FLOPs of what the launch replaces: both projections + the transposed convolution
   if (timed) prof_end(slot, (double)a.fold_nseq * a.T * (2.0 * F * 64.0 * a.nch + 2.0 * 32.0 * a.nch * a.fold_N + 2.0 * a.fold_N * 16.0), stream);
   SEPR_CHECK_LAUNCH("glumlp_fold_kernel");
@@ -866,6 +878,18 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
         const char* e = getenv("SEPR_GF_BIG_RING");
         return e && e[0] ? atoi(e) : 0;
       }();
+      if (big_ring >= 2 && !a.train && F == 128) {
+        // EXPERIMENT (round 6): the one-wave-per-SIMD regime at F = 128 - four 64-frame waves (MT = 4, 512 registers), one workgroup per CU;
+        // 2 = two-barrier form with the seam exchange (254-frame tiles), 3 = ring form without it (248-frame tiles)
+        const int cus = lat_max_tiles();
+        if (big_ring == 2) {
+          const int nt = (a.M + 253) / 254;
+          hipLaunchKernelGGL((gcfn_fused3_kernel<128, 4, 4>), dim3(nt < cus ? nt : cus), dim3(256), 0, stream, a);
+        } else {
+          const int nt = (a.M + 247) / 248;
+          hipLaunchKernelGGL((gcfn_fused3_kernel<128, 4, 4, 0, false, false, 3>), dim3(nt < cus ? nt : cus), dim3(256), 0, stream, a);
+        }
+      } else
       if (big_ring && !a.train && F == 128) {
         const int nt8 = (a.M + 8 * 30 - 1) / (8 * 30);
         const int cus = lat_max_tiles();

@@ -83,7 +83,8 @@ class Packed:
     def glumlp_fused(self, w1, b1, w2) -> dict:
         """Fused Linear -> GLU -> Linear (SpkSplit, OutputLayer) for F = 128 in bf16x3 mode; ``{}`` otherwise."""
         F, H, N = w1.shape[1], w1.shape[0] // 2, w2.shape[0]
-        if self.precision != "bf16x3" or F != 128 or H % 32 or N % 128 or not self.fuse_mlp:
+        if (self.precision != "bf16x3" or F not in (128, 256) or H % 32 or N % F or not self.fuse_mlp
+                or (F == 256 and os.environ.get("SEPR_FUSE_MLP256", "0") != "1")):      # (F = 256: built, measured no gain - 426 vs 426 utt/s; off)
             return {}
         w1p, w2p = pack_glumlp_fused(w1, b1, w2)
         self.keep += [w1p, w2p]
@@ -92,7 +93,8 @@ class Packed:
     def glumlp_fold(self, w1, w2, b2, dec_weight) -> dict:
         """OutputLayer's second projection with the AudioDecoder folded in (heads without a mask; bf16x3, F = 128, k = 16)."""
         F, H = w1.shape[1], w1.shape[0] // 2
-        if (self.precision != "bf16x3" or F != 128 or H % 32 or w2.shape[0] % 128 or not self.fuse_mlp or dec_weight.shape[2] != 16
+        if (self.precision != "bf16x3" or F not in (128, 256) or H % 32 or w2.shape[0] % F or not self.fuse_mlp or dec_weight.shape[2] != 16
+                or (F == 256 and os.environ.get("SEPR_FUSE_MLP256", "0") != "1")
                 or os.environ.get("SEPR_FOLD_HEAD", "1") == "0"):
             return {}
         w2p, bf = pack_glumlp_fold(w2, b2, dec_weight)
@@ -263,11 +265,12 @@ def pack_gcfn_fused_batched(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.Ten
 
 def pack_glumlp_fused(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor):
     """Weights of the plain GLU-MLP mode of the fused GCFN kernel (``gcfn_fused3_kernel<..., MODE = 1>``):
-    ``y = w2 . GLU(w1 x + b1)`` with ``w1`` ``[2H, F]`` (value rows, then gate rows), ``w2`` ``[N, H]``, N a multiple of 128.
+    ``y = w2 . GLU(w1 x + b1)`` with ``w1`` ``[2H, F]`` (value rows, then gate rows), ``w2`` ``[N, H]``, N a multiple of F (one kernel launch
+    writes F output columns: 128 for Base, 256 for the Large variants).
 
     * ``w1p``: per 32-channel hidden chunk the fragments ``[v0 v1 g0 g1][F/32][2][64][8]`` bf16 + the 4 KB constants block of
       ``pack_gcfn_fused`` with only the biases filled in; the gate rows and their bias carry the -log2(e) of ``glu_prescaled``;
-    * ``w2p`` ``[N/128][H/32][8][2][64][8]`` bf16: for every block of 128 output channels the K slices in k-slot order with the
+    * ``w2p`` ``[N/F][H/32][F/16][2][64][8]`` bf16: for every block of F output channels the K slices in k-slot order with the
       tile-pair row interleave of ``pack_gcfn_fused`` (one kernel launch per block)."""
     F, H, N = w1.shape[1], w1.shape[0] // 2, w2.shape[0]
     nch = H // 32
@@ -287,11 +290,11 @@ def pack_glumlp_fused(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor):
             cst[j * 160 + 16:j * 160 + 32] = b1f[H + v:H + v + 16]
         chunks.append(torch.cat([frag, cst.view(torch.uint8)]))
     w1p = torch.stack(chunks, 0).contiguous()
-    ft = torch.arange(8, device=dev)[:, None, None]
+    ft = torch.arange(F // 16, device=dev)[:, None, None]
     q = torch.arange(4, device=dev)[None, :, None]
     r = torch.arange(4, device=dev)[None, None, :]
     rows = (32 * (ft // 2) + 8 * q + 4 * (ft % 2) + r).reshape(-1)
-    w2p = torch.stack([_kslot_frags(w2.detach()[128 * h:128 * h + 128][rows], nch) for h in range(N // 128)], 0).contiguous()
+    w2p = torch.stack([_kslot_frags(w2.detach()[F * h:F * h + F][rows], nch) for h in range(N // F)], 0).contiguous()
     return w1p, w2p
 
 
