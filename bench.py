@@ -173,7 +173,7 @@ def self_launch(args) -> int:
 PMC_KERNEL_RE = "gcfn_fused3_kernel<[0-9]+, [0-9], [0-9], 0, false, false, [0-9]>"     # the GCFN instantiations of the fused kernel (not the plain GLU-MLP mode)
 
 
-LARGE_KERNEL_RE = "gemm_x3w?_kernel<1, 7, 1>"       # Large's GCFN up-projection (wide or narrow core), TAG 1
+LARGE_KERNEL_RE = "gcfn_fused3_kernel<256, 2, 4, 0, false, false, 0>"       # Large: the fused F = 256 GCFN (round 6; before: gemm_x3w?_kernel<1, 7, 1>)
 TN_KERNEL_RE = "gemm_tn_kernel"      # every instantiation of the weight-gradient contraction (the training line's roofline kernel)
 
 
@@ -361,7 +361,7 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
     n_launch = max(n_l.value, 1)
     sec = ms.value / 1e3
     algo_tf = (fl.value / 1e12) / sec if sec > 0 else 0.0            # algorithmic fp32 FLOPs / launch time
-    fused = precision == "bf16x3" and F in (64, 128)
+    fused = precision == "bf16x3" and F in (64, 128, 256) and os.environ.get("SEPR_FUSE_GCFN", "1") != "0" and not (F == 256 and os.environ.get("SEPR_FUSE_GCFN256", "1") == "0")
     # rows per launch: the fused kernel reports 18F^2 + 36F FLOPs per row (both projections + the conv), the generic
     # up-projection 2 * 6F * F per row
     rows = fl.value / (18.0 * F * F + 36.0 * F) if fused else fl.value / (12.0 * F * F)
@@ -390,8 +390,10 @@ def measure_infer(args, variant, steps, warmup, rank, world, dev, lib, full):
         mult = 3.0
         peak, ceiling = BF16_MFMA_PEAK_TFLOPS, 1.0 / mult
         dtype = "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)"
-        kern = ("gcfn_fused3_kernel<F,2,4> (and its <F,1,6> instantiation for launches under 17000 rows; whole GCFN block in "
-                "one launch: LayerNorm, F->6F MFMA, depthwise conv k=3 + GLU, 3F->F MFMA, LayerScale, residual)"
+        kern = (("gcfn_fused3_kernel<256,2,4> (round 6: the row-stationary GCFN at F = 256 in the one-wave-per-SIMD regime - four 30-frame waves with 512 "
+                 "registers each, one 106 KB workgroup per CU, inline-asm LDS-DMA weight chunks; whole GCFN block in one launch)" if F == 256 else
+                 "gcfn_fused3_kernel<F,2,4> (and its ring-form <F,1,4..6,..,3> instantiations for launches of at most one tile per CU; whole GCFN block in "
+                 "one launch: LayerNorm, F->6F MFMA, depthwise conv k=3 + GLU, 3F->F MFMA, LayerScale, residual)")
                 if fused else
                 "gemm_x3w_kernel<PRO_NORM,EPI_DWGLU,1> (GCFN F->6F projection of the generic path on the 128x256 wide core - "
                 "gemm_x3_kernel for launches too small for it: LayerNorm prologue, bf16x3 MFMA, depthwise-conv+GLU epilogue)")

@@ -58,3 +58,7 @@ VARIANT_noasmcf = -DSEPR_CF_ASMDMA=0 -DSEPR_SPK_ASMDMA=0
 # round 6, review item 4: what does the epilogue's second read of x cost?  gfa128 = no residual read (wrong results), gfa256 = residual read from a cold range
 VARIANT_gfa128 = -DSEPR_GF_ABL=128
 VARIANT_gfa256 = -DSEPR_GF_ABL=256
+# round 6: LDS fragment read-ahead / phase order of the fused GCFN, measured on the F = 256 (one-wave-per-SIMD) instantiation
+VARIANT_gfr3 = -DSEPR_GF3_RING=3
+VARIANT_gfr4 = -DSEPR_GF3_RING=4
+VARIANT_gfuf0 = -DSEPR_GF3_UPFIRST=0
