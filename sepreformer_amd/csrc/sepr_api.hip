@@ -374,7 +374,7 @@ static int spkattn_fwd_impl(const float* x, const float* x_stats, float* y, floa
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long M = (long long)nS * T;
   if (M > 0x7fffffffLL / 8) return SEPR_EINVAL;
-  if (w->fused_qkv_p && w->fused_out_p && S == 2 && F == 128 && H == 8 && x != y) {
+  if (w->fused_qkv_p && w->fused_out_p && S == 2 && ((F == 128 && H == 8) || (F == 256 && H == 8)) && x != y) {   // 16- / 32-channel heads
     // one kernel: LayerNorm + q/k/v + attention across the two speakers + output projection + LayerScale + residual
     SpkFusedArgs f;
     f.x = x; f.y = y; f.NF = (int)(M / 2); f.T = T;

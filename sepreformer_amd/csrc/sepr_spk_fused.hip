@@ -36,8 +36,12 @@ struct SpkFusedArgs {
   float eps, inv_sqrt_dk;
 };
 
-template <int F, int NW>
-__global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const SpkFusedArgs a) {
+// DK32 (round 6, the Large variants: F = 256, 8 heads of 32 channels): a 32-channel chunk is ONE head - its two 16-channel tile triples
+// (q0 k0 v0 | q1 k1 v1, the same packed layout) - so the 2x2 scores sum both tiles' partial dot products before the softmax and both tiles
+// are mixed with the same probabilities.  128 registers of frame planes + 128 of accumulators: the one-wave-per-SIMD regime (one 136 KB
+// workgroup per CU), like gcfn_fused3_kernel<256, ..>.
+template <int F, int NW, bool DK32 = false>
+__global__ __launch_bounds__(64 * NW, F > 128 ? 1 : (2 * NW) / 4) void spk_fused_kernel(const SpkFusedArgs a) {
   constexpr int MT = 2;                  // = speakers
   constexpr int NT = 64 * NW;
   constexpr int TILE = 16 * NW;          // frames per workgroup tile
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const 
   constexpr int OS = F + 4;
   __shared__ __attribute__((aligned(16))) uint4 wl[W1F_U4 + W2_U4 + 2 * CS_U4];
   static_assert(sizeof(uint4) * (W1F_U4 + W2_U4) >= sizeof(float) * 64 * OS, "epilogue staging must fit");
-  static_assert(W1F_U4 % NT == 0 && CS_U4 % NT == 0 && W2_U4 % NT == 0 && W1F_U4 / NT <= 16 && (16 * MT * NW) % 64 == 0, "copy / epilogue partition");
+  static_assert(W1F_U4 % NT == 0 && CS_U4 % NT == 0 && W2_U4 % NT == 0 && W1F_U4 / NT <= 24 && (16 * MT * NW) % 64 == 0, "copy / epilogue partition");
   const uint4* const w1s = wl;
   const uint4* const w2s = wl + W1F_U4;
   uint4* const csl = wl + W1F_U4 + W2_U4;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const 
       unsigned loff = (unsigned)lane * 16u;
       asm volatile("" : "+v"(loff));
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < 24; ++i) {       // (24: the q/k/v fragments of a head at F = 256 are 96 KB)
         if (i >= nblk) break;
 #if SEPR_SPK_ASMDMA
         glds16_asm(gbase + (i * NW + ws) * 64, loff, __builtin_amdgcn_readfirstlane(lds_addr(lbase + (i * NW + ws) * 64)));
@@ -171,6 +175,8 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const 
     dma_barrier();     // head pair 0 landed
     for (int c = 0; c < ((SEPR_SPK_ABL & 4) ? 0 : NCH); ++c) {
       bf16x8 gh[MT], gw[MT];          // mixed values (bf16 hi / lo) in output-projection k-slot order, per speaker
+      [[maybe_unused]] float sc0[MT][MT];          // DK32: the first tile's partial scores and v values
+      [[maybe_unused]] f32x4 v0[MT];
       uint4 fb[4][2];                 // fragment ring: the next PAIR of MFMA groups in flight under the current pair
       ld_up(0, 0, fb[0]);
       ld_up(0, 1, fb[1]);
@@ -237,11 +243,37 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const 
             p = fmaf(pq[0][qa][2], pq[1][kc][2], p);
             p = fmaf(pq[0][qa][3], pq[1][kc][3], p);
 #if (SEPR_SPK_ABL & 8) == 0
-            p += __shfl_xor(p, 16, 64);          // the head's 16 channels live in the 4 lane groups
+            p += __shfl_xor(p, 16, 64);          // the tile's 16 channels live in the 4 lane groups
             p += __shfl_xor(p, 32, 64);
 #endif
             sc[qa][kc] = p;
           }
+        if constexpr (DK32) {
+          // one 32-channel head: tile 0 parks its partial scores and its v values, tile 1 completes the scores and mixes both tiles
+          if (hh == 0) {
+#pragma unroll
+            for (int qa = 0; qa < MT; ++qa)
+#pragma unroll
+              for (int kc = 0; kc < MT; ++kc) sc0[qa][kc] = sc[qa][kc];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) v0[mt] = pq[2][mt];
+          } else {
+#pragma unroll
+            for (int qa = 0; qa < MT; ++qa) {
+              const float p0 = sigmoid_f(((sc0[qa][0] + sc[qa][0]) - (sc0[qa][1] + sc[qa][1])) * a.inv_sqrt_dk);
+              const float p1 = 1.0f - p0;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float o0 = fmaf(p0, v0[0][r], p1 * v0[1][r]), o1 = fmaf(p0, pq[2][0][r], p1 * pq[2][1][r]);
+                const __bf16 h0 = (__bf16)o0, h1 = (__bf16)o1;
+                gh[qa][r] = h0;
+                gw[qa][r] = (__bf16)(o0 - (float)h0);
+                gh[qa][4 + r] = h1;
+                gw[qa][4 + r] = (__bf16)(o1 - (float)h1);
+              }
+            }
+          }
+        } else {
 #pragma unroll
         for (int qa = 0; qa < MT; ++qa) {
           // softmax over two keys: p0 = 1 / (1 + exp(s1 - s0)), p1 = 1 - p0
@@ -254,6 +286,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void spk_fused_kernel(const 
             gh[qa][4 * hh + r] = hb;
             gw[qa][4 * hh + r] = (__bf16)(o - (float)hb);
           }
+        }
         }
       }
       // ---- output-projection K step of this head pair -------------------------------------------------------------
@@ -344,13 +377,14 @@ int launch_spk_fused(const SpkFusedArgs& a, int F, int site, hipStream_t stream)
   if (a.NF <= 0) return SEPR_OK;
   if (!a.x || !a.y || !a.w1p || !a.w2p || !a.bo || !a.ls || a.T <= 0 || a.NF % a.T != 0) return SEPR_EINVAL;
   if (a.x == a.y) return SEPR_EINVAL;
-  if (F != 128) return SEPR_EINVAL;
+  if (F != 128 && F != 256) return SEPR_EINVAL;
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
   const int ntiles = (a.NF + 63) / 64;
   const int cap = persistent_grid();
   const int grid = ntiles < cap ? ntiles : cap;
-  hipLaunchKernelGGL((spk_fused_kernel<128, 4>), dim3(grid), dim3(256), 0, stream, a);
+  if (F == 256) hipLaunchKernelGGL((spk_fused_kernel<256, 4, true>), dim3(ntiles < cap / 2 ? ntiles : cap / 2), dim3(256), 0, stream, a);   // 32-channel heads, one workgroup per CU
+  else hipLaunchKernelGGL((spk_fused_kernel<128, 4>), dim3(grid), dim3(256), 0, stream, a);
   // algorithmic FLOPs: q/k/v and output projections of both speakers' rows
   if (timed) prof_end(slot, 2.0 * a.NF * (2.0 * F * 3 * F + 2.0 * F * F), stream);
   SEPR_CHECK_LAUNCH("spk_fused_kernel");

@@ -136,7 +136,8 @@ class Packed:
     def spk_fused(self, sd, p: str, heads: int, num_spks: int) -> dict:
         """Fused speaker-attention weight forms (bf16x3, F = 128, 16-channel heads, two speakers); else empty."""
         F = sd[p + ".layer_norm.weight"].shape[0]
-        if self.precision != "bf16x3" or F != 128 or F // heads != 16 or num_spks != 2 or not self.fuse_spk:
+        if (self.precision != "bf16x3" or (F, F // heads) not in ((128, 16), (256, 32)) or num_spks != 2 or not self.fuse_spk
+                or (F == 256 and os.environ.get("SEPR_FUSE_SPK256", "1") == "0")):
             return {}
         wqkv = torch.cat([sd[f"{p}.linear_{n}.weight"] for n in "qkv"], dim=0)
         bqkv = torch.cat([sd[f"{p}.linear_{n}.bias"] for n in "qkv"], dim=0)
