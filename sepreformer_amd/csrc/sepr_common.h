@@ -139,7 +139,15 @@ __device__ __forceinline__ void rowstats_one(const float* __restrict__ p, int nf
 // (scalar-base form: wave-uniform 64-bit source base in an SGPR pair + one 32-bit per-lane byte offset - no 64-bit per-lane addresses to
 //  keep alive or spill; a spilled address would be re-loaded by a scratch_load, and the wait for THAT drains every copy in flight)
 __device__ __forceinline__ void glds16_asm(const void* src_wave, unsigned lane_off, unsigned lds_wave) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(src_wave), "s"(lds_wave) : "memory", "m0");
+  // s_nop 4: the instructions inside an asm statement are invisible to hipcc's hazard recognizer.  The source base may have been written by
+  // a VALU instruction just before the statement (v_readfirstlane / v_readlane - e.g. an SGPR restored from its spill lane), and "VALU writes
+  // SGPR -> VMEM reads that SGPR" needs 5 wait states on gfx9-family parts; the same gap covers "s_mov m0 -> LDS-DMA".
+#ifndef SEPR_GLDS_NOP
+#define SEPR_GLDS_NOP 3     // s_mov (1) + s_nop 3 (4) = the 5 wait states; 0 = round 6's first form, A/B only (tools/variants.mk gldsnop0): +0.7 % Base, +1.7 % Large, unsafe
+#endif
+#define SEPR_STR2(x) #x
+#define SEPR_STR(x) SEPR_STR2(x)
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop " SEPR_STR(SEPR_GLDS_NOP) "\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(src_wave), "s"(lds_wave) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
 #pragma clang diagnostic pop
