@@ -540,6 +540,23 @@ int sepr_train_pack_gcfn_fused(const void* const* w1, const void* const* b1, con
 int sepr_train_defer_begin(void* arena, size_t arena_bytes);
 int sepr_train_defer_flush(int close, sepr_stream_t stream);
 
+/* ---- weight-gradient side stream (ABI 4.10) ----------------------------------------------------------------------------------
+ * Nothing inside a backward walk reads what the weight-gradient contractions write (parameter gradients, or the arena slots of deferred
+ * finishers), and they are HBM-bound while the input-gradient chain beside them is VALU- / MFMA-bound.  sepr_train_wgrad_stream(side)
+ * registers a second stream on the calling host thread: every contraction (+ its split-M reduction, + finishers that are not deferred) issued
+ * by the sepr_*_bwd entry points of that thread is then launched on `side`, ordered behind everything the caller's stream has been given so
+ * far (one event per launch), and overlaps the rest of the walk.  The caller owns two obligations:
+ *   - workspace re-use: a workspace handed to a *_bwd call is read by side-stream kernels after the call returns.  Alternate two
+ *     workspaces and bracket them: sepr_train_wgrad_mark(slot) after the call that used workspace `slot`, sepr_train_wgrad_wait(slot, stream)
+ *     before the next call that re-uses it (and keep the call's input tensors alive as long);
+ *   - joins: sepr_train_defer_flush and sepr_train_wgrad_join(stream) make `stream` wait for everything issued on the side stream - before
+ *     gradients are read (all-reduce, optimizer), before the window closes, before the end of a hipGraph capture.
+ * sepr_train_wgrad_stream(NULL) unregisters (after a join).  Gradients are bit-identical with and without a side stream. */
+int sepr_train_wgrad_stream(sepr_stream_t side);
+int sepr_train_wgrad_join(sepr_stream_t stream);
+int sepr_train_wgrad_mark(int slot);
+int sepr_train_wgrad_wait(int slot, sepr_stream_t stream);
+
 /* PIT_SISNR_time backward (criterions.py:191-217): d(sum_b loss[b] * gl[b]) / d est.  est, tgt, dest [S,B,T]; perm from the forward. */
 int sepr_pit_sisnr_bwd(const float* est, const float* tgt, const int* perm, const float* gl, int S, int B, int T, double eps,
                        double clamp_min, float* dest, void* ws, size_t ws_bytes, sepr_stream_t stream);

@@ -461,13 +461,16 @@ size_t tn_workspace_bytes(int M, int N, int K) {
   return align_up((size_t)p.nsplit * ((size_t)N * K + N) * sizeof(float));
 }
 
-int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream_t s) {
+int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream_t s_main) {
   if (a.M <= 0) return SEPR_OK;
   if (!a.A || !a.B || !a.G || a.N <= 0 || a.K <= 0 || (a.N % 4) || (a.K % 4) || (a.lda % 4) || (a.ldb % 4)) return SEPR_EINVAL;
   if (a.B2 && ((a.ksplit % 4) || (a.ldb2 % 4))) return SEPR_EINVAL;
   const TnPlan p = tn_plan(a.M, a.N, a.K);
   const size_t need = tn_workspace_bytes(a.M, a.N, a.K);
   if (!ws || ws_bytes < need) return SEPR_EWORKSPACE;
+  // contraction + its split-M reduction run on the registered weight-gradient side stream when there is one (sepr_train.h wgrad_stream):
+  // nothing in a backward walk consumes their output before the window's join
+  hipStream_t s = wgrad_stream(s_main);
   float* part = static_cast<float*>(ws);
   float* cpart = part + (size_t)p.nsplit * a.N * a.K;
   const int grid = p.tn * p.tk * p.nsplit;

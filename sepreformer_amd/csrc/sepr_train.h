@@ -205,6 +205,15 @@ int launch_finish_linear_ls(const float* Gr, const float* s, const float* W, con
 float* fin_alloc(size_t count);      // nullptr: no window open on this thread, or the arena is full
 int fin_flush(hipStream_t st);       // launches and empties the queue (the window stays open)
 
+// Weight-gradient side stream (round 6; include/sepr.h sepr_train_wgrad_stream).  Nothing in a backward walk reads what the weight-gradient
+// contractions write (parameter gradients, or arena slots of the deferred finishers), so while a side stream is registered on the calling
+// thread they - gemm_tn + its split-M reduction, and finishers that are not deferred - are launched THERE, behind an event recorded on the
+// caller's stream (their inputs are complete), and run concurrently with the input-gradient chain (HBM-bound contractions beside VALU- /
+// MFMA-bound kernels).  wgrad_stream(main) returns the stream to launch on.  Joins: sepr_train_defer_flush and sepr_train_wgrad_join make the
+// caller's stream wait for everything issued on the side stream; sepr_train_wgrad_mark / _wait order the re-use of a workspace.
+hipStream_t wgrad_stream(hipStream_t main);
+void wgrad_join(hipStream_t main);
+
 // ---- attention with stored probabilities (sepr_train_attn.hip) ----------------------------------------------------
 size_t relattn_train_ws(int n, int Tp, int F, int H);
 // QKV [n,Tp,3F] -> O [n,Tp,F]; P [n,H,Tp,Tp] = softmax probabilities (saved for the backward)

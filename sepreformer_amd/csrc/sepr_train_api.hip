@@ -419,6 +419,7 @@ int cla_bwd(const float* x, const float* dy, float* dx, int n, int T, int F, int
   SEPR_TRY(wgrad(dd, 2 * F, k.c, F, nullptr, g->w2, g->b2, M, 2 * F, F, 1, x3, tnw, tnb, st));                   // linear2 (direct)
   SEPR_TRY(plain(dd, 2 * F, dc, F, M, F, 2 * F, w->l2_t, nullptr, st));
   SEPR_TRY(launch_dwconv_wgrad(k.u, dc, n, T, F, K, g->dw_w, g->dw_b, wgw, wgb, st));
+  wgrad_join(st);   // dd (dz) is re-used for da below while linear2's contraction - on the weight-gradient side stream, if one is registered - may still read it
   if (F % 128 == 0 && K == 65) {   // correlation with reversed taps, GLU backward in its epilogue (round 4): dd := da [M][2F]
     SEPR_TRY(launch_dwconv_same_glu_bwd(dc, k.a, dd, n, T, F, K, w->dw_wf, w->zeros, st));
   } else {

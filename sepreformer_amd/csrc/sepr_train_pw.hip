@@ -1612,6 +1612,7 @@ int launch_finish_norm_linear(const float* dWh, const float* s, const float* W, 
     g_fin.jobs.push_back(FinJob{0, N, K, 0, dWh, s, W, g, b, dW_g, dbias_g, dg_g, db_g});
     return SEPR_OK;
   }
+  st = wgrad_stream(st);       // (not deferred: behind the reduction that produced dWh, wherever that ran)
   hipLaunchKernelGGL(finish_norm_kernel, dim3(N + (K + 63) / 64), dim3(1024), 0, st, dWh, s, W, g, b, dW_g, dbias_g, dg_g, db_g, N, K);
   SEPR_CHECK_LAUNCH("finish_norm_linear kernels");
   return SEPR_OK;
@@ -1623,12 +1624,79 @@ int launch_finish_linear_ls(const float* Gr, const float* s, const float* W, con
     g_fin.jobs.push_back(FinJob{1, N, K, 0, Gr, s, W, bias, ls, dW_g, dbias_g, dls_g, nullptr});
     return SEPR_OK;
   }
+  st = wgrad_stream(st);
   hipLaunchKernelGGL(finish_ls_kernel, dim3(N), dim3(64), 0, st, Gr, s, W, bias, ls, dW_g, dbias_g, dls_g, N, K);
   SEPR_CHECK_LAUNCH("finish_ls_kernel");
   return SEPR_OK;
 }
 
 }  // namespace sepr
+
+namespace sepr {
+namespace {
+struct WgradSide {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr, mark[2] = {nullptr, nullptr};
+  bool marked[2] = {false, false};
+  bool dirty = false;          // something was launched on the side stream since the last join
+  bool forked = false;         // ... since the stream was registered (before that a mark has nothing to wait for - and, inside a hipGraph capture,
+                               // the side stream is not part of the capture yet: an event recorded on it could not be waited for)
+};
+thread_local WgradSide g_wg;
+}  // namespace
+hipStream_t wgrad_stream(hipStream_t main) {
+  if (!g_wg.side) return main;
+  (void)hipEventRecord(g_wg.fork, main);                 // everything the caller has issued so far (the contraction's inputs) ...
+  (void)hipStreamWaitEvent(g_wg.side, g_wg.fork, 0);     // ... happens before what follows on the side stream
+  g_wg.dirty = true;
+  g_wg.forked = true;
+  return g_wg.side;
+}
+void wgrad_join(hipStream_t main) {
+  if (!g_wg.side || !g_wg.dirty) return;
+  (void)hipEventRecord(g_wg.join, g_wg.side);
+  (void)hipStreamWaitEvent(main, g_wg.join, 0);
+  g_wg.dirty = false;
+}
+}  // namespace sepr
+
+extern "C" int sepr_train_wgrad_stream(sepr_stream_t side) {
+  using namespace sepr;
+  if (side && !g_wg.fork) {
+    if (hipEventCreateWithFlags(&g_wg.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g_wg.join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_wg.mark[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g_wg.mark[1], hipEventDisableTiming) != hipSuccess)
+      return SEPR_EHIP;
+  }
+  if (!side && g_wg.side && g_wg.dirty) return SEPR_EINVAL;      // join first (sepr_train_wgrad_join / sepr_train_defer_flush)
+  g_wg.side = static_cast<hipStream_t>(side);
+  g_wg.marked[0] = g_wg.marked[1] = false;
+  g_wg.dirty = false;
+  g_wg.forked = false;
+  return SEPR_OK;
+}
+extern "C" int sepr_train_wgrad_join(sepr_stream_t stream) {
+  sepr::wgrad_join(static_cast<hipStream_t>(stream));
+  return SEPR_OK;
+}
+extern "C" int sepr_train_wgrad_mark(int slot) {
+  using namespace sepr;
+  if (slot < 0 || slot > 1) return SEPR_EINVAL;
+  if (!g_wg.side) return SEPR_OK;
+  if (!g_wg.forked) {          // nothing has run on the side stream in this window
+    g_wg.marked[slot] = false;
+    return SEPR_OK;
+  }
+  (void)hipEventRecord(g_wg.mark[slot], g_wg.side);
+  g_wg.marked[slot] = true;
+  return SEPR_OK;
+}
+extern "C" int sepr_train_wgrad_wait(int slot, sepr_stream_t stream) {
+  using namespace sepr;
+  if (slot < 0 || slot > 1) return SEPR_EINVAL;
+  if (!g_wg.side || !g_wg.marked[slot]) return SEPR_OK;
+  (void)hipStreamWaitEvent(static_cast<hipStream_t>(stream), g_wg.mark[slot], 0);
+  return SEPR_OK;
+}
 
 extern "C" int sepr_train_defer_begin(void* arena, size_t arena_bytes) {
   using namespace sepr;
@@ -1643,6 +1711,7 @@ extern "C" int sepr_train_defer_begin(void* arena, size_t arena_bytes) {
 }
 extern "C" int sepr_train_defer_flush(int close, sepr_stream_t stream) {
   using namespace sepr;
+  wgrad_join(static_cast<hipStream_t>(stream));      // the queued finishers read what the side stream's reductions wrote
   if (!g_fin.open) return SEPR_OK;
   const int rc = fin_flush(static_cast<hipStream_t>(stream));
   if (close) g_fin.open = false;

@@ -176,6 +176,10 @@ SIGNATURES = {
     "sepr_train_fold_bias": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp]),
     "sepr_train_defer_begin": (_i, [_fp, _sz]),
     "sepr_train_defer_flush": (_i, [_i, _fp]),
+    "sepr_train_wgrad_stream": (_i, [_fp]),
+    "sepr_train_wgrad_join": (_i, [_fp]),
+    "sepr_train_wgrad_mark": (_i, [_i]),
+    "sepr_train_wgrad_wait": (_i, [_i, _fp]),
     "sepr_train_pack_gcfn_fused": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _fp]),
     "sepr_pit_sisnr_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _d, _d, _fp, _fp, _sz, _fp]),
     "sepr_pit_sisnr_mag_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
