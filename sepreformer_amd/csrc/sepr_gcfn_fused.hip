@@ -96,6 +96,10 @@ struct bool_c { static constexpr bool value = V; };
                             // s_waitcnt vmcnt(0) in front of the first LDS read behind a copy it knows about - tools/isa_trace.py shows one in
                             // the middle of the up-projection of the 4-wave kernel); the copies are then waited for at the two chunk barriers only
 #endif
+#ifndef SEPR_GF3_FENCE256
+#define SEPR_GF3_FENCE256 1   // 0 (A/B): no scheduling fences around the MFMA groups of the F = 256 (one-wave-per-SIMD) instantiations
+#endif
+#define SEPR_GF3_SCHED_FENCE() do { if constexpr (F <= 128 || SEPR_GF3_FENCE256) __builtin_amdgcn_sched_barrier(0); } while (0)
 #ifndef SEPR_GF3_RESX
 #define SEPR_GF3_RESX 0   // EXPERIMENT (round-3 review item 6): 1 = the residual x is rebuilt from the bf16 hi + lo planes the wave
                           // already holds ((hi + lo) / rstd + mean, 2^-17 relative) instead of being re-read from HBM in the
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128 || MT > 2) ? (NW > 4 ?
           for (int g = 0; g < 2 * KS; ++g) {
             if ((SEPR_GF_ABL & 96) && rep3 > 0 && g < RD) ld_up(j, g, fb[g % (RD + 1)]);   // (proxy: each pass re-reads its fragments)
             if (g + RD < 2 * KS) ld_up(j, g + RD, fb[(g + RD) % (RD + 1)]);
-            __builtin_amdgcn_sched_barrier(0);
+            SEPR_GF3_SCHED_FENCE();
             const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[g % (RD + 1)][0]);
             [[maybe_unused]] const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[g % (RD + 1)][ONE ? 0 : 1]);
             const int ks = g >> 1;
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128 || MT > 2) ? (NW > 4 ?
                 for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], hg[mt], 0, 0, 0);
               }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            SEPR_GF3_SCHED_FENCE();
           }
           if (SEPR_GF3_PRIO) __builtin_amdgcn_s_setprio(0);
           if (j == 0) {                            // the second tile pair's first fragments arrive under the conv
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128 || MT > 2) ? (NW > 4 ?
 #pragma unroll
         for (int ft = 0; ft < FT; ++ft) {
           if (ft + RD < FT) ld_dn(ft + RD, fb[(ft + RD) % (RD + 1)]);
-          __builtin_amdgcn_sched_barrier(0);
+          SEPR_GF3_SCHED_FENCE();
           const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&fb[ft % (RD + 1)][0]);
           [[maybe_unused]] const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&fb[ft % (RD + 1)][ONE ? 0 : 1]);
 #pragma unroll
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128 || MT > 2) ? (NW > 4 ?
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh[mt], acc[ft][mt], 0, 0, 0);
           }
-          __builtin_amdgcn_sched_barrier(0);
+          SEPR_GF3_SCHED_FENCE();
         }
         if (SEPR_GF3_PRIO) __builtin_amdgcn_s_setprio(0);
         if constexpr (LAT == 0) {

@@ -64,3 +64,4 @@ VARIANT_gfr4 = -DSEPR_GF3_RING=4
 VARIANT_gfuf0 = -DSEPR_GF3_UPFIRST=0
 # round 6: wait states between the SGPR-base set-up and the inline-asm LDS-DMA (product: 4 = hazard-safe; 0 = the first form, A/B only)
 VARIANT_gldsnop0 = -DSEPR_GLDS_NOP=0
+VARIANT_gfnofence = -DSEPR_GF3_FENCE256=0
