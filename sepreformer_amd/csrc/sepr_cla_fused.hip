@@ -44,13 +44,13 @@ constexpr int CF_NW = 4, CF_NT = 256, CF_MT = 2;
 
 // ---- shared pieces -----------------------------------------------------------------------------------------------
 // 32 frames of a wave -> bf16 hi/lo B fragments; NORM: LayerNorm without affine (gamma/beta live in the weights)
-template <int F, bool NORM>
+template <int F, bool NORM, int MT = CF_MT>
 __device__ __forceinline__ void load_frames(const float* __restrict__ X, int m0, int M, float eps, int fi, int fg,
-                                            bf16x8 (&xh)[CF_MT][F / 32], bf16x8 (&xl)[CF_MT][F / 32]) {
+                                            bf16x8 (&xh)[MT][F / 32], bf16x8 (&xl)[MT][F / 32]) {
   constexpr int KS = F / 32;
 #pragma unroll
-  for (int mt = 0; mt < CF_MT; ++mt) {
-    const int m = m0 + CF_MT * fi + mt;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + MT * fi + mt;
     const bool valid = m < M;
     const float* xp = X + (long long)(valid ? m : 0) * F + 8 * fg;
     float v[KS][8];
@@ -127,10 +127,10 @@ __device__ __forceinline__ void dma_barrier() {
 // [F x 32 frames] register tile -> LDS -> row-contiguous stores
 //   ST_PLAIN: y = tile;  ST_RES: y = res + ls * (tile + b);  ST_GATE: y = res + sigmoid(tile) * att[seq, t / fac]
 constexpr int ST_PLAIN = 0, ST_RES = 1, ST_GATE = 2;
-template <int F, int MODE>
-__device__ __forceinline__ void store_tile(const f32x4 (&acc)[F / 16][CF_MT], float* Os, const ClaFusedArgs& a, int tile0,
+template <int F, int MODE, int MT = CF_MT>
+__device__ __forceinline__ void store_tile(const f32x4 (&acc)[F / 16][MT], float* Os, const ClaFusedArgs& a, int tile0,
                                            int tid, int w, int fi, int fg) {
-  constexpr int FT = F / 16, OS = F + 4, MT = CF_MT;
+  constexpr int FT = F / 16, OS = F + 4;
   constexpr int EH = (16 * MT * CF_NW) / 64, WPP = 64 / (16 * MT);
   constexpr int Q = F / 4, RPP = CF_NT / Q, NP = 64 / RPP;
   static_assert(64 % RPP == 0, "epilogue pass partition");
@@ -199,10 +199,12 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[F / 16][CF_MT], fl
 // (network.py:132-135,151-153): the same chunk walk with the four tiles of a chunk as four plain output tiles
 // (64 output channels per chunk) and the gate applied in the store pass.
 // F = 256 (Large, round 6): 128 registers of frame planes + 128 of output tile - the ONE-wave-per-SIMD regime (one 139 KB workgroup per CU)
-template <int F, bool GATE>
+// MT = 1 (round 6): 16-frame waves, 64-frame tiles - for launches with fewer 128-frame tiles than half the CUs (batch 1: Engine._inference_sample): twice
+// the workgroups, half the dependent chain per workgroup; a frame's arithmetic does not depend on the tiling (bit-identical)
+template <int F, bool GATE, int MT = CF_MT>
 __global__ __launch_bounds__(CF_NT, F > 128 ? 1 : 2) void cla_head_kernel(const ClaFusedArgs a) {
-  constexpr int MT = CF_MT, NW = CF_NW, NT = CF_NT;
-  constexpr int TILE = 32 * NW;
+  constexpr int NW = CF_NW, NT = CF_NT;
+  constexpr int TILE = 16 * MT * NW;
   constexpr int KS = F / 32;
   constexpr int NCH = GATE ? F / 64 : F / 32;   // output channels per chunk: 64 plain or 32 gated
   constexpr int FT = F / 16;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(CF_NT, F > 128 ? 1 : 2) void cla_head_kernel(const 
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     bf16x8 xh[MT][KS], xl[MT][KS];
-    load_frames<F, true>(a.x, tile * TILE + w * 32, a.M, a.eps, fi, fg, xh, xl);
+    load_frames<F, true, MT>(a.x, tile * TILE + w * 16 * MT, a.M, a.eps, fi, fg, xh, xl);
     f32x4 acc[FT][MT];                   // gated values: channel tile ft = 2*c + j
 
     __syncthreads();   // the previous tile's epilogue staging is fully consumed
@@ -295,17 +297,17 @@ __global__ __launch_bounds__(CF_NT, F > 128 ? 1 : 2) void cla_head_kernel(const 
       }
       dma_barrier();   // chunk c fully read by every wave, chunk c+1 landed
     }
-    store_tile<F, GATE ? ST_GATE : ST_PLAIN>(acc, reinterpret_cast<float*>(wl), a, tile * TILE, tid, w, fi, fg);
+    store_tile<F, GATE ? ST_GATE : ST_PLAIN, MT>(acc, reinterpret_cast<float*>(wl), a, tile * TILE, tid, w, fi, fg);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // tail: y = x + ls * Linear3(GELU(Linear2'(c)))      (eval BatchNorm folded into Linear2')
 // ---------------------------------------------------------------------------------------------------------------------
-template <int F>
+template <int F, int MT = CF_MT>
 __global__ __launch_bounds__(CF_NT, F > 128 ? 1 : 2) void cla_tail_kernel(const ClaFusedArgs a) {
-  constexpr int MT = CF_MT, NW = CF_NW, NT = CF_NT;
-  constexpr int TILE = 32 * NW;
+  constexpr int NW = CF_NW, NT = CF_NT;
+  constexpr int TILE = 16 * MT * NW;
   constexpr int KS = F / 32;
   constexpr int NCH = 2 * F / 64;        // 64 hidden channels per chunk
   constexpr int FT = F / 16;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(CF_NT, F > 128 ? 1 : 2) void cla_tail_kernel(const 
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     bf16x8 xh[MT][KS], xl[MT][KS];
-    load_frames<F, false>(a.x, tile * TILE + w * 32, a.M, 0.f, fi, fg, xh, xl);
+    load_frames<F, false, MT>(a.x, tile * TILE + w * 16 * MT, a.M, 0.f, fi, fg, xh, xl);
     f32x4 acc[FT][MT];
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
@@ -420,8 +422,18 @@ __global__ __launch_bounds__(CF_NT, F > 128 ? 1 : 2) void cla_tail_kernel(const 
       dma_barrier();                             // down-projection fragments consumed; chunk c+1's up-projection
       if (c + 1 < NCH) dma_w2(c + 1);            // fragments have landed
     }
-    store_tile<F, ST_RES>(acc, reinterpret_cast<float*>(wl), a, tile * TILE, tid, w, fi, fg);
+    store_tile<F, ST_RES, MT>(acc, reinterpret_cast<float*>(wl), a, tile * TILE, tid, w, fi, fg);
   }
+}
+
+// small launches (round 6): when even the 64-frame tiles of the MT = 1 instantiations leave workgroup slots free (cap = two per CU), a launch's
+// duration is one workgroup's dependent chain - halve it.  SEPR_CF_SMALL=<max 64-frame tiles> overrides the bound (0: never; A/B).
+static bool small_launch(int M, int cap) {
+  static const int bound = [] {
+    const char* e = getenv("SEPR_CF_SMALL");
+    return e ? atoi(e) : -1;
+  }();
+  return (M + 63) / 64 <= (bound < 0 ? cap : bound);
 }
 
 int launch_cla_head(const ClaFusedArgs& a, int F, int site, hipStream_t stream) {
@@ -432,6 +444,7 @@ int launch_cla_head(const ClaFusedArgs& a, int F, int site, hipStream_t stream) 
   const int ntiles = (a.M + 127) / 128;
   const int cap = persistent_grid();
   if (F == 256) hipLaunchKernelGGL((cla_head_kernel<256, false>), dim3(ntiles < cap / 2 ? ntiles : cap / 2), dim3(CF_NT), 0, stream, a);   // one workgroup per CU
+  else if (small_launch(a.M, cap)) hipLaunchKernelGGL((cla_head_kernel<128, false, 1>), dim3((a.M + 63) / 64), dim3(CF_NT), 0, stream, a);
   else hipLaunchKernelGGL((cla_head_kernel<128, false>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
   if (timed) prof_end(slot, (double)a.M * 2.0 * F * 2 * F, stream);
   SEPR_CHECK_LAUNCH("cla_head_kernel");
@@ -447,6 +460,7 @@ int launch_ega_gate(const ClaFusedArgs& a, int F, int site, hipStream_t stream) 
   const int ntiles = (a.M + 127) / 128;
   const int cap = persistent_grid();
   if (F == 256) hipLaunchKernelGGL((cla_head_kernel<256, true>), dim3(ntiles < cap / 2 ? ntiles : cap / 2), dim3(CF_NT), 0, stream, a);
+  else if (small_launch(a.M, cap)) hipLaunchKernelGGL((cla_head_kernel<128, true, 1>), dim3((a.M + 63) / 64), dim3(CF_NT), 0, stream, a);
   else hipLaunchKernelGGL((cla_head_kernel<128, true>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
   if (timed) prof_end(slot, (double)a.M * 2.0 * F * F, stream);
   SEPR_CHECK_LAUNCH("ega_gate_kernel");
@@ -461,6 +475,7 @@ int launch_cla_tail(const ClaFusedArgs& a, int F, int site, hipStream_t stream) 
   const int ntiles = (a.M + 127) / 128;
   const int cap = persistent_grid();
   if (F == 256) hipLaunchKernelGGL((cla_tail_kernel<256>), dim3(ntiles < cap / 2 ? ntiles : cap / 2), dim3(CF_NT), 0, stream, a);
+  else if (small_launch(a.M, cap)) hipLaunchKernelGGL((cla_tail_kernel<128, 1>), dim3((a.M + 63) / 64), dim3(CF_NT), 0, stream, a);
   else hipLaunchKernelGGL((cla_tail_kernel<128>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
   if (timed) prof_end(slot, (double)a.M * (2.0 * F * 2 * F + 2.0 * 2 * F * F), stream);
   SEPR_CHECK_LAUNCH("cla_tail_kernel");
