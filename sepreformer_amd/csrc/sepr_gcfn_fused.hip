@@ -716,6 +716,318 @@ __global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128 || MT > 2) ? (NW > 4 ?
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// gcfn_hs_kernel (round 6): the HIDDEN-SPLIT form for launches with fewer tiles than CUs (batch 1, Engine._inference_sample).
+// In the row-stationary kernel above every wave walks the WHOLE hidden dimension for its own 16*MT frames: with one 16-frame wave per SIMD
+// each weight fragment read from LDS feeds three MFMAs, every wave reads all 590 KB of packed weights out of LDS, and the tile pays 12
+// chunk barriers - 23.5 us per launch where the MFMAs alone are 5.8 us (profiles/r06_b1_launches.txt).  Here the four waves of a workgroup
+// hold the SAME 16*MT frames and split the hidden dimension instead:
+//   phase 1  wave w owns chunks w, w+4, w+8: up-projection, conv, GLU for all frames of the tile.  A weight fragment has exactly one
+//            reader, so it goes global -> registers (one coalesced 1 KiB load per fragment, requested a half-chunk ahead), not through LDS;
+//            each fragment now feeds 3*MT MFMAs.  The gated tensor (bf16 hi / lo, already in the down-projection's B-fragment lane
+//            layout) is written to LDS: [chunk = K step][plane][frame tile][lane] x 16 B;
+//   barrier  the only one of the tile;
+//   phase 2  wave w owns output tiles 2w, 2w+1 (32 of the 128 channels) for all frames: the K steps are walked in chunk order with the
+//            three products in the order of the kernel above, B fragments from LDS, its 48 KB slice of W2 global -> registers (requested
+//            under the last chunk's conv).  A lane ends with 8 consecutive channels of a frame: bias, LayerScale, residual, direct stores.
+// Every accumulator sees exactly the operand sequence of gcfn_fused3_kernel (same packed weights, same products, same order): the result
+// is bit-identical, which the parity tests check against the batched launch (tests/test_gpu_parity.py).  F = 128 only.
+// ---------------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256, 1) void gcfn_hs_kernel(const GcfnFusedArgs a) {
+  constexpr int F = 128, KS = F / 32, NW = 4, NCH = 3 * F / 32, CPW = NCH / NW, FT = F / 16, FTW = FT / NW;
+  constexpr int W1F_U4 = 4 * KS * 2 * 64, CS_U4 = 256, W1_U4 = W1F_U4 + CS_U4, W2_U4 = FT * 2 * 64;
+  constexpr int TILE = 16 * MT - 2;                  // output frames per workgroup (first and last frame of the tile are recomputed halo)
+  constexpr int CSF = 320;                           // live floats of a chunk's constant block ([2 tile pairs][10][16])
+  static_assert(CPW * NW == NCH && FTW * NW == FT && FTW == 2, "hidden / output split over the four waves");
+  __shared__ __attribute__((aligned(16))) uint4 hs[NCH * 2 * MT * 64];     // gated tensor: [K step][plane][frame tile][lane]
+  __shared__ __attribute__((aligned(16))) float cst[NW][CPW][CSF];          // this wave's chunk constants (wave-private: no barrier)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const uint4* const W1g = static_cast<const uint4*>(a.w1p);
+  const uint4* const W2g = static_cast<const uint4*>(a.w2p);
+  const int tile = blockIdx.x;
+  const int mw0 = tile * TILE - 1;
+
+  // wave-uniform bases + ONE 32-bit per-lane byte offset (SGPR-base addressing: no 64-bit per-lane pointers to keep alive across the tile)
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+  const unsigned loff = (unsigned)lane * 16u;
+  auto ldu = [&](const uint4* base, int blk) -> uint4 {   // 16 bytes of this lane from the 1 KiB block blk behind the wave-uniform base
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base + blk * 64) + loff);
+  };
+  // fragments of one tile pair j of chunk c: [value | gate][K step][plane]
+  auto ld_w1 = [&](int c, int j, uint4 (&d)[16]) {
+    const uint4* base = W1g + (long long)c * W1_U4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k2 = 0; k2 < 2 * KS; ++k2) d[t * 2 * KS + k2] = ldu(base, (t * 2 + j) * KS * 2 + k2);
+  };
+  // this wave's W2 fragments of K steps 4q .. 4q+3: [step][tile 2w | 2w+1][plane]
+  auto ld_w2 = [&](int q, uint4 (&d)[16]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4* base = W2g + (long long)(4 * q + s) * W2_U4 + (FTW * ws) * 2 * 64;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[s * 4 + e] = ldu(base, e);
+    }
+  };
+  // request order = arrival order: the chunk constants and the frames first (the LayerNorm starts as soon as they are in), the first
+  // chunk's 32 KB of fragments land under it
+  uint4 ct[CPW][2];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const uint4* base = W1g + (long long)(ws + NW * i) * W1_U4 + W1F_U4;
+    ct[i][0] = ldu(base, 0);
+    ct[i][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base + 64) + (loff & 255u));
+  }
+  // ---- the tile's frames (every wave holds all of them; lane fi holds frames MT*fi .. MT*fi + MT-1): load, LayerNorm, split ----
+  bf16x8 xh[MT][KS], xl[MT][KS];
+  float f0[MT], f2[MT];
+  bool edge_lane = false;
+  float xv[MT][KS][8];
+  bool vld[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mw0 + MT * fi + mt;
+    const bool valid = (m >= 0 && m < a.M);
+    vld[mt] = valid;
+    const int trow = valid ? m % a.T : -2;
+    f0[mt] = (trow == 0) ? 0.f : 1.f;
+    f2[mt] = (trow == a.T - 1) ? 0.f : 1.f;
+    edge_lane = edge_lane || trow == 0 || trow == a.T - 1;
+    const float* xp = a.x + (long long)(valid ? m : 0) * F + 8 * fg;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 p = ld4(xp + 32 * ks), q = ld4(xp + 32 * ks + 4);
+      xv[mt][ks][0] = p.x; xv[mt][ks][1] = p.y; xv[mt][ks][2] = p.z; xv[mt][ks][3] = p.w;
+      xv[mt][ks][4] = q.x; xv[mt][ks][5] = q.y; xv[mt][ks][6] = q.z; xv[mt][ks][7] = q.w;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  uint4 wa[16], wb[16], wc[16];
+  ld_w1(ws, 0, wa);
+  ld_w1(ws, 1, wb);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float (&v)[KS][8] = xv[mt];
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[ks][e];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / F);
+    float d = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float c = v[ks][e] - mean;
+        d = fmaf(c, c, d);
+      }
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    const float rstd = vld[mt] ? 1.0f / sqrtf(d * (1.0f / F) + a.eps) : 0.f;   // invalid frames: exactly zero
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 h, l;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xn = (v[ks][e] - mean) * rstd;
+        const __bf16 hh = (__bf16)xn;
+        h[e] = hh;
+        l[e] = (__bf16)(xn - (float)hh);
+      }
+      xh[mt][ks] = h;
+      xl[mt][ks] = l;
+    }
+  }
+  const bool edge = __builtin_amdgcn_ballot_w64(edge_lane) != 0ull;   // wave-uniform
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    reinterpret_cast<uint4*>(&cst[w][i][0])[lane] = ct[i][0];
+    if (lane < 16) reinterpret_cast<uint4*>(&cst[w][i][0])[64 + lane] = ct[i][1];
+  }
+
+  // ---- phase 1: this wave's chunks ----------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int c = ws + NW * i;
+    const bool last = i + 1 == CPW;
+    f32x4 hvA[2][MT], hgA[2][MT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float* cs = &cst[w][i][0] + j * 160 + 4 * fg;
+      uint4 (&wf)[16] = j == 0 ? wa : wb;
+      f32x4 (&hv)[MT] = hvA[j];
+      f32x4 (&hg)[MT] = hgA[j];
+      {
+        const float4 bv = ld4(cs), bg = ld4(cs + 16);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          hv[mt] = (f32x4){bv.x, bv.y, bv.z, bv.w};
+          hg[mt] = (f32x4){bg.x, bg.y, bg.z, bg.w};
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 vh = *reinterpret_cast<const bf16x8*>(&wf[2 * ks]), vl = *reinterpret_cast<const bf16x8*>(&wf[2 * ks + 1]);
+        const bf16x8 gh_ = *reinterpret_cast<const bf16x8*>(&wf[2 * KS + 2 * ks]), gl_ = *reinterpret_cast<const bf16x8*>(&wf[2 * KS + 2 * ks + 1]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, xh[mt][ks], hv[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh_, xh[mt][ks], hg[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, xl[mt][ks], hv[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh_, xl[mt][ks], hg[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, xh[mt][ks], hv[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hg[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl_, xh[mt][ks], hg[mt], 0, 0, 0);
+      }
+      // the registers of this tile pair's fragments are free: request what runs in them next (the next chunk's pair, or W2)
+      // (scheduling fences: hipcc otherwise sinks the loads down to their first use - and waits for each of them there)
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last) ld_w1(c + NW, j, wf);
+      else ld_w2(j, wf);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (last) ld_w2(2, wc);     // (the frame planes are dead from here on)
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 gh[MT], gw[MT];      // gated values (bf16 hi / lo) in down-projection k-slot order
+    auto conv = [&](int j, auto edge_c) {
+      constexpr bool EDGE = decltype(edge_c)::value;
+      const float* cs = &cst[w][i][0] + j * 160 + 4 * fg;
+      f32x4 (&hv)[MT] = hvA[j];
+      f32x4 (&hg)[MT] = hgA[j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float wv0 = cs[2 * 16 + r], wv1 = cs[3 * 16 + r], wv2 = cs[4 * 16 + r];
+        const float wg0 = cs[5 * 16 + r], wg1 = cs[6 * 16 + r], wg2 = cs[7 * 16 + r];
+        const float cbv = cs[8 * 16 + r], cbg = cs[9 * 16 + r];
+        float cv[MT], cg[MT], pv[MT], pg[MT], nv[MT], ng[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          cv[mt] = hv[mt][r];
+          cg[mt] = hg[mt][r];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {   // the rotations wrap onto the two halo frames only
+          pv[mt] = mt > 0 ? cv[mt - 1] : dpp_ror1(cv[MT - 1]);
+          pg[mt] = mt > 0 ? cg[mt - 1] : dpp_ror1(cg[MT - 1]);
+          nv[mt] = mt + 1 < MT ? cv[mt + 1] : dpp_rol1(cv[0]);
+          ng[mt] = mt + 1 < MT ? cg[mt + 1] : dpp_rol1(cg[0]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float a0v = EDGE ? wv0 * f0[mt] : wv0, a2v = EDGE ? wv2 * f2[mt] : wv2;
+          const float a0g = EDGE ? wg0 * f0[mt] : wg0, a2g = EDGE ? wg2 * f2[mt] : wg2;
+          const float val = fmaf(a2v, nv[mt], fmaf(wv1, cv[mt], fmaf(a0v, pv[mt], cbv)));
+          const float gat = fmaf(a2g, ng[mt], fmaf(wg1, cg[mt], fmaf(a0g, pg[mt], cbg)));
+          const float g1 = glu_prescaled(val, gat);
+          const __bf16 hh = (__bf16)g1;
+          gh[mt][4 * j + r] = hh;
+          gw[mt][4 * j + r] = (__bf16)(g1 - (float)hh);
+        }
+      }
+    };
+    // (the sequence-boundary form of the conv is taken by the whole wave or not at all: one small branch per chunk, the MFMA code is common)
+    if (edge) {
+      conv(0, bool_c<true>{});
+      conv(1, bool_c<true>{});
+    } else {
+      conv(0, bool_c<false>{});
+      conv(1, bool_c<false>{});
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      *reinterpret_cast<bf16x8*>(&hs[((c * 2 + 0) * MT + mt) * 64 + lane]) = gh[mt];
+      *reinterpret_cast<bf16x8*>(&hs[((c * 2 + 1) * MT + mt) * 64 + lane]) = gw[mt];
+    }
+  }
+
+  // the residual rows (8 consecutive channels of this wave's 32 per lane and frame) fly under the barrier and phase 2
+  float4 xr[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mw0 + MT * fi + mt;
+    const float* xp = a.x + (long long)((m >= 0 && m < a.M) ? m : 0) * F + 32 * w + 8 * fg;
+    xr[mt][0] = ld4(xp);
+    xr[mt][1] = ld4(xp + 4);
+  }
+  __syncthreads();
+
+  // ---- phase 2: output tiles 2w, 2w+1 over all K steps, chunk order ---------------------------------------------------------------
+  f32x4 acc[FTW][MT];
+#pragma unroll
+  for (int t = 0; t < FTW; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 hb[2][2][MT];             // [ring][plane][frame tile]
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) hb[0][pl][mt] = hs[((0 * 2 + pl) * MT + mt) * 64 + lane];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) {
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hb[(c + 1) & 1][pl][mt] = hs[(((c + 1) * 2 + pl) * MT + mt) * 64 + lane];
+    }
+    uint4 (&wq)[16] = (c >> 2) == 0 ? wa : ((c >> 2) == 1 ? wb : wc);
+    const int s = c & 3;
+    bf16x8 gh[MT], gw[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      gh[mt] = *reinterpret_cast<const bf16x8*>(&hb[c & 1][0][mt]);
+      gw[mt] = *reinterpret_cast<const bf16x8*>(&hb[c & 1][1][mt]);
+    }
+    bf16x8 wh[FTW], wlo[FTW];
+#pragma unroll
+    for (int t = 0; t < FTW; ++t) {
+      wh[t] = *reinterpret_cast<const bf16x8*>(&wq[s * 4 + t * 2]);
+      wlo[t] = *reinterpret_cast<const bf16x8*>(&wq[s * 4 + t * 2 + 1]);
+    }
+#pragma unroll
+    for (int t = 0; t < FTW; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t], gh[mt], acc[t][mt], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < FTW; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t], gw[mt], acc[t][mt], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < FTW; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[t], gh[mt], acc[t][mt], 0, 0, 0);
+  }
+
+  // ---- epilogue: y = x + ls * (acc + b2); fragment row 4 fg + r of tile 2w + t is channel 32 w + 8 fg + 4 t + r ---------------------
+  {
+#pragma clang fp contract(off)
+    const int ch = 32 * w + 8 * fg;
+    const float4 b2a = ld4(a.b2 + ch), b2b = ld4(a.b2 + ch + 4), lsa = ld4(a.ls + ch), lsb = ld4(a.ls + ch + 4);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int lr = MT * fi + mt, m = mw0 + lr;
+      if (lr >= 1 && lr <= 16 * MT - 2 && m < a.M) {
+        const f32x4 o0 = acc[0][mt], o1 = acc[1][mt];
+        const float4 v0 = make_float4(o0[0] + b2a.x, o0[1] + b2a.y, o0[2] + b2a.z, o0[3] + b2a.w);
+        const float4 v1 = make_float4(o1[0] + b2b.x, o1[1] + b2b.y, o1[2] + b2b.z, o1[3] + b2b.w);
+        float* yp = a.y + (long long)m * F + ch;
+        st4(yp, make_float4(fmaf(v0.x, lsa.x, xr[mt][0].x), fmaf(v0.y, lsa.y, xr[mt][0].y), fmaf(v0.z, lsa.z, xr[mt][0].z), fmaf(v0.w, lsa.w, xr[mt][0].w)));
+        st4(yp + 4, make_float4(fmaf(v1.x, lsb.x, xr[mt][1].x), fmaf(v1.y, lsb.y, xr[mt][1].y), fmaf(v1.z, lsb.z, xr[mt][1].z), fmaf(v1.w, lsb.w, xr[mt][1].w)));
+      }
+    }
+  }
+}
+
 // (The X/Y two-group experiment "v5" - one 8-wave workgroup per CU, MFMA stream and VALU stream in sibling waves - was
 //  measured not faster in round 2 and removed in round 4; it lives in git history at a01c6d4, sepr_gcfn_fused5.inc.)
 // (A one-workgroup-per-CU, software-pipelined variant of this kernel - "v4", 8 waves, doubled weight buffers, one
@@ -738,6 +1050,14 @@ static int lat_nw() {   // A/B: SEPR_GF_LAT_NW=6 keeps the 6-wave tiles for ever
   static const int v = [] {
     const char* e = getenv("SEPR_GF_LAT_NW");
     return e && e[0] ? atoi(e) : 4;
+  }();
+  return v;
+}
+static int hs_form() {   // frame tiles per wave of the hidden-split form (gcfn_hs_kernel): 2 (default) or 4; SEPR_GF_HS=0 switches it off
+  static const int v = [] {
+    const char* e = getenv("SEPR_GF_HS");
+    const int m = e && e[0] ? atoi(e) : 2;
+    return (m == 2 || m == 4) ? m : 0;
   }();
   return v;
 }
@@ -860,6 +1180,11 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
     } else if (a.train) {
       if (F == 128) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 0, true>), dim3(grid), dim3(384), 0, stream, a);
       else hipLaunchKernelGGL((gcfn_fused3_kernel<64, 1, 6, 0, true>), dim3(grid), dim3(384), 0, stream, a);
+    } else if (F == 128 && hs_form() && (a.M + 16 * hs_form() - 3) / (16 * hs_form() - 2) <= lat_max_tiles()) {
+      // one tile per CU at most: the hidden-split form (gcfn_hs_kernel), 30-frame tiles (62-frame ones: SEPR_GF_HS=4)
+      const int mt = hs_form(), nt = (a.M + 16 * mt - 3) / (16 * mt - 2);
+      if (mt == 2) hipLaunchKernelGGL((gcfn_hs_kernel<2>), dim3(nt), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((gcfn_hs_kernel<4>), dim3(nt), dim3(256), 0, stream, a);
     } else if (F == 128) {
       const int lat = ntiles <= lat_max_tiles() ? lat_ring() : 0;
       const int nt4 = (a.M + 4 * 14 - 1) / (4 * 14);
