@@ -733,11 +733,20 @@ __global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128 || MT > 2) ? (NW > 4 ?
 // Every accumulator sees exactly the operand sequence of gcfn_fused3_kernel (same packed weights, same products, same order): the result
 // is bit-identical, which the parity tests check against the batched launch (tests/test_gpu_parity.py).  F = 128 only.
 // ---------------------------------------------------------------------------------------------------------
-template <int MT>
-__global__ __launch_bounds__(256, 1) void gcfn_hs_kernel(const GcfnFusedArgs a) {
-  constexpr int F = 128, KS = F / 32, NW = 4, NCH = 3 * F / 32, CPW = NCH / NW, FT = F / 16, FTW = FT / NW;
+#ifndef SEPR_HS_WGS
+#define SEPR_HS_WGS 1   // workgroups per CU the 30-frame instantiation is compiled for; 2 (256 registers per wave) spills 124 dwords: the tile's
+                        // live set is 64 (frame planes) + 128 (fragment prefetch) + 48 (accumulators, gated planes) + the conv's temporaries
+#endif
+// PLAIN (MODE 1 of the kernel above: SpkSplit's and OutputLayer's GLU-MLP): no LayerNorm, conv, halo, LayerScale, residual; CPW = hidden
+// chunks per wave (a.nch = 4 CPW chunks: 2 for OutputLayer, 4 for SpkSplit, 3 for the GCFN block), input / output row maps as there.
+template <int MT, int CPW = 3, bool PLAIN = false>
+__global__ __launch_bounds__(256, MT == 2 ? SEPR_HS_WGS : 1) void gcfn_hs_kernel(const GcfnFusedArgs a) {
+  constexpr int F = 128, KS = F / 32, NW = 4, NCH = NW * CPW, FT = F / 16, FTW = FT / NW;
+  constexpr int NG = NCH / 4;                        // groups of 4 K steps of the down-projection (one 16-fragment register block each)
+  static_assert(PLAIN || CPW == 3, "the GCFN block has 3F / 32 = 12 hidden chunks");
   constexpr int W1F_U4 = 4 * KS * 2 * 64, CS_U4 = 256, W1_U4 = W1F_U4 + CS_U4, W2_U4 = FT * 2 * 64;
-  constexpr int TILE = 16 * MT - 2;                  // output frames per workgroup (first and last frame of the tile are recomputed halo)
+  constexpr int HALO = PLAIN ? 0 : 1;
+  constexpr int TILE = 16 * MT - 2 * HALO;           // output frames per workgroup (GCFN: first and last frame of the tile are recomputed halo)
   constexpr int CSF = 320;                           // live floats of a chunk's constant block ([2 tile pairs][10][16])
   static_assert(CPW * NW == NCH && FTW * NW == FT && FTW == 2, "hidden / output split over the four waves");
   __shared__ __attribute__((aligned(16))) uint4 hs[NCH * 2 * MT * 64];     // gated tensor: [K step][plane][frame tile][lane]
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(256, 1) void gcfn_hs_kernel(const GcfnFusedArgs a) 
   const uint4* const W1g = static_cast<const uint4*>(a.w1p);
   const uint4* const W2g = static_cast<const uint4*>(a.w2p);
   const int tile = blockIdx.x;
-  const int mw0 = tile * TILE - 1;
+  const int mw0 = tile * TILE - HALO;
 
   // wave-uniform bases + ONE 32-bit per-lane byte offset (SGPR-base addressing: no 64-bit per-lane pointers to keep alive across the tile)
   const int ws = __builtin_amdgcn_readfirstlane(w);
@@ -792,11 +801,13 @@ __global__ __launch_bounds__(256, 1) void gcfn_hs_kernel(const GcfnFusedArgs a) 
     const int m = mw0 + MT * fi + mt;
     const bool valid = (m >= 0 && m < a.M);
     vld[mt] = valid;
-    const int trow = valid ? m % a.T : -2;
+    const int trow = (valid && !PLAIN) ? m % a.T : -2;
     f0[mt] = (trow == 0) ? 0.f : 1.f;
     f2[mt] = (trow == a.T - 1) ? 0.f : 1.f;
     edge_lane = edge_lane || trow == 0 || trow == a.T - 1;
-    const float* xp = a.x + (long long)(valid ? m : 0) * F + 8 * fg;
+    long long mi = valid ? m : 0;
+    if (PLAIN && a.in_rows > 0) mi = (long long)(mi / a.in_rows) * a.in_src + mi % a.in_rows;
+    const float* xp = a.x + mi * F + 8 * fg;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const float4 p = ld4(xp + 32 * ks), q = ld4(xp + 32 * ks + 4);
@@ -819,7 +830,7 @@ __global__ __launch_bounds__(256, 1) void gcfn_hs_kernel(const GcfnFusedArgs a) 
       for (int e = 0; e < 8; ++e) s += v[ks][e];
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / F);
+    const float mean = PLAIN ? 0.f : s * (1.0f / F);
     float d = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -830,7 +841,7 @@ __global__ __launch_bounds__(256, 1) void gcfn_hs_kernel(const GcfnFusedArgs a) 
       }
     d += __shfl_xor(d, 16, 64);
     d += __shfl_xor(d, 32, 64);
-    const float rstd = vld[mt] ? 1.0f / sqrtf(d * (1.0f / F) + a.eps) : 0.f;   // invalid frames: exactly zero
+    const float rstd = vld[mt] ? (PLAIN ? 1.0f : 1.0f / sqrtf(d * (1.0f / F) + a.eps)) : 0.f;   // invalid frames: exactly zero
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       bf16x8 h, l;
@@ -892,11 +903,13 @@ __global__ __launch_bounds__(256, 1) void gcfn_hs_kernel(const GcfnFusedArgs a) 
       // the registers of this tile pair's fragments are free: request what runs in them next (the next chunk's pair, or W2)
       // (scheduling fences: hipcc otherwise sinks the loads down to their first use - and waits for each of them there)
       __builtin_amdgcn_sched_barrier(0);
-      if (!last) ld_w1(c + NW, j, wf);
-      else ld_w2(j, wf);
+      if (!(SEPR_GF_ABL & 512)) {   // (timing ablation 512, wrong results: the weight fragments are requested once)
+        if (!last) ld_w1(c + NW, j, wf);
+        else if (j < NG) ld_w2(j, wf);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (last) ld_w2(2, wc);     // (the frame planes are dead from here on)
+    if (last && NG > 2 && !(SEPR_GF_ABL & 512)) ld_w2(2, wc);     // (the frame planes are dead from here on)
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 gh[MT], gw[MT];      // gated values (bf16 hi / lo) in down-projection k-slot order
     auto conv = [&](int j, auto edge_c) {
@@ -935,6 +948,26 @@ __global__ __launch_bounds__(256, 1) void gcfn_hs_kernel(const GcfnFusedArgs a) 
         }
       }
     };
+    if constexpr (PLAIN) {   // no conv: GLU straight on the projection (the gate rows of W1 / b1 are pre-scaled by -log2 e)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float g1 = glu_prescaled(hvA[j][mt][r], hgA[j][mt][r]);
+            const __bf16 hh = (__bf16)g1;
+            gh[mt][4 * j + r] = hh;
+            gw[mt][4 * j + r] = (__bf16)(g1 - (float)hh);
+          }
+    } else
+    if (SEPR_GF_ABL & 1024) {   // (timing ablation 1024, wrong results: no conv / GLU / split)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        gh[mt] = *reinterpret_cast<const bf16x8*>(&hvA[0][mt]);
+        gw[mt] = *reinterpret_cast<const bf16x8*>(&hgA[1][mt]);
+      }
+    } else
     // (the sequence-boundary form of the conv is taken by the whole wave or not at all: one small branch per chunk, the MFMA code is common)
     if (edge) {
       conv(0, bool_c<true>{});
@@ -956,8 +989,8 @@ __global__ __launch_bounds__(256, 1) void gcfn_hs_kernel(const GcfnFusedArgs a) 
   for (int mt = 0; mt < MT; ++mt) {
     const int m = mw0 + MT * fi + mt;
     const float* xp = a.x + (long long)((m >= 0 && m < a.M) ? m : 0) * F + 32 * w + 8 * fg;
-    xr[mt][0] = ld4(xp);
-    xr[mt][1] = ld4(xp + 4);
+    xr[mt][0] = PLAIN ? zero4() : ld4(xp);
+    xr[mt][1] = PLAIN ? zero4() : ld4(xp + 4);
   }
   __syncthreads();
 
@@ -980,7 +1013,7 @@ __global__ __launch_bounds__(256, 1) void gcfn_hs_kernel(const GcfnFusedArgs a) 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) hb[(c + 1) & 1][pl][mt] = hs[(((c + 1) * 2 + pl) * MT + mt) * 64 + lane];
     }
-    uint4 (&wq)[16] = (c >> 2) == 0 ? wa : ((c >> 2) == 1 ? wb : wc);
+    uint4 (&wq)[16] = (c >> 2) % 3 == 0 ? wa : ((c >> 2) % 3 == 1 ? wb : wc);
     const int s = c & 3;
     bf16x8 gh[MT], gw[MT];
 #pragma unroll
@@ -1006,20 +1039,34 @@ __global__ __launch_bounds__(256, 1) void gcfn_hs_kernel(const GcfnFusedArgs a) 
     for (int t = 0; t < FTW; ++t)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[t], gh[mt], acc[t][mt], 0, 0, 0);
+    if (s == 3 && (c >> 2) + 3 < NG) {   // (SpkSplit: 16 K steps) this group's register block takes the fragments of the group three ahead
+      __builtin_amdgcn_sched_barrier(0);
+      ld_w2((c >> 2) + 3, wq);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // ---- epilogue: y = x + ls * (acc + b2); fragment row 4 fg + r of tile 2w + t is channel 32 w + 8 fg + 4 t + r ---------------------
   {
 #pragma clang fp contract(off)
     const int ch = 32 * w + 8 * fg;
-    const float4 b2a = ld4(a.b2 + ch), b2b = ld4(a.b2 + ch + 4), lsa = ld4(a.ls + ch), lsb = ld4(a.ls + ch + 4);
+    const float4 b2a = ld4(a.b2 + ch), b2b = ld4(a.b2 + ch + 4);
+    const float4 lsa = PLAIN ? zero4() : ld4(a.ls + ch), lsb = PLAIN ? zero4() : ld4(a.ls + ch + 4);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int lr = MT * fi + mt, m = mw0 + lr;
-      if (lr >= 1 && lr <= 16 * MT - 2 && m < a.M) {
+      if (lr >= HALO && lr <= 16 * MT - 1 - HALO && m < a.M) {
         const f32x4 o0 = acc[0][mt], o1 = acc[1][mt];
         const float4 v0 = make_float4(o0[0] + b2a.x, o0[1] + b2a.y, o0[2] + b2a.z, o0[3] + b2a.w);
         const float4 v1 = make_float4(o1[0] + b2b.x, o1[1] + b2b.y, o1[2] + b2b.z, o1[3] + b2b.w);
+        if constexpr (PLAIN) {
+          long long mo = m;
+          if (a.out_S > 0) mo = ((long long)(mo / a.out_T) * a.out_S + a.out_s) * a.out_T + mo % a.out_T;
+          float* yq = a.y + mo * a.ldy + a.col_off + ch;
+          st4(yq, v0);
+          st4(yq + 4, v1);
+          continue;
+        }
         float* yp = a.y + (long long)m * F + ch;
         st4(yp, make_float4(fmaf(v0.x, lsa.x, xr[mt][0].x), fmaf(v0.y, lsa.y, xr[mt][0].y), fmaf(v0.z, lsa.z, xr[mt][0].z), fmaf(v0.w, lsa.w, xr[mt][0].w)));
         st4(yp + 4, make_float4(fmaf(v1.x, lsb.x, xr[mt][1].x), fmaf(v1.y, lsb.y, xr[mt][1].y), fmaf(v1.z, lsb.z, xr[mt][1].z), fmaf(v1.w, lsb.w, xr[mt][1].w)));
@@ -1053,14 +1100,6 @@ static int lat_nw() {   // A/B: SEPR_GF_LAT_NW=6 keeps the 6-wave tiles for ever
   }();
   return v;
 }
-static int hs_form() {   // frame tiles per wave of the hidden-split form (gcfn_hs_kernel): 2 (default) or 4; SEPR_GF_HS=0 switches it off
-  static const int v = [] {
-    const char* e = getenv("SEPR_GF_HS");
-    const int m = e && e[0] ? atoi(e) : 2;
-    return (m == 2 || m == 4) ? m : 0;
-  }();
-  return v;
-}
 static int lat_max_tiles() {
   static const int v = [] {
     int dev = 0, cus = 256;
@@ -1068,6 +1107,35 @@ static int lat_max_tiles() {
     return cus;
   }();
   return v;
+}
+
+// Frame tiles per wave (2 / 3: 30- / 46-frame workgroup tiles) of the hidden-split form for a launch of M rows, 0 = not taken.  The launch must fit
+// one workgroup per CU; SEPR_GF_HS=0 switches the form off, 2 / 3 / 4 force one tile size (A/B; 4 = 62-frame tiles, measured no faster than the
+// ring form it would replace: profiles/r06_gcfn_hidden_split.txt).
+static int hs_tiles(int M) {
+  static const int force = [] {
+    const char* e = getenv("SEPR_GF_HS");
+    return e && e[0] ? atoi(e) : -1;
+  }();
+  const int cus = lat_max_tiles();
+  if (force == 0) return 0;
+  if (force >= 2 && force <= 4) return (M + 16 * force - 3) / (16 * force - 2) <= cus ? force : 0;
+  for (int mt = 2; mt <= 3; ++mt)
+    if ((M + 16 * mt - 3) / (16 * mt - 2) <= cus) return mt;
+  return 0;
+}
+
+static int hs_tiles_plain(int M) {   // same for the PLAIN instantiations (no halo: 32- / 48-frame tiles); SEPR_GF_HS_PLAIN=0 switches them off
+  static const int on = [] {
+    const char* e = getenv("SEPR_GF_HS_PLAIN");
+    const char* g = getenv("SEPR_GF_HS");
+    return !((e && e[0] == '0') || (g && g[0] == '0'));
+  }();
+  if (!on) return 0;
+  const int cus = lat_max_tiles();
+  for (int mt = 2; mt <= 3; ++mt)
+    if ((M + 16 * mt - 1) / (16 * mt) <= cus) return mt;
+  return 0;
 }
 
 // Plain GLU-MLP (MODE 1): one launch computes F = 128 output columns; a wider output takes one launch per 128 columns
@@ -1086,6 +1154,14 @@ int launch_glumlp_fused(const GcfnFusedArgs& a, int F, int site, hipStream_t str
     SEPR_CHECK_LAUNCH("glumlp_fused_kernel<256>");
     return SEPR_OK;
   }
+  if (const int mt = (a.nch == 8 || a.nch == 16) ? hs_tiles_plain(a.M) : 0) {
+    // one tile per CU at most: the hidden-split form (gcfn_hs_kernel, PLAIN), 32- or 48-frame tiles
+    const int nt = (a.M + 16 * mt - 1) / (16 * mt);
+    if (a.nch == 8 && mt == 2) hipLaunchKernelGGL((gcfn_hs_kernel<2, 2, true>), dim3(nt), dim3(256), 0, stream, a);
+    else if (a.nch == 8) hipLaunchKernelGGL((gcfn_hs_kernel<3, 2, true>), dim3(nt), dim3(256), 0, stream, a);
+    else if (mt == 2) hipLaunchKernelGGL((gcfn_hs_kernel<2, 4, true>), dim3(nt), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gcfn_hs_kernel<3, 4, true>), dim3(nt), dim3(256), 0, stream, a);
+  } else
   if (a.M < 12000) {
     const int ntiles = (a.M + 95) / 96;
     // one tile per CU at most: the latency form (3-stage weight ring, one workgroup per CU), 4 waves (one per SIMD) when that still fits
@@ -1180,10 +1256,11 @@ int launch_gcfn_fused(const GcfnFusedArgs& a_in, int F, int site, hipStream_t st
     } else if (a.train) {
       if (F == 128) hipLaunchKernelGGL((gcfn_fused3_kernel<128, 1, 6, 0, true>), dim3(grid), dim3(384), 0, stream, a);
       else hipLaunchKernelGGL((gcfn_fused3_kernel<64, 1, 6, 0, true>), dim3(grid), dim3(384), 0, stream, a);
-    } else if (F == 128 && hs_form() && (a.M + 16 * hs_form() - 3) / (16 * hs_form() - 2) <= lat_max_tiles()) {
-      // one tile per CU at most: the hidden-split form (gcfn_hs_kernel), 30-frame tiles (62-frame ones: SEPR_GF_HS=4)
-      const int mt = hs_form(), nt = (a.M + 16 * mt - 3) / (16 * mt - 2);
+    } else if (F == 128 && hs_tiles(a.M) > 0) {
+      // one tile per CU at most: the hidden-split form (gcfn_hs_kernel) with the smallest tile that fits the launch on the chip
+      const int mt = hs_tiles(a.M), nt = (a.M + 16 * mt - 3) / (16 * mt - 2);
       if (mt == 2) hipLaunchKernelGGL((gcfn_hs_kernel<2>), dim3(nt), dim3(256), 0, stream, a);
+      else if (mt == 3) hipLaunchKernelGGL((gcfn_hs_kernel<3>), dim3(nt), dim3(256), 0, stream, a);
       else hipLaunchKernelGGL((gcfn_hs_kernel<4>), dim3(nt), dim3(256), 0, stream, a);
     } else if (F == 128) {
       const int lat = ntiles <= lat_max_tiles() ? lat_ring() : 0;

@@ -65,3 +65,7 @@ VARIANT_gfuf0 = -DSEPR_GF3_UPFIRST=0
 # round 6: wait states between the SGPR-base set-up and the inline-asm LDS-DMA (product: 4 = hazard-safe; 0 = the first form, A/B only)
 VARIANT_gldsnop0 = -DSEPR_GLDS_NOP=0
 VARIANT_gfnofence = -DSEPR_GF3_FENCE256=0
+# round 6: timing ablations of the hidden-split GCFN form (wrong results): 512 = weight fragments requested once, 1024 = no conv / GLU, 1536 = both
+VARIANT_hsa512 = -DSEPR_GF_ABL=512
+VARIANT_hsa1024 = -DSEPR_GF_ABL=1024
+VARIANT_hsa1536 = -DSEPR_GF_ABL=1536
