@@ -1109,9 +1109,9 @@ static int lat_max_tiles() {
   return v;
 }
 
-// Frame tiles per wave (2 / 3: 30- / 46-frame workgroup tiles) of the hidden-split form for a launch of M rows, 0 = not taken.  The launch must fit
-// one workgroup per CU; SEPR_GF_HS=0 switches the form off, 2 / 3 / 4 force one tile size (A/B; 4 = 62-frame tiles, measured no faster than the
-// ring form it would replace: profiles/r06_gcfn_hidden_split.txt).
+// Frame tiles per wave (2 / 3 / 4: 30- / 46- / 62-frame workgroup tiles) of the hidden-split form for a launch of M rows, 0 = not taken: the smallest
+// tile with which the launch fits one workgroup per CU (per-launch times by size: profiles/r06_gcfn_hidden_split.txt).  SEPR_GF_HS=0 switches the
+// form off, 2 / 3 / 4 force one tile size (A/B).
 static int hs_tiles(int M) {
   static const int force = [] {
     const char* e = getenv("SEPR_GF_HS");
@@ -1120,7 +1120,7 @@ static int hs_tiles(int M) {
   const int cus = lat_max_tiles();
   if (force == 0) return 0;
   if (force >= 2 && force <= 4) return (M + 16 * force - 3) / (16 * force - 2) <= cus ? force : 0;
-  for (int mt = 2; mt <= 3; ++mt)
+  for (int mt = 2; mt <= 4; ++mt)
     if ((M + 16 * mt - 3) / (16 * mt - 2) <= cus) return mt;
   return 0;
 }

@@ -1,32 +1,55 @@
 #!/usr/bin/env python3
-"""Round 6: the hidden-split GCFN form (gcfn_hs_kernel, SEPR_GF_HS=2|4) against the oracle AND bitwise against the batched kernel
-(SEPR_GF_HS=0, own process): prints per-shape agreement, a sha256 of every output and - on a mismatch - where the rows differ."""
+"""The hidden-split GCFN / GLU-MLP form (gcfn_hs_kernel) against the oracle and - across processes - bitwise against the row-stationary kernels
+it replaces for small launches (SEPR_GF_HS=0): prints, per case, the agreement with the oracle and a sha256 of the output; on a mismatch, where
+the rows differ.  tests/test_gpu_parity.py::test_gcfn_hidden_split_bitwise runs it under both settings and compares the lines.
+R6_HS_TIME=1 adds per-launch times at sizes around the form boundaries (profiles/r06_gcfn_hidden_split.txt)."""
 import hashlib
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests.test_gpu_parity import gpu_model, rnd, orc   # noqa: E402
+from sepreformer_amd.synth import synth_mixture          # noqa: E402
 
 m, sd = gpu_model("SepReformer_Base_WSJ0", "bf16x3")
 eng = m.engine()
 eng.prepare(8, 2400, 2400)
-dump = os.environ.get("R6_HS_DUMP")
-for n, T in ((1, 1), (2, 37), (1, 30), (1, 31), (3, 300), (5, 2), (2, 127), (1, 253), (1, 2000), (2, 2300), (1, 7680), (1, 7681)):
+# (n sequences, T frames): tile ends on / next to sequence ends, every tile size's last full launch and the first launch past it
+CASES = ((1, 1), (2, 37), (1, 30), (1, 31), (3, 300), (5, 2), (2, 127), (1, 253), (1, 2000), (2, 2300), (1, 7680), (1, 7681), (1, 9000),
+         (3, 3925), (1, 11777), (1, 13000), (2, 7936), (1, 15873))
+for n, T in CASES:
     x = rnd(n, T, m.cfg.feat, seed=T)
     y = eng.gcfn(x.cuda(), eng.pk.enc_stages[0]["g"][0][1], n, T).cpu()
     ref = orc.gcfn(sd, "separator.enc_stages.0.g_block_1.block.gcfn", x)
     db = orc.agreement_db(y, ref)
-    line = f"{n} {T} {db:.1f} {hashlib.sha256(y.numpy().tobytes()).hexdigest()[:16]}"
+    line = f"gcfn {n} {T} {db:.1f} {hashlib.sha256(y.numpy().tobytes()).hexdigest()[:16]}"
     if db < 80:
         d = (y - ref).abs().reshape(n * T, -1)
         bad = (d.max(1).values > 1e-3).nonzero().flatten().tolist()
         cols = (d.max(0).values > 1e-3).nonzero().flatten().tolist()
         line += f" bad_rows[{len(bad)}]={bad[:24]} bad_cols[{len(cols)}]={cols[:40]}"
     print(line, flush=True)
-    if dump:
-        np.save(os.path.join(dump, f"hs_{n}_{T}.npy"), y.numpy())
+# the whole separator on one utterance: SpkSplit's and OutputLayer's GLU-MLP launches take the PLAIN instantiations
+for L in (4000, 32000, 47001):
+    out = m(synth_mixture(1, L, seed=L).cuda())
+    hh = hashlib.sha256(b"".join(t.cpu().numpy().tobytes() for grp in out for t in grp)).hexdigest()[:16]
+    print(f"model 1 {L} {hh}", flush=True)
+
+if os.environ.get("R6_HS_TIME"):
+    # per-launch time of the GCFN block at launch sizes around the form boundaries (200 back-to-back launches between two HIP events)
+    for M in (2000, 7680, 8000, 11776, 12000, 15000, 15872, 16000):
+        x = rnd(1, M, m.cfg.feat, seed=M).cuda()
+        wgt = eng.pk.enc_stages[0]["g"][0][1]
+        for _ in range(20):
+            eng.gcfn(x, wgt, 1, M)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            eng.gcfn(x, wgt, 1, M)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"time M={M}: {e0.elapsed_time(e1) * 5:.1f} us per launch (includes launch gaps)", flush=True)
