@@ -32,10 +32,18 @@ for n, T in CASES:
         cols = (d.max(0).values > 1e-3).nonzero().flatten().tolist()
         line += f" bad_rows[{len(bad)}]={bad[:24]} bad_cols[{len(cols)}]={cols[:40]}"
     print(line, flush=True)
+def flat(o):
+    if torch.is_tensor(o):
+        yield o
+    else:
+        for e in o:
+            yield from flat(e)
+
+
 # the whole separator on one utterance: SpkSplit's and OutputLayer's GLU-MLP launches take the PLAIN instantiations
 for L in (4000, 32000, 47001):
     out = m(synth_mixture(1, L, seed=L).cuda())
-    hh = hashlib.sha256(b"".join(t.cpu().numpy().tobytes() for grp in out for t in grp)).hexdigest()[:16]
+    hh = hashlib.sha256(b"".join(t.cpu().numpy().tobytes() for t in flat(out))).hexdigest()[:16]
     print(f"model 1 {L} {hh}", flush=True)
 
 if os.environ.get("R6_HS_TIME"):
