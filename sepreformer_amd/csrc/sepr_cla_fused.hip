@@ -426,6 +426,187 @@ __global__ __launch_bounds__(CF_NT, F > 128 ? 1 : 2) void cla_tail_kernel(const 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// cla_tail_hs_kernel (round 6): the HIDDEN-SPLIT form of the tail for launches of at most one tile per CU (batch 1) - the design of
+// gcfn_hs_kernel (sepr_gcfn_fused.hip).  The four waves hold the SAME 16*MT frames; wave w owns hidden chunk w (64 channels: four tiles up)
+// and then output tiles 2w, 2w+1 over all 8 K steps.  Weight fragments have one reader each and go global -> registers (the 32 KB of a wave's
+// chunk are requested at the start; the registers of a tile's fragments take the wave's W3 fragments as soon as the tile is multiplied);
+// the activated planes cross the waves once through LDS, in the B-fragment lane layout they already have; ONE barrier.  Same packed
+// weights, same products in the same order as cla_tail_kernel: bit-identical (tests/test_gpu_parity.py).  F = 128.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256, 1) void cla_tail_hs_kernel(const ClaFusedArgs a) {
+  constexpr int F = 128, KS = F / 32, NW = 4, NCH = 2 * F / 64, FT = F / 16, FTW = FT / NW, NQ = 2 * NCH;
+  constexpr int W1F_U4 = 4 * KS * 2 * 64, CS_U4 = 256, W1_U4 = W1F_U4 + CS_U4, W2_U4 = 2 * FT * 2 * 64;
+  constexpr int TILE = 16 * MT;
+  static_assert(NCH == NW && FTW == 2, "one hidden chunk and two output tiles per wave");
+  __shared__ __attribute__((aligned(16))) uint4 hs[NQ * 2 * MT * 64];   // activated tensor: [K step][plane][frame tile][lane]
+  __shared__ __attribute__((aligned(16))) float cst[NW][64];            // this wave's chunk biases [4 tiles][16] (wave-private: no barrier)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+  const unsigned loff = (unsigned)lane * 16u;
+  const uint4* const W1g = static_cast<const uint4*>(a.w1p) + (long long)ws * W1_U4;
+  const uint4* const W2g = static_cast<const uint4*>(a.w2p);
+  auto ldu = [&](const uint4* base, int blk) -> uint4 {   // 16 bytes of this lane from the 1 KiB block blk behind the wave-uniform base
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base + blk * 64) + loff);
+  };
+  const int tile0 = blockIdx.x * TILE;
+  // request order = arrival order: biases, frames, then the chunk's fragments
+  const uint4 cb = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(W1g + W1F_U4) + (loff & 255u));
+  bf16x8 xh[MT][KS], xl[MT][KS];
+  float xv[MT][KS][8];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = tile0 + MT * fi + mt;
+    const float* xp = a.x + (long long)(m < a.M ? m : 0) * F + 8 * fg;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 p = ld4(xp + 32 * ks), q = ld4(xp + 32 * ks + 4);
+      xv[mt][ks][0] = p.x; xv[mt][ks][1] = p.y; xv[mt][ks][2] = p.z; xv[mt][ks][3] = p.w;
+      xv[mt][ks][4] = q.x; xv[mt][ks][5] = q.y; xv[mt][ks][6] = q.z; xv[mt][ks][7] = q.w;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  uint4 wr[4][2 * KS];      // tile j of the chunk: [K step][plane]; later this wave's W3 fragments of K steps 2j, 2j+1: [step][tile][plane]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k2 = 0; k2 < 2 * KS; ++k2) wr[j][k2] = ldu(W1g, j * 2 * KS + k2);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 h, l;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xn = xv[mt][ks][e];
+        const __bf16 hh = (__bf16)xn;
+        h[e] = hh;
+        l[e] = (__bf16)(xn - (float)hh);
+      }
+      xh[mt][ks] = h;
+      xl[mt][ks] = l;
+    }
+  if (lane < 16) reinterpret_cast<uint4*>(&cst[w][0])[lane] = cb;
+
+  // ---- phase 1: this wave's hidden chunk ---------------------------------------------------------------------------------------
+  bf16x8 gh[2][MT], gw[2][MT];     // activated values (bf16 hi / lo) of the chunk's two K steps, k-slot order
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 h[MT];
+    {
+      const float4 bv = ld4(&cst[w][0] + j * 16 + 4 * fg);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) h[mt] = (f32x4){bv.x, bv.y, bv.z, bv.w};
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&wr[j][2 * ks]);
+      const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&wr[j][2 * ks + 1]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) h[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], h[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) h[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], h[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) h[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], h[mt], 0, 0, 0);
+    }
+    // (scheduling fences: hipcc otherwise sinks the loads down to their first use - and waits for each of them there)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < FTW; ++t)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wr[j][(s * FTW + t) * 2 + pl] = ldu(W2g + (long long)j * W2_U4, ((s * FT + FTW * ws + t) * 2 + pl));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float o = gelu_fast(h[mt][r]);
+        const __bf16 hb = (__bf16)o;
+        gh[j >> 1][mt][4 * (j & 1) + r] = hb;
+        gw[j >> 1][mt][4 * (j & 1) + r] = (__bf16)(o - (float)hb);
+      }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      *reinterpret_cast<bf16x8*>(&hs[(((2 * w + s) * 2 + 0) * MT + mt) * 64 + lane]) = gh[s][mt];
+      *reinterpret_cast<bf16x8*>(&hs[(((2 * w + s) * 2 + 1) * MT + mt) * 64 + lane]) = gw[s][mt];
+    }
+  // the residual rows (this lane's 2 x 4 channels per frame) fly under the barrier and phase 2
+  float4 xr[MT][FTW];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = tile0 + MT * fi + mt;
+    const float* rp = a.res + (long long)(m < a.M ? m : 0) * F + 32 * w + 4 * fg;
+#pragma unroll
+    for (int t = 0; t < FTW; ++t) xr[mt][t] = ld4(rp + 16 * t);
+  }
+  __syncthreads();
+
+  // ---- phase 2: output tiles 2w, 2w+1 over the 8 K steps, in order --------------------------------------------------------------
+  f32x4 acc[FTW][MT];
+#pragma unroll
+  for (int t = 0; t < FTW; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 hb[2][2][MT];             // [ring][plane][frame tile]
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) hb[0][pl][mt] = hs[((0 * 2 + pl) * MT + mt) * 64 + lane];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (q + 1 < NQ) {
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hb[(q + 1) & 1][pl][mt] = hs[(((q + 1) * 2 + pl) * MT + mt) * 64 + lane];
+    }
+    bf16x8 ah[MT], aw[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      ah[mt] = *reinterpret_cast<const bf16x8*>(&hb[q & 1][0][mt]);
+      aw[mt] = *reinterpret_cast<const bf16x8*>(&hb[q & 1][1][mt]);
+    }
+#pragma unroll
+    for (int t = 0; t < FTW; ++t) {
+      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&wr[q >> 1][((q & 1) * FTW + t) * 2]);
+      const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&wr[q >> 1][((q & 1) * FTW + t) * 2 + 1]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[mt], acc[t][mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, aw[mt], acc[t][mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ah[mt], acc[t][mt], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: y = res + ls * (acc + b3); fragment row 4 fg + r of tile 2w + t is channel 32 w + 16 t + 4 fg + r ----------------
+  {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int t = 0; t < FTW; ++t) {
+      const int ch = 32 * w + 16 * t + 4 * fg;
+      const float4 bb = ld4(a.b3 + ch), lsv = ld4(a.ls + ch);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = tile0 + MT * fi + mt;
+        if (m < a.M) {
+          const f32x4 o = acc[t][mt];
+          st4(a.y + (long long)m * F + ch, make_float4(fmaf(o[0] + bb.x, lsv.x, xr[mt][t].x), fmaf(o[1] + bb.y, lsv.y, xr[mt][t].y),
+                                                        fmaf(o[2] + bb.z, lsv.z, xr[mt][t].z), fmaf(o[3] + bb.w, lsv.w, xr[mt][t].w)));
+        }
+      }
+    }
+  }
+}
+
 // small launches (round 6): when even the 64-frame tiles of the MT = 1 instantiations leave workgroup slots free (cap = two per CU), a launch's
 // duration is one workgroup's dependent chain - halve it.  SEPR_CF_SMALL=<max 64-frame tiles> overrides the bound (0: never; A/B).
 static bool small_launch(int M, int cap) {
@@ -474,7 +655,16 @@ int launch_cla_tail(const ClaFusedArgs& a, int F, int site, hipStream_t stream) 
   const bool timed = prof_begin(site, stream, &slot);
   const int ntiles = (a.M + 127) / 128;
   const int cap = persistent_grid();
+  // at most one tile per CU: the hidden-split form, 32- or 64-frame tiles (SEPR_CF_HS=0 switches it off, 2 / 4 force a tile size)
+  static const int hs_force = [] {
+    const char* e = getenv("SEPR_CF_HS");
+    return e && e[0] ? atoi(e) : -1;
+  }();
+  const int cus = cap / 2;
+  const int hs_mt = hs_force == 0 ? 0 : (hs_force == 4 ? ((a.M + 63) / 64 <= cus ? 4 : 0) : ((a.M + 31) / 32 <= cus ? 2 : (hs_force < 0 && (a.M + 63) / 64 <= cus ? 4 : 0)));
   if (F == 256) hipLaunchKernelGGL((cla_tail_kernel<256>), dim3(ntiles < cap / 2 ? ntiles : cap / 2), dim3(CF_NT), 0, stream, a);
+  else if (hs_mt == 2) hipLaunchKernelGGL((cla_tail_hs_kernel<2>), dim3((a.M + 31) / 32), dim3(256), 0, stream, a);
+  else if (hs_mt == 4) hipLaunchKernelGGL((cla_tail_hs_kernel<4>), dim3((a.M + 63) / 64), dim3(256), 0, stream, a);
   else if (small_launch(a.M, cap)) hipLaunchKernelGGL((cla_tail_kernel<128, 1>), dim3((a.M + 63) / 64), dim3(CF_NT), 0, stream, a);
   else hipLaunchKernelGGL((cla_tail_kernel<128>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
   if (timed) prof_end(slot, (double)a.M * (2.0 * F * 2 * F + 2.0 * 2 * F * F), stream);

@@ -485,20 +485,22 @@ def test_gcfn_hidden_split_bitwise():
     """Launches with at most one tile per CU (batch 1) take gcfn_hs_kernel: the four waves of a workgroup split the hidden dimension instead of
     the frames.  Same packed weights, same products in the same order - the outputs must be BIT-identical to the row-stationary kernels
     (SEPR_GF_HS=0, read once per process -> own processes) for the GCFN block at every tile size (30 / 46 / 62 frames, boundaries included) and
-    for a whole batch-1 forward (SpkSplit / OutputLayer GLU-MLP: the PLAIN instantiations); every GCFN case also agrees with the oracle."""
+    for a whole batch-1 forward (SpkSplit / OutputLayer GLU-MLP: the PLAIN instantiations); the CLA block's tail has the same form
+    (cla_tail_hs_kernel, SEPR_CF_HS=0 = cla_tail_kernel).  Every block case also agrees with the oracle."""
     import subprocess
     import sys
     outs = []
     for hs in ("0", ""):
-        env = dict(os.environ, SEPR_GF_HS=hs)
+        env = dict(os.environ, SEPR_GF_HS=hs, SEPR_CF_HS=hs)
         if not hs:
             env.pop("SEPR_GF_HS")
+            env.pop("SEPR_CF_HS")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r6_hs_check.py")], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("gcfn ", "model "))]
-        assert len(lines) >= 21, r.stdout[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("gcfn ", "cla ", "model "))]
+        assert len(lines) >= 32, r.stdout[-2000:]
         for ln in lines:
-            if ln.startswith("gcfn "):
+            if ln.startswith(("gcfn ", "cla ")):
                 assert float(ln.split()[3]) >= 80.0, ln
         outs.append(lines)
     assert outs[0] == outs[1], [(a, b) for a, b in zip(*outs) if a != b]

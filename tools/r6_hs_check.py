@@ -32,6 +32,14 @@ for n, T in CASES:
         cols = (d.max(0).values > 1e-3).nonzero().flatten().tolist()
         line += f" bad_rows[{len(bad)}]={bad[:24]} bad_cols[{len(cols)}]={cols[:40]}"
     print(line, flush=True)
+# the CLA block (cla_tail_hs_kernel: 32- / 64-frame tiles; boundaries 8192 / 16384 rows)
+for n, T in ((1, 1), (2, 37), (1, 32), (1, 33), (3, 300), (1, 2000), (1, 8192), (1, 8193), (2, 8000), (1, 16384), (1, 16385)):
+    x = rnd(n, T, m.cfg.feat, seed=T + 1)
+    y = eng.cla(x.cuda(), eng.pk.enc_stages[0]["l"][0][0], n, T).cpu()
+    db = orc.agreement_db(y, orc.cla(sd, "separator.enc_stages.0.l_block_1.block.cla", x))
+    print(f"cla {n} {T} {db:.1f} {hashlib.sha256(y.numpy().tobytes()).hexdigest()[:16]}", flush=True)
+
+
 def flat(o):
     if torch.is_tensor(o):
         yield o
