@@ -41,6 +41,7 @@ DEFAULT_PRECISION = "bf16x3"
 # (device index, precision, weights key, id of the owning module) -> PackedModel; see Model._packed
 _PACK_CACHE: Dict[tuple, PackedModel] = {}
 _PACK_LOCK = threading.Lock()
+_OPTIMISTIC = os.environ.get("SEPR_OPTIMISTIC", "1") != "0"      # Model.forward: enqueue first, verify the weights identity behind it
 _UIDS = itertools.count(1)
 
 
@@ -353,8 +354,9 @@ class Model(torch.nn.Module):
         (reference engine.py:64,98,130,167 with several device ids) hit the copy packed by an earlier replica on the
         same device instead of re-packing ~750 tensors per call."""
         origin = self._origin[0]() if self._is_replica_module() else self
-        key = (dev.index if dev.index is not None else torch.cuda.current_device(), self.infer_precision,
-               (origin if origin is not None else self)._weights_key(), self._uid)
+        wkey = (origin if origin is not None else self)._weights_key()
+        self.__dict__["_last_wkey"] = (wkey, self.infer_precision)
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), self.infer_precision, wkey, self._uid)
         with _PACK_LOCK:
             pk = _PACK_CACHE.get(key)
             if pk is not None:
@@ -386,6 +388,7 @@ class Model(torch.nn.Module):
         if self._engine is None or self._engine.pk is not pk:
             with torch.cuda.device(dev):
                 self._engine = SeparatorEngine(self.cfg, pk, dev)
+        self.__dict__["_engine_wkey"] = self.__dict__.get("_last_wkey")      # the weights identity self._engine was packed from
         return self._engine
 
     # ---- forward -------------------------------------------------------------------------------------
@@ -397,14 +400,30 @@ class Model(torch.nn.Module):
             raise RuntimeError("input tensor is not on the HIP device (no CPU fallback exists)")
         if self.training:
             return self._forward_train(x)
+
+        def run(eng):
+            with torch.cuda.device(x.device):
+                if self.use_graphs:
+                    return eng.forward_graphed(x.to(torch.float32), with_aux=self.compute_aux)
+                if self.effective_pipelines(x.shape[0]) > 1:
+                    return eng.forward_split(x.to(torch.float32), with_aux=self.compute_aux, parts=self.effective_pipelines(x.shape[0]))
+                return eng.forward(x.to(torch.float32), with_aux=self.compute_aux)
+
+        # Single-utterance latency: checking the identity of 1390 weight tensors (_weights_key, ~0.3 ms) BEFORE the first launch is ~8 % of a
+        # batch-1 forward.  With an engine from an earlier call the forward is enqueued first, from its packed weights, and the identity is
+        # checked while the device works; the (rare) mismatch discards that result and takes the regular path below - nothing computed from
+        # stale weights is ever returned.  (SEPR_OPTIMISTIC=0 restores the check-first order.)
+        eng0 = self._engine
+        if (_OPTIMISTIC and eng0 is not None and not self._is_replica_module() and eng0.device == x.device
+                and self.__dict__.get("_engine_wkey") is not None):
+            out0 = run(eng0)
+            if (self._weights_key(), self.infer_precision) == self.__dict__.get("_engine_wkey"):
+                wav, aux = out0
+                T = x.shape[-1]
+                return [wav[s] for s in range(self.num_spks)], [[a[s][..., :T] for s in range(self.num_spks)] for a in aux]
+            del out0
         eng = self.engine(x.device if self._is_replica_module() else None)
-        with torch.cuda.device(x.device):
-            if self.use_graphs:
-                wav, aux = eng.forward_graphed(x.to(torch.float32), with_aux=self.compute_aux)
-            elif self.effective_pipelines(x.shape[0]) > 1:
-                wav, aux = eng.forward_split(x.to(torch.float32), with_aux=self.compute_aux, parts=self.effective_pipelines(x.shape[0]))
-            else:
-                wav, aux = eng.forward(x.to(torch.float32), with_aux=self.compute_aux)
+        wav, aux = run(eng)
         T = x.shape[-1]
         audio = [wav[s] for s in range(self.num_spks)]
         audio_aux = [[a[s][..., :T] for s in range(self.num_spks)] for a in aux]

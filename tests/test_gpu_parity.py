@@ -481,6 +481,36 @@ def test_gcfn_small_rows_forced_big_kernel():
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_forward_follows_weight_updates():
+    """Model.forward enqueues with the engine packed by an earlier call and checks the identity of the weights behind the launches
+    (model.py, single-utterance latency); a forward after ANY visible weight change must still return what the new weights give:
+    in-place update (version counter), re-assigned .data (storage address), load_state_dict, and - for writes through .data, which no
+    counter sees - after invalidate_packed()."""
+    def fresh_like(m):
+        f = Model.from_config(VARIANTS["tiny"], init_seed=0, precision="bf16x3").eval().to("cuda")
+        f.load_state_dict(m.state_dict())
+        return f
+
+    m = Model.from_config(VARIANTS["tiny"], init_seed=0, precision="bf16x3").load_synthetic_(0).eval().to("cuda")
+    x = torch.from_numpy(synth_sources(1, 4000, seed=3)).sum(1).cuda()
+    y0 = m(x)[0][0].clone()
+    assert m._engine is not None and torch.equal(m(x)[0][0], y0)          # second call: the enqueue-first path, same weights
+    p = next(t for n, t in m.named_parameters() if n.endswith("weight") and t.dim() >= 2)
+    with torch.no_grad():
+        p.mul_(1.25)                                                        # in-place: _version moves
+    y1 = m(x)[0][0].clone()
+    assert not torch.equal(y1, y0) and torch.equal(y1, fresh_like(m)(x)[0][0])
+    p.data = p.data * 0.5                                                   # re-assigned storage
+    y2 = m(x)[0][0].clone()
+    assert not torch.equal(y2, y1) and torch.equal(y2, fresh_like(m)(x)[0][0])
+    m.load_state_dict(fresh_like(m).state_dict())                           # copy_ into the same storages, same values
+    assert torch.equal(m(x)[0][0], y2)
+    p.data.mul_(2.0)                                                        # invisible to the counters ...
+    m.invalidate_packed()                                                   # ... hence the explicit switch
+    y3 = m(x)[0][0].clone()
+    assert not torch.equal(y3, y2) and torch.equal(y3, fresh_like(m)(x)[0][0])
+
+
 def test_gcfn_hidden_split_bitwise():
     """Launches with at most one tile per CU (batch 1) take gcfn_hs_kernel: the four waves of a workgroup split the hidden dimension instead of
     the frames.  Same packed weights, same products in the same order - the outputs must be BIT-identical to the row-stationary kernels
