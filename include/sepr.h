@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SEPR_VERSION 410 /* minor*100 + patch ("ABI 4.10").  Any struct-layout or context-size change bumps the MINOR number
+#define SEPR_VERSION 411 /* minor*100 + patch ("ABI 4.11").  Any struct-layout or context-size change bumps the MINOR number
                             (3.01 -> 3.03 grew sepr_ega_w under a patch bump: a caller built against 3.01 would have passed a short
                             struct).  A binding must compare sepr_version() with the SEPR_VERSION it was written against before its
                             first call: sepreformer_amd/lib.py refuses to load a library whose version differs. */
@@ -126,6 +126,12 @@ typedef struct {
                                [4 tiles][F/32][plane][64][8] bf16 (gamma folded) + 4 KB fp32 constants [4][16] biases */
   const void* pe_k_planes;  /* optional (bf16x3; pack.py, ABI 3.02): pe_k split ONCE into bf16 planes [2: hi, lo][2*maxlen][F/H] -
                                the attention kernel then stages its relative-position band without a per-tile VALU split */
+  const void* fused_qkv_p;  /* optional (bf16x3, F = 128; pack.py::pack_gate_fused on self_attn's in-projection, ABI 4.11): the [3F, F]
+                               q / k / v projection behind its LayerNorm in the gate's chunk form (6 chunks of 64 output channels) -
+                               pooling + LayerNorm + projection then run as ONE launch (sepr_cla_fused.hip launch_ega_qkv) */
+  const void* fused_out_p;  /* optional (bf16x3, F = 128, with fused_gate_p; pack.py::pack_outproj_fused, ABI 4.11): self_attn.linear_out as
+                               fragments [F/16][F/32][plane][64][8] bf16 - the gate launch then computes its tile's rows of
+                               LayerScale(linear_out(.)) itself and the separate output projection is gone */
 } sepr_ega_w;
 
 /* DownConvLayer, modules/module.py:63-78 (eval BN folded: y = gelu(conv_nobias * scale + shift)) */

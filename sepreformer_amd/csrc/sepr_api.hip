@@ -41,9 +41,17 @@ struct ClaFusedArgs {
   float eps;
   const float* att;
   int T, Tp, fac;
+  int ldy, pool;
+  const float* o;
+  float* att_w;
+  const void* wop;
+  const float* bo;
+  const float* lso;
+  int Mp;
 };
 size_t pit_workspace_bytes(int S, int B, int T);                                      // sepr_criterion.hip
 int launch_ega_gate(const ClaFusedArgs& a, int F, int site, hipStream_t stream);      // sepr_cla_fused.hip
+int launch_ega_qkv(const ClaFusedArgs& a, int F, int site, hipStream_t stream);       // sepr_cla_fused.hip
 int launch_cla_head(const ClaFusedArgs& a, int F, int site, hipStream_t stream);      // sepr_cla_fused.hip
 int launch_cla_tail(const ClaFusedArgs& a, int F, int site, hipStream_t stream);
 
@@ -246,13 +254,13 @@ static int cla_fwd_impl(const float* x, const float* x_stats, float* y, float* y
     ClaFusedArgs h;
     h.x = x; h.res = nullptr; h.y = u; h.M = (int)M;
     h.w1p = w->fused_w1p; h.w2p = nullptr; h.b3 = nullptr; h.ls = nullptr; h.eps = LN_EPS;
-    h.att = nullptr; h.T = 0; h.Tp = 0; h.fac = 0;
+    h.att = nullptr; h.T = 0; h.Tp = 0; h.fac = 0; h.ldy = 0; h.pool = 0; h.o = nullptr; h.att_w = nullptr; h.wop = nullptr; h.bo = nullptr; h.lso = nullptr; h.Mp = 0;
     SEPR_TRY(launch_cla_head(h, F, SEPR_SITE_CLA, st));
     SEPR_TRY(launch_dwconv_same(u, c, n, T, F, K, w->dw_w, w->dw_b, st));
     ClaFusedArgs t;
     t.x = c; t.res = x; t.y = y; t.M = (int)M;
     t.w1p = w->fused_w2p; t.w2p = w->fused_w3p; t.b3 = w->b3; t.ls = w->ls; t.eps = 0.f;
-    t.att = nullptr; t.T = 0; t.Tp = 0; t.fac = 0;
+    t.att = nullptr; t.T = 0; t.Tp = 0; t.fac = 0; t.ldy = 0; t.pool = 0; t.o = nullptr; t.att_w = nullptr; t.wop = nullptr; t.bo = nullptr; t.lso = nullptr; t.Mp = 0;
     SEPR_TRY(launch_cla_tail(t, F, SEPR_SITE_CLA, st));
     return y_stats ? launch_rowstats(y, y_stats, M, F, LN_EPS, st) : SEPR_OK;
   }
@@ -316,6 +324,15 @@ static int ega_fwd_impl(const float* x, const float* x_stats, float* y, float* y
   if (!ar.ok()) return SEPR_EWORKSPACE;
   const float* xpool = x;
   const float* stats_p = stats_pws;
+  const bool qkv_fused = w->fused_qkv_p && F == 128 && !x_stats;
+  if (qkv_fused) {
+    // ONE launch: adaptive_avg_pool1d, LayerNorm, q / k / v (network.py:146, :99-102) - no pooled copy of x, no statistics pass
+    ClaFusedArgs q;
+    q.x = x; q.res = nullptr; q.y = qkv; q.M = (int)Mp;
+    q.w1p = w->fused_qkv_p; q.w2p = nullptr; q.b3 = nullptr; q.ls = nullptr; q.eps = LN_EPS;
+    q.att = nullptr; q.T = 0; q.Tp = 0; q.fac = 0; q.ldy = 3 * F; q.pool = fac; q.o = nullptr; q.att_w = nullptr; q.wop = nullptr; q.bo = nullptr; q.lso = nullptr; q.Mp = 0;
+    SEPR_TRY(launch_ega_qkv(q, F, SEPR_SITE_ATTN_PROJ, st));
+  } else
   if (fac > 1) {  // adaptive_avg_pool1d + the LayerNorm statistics of the pooled rows  (network.py:146, :99)
     SEPR_TRY(launch_pool_stats(x, xd, stats_pws, n, Tp, fac, F, LN_EPS, st));
     xpool = xd;
@@ -324,7 +341,7 @@ static int ega_fwd_impl(const float* x, const float* x_stats, float* y, float* y
   } else {
     SEPR_TRY(launch_rowstats(xpool, stats_pws, Mp, F, LN_EPS, st));
   }
-  {  // MHA: LayerNorm -> q,k,v                                             (network.py:99-102)
+  if (!qkv_fused) {  // MHA: LayerNorm -> q,k,v                              (network.py:99-102)
     GemmArgs a = gemm_args_zero();
     a.M = (int)Mp; a.N = 3 * F; a.K = F;
     a.A = xpool; a.lda = F; a.stats = stats_p; a.gamma = w->attn.ln_g; a.beta = w->attn.ln_b;
@@ -332,7 +349,8 @@ static int ega_fwd_impl(const float* x, const float* x_stats, float* y, float* y
     SEPR_TRY(project(PRO_NORM, EPI_STORE, a, w->attn.x3_qkv, SEPR_SITE_ATTN_PROJ, st));
   }
   SEPR_TRY(launch_relattn(qkv, o, n, Tp, F, H, w->pe_k, w->maxlen, relattn_x3(w), st, w->pe_k_planes));   // (network.py:106-122)
-  {  // linear_out * LayerScale (no residual inside MHA)                    (network.py:124)
+  const bool out_fused = w->fused_gate_p && w->fused_out_p && F == 128 && 64 % fac == 0;
+  if (!out_fused) {  // linear_out * LayerScale (no residual inside MHA)      (network.py:124)
     GemmArgs a = gemm_args_zero();
     a.M = (int)Mp; a.N = F; a.K = F;
     a.A = o; a.lda = F; a.W = w->attn.wo; a.bias = w->attn.bo;
@@ -343,7 +361,11 @@ static int ega_fwd_impl(const float* x, const float* x_stats, float* y, float* y
     ClaFusedArgs g;
     g.x = x; g.res = x; g.y = y; g.M = (int)M;
     g.w1p = w->fused_gate_p; g.w2p = nullptr; g.b3 = nullptr; g.ls = nullptr; g.eps = LN_EPS;
-    g.att = att; g.T = T; g.Tp = Tp; g.fac = fac;
+    g.att = att; g.T = T; g.Tp = Tp; g.fac = fac; g.ldy = 0; g.pool = 0;
+    g.o = nullptr; g.att_w = nullptr; g.wop = nullptr; g.bo = nullptr; g.lso = nullptr; g.Mp = 0;
+    if (out_fused) {   // linear_out + LayerScale of the attention inside the gate launch (the tile's own pooled rows)
+      g.o = o; g.att_w = att; g.wop = w->fused_out_p; g.bo = w->attn.bo; g.lso = w->attn.ls; g.Mp = (int)Mp;
+    }
     SEPR_TRY(launch_ega_gate(g, F, SEPR_SITE_EGA_GATE, st));
     return y_stats ? launch_rowstats(y, y_stats, M, F, LN_EPS, st) : SEPR_OK;
   }

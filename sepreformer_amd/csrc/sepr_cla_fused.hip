@@ -36,6 +36,16 @@ struct ClaFusedArgs {
   float eps;
   const float* att;   // gate: pooled attention output [n, Tp, F]
   int T, Tp, fac;     // gate: frames per sequence, pooled frames, T / Tp
+  int ldy, pool;      // q / k / v form (launch_ega_qkv): output row stride (3F) and the pooling factor of the input rows (row m = mean of rows
+                      // m*pool .. m*pool + pool-1 of x, adaptive_avg_pool1d with T % Tp == 0); 0 elsewhere
+  // gate with the attention's output projection folded in (o != null): att rows of a tile = ls_o * (Linear_out(o rows) + b_o) are computed by
+  // the tile's workgroup into att_w (= att) before its epilogue reads them - the separate projection launch is gone
+  const float* o;     // attention output before linear_out [Mp, F]
+  float* att_w;       // = att, writable
+  const void* wop;    // linear_out weights as fragments [F/16][F/32][plane][64][8] bf16 (pack.py::pack_outproj_fused)
+  const float* bo;    // [F]
+  const float* lso;   // [F] the attention's LayerScale
+  int Mp;             // pooled rows
 };
 
 namespace {
@@ -98,6 +108,87 @@ __device__ __forceinline__ void load_frames(const float* __restrict__ X, int m0,
   }
 }
 
+// the q / k / v form's frames: row m = mean of `pool` consecutive rows of X (summed in row order, then * 1/pool, like pool_stats_kernel), LayerNorm
+template <int F, int MT>
+__device__ __forceinline__ void load_frames_pooled(const float* __restrict__ X, int m0, int M, int pool, float eps, int fi, int fg,
+                                                   bf16x8 (&xh)[MT][F / 32], bf16x8 (&xl)[MT][F / 32]) {
+  constexpr int KS = F / 32;
+  const float inv = 1.0f / (float)pool;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + MT * fi + mt;
+    const bool valid = m < M;
+    const float* xp = X + (long long)(valid ? m : 0) * pool * F + 8 * fg;
+    float v[KS][8];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 p = ld4(xp + 32 * ks), q = ld4(xp + 32 * ks + 4);
+      v[ks][0] = p.x; v[ks][1] = p.y; v[ks][2] = p.z; v[ks][3] = p.w;
+      v[ks][4] = q.x; v[ks][5] = q.y; v[ks][6] = q.z; v[ks][7] = q.w;
+    }
+    // RB rows requested together (clamped addresses past the last one), added in row order: the sum does not depend on RB
+    constexpr int RB = MT == 1 ? 4 : 2;
+    for (int j0 = 1; j0 < pool; j0 += RB) {
+      float4 pq[RB][KS][2];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const float* xq = xp + (long long)(j0 + i < pool ? j0 + i : 0) * F;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          pq[i][ks][0] = ld4(xq + 32 * ks);
+          pq[i][ks][1] = ld4(xq + 32 * ks + 4);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        if (j0 + i < pool) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const float4 p = pq[i][ks][0], q = pq[i][ks][1];
+            v[ks][0] += p.x; v[ks][1] += p.y; v[ks][2] += p.z; v[ks][3] += p.w;
+            v[ks][4] += q.x; v[ks][5] += q.y; v[ks][6] += q.z; v[ks][7] += q.w;
+          }
+        }
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[ks][e] *= inv;
+        s += v[ks][e];
+      }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / F);
+    float d = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float c = v[ks][e] - mean;
+        d = fmaf(c, c, d);
+      }
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    const float rstd = 1.0f / sqrtf(d * (1.0f / F) + eps);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 h, l;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xn = (v[ks][e] - mean) * rstd;
+        const __bf16 hh = (__bf16)xn;
+        h[e] = hh;
+        l[e] = (__bf16)(xn - (float)hh);
+      }
+      xh[mt][ks] = h;
+      xl[mt][ks] = l;
+    }
+  }
+}
+
 #ifndef SEPR_CF_ASMDMA
 #define SEPR_CF_ASMDMA 1   // inline-asm LDS-DMA (sepr_common.h glds16_asm): the copies are waited for at the chunk barriers only
 #endif
@@ -129,7 +220,7 @@ __device__ __forceinline__ void dma_barrier() {
 constexpr int ST_PLAIN = 0, ST_RES = 1, ST_GATE = 2;
 template <int F, int MODE, int MT = CF_MT>
 __device__ __forceinline__ void store_tile(const f32x4 (&acc)[F / 16][MT], float* Os, const ClaFusedArgs& a, int tile0,
-                                           int tid, int w, int fi, int fg) {
+                                           int tid, int w, int fi, int fg, int ldy = F, int col = 0) {
   constexpr int FT = F / 16, OS = F + 4;
   constexpr int EH = (16 * MT * CF_NW) / 64, WPP = 64 / (16 * MT);
   constexpr int Q = F / 4, RPP = CF_NT / Q, NP = 64 / RPP;
@@ -174,7 +265,7 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[F / 16][MT], float
       for (int p = 0; p < NP; ++p) {
         if (mrow[p] >= 0) {
           const float4 o = ld4(Os + (rr + p * RPP) * OS + 4 * q4);
-          float* dst = a.y + (long long)mrow[p] * F + 4 * q4;
+          float* dst = a.y + (long long)mrow[p] * ldy + col + 4 * q4;
           if (MODE == ST_RES) {
             st4(dst, make_float4(fmaf(o.x + bb.x, lsv.x, xr[p].x), fmaf(o.y + bb.y, lsv.y, xr[p].y),
                                  fmaf(o.z + bb.z, lsv.z, xr[p].z), fmaf(o.w + bb.w, lsv.w, xr[p].w)));
@@ -201,8 +292,13 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[F / 16][MT], float
 // F = 256 (Large, round 6): 128 registers of frame planes + 128 of output tile - the ONE-wave-per-SIMD regime (one 139 KB workgroup per CU)
 // MT = 1 (round 6): 16-frame waves, 64-frame tiles - for launches with fewer 128-frame tiles than half the CUs (batch 1: Engine._inference_sample): twice
 // the workgroups, half the dependent chain per workgroup; a frame's arithmetic does not depend on the tiling (bit-identical)
-template <int F, bool GATE, int MT = CF_MT>
+// QKV (round 6; with GATE's plain-tile chunks): the EGA attention's input side in ONE launch - adaptive average pooling of the frames,
+// LayerNorm, q / k / v projection (network.py:146, :99-102): three output groups of F channels, each the gate's chunk walk, stored to the
+// [rows, 3F] tensor the attention kernel reads.  Replaces pool_stats_kernel + the generic projection (and the pooled copy of x).
+template <int F, bool GATE, int MT = CF_MT, bool QKV = false>
 __global__ __launch_bounds__(CF_NT, F > 128 ? 1 : 2) void cla_head_kernel(const ClaFusedArgs a) {
+  static_assert(!QKV || GATE, "the q / k / v form uses the plain-tile chunks");
+  constexpr int NG = QKV ? 3 : 1;
   constexpr int NW = CF_NW, NT = CF_NT;
   constexpr int TILE = 16 * MT * NW;
   constexpr int KS = F / 32;
@@ -224,16 +320,84 @@ __global__ __launch_bounds__(CF_NT, F > 128 ? 1 : 2) void cla_head_kernel(const 
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     bf16x8 xh[MT][KS], xl[MT][KS];
-    load_frames<F, true, MT>(a.x, tile * TILE + w * 16 * MT, a.M, a.eps, fi, fg, xh, xl);
+    if constexpr (QKV) load_frames_pooled<F, MT>(a.x, tile * TILE + w * 16 * MT, a.M, a.pool, a.eps, fi, fg, xh, xl);
+    else load_frames<F, true, MT>(a.x, tile * TILE + w * 16 * MT, a.M, a.eps, fi, fg, xh, xl);
+    if constexpr (GATE && !QKV) {
+      if (a.o) {
+        // ---- folded output projection of the attention: this tile's pooled rows p0 .. p0 + R-1 (fac | TILE: they belong to no other tile).
+        //      Wave w owns output tiles 2w, 2w+1; rows as B fragments straight from o, weights global -> registers (one reader per fragment).
+        constexpr int FTW = FT / NW;
+        static_assert(FTW * NW == FT, "output tiles over the waves");
+        const int R = TILE / a.fac, p0 = (tile * TILE) / a.fac;
+        const int ws = __builtin_amdgcn_readfirstlane(w);
+        const unsigned loff = (unsigned)lane * 16u;
+        const uint4* const Wob = static_cast<const uint4*>(a.wop) + (long long)(FTW * ws) * KS * 2 * 64;
+        uint4 wo[FTW][KS][2];
+#pragma unroll
+        for (int t = 0; t < FTW; ++t)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+              wo[t][ks][pl] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Wob + ((t * KS + ks) * 2 + pl) * 64) + loff);
+        float4 bov[FTW], lov[FTW];
+#pragma unroll
+        for (int t = 0; t < FTW; ++t) {
+          bov[t] = ld4(a.bo + 16 * (FTW * w + t) + 4 * fg);
+          lov[t] = ld4(a.lso + 16 * (FTW * w + t) + 4 * fg);
+        }
+        for (int nt = 0; nt * 16 < R; ++nt) {
+          const int pr = p0 + 16 * nt + fi;
+          const bool ok = 16 * nt + fi < R && pr < a.Mp;
+          const float* op = a.o + (long long)(ok ? pr : 0) * F + 8 * fg;
+          bf16x8 oh[KS], ol[KS];
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const float4 p = ld4(op + 32 * ks), q = ld4(op + 32 * ks + 4);
+            const float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const __bf16 hh = (__bf16)v[e];
+              oh[ks][e] = hh;
+              ol[ks][e] = (__bf16)(v[e] - (float)hh);
+            }
+          }
+          f32x4 pa[FTW];
+#pragma unroll
+          for (int t = 0; t < FTW; ++t) pa[t] = (f32x4){bov[t].x, bov[t].y, bov[t].z, bov[t].w};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < FTW; ++t) {
+              const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&wo[t][ks][0]), wlo = *reinterpret_cast<const bf16x8*>(&wo[t][ks][1]);
+              pa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, oh[ks], pa[t], 0, 0, 0);
+              pa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ol[ks], pa[t], 0, 0, 0);
+              pa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, oh[ks], pa[t], 0, 0, 0);
+            }
+          if (ok) {
+#pragma unroll
+            for (int t = 0; t < FTW; ++t)
+              st4(a.att_w + (long long)pr * F + 16 * (FTW * w + t) + 4 * fg,
+                  make_float4(pa[t][0] * lov[t].x, pa[t][1] * lov[t].y, pa[t][2] * lov[t].z, pa[t][3] * lov[t].w));
+          }
+        }
+        // (the stores reach the other waves of the workgroup through the __syncthreads() of the chunk walk below: the epilogue reads them after it)
+      }
+    }
+    // (small launches: the three output groups are three workgroups - grid.y = 3 - each with its own copy of the frames)
+    const int g0 = gridDim.y > 1 ? (int)blockIdx.y : 0, g1 = gridDim.y > 1 ? g0 + 1 : NG;
+#pragma unroll 1
+    for (int grp = g0; grp < g1; ++grp) {
+    const uint4* const Wg = W1g + (long long)grp * NCH * W1_U4;
     f32x4 acc[FT][MT];                   // gated values: channel tile ft = 2*c + j
 
-    __syncthreads();   // the previous tile's epilogue staging is fully consumed
-    dma_blocks(W1g, wl, W1_U4 / NT, lane, w);
+    __syncthreads();   // the previous tile's (group's) epilogue staging is fully consumed
+    dma_blocks(Wg, wl, W1_U4 / NT, lane, w);
     dma_barrier();
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const uint4* const w1s = wl + (c & 1) * W1_U4;
-      if (c + 1 < NCH) dma_blocks(W1g + (long long)(c + 1) * W1_U4, wl + ((c + 1) & 1) * W1_U4, W1_U4 / NT, lane, w);
+      if (c + 1 < NCH) dma_blocks(Wg + (long long)(c + 1) * W1_U4, wl + ((c + 1) & 1) * W1_U4, W1_U4 / NT, lane, w);
       auto ld_up = [&](int j, int g, uint4 (&d)[2]) {   // g = 2*ks + (0 value tile | 1 gate tile)
         const uint4* p = w1s + ((((g & 1) * 2 + j) * KS + (g >> 1)) * 2) * 64 + lane;
         d[0] = p[0];
@@ -297,7 +461,8 @@ __global__ __launch_bounds__(CF_NT, F > 128 ? 1 : 2) void cla_head_kernel(const 
       }
       dma_barrier();   // chunk c fully read by every wave, chunk c+1 landed
     }
-    store_tile<F, GATE ? ST_GATE : ST_PLAIN, MT>(acc, reinterpret_cast<float*>(wl), a, tile * TILE, tid, w, fi, fg);
+    store_tile<F, (GATE && !QKV) ? ST_GATE : ST_PLAIN, MT>(acc, reinterpret_cast<float*>(wl), a, tile * TILE, tid, w, fi, fg, QKV ? a.ldy : F, grp * F);
+    }
   }
 }
 
@@ -636,6 +801,7 @@ int launch_ega_gate(const ClaFusedArgs& a, int F, int site, hipStream_t stream) 
   if (a.M <= 0) return SEPR_OK;
   if (!a.x || !a.res || !a.att || !a.y || !a.w1p || a.x == a.y || (F != 128 && F != 256) || a.T <= 0 || a.Tp <= 0 || a.fac <= 0)
     return SEPR_EINVAL;
+  if (a.o && (!a.att_w || a.att_w != a.att || !a.wop || !a.bo || !a.lso || a.Mp <= 0 || F != 128 || 64 % a.fac != 0)) return SEPR_EINVAL;
   long long slot = -1;
   const bool timed = prof_begin(site, stream, &slot);
   const int ntiles = (a.M + 127) / 128;
@@ -645,6 +811,22 @@ int launch_ega_gate(const ClaFusedArgs& a, int F, int site, hipStream_t stream) 
   else hipLaunchKernelGGL((cla_head_kernel<128, true>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
   if (timed) prof_end(slot, (double)a.M * 2.0 * F * F, stream);
   SEPR_CHECK_LAUNCH("ega_gate_kernel");
+  return SEPR_OK;
+}
+
+// pooling + LayerNorm + q / k / v projection of the EGA attention: a.x = block input [M * pool, F], a.y = qkv [M, 3F] (a.ldy = 3F), a.M = pooled rows
+int launch_ega_qkv(const ClaFusedArgs& a, int F, int site, hipStream_t stream) {
+  if (a.M <= 0) return SEPR_OK;
+  if (!a.x || !a.y || !a.w1p || a.x == a.y || F != 128 || a.pool <= 0 || a.ldy < 3 * F) return SEPR_EINVAL;
+  long long slot = -1;
+  const bool timed = prof_begin(site, stream, &slot);
+  const int ntiles = (a.M + 127) / 128;
+  const int cap = persistent_grid();
+  if (small_launch(3 * a.M, cap)) hipLaunchKernelGGL((cla_head_kernel<128, true, 1, true>), dim3((a.M + 63) / 64, 3), dim3(CF_NT), 0, stream, a);
+  else if (small_launch(a.M, cap)) hipLaunchKernelGGL((cla_head_kernel<128, true, 1, true>), dim3((a.M + 63) / 64), dim3(CF_NT), 0, stream, a);
+  else hipLaunchKernelGGL((cla_head_kernel<128, true, CF_MT, true>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
+  if (timed) prof_end(slot, (double)a.M * 2.0 * F * 3 * F, stream);
+  SEPR_CHECK_LAUNCH("ega_qkv_kernel");
   return SEPR_OK;
 }
 

@@ -48,7 +48,7 @@ MhaW = _struct("MhaW", ["ln_g", "ln_b", "wqkv", "bqkv", "wo", "bo", "ls"], ["x3_
 
 class EgaW(C.Structure):
     _fields_ = [("attn", MhaW), ("gate_ln_g", _fp), ("gate_ln_b", _fp), ("gate_w", _fp), ("gate_b", _fp),
-                ("pe_k", _fp), ("maxlen", C.c_int), ("x3_gate", X3W), ("fused_gate_p", _fp), ("pe_k_planes", _fp)]
+                ("pe_k", _fp), ("maxlen", C.c_int), ("x3_gate", X3W), ("fused_gate_p", _fp), ("pe_k_planes", _fp), ("fused_qkv_p", _fp), ("fused_out_p", _fp)]
 
 
 DownW = _struct("DownW", ["w", "scale", "shift"])
@@ -196,7 +196,7 @@ _lib: Optional[C.CDLL] = None
 _lock = threading.Lock()
 
 
-ABI_VERSION = 410          # include/sepr.h SEPR_VERSION this binding mirrors (tests/test_boundary_cpu.py keeps the two equal)
+ABI_VERSION = 411          # include/sepr.h SEPR_VERSION this binding mirrors (tests/test_boundary_cpu.py keeps the two equal)
 
 
 class SeprLibraryError(RuntimeError):

@@ -133,6 +133,22 @@ class Packed:
         self.keep.append(wp)
         return {"fused_gate_p": wp.data_ptr()}
 
+    def qkv_fused(self, sd, p: str) -> dict:
+        """EGA attention in-projection ``[3F, F]`` behind its LayerNorm in the gate's chunk form (bf16x3, F = 128): pooling + LayerNorm +
+        q / k / v in one launch (``launch_ega_qkv``).  ``SEPR_FUSE_QKV=0`` keeps pool_stats + the generic projection."""
+        F = sd[p + ".layer_norm.weight"].shape[0]
+        if self.precision != "bf16x3" or F != 128 or not self.fuse_gate or os.environ.get("SEPR_FUSE_QKV", "1") == "0":
+            return {}
+        wqkv = torch.cat([sd[f"{p}.linear_{n}.weight"] for n in "qkv"], dim=0)
+        bqkv = torch.cat([sd[f"{p}.linear_{n}.bias"] for n in "qkv"], dim=0)
+        wp = pack_gate_fused(wqkv, bqkv, sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"])
+        wo = _split_frag(sd[p + ".linear_out.weight"].detach().float()).contiguous()     # [F/16][F/32][2][64][8] bf16: the gate launch's folded
+        self.keep += [wp, wo]                                                              # output projection (SEPR_FUSE_OUT=0: separate launch)
+        out = {"fused_qkv_p": wp.data_ptr()}
+        if os.environ.get("SEPR_FUSE_OUT", "1") != "0":
+            out["fused_out_p"] = wo.data_ptr()
+        return out
+
     def spk_fused(self, sd, p: str, heads: int, num_spks: int) -> dict:
         """Fused speaker-attention weight forms (bf16x3, F = 128, 16-channel heads, two speakers); else empty."""
         F = sd[p + ".layer_norm.weight"].shape[0]
@@ -334,10 +350,9 @@ def _chunk_frags(wm: torch.Tensor, bm: torch.Tensor, bases) -> torch.Tensor:
 def pack_gate_fused(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
     """EGA gate projection ``[F,F]`` behind a LayerNorm for the fused gate kernel: per 64 output channels four
     16-row tiles (gamma folded into the weights, beta into the bias)."""
-    F = w.shape[1]
     wf = (w.detach().double() * gamma.detach().double()[None, :]).float()
     bf = (b.detach().double() + w.detach().double() @ beta.detach().double()).float()
-    return torch.stack([_chunk_frags(wf, bf, [64 * c + 16 * j for j in range(4)]) for c in range(F // 64)], 0).contiguous()
+    return torch.stack([_chunk_frags(wf, bf, [64 * c + 16 * j for j in range(4)]) for c in range(w.shape[0] // 64)], 0).contiguous()
 
 
 def pack_cla_fused(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w2: torch.Tensor,
@@ -445,7 +460,7 @@ def pack_ega(pk: Packed, sd, p: str, pe_ptr: int, maxlen: int, pe_planes_ptr: in
         pe_k=pe_ptr, maxlen=maxlen, pe_k_planes=pe_planes_ptr,
         x3_gate=pk.x3(sd[p + ".block.linear.1.weight"], sd[p + ".block.linear.1.bias"],
                       sd[p + ".block.linear.0.weight"], sd[p + ".block.linear.0.bias"]),
-        **pk.gate_fused(sd, p))
+        **pk.gate_fused(sd, p), **pk.qkv_fused(sd, p + ".block.self_attn"))
 
 
 def pack_down(pk: Packed, sd, p: str) -> L.DownW:

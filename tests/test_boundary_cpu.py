@@ -173,7 +173,7 @@ def test_struct_layouts_match_header():
         assert fields == [f for f, _ in cls._fields_], cname
         n_x3 = len(re.findall(r"sepr_x3_w\s+\w+;", body))
         assert ctypes.sizeof(cls) == 8 * (len(fields) - n_x3) + 16 * n_x3
-    assert [f for f, _ in L.EgaW._fields_] == ["attn", "gate_ln_g", "gate_ln_b", "gate_w", "gate_b", "pe_k", "maxlen", "x3_gate", "fused_gate_p", "pe_k_planes"]
+    assert [f for f, _ in L.EgaW._fields_] == ["attn", "gate_ln_g", "gate_ln_b", "gate_w", "gate_b", "pe_k", "maxlen", "x3_gate", "fused_gate_p", "pe_k_planes", "fused_qkv_p", "fused_out_p"]
 
 
 def test_pack_glumlp_fused_layout():

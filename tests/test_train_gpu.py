@@ -1371,13 +1371,13 @@ def test_train_step_base_4s_gradients_match_oracle(B, bar):
     soft.done()
 
 
-def test_train_step_base_0p5s_batch16_gradients_match_oracle():
-    """The bench's batch regime (round 6): a batch of SIXTEEN at Base width (0.5 s utterances, so the oracle stays cheap) - 16 sequences in
-    every BatchNorm statistic and weight-gradient contraction - with every gradient tensor against the oracle at the 80 dB bar of the
-    batch-1 / batch-4 tests (auxiliary ReLU gates frozen to the device's)."""
-    B, T = 16, 4000
+def test_train_step_base_0p25s_batch16_gradients_match_oracle():
+    """The bench's batch regime (round 6): a batch of SIXTEEN at Base width (0.25 s utterances, so the oracle stays cheap: the suite-time
+    budget; 0.5 s measured the same bars) - 16 sequences in every BatchNorm statistic and weight-gradient contraction - with every
+    gradient tensor against the oracle at the 80 dB bar of the batch-1 / batch-4 tests (auxiliary ReLU gates frozen to the device's)."""
+    B, T = 16, 2000
     cfg, m, audio, aux, loss, sdl, o_audio, o_aux, o_loss = _frozen_gate_step("bf16x3", B, T, seed=43)
-    soft = Soft("train_step.base_0p5s.bf16x3.full_frozen_gates.b16")
+    soft = Soft("train_step.base_0p25s.bf16x3.full_frozen_gates.b16")
     soft.agree("main", torch.stack(list(audio), 0), torch.stack([a.detach() for a in o_audio], 0))
     assert abs(float(loss) - float(o_loss)) < 5e-3, (float(loss), float(o_loss))
     gscale = max(float(v.grad.abs().max()) for v in sdl.values() if v.requires_grad and v.grad is not None)
