@@ -32,7 +32,7 @@ for e in ev[1:]:
         groups.append(cur); cur = []
     cur.append(e)
 groups.append(cur)
-groups = [g for g in groups if 250 < len(g) < 400][-8:]
+groups = [g for g in groups if 150 < len(g) < 400][-8:]
 def short(n): return n.replace("sepr::", "").replace("void ", "").replace("(anonymous namespace)::", "")[:44]
 for gi, g in enumerate(groups):
     t0, t1 = g[0][0], max(e[1] for e in g)
