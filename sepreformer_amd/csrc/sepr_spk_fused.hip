@@ -373,6 +373,241 @@ __global__ __launch_bounds__(64 * NW, F > 128 ? 1 : (2 * NW) / 4) void spk_fused
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// spk_hs_kernel (round 6): the HIDDEN-SPLIT form for launches of at most one tile per CU (batch 1) - the design of gcfn_hs_kernel
+// (sepr_gcfn_fused.hip).  The four waves hold the SAME 16*FMT frames of both speakers; wave w owns head pair w (q, k, v of its two heads,
+// the 2x2 speaker attention, the mix), then output tiles 2w, 2w+1 over the four K steps.  Weight fragments have one reader each and go
+// global -> registers; the mixed planes cross the waves once through LDS in the B-fragment lane layout they already have; ONE barrier.
+// Same packed weights, same products in the same order per accumulator as spk_fused_kernel<128, 4>: bit-identical.  F = 128, 16-channel heads.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int FMT>
+__global__ __launch_bounds__(256, 1) void spk_hs_kernel(const SpkFusedArgs a) {
+  constexpr int F = 128, KS = F / 32, NW = 4, NCH = F / 32, FT = F / 16, FTW = FT / NW, S = 2, MT = S * FMT;
+  constexpr int W1F_U4 = 6 * KS * 2 * 64, CS_U4 = 256, W1_U4 = W1F_U4 + CS_U4, W2_U4 = FT * 2 * 64;
+  constexpr int TILE = 16 * FMT;
+  static_assert(NCH == NW && FTW == 2, "one head pair and two output tiles per wave");
+  __shared__ __attribute__((aligned(16))) uint4 hs[NCH * 2 * MT * 64];   // mixed tensor: [K step = head pair][plane][speaker x frame tile][lane]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+  const unsigned loff = (unsigned)lane * 16u;
+  const uint4* const W1g = static_cast<const uint4*>(a.w1p) + (long long)ws * W1_U4;
+  const uint4* const W2g = static_cast<const uint4*>(a.w2p);
+  auto ldu = [&](const uint4* base, int blk) -> uint4 {   // 16 bytes of this lane from the 1 KiB block blk behind the wave-uniform base
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base + blk * 64) + loff);
+  };
+  const int f0 = blockIdx.x * TILE;
+  // rows of this lane: index m2 = 2 * frame tile + speaker
+  long long mrow[MT];
+  bool okf[FMT];
+#pragma unroll
+  for (int q = 0; q < FMT; ++q) {
+    const int f = f0 + 16 * q + fi;
+    okf[q] = f < a.NF;
+    const int b = okf[q] ? f / a.T : 0, t = okf[q] ? f - b * a.T : 0;
+#pragma unroll
+    for (int sp = 0; sp < S; ++sp) mrow[2 * q + sp] = (long long)(b * S + sp) * a.T + t;
+  }
+  // request order = arrival order: biases, frames, the head pair's fragments
+  float4 bias[3][2];
+  {
+    const float* csg = reinterpret_cast<const float*>(W1g + W1F_U4) + 4 * fg;
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) bias[tt][hh] = ld4(csg + (tt * 2 + hh) * 16);
+  }
+  float xv[MT][KS][8];
+#pragma unroll
+  for (int m2 = 0; m2 < MT; ++m2) {
+    const float* xp = a.x + mrow[m2] * F + 8 * fg;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 p = ld4(xp + 32 * ks), q = ld4(xp + 32 * ks + 4);
+      xv[m2][ks][0] = p.x; xv[m2][ks][1] = p.y; xv[m2][ks][2] = p.z; xv[m2][ks][3] = p.w;
+      xv[m2][ks][4] = q.x; xv[m2][ks][5] = q.y; xv[m2][ks][6] = q.z; xv[m2][ks][7] = q.w;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  uint4 wr[2][3 * KS * 2];     // head hh of the pair: [K step][q | k | v][plane]; wr[0] later takes this wave's W_out fragments [K step][tile][plane]
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wr[hh][(ks * 3 + tt) * 2 + pl] = ldu(W1g, ((tt * 2 + hh) * KS + ks) * 2 + pl);
+  __builtin_amdgcn_sched_barrier(0);
+  bf16x8 xh[MT][KS], xl[MT][KS];
+#pragma unroll
+  for (int m2 = 0; m2 < MT; ++m2) {
+    float (&v)[KS][8] = xv[m2];
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[ks][e];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / F);
+    float d = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float c = v[ks][e] - mean;
+        d = fmaf(c, c, d);
+      }
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    const float rstd = 1.0f / sqrtf(d * (1.0f / F) + a.eps);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 h, l;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xn = (v[ks][e] - mean) * rstd;
+        const __bf16 hh = (__bf16)xn;
+        h[e] = hh;
+        l[e] = (__bf16)(xn - (float)hh);
+      }
+      xh[m2][ks] = h;
+      xl[m2][ks] = l;
+    }
+  }
+
+  // ---- phase 1: this wave's head pair ---------------------------------------------------------------------------------------------
+  bf16x8 gh[MT], gw[MT];          // mixed values (bf16 hi / lo) in output-projection k-slot order
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    f32x4 pq[3][MT];
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+      for (int m2 = 0; m2 < MT; ++m2) pq[tt][m2] = (f32x4){bias[tt][hh].x, bias[tt][hh].y, bias[tt][hh].z, bias[tt][hh].w};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 wh[3], wlo[3];
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {
+        wh[tt] = *reinterpret_cast<const bf16x8*>(&wr[hh][(ks * 3 + tt) * 2]);
+        wlo[tt] = *reinterpret_cast<const bf16x8*>(&wr[hh][(ks * 3 + tt) * 2 + 1]);
+      }
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+        for (int m2 = 0; m2 < MT; ++m2) pq[tt][m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[tt], xh[m2][ks], pq[tt][m2], 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+        for (int m2 = 0; m2 < MT; ++m2) pq[tt][m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[tt], xl[m2][ks], pq[tt][m2], 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+        for (int m2 = 0; m2 < MT; ++m2) pq[tt][m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[tt], xh[m2][ks], pq[tt][m2], 0, 0, 0);
+    }
+    if (hh == 0) {   // head 0's fragment registers are free: this wave's W_out fragments (4 K steps x 2 tiles x 2 planes) fly under head 1
+      // (scheduling fences: hipcc otherwise sinks the loads down to their first use - and waits for each of them there)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int t = 0; t < FTW; ++t)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) wr[0][(c * FTW + t) * 2 + pl] = ldu(W2g + (long long)c * W2_U4, (FTW * ws + t) * 2 + pl);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- 2x2 attention across the speakers of each frame (network.py:106-122 with T = S) ----------------------------------------
+#pragma unroll
+    for (int q = 0; q < FMT; ++q) {
+      float sc[S][S];
+#pragma unroll
+      for (int qa = 0; qa < S; ++qa)
+#pragma unroll
+        for (int kc = 0; kc < S; ++kc) {
+          float p = pq[0][2 * q + qa][0] * pq[1][2 * q + kc][0];
+          p = fmaf(pq[0][2 * q + qa][1], pq[1][2 * q + kc][1], p);
+          p = fmaf(pq[0][2 * q + qa][2], pq[1][2 * q + kc][2], p);
+          p = fmaf(pq[0][2 * q + qa][3], pq[1][2 * q + kc][3], p);
+          p += __shfl_xor(p, 16, 64);          // the tile's 16 channels live in the 4 lane groups
+          p += __shfl_xor(p, 32, 64);
+          sc[qa][kc] = p;
+        }
+#pragma unroll
+      for (int qa = 0; qa < S; ++qa) {
+        // softmax over two keys: p0 = 1 / (1 + exp(s1 - s0)), p1 = 1 - p0
+        const float p0 = sigmoid_f((sc[qa][0] - sc[qa][1]) * a.inv_sqrt_dk);
+        const float p1 = 1.0f - p0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float o = fmaf(p0, pq[2][2 * q + 0][r], p1 * pq[2][2 * q + 1][r]);
+          const __bf16 hb = (__bf16)o;
+          gh[2 * q + qa][4 * hh + r] = hb;
+          gw[2 * q + qa][4 * hh + r] = (__bf16)(o - (float)hb);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m2 = 0; m2 < MT; ++m2) {
+    *reinterpret_cast<bf16x8*>(&hs[((w * 2 + 0) * MT + m2) * 64 + lane]) = gh[m2];
+    *reinterpret_cast<bf16x8*>(&hs[((w * 2 + 1) * MT + m2) * 64 + lane]) = gw[m2];
+  }
+  // the residual rows (this lane's 2 x 4 channels per row) fly under the barrier and phase 2
+  float4 xr[MT][FTW];
+#pragma unroll
+  for (int m2 = 0; m2 < MT; ++m2)
+#pragma unroll
+    for (int t = 0; t < FTW; ++t) xr[m2][t] = ld4(a.x + mrow[m2] * F + 32 * w + 16 * t + 4 * fg);
+  __syncthreads();
+
+  // ---- phase 2: output tiles 2w, 2w+1 over the four K steps, in order -----------------------------------------------------------------
+  f32x4 acc[FTW][MT];
+#pragma unroll
+  for (int t = 0; t < FTW; ++t)
+#pragma unroll
+    for (int m2 = 0; m2 < MT; ++m2) acc[t][m2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    bf16x8 ah[MT], aw[MT];
+#pragma unroll
+    for (int m2 = 0; m2 < MT; ++m2) {
+      ah[m2] = *reinterpret_cast<const bf16x8*>(&hs[((c * 2 + 0) * MT + m2) * 64 + lane]);
+      aw[m2] = *reinterpret_cast<const bf16x8*>(&hs[((c * 2 + 1) * MT + m2) * 64 + lane]);
+    }
+#pragma unroll
+    for (int t = 0; t < FTW; ++t) {
+      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&wr[0][(c * FTW + t) * 2]);
+      const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&wr[0][(c * FTW + t) * 2 + 1]);
+#pragma unroll
+      for (int m2 = 0; m2 < MT; ++m2) acc[t][m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[m2], acc[t][m2], 0, 0, 0);
+#pragma unroll
+      for (int m2 = 0; m2 < MT; ++m2) acc[t][m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, aw[m2], acc[t][m2], 0, 0, 0);
+#pragma unroll
+      for (int m2 = 0; m2 < MT; ++m2) acc[t][m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ah[m2], acc[t][m2], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: y = x + ls * (acc + bo); fragment row 4 fg + r of tile 2w + t is channel 32 w + 16 t + 4 fg + r --------------------
+  {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int t = 0; t < FTW; ++t) {
+      const int ch = 32 * w + 16 * t + 4 * fg;
+      const float4 bo = ld4(a.bo + ch), lsv = ld4(a.ls + ch);
+#pragma unroll
+      for (int m2 = 0; m2 < MT; ++m2) {
+        if (okf[m2 >> 1]) {
+          const f32x4 o = acc[t][m2];
+          st4(a.y + mrow[m2] * F + ch, make_float4(fmaf(o[0] + bo.x, lsv.x, xr[m2][t].x), fmaf(o[1] + bo.y, lsv.y, xr[m2][t].y),
+                                                   fmaf(o[2] + bo.z, lsv.z, xr[m2][t].z), fmaf(o[3] + bo.w, lsv.w, xr[m2][t].w)));
+        }
+      }
+    }
+  }
+}
+
 int launch_spk_fused(const SpkFusedArgs& a, int F, int site, hipStream_t stream) {
   if (a.NF <= 0) return SEPR_OK;
   if (!a.x || !a.y || !a.w1p || !a.w2p || !a.bo || !a.ls || a.T <= 0 || a.NF % a.T != 0) return SEPR_EINVAL;
@@ -383,6 +618,15 @@ int launch_spk_fused(const SpkFusedArgs& a, int F, int site, hipStream_t stream)
   const int ntiles = (a.NF + 63) / 64;
   const int cap = persistent_grid();
   const int grid = ntiles < cap ? ntiles : cap;
+  // at most one tile per CU: the hidden-split form, 16- or 32-frame tiles (SEPR_SPK_HS=0 switches it off)
+  static const bool hs_on = [] {
+    const char* e = getenv("SEPR_SPK_HS");
+    return !(e && e[0] == '0');
+  }();
+  const int cus = cap / 2;
+  if (F == 128 && hs_on && (a.NF + 15) / 16 <= cus) hipLaunchKernelGGL((spk_hs_kernel<1>), dim3((a.NF + 15) / 16), dim3(256), 0, stream, a);
+  else if (F == 128 && hs_on && (a.NF + 31) / 32 <= cus) hipLaunchKernelGGL((spk_hs_kernel<2>), dim3((a.NF + 31) / 32), dim3(256), 0, stream, a);
+  else
   if (F == 256) hipLaunchKernelGGL((spk_fused_kernel<256, 4, true>), dim3(ntiles < cap / 2 ? ntiles : cap / 2), dim3(256), 0, stream, a);   // 32-channel heads, one workgroup per CU
   else hipLaunchKernelGGL((spk_fused_kernel<128, 4>), dim3(grid), dim3(256), 0, stream, a);
   // algorithmic FLOPs: q/k/v and output projections of both speakers' rows

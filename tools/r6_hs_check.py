@@ -40,6 +40,14 @@ for n, T in ((1, 1), (2, 37), (1, 32), (1, 33), (3, 300), (1, 2000), (1, 8192), 
     print(f"cla {n} {T} {db:.1f} {hashlib.sha256(y.numpy().tobytes()).hexdigest()[:16]}", flush=True)
 
 
+# the speaker attention (spk_hs_kernel: 16- / 32-frame tiles; boundaries 4096 / 8192 frames); n = mixtures x 2 speakers
+w_att = eng.pk.dec_stages[0]["spk"][0][0]
+for n, T in ((2, 1), (4, 33), (2, 4096), (2, 4097), (4, 2500), (2, 8000), (2, 8193)):
+    x = rnd(n, T, m.cfg.feat, seed=T + 2)
+    y = eng.spkattn(x.cuda(), w_att, n, T).cpu()
+    print(f"spk {n} {T} {hashlib.sha256(y.numpy().tobytes()).hexdigest()[:16]}", flush=True)
+
+
 def flat(o):
     if torch.is_tensor(o):
         yield o
