@@ -772,6 +772,190 @@ __global__ __launch_bounds__(256, 1) void cla_tail_hs_kernel(const ClaFusedArgs 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// cla_head_hs_kernel (round 6): the output-split form of the three head-type launches for at most one tile per CU (batch 1).  The four waves
+// hold the SAME 16*MT frames (LayerNorm computed by each) and split the OUTPUT tiles; a weight fragment has one reader and goes global ->
+// registers; no LDS, no barrier, direct stores.  Per accumulator the operand sequence of cla_head_kernel: bit-identical.
+//   HS_GLU   CLA head:  wave w = chunk w (v0 v1 g0 g1 -> 32 gated channels)
+//   HS_GATE  EGA gate with the folded output projection (a.o set): wave w = output tiles 2w, 2w+1 of BOTH projections - the attention's
+//            LayerScale(linear_out(o)) of a frame's pooled row is computed in the lane that needs it (one N tile per frame tile, rows chosen
+//            per lane) and never leaves the registers
+//   HS_QKV   pooling + LayerNorm + q / k / v: wave w = output tiles 6w .. 6w+5 of the [rows, 3F] tensor
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int HS_GLU = 0, HS_GATE = 1, HS_QKV = 2;
+template <int MODE, int MT>
+__global__ __launch_bounds__(256, 1) void cla_head_hs_kernel(const ClaFusedArgs a) {
+  constexpr int F = 128, KS = F / 32;
+  constexpr int W1F_U4 = 4 * KS * 2 * 64, CS_U4 = 256, W1_U4 = W1F_U4 + CS_U4;
+  constexpr int NTW = MODE == HS_GLU ? 4 : (MODE == HS_GATE ? 2 : 6);     // plain 16-row tiles of the projection per wave
+  constexpr int TILE = 16 * MT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+  const unsigned loff = (unsigned)lane * 16u;
+  const uint4* const W1g = static_cast<const uint4*>(a.w1p);
+  auto ldu = [&](const uint4* base, int blk) -> uint4 {   // 16 bytes of this lane from the 1 KiB block blk behind the wave-uniform base
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base + blk * 64) + loff);
+  };
+  const int tile0 = blockIdx.x * TILE;
+  // this wave's tile i: global plain-tile index gt = NTW * w + i -> chunk gt / 4, tile gt % 4 of the packed weights
+  float4 bias[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int gt = NTW * ws + i;
+    bias[i] = ld4(reinterpret_cast<const float*>(W1g + (long long)(gt >> 2) * W1_U4 + W1F_U4) + (gt & 3) * 16 + 4 * fg);
+  }
+  // all of this wave's fragments are requested before the frames (they land under the frame loads and the LayerNorm; hipcc would otherwise
+  // sink each load to its first use and wait for it there: 23 us instead of 13 for the q / k / v form)
+  uint4 wf[NTW][KS][2];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int gt = NTW * ws + i;
+    const uint4* const base = W1g + (long long)(gt >> 2) * W1_U4 + (gt & 3) * KS * 2 * 64;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      wf[i][ks][0] = ldu(base, ks * 2);
+      wf[i][ks][1] = ldu(base, ks * 2 + 1);
+    }
+  }
+  // gate: the folded output projection's fragments and the pooled attention rows of this lane's frames, requested up front as well
+  constexpr int NTO = MODE == HS_GATE ? NTW : 1, MTO = MODE == HS_GATE ? MT : 1;
+  uint4 wo[NTO][KS][2];
+  float4 orow[MTO][KS][2];
+  if constexpr (MODE == HS_GATE) {
+    const uint4* const Wob = static_cast<const uint4*>(a.wop) + (long long)(NTW * ws) * KS * 2 * 64;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wo[t][ks][pl] = ldu(Wob, (t * KS + ks) * 2 + pl);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = tile0 + MT * fi + mt;
+      const int mc = m < a.M ? m : 0;
+      const int seq = mc / a.T, t_ = mc - seq * a.T;
+      const float* op = a.o + ((long long)seq * a.Tp + t_ / a.fac) * F + 8 * fg;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        orow[mt][ks][0] = ld4(op + 32 * ks);
+        orow[mt][ks][1] = ld4(op + 32 * ks + 4);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- frames (every wave holds all of them; lane fi holds frames MT*fi .. MT*fi + MT-1) ----
+  bf16x8 xh[MT][KS], xl[MT][KS];
+  if constexpr (MODE == HS_QKV) load_frames_pooled<F, MT>(a.x, tile0, a.M, a.pool, a.eps, fi, fg, xh, xl);
+  else load_frames<F, true, MT>(a.x, tile0, a.M, a.eps, fi, fg, xh, xl);
+  f32x4 acc[NTW][MT];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[i][mt] = (f32x4){bias[i].x, bias[i].y, bias[i].z, bias[i].w};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&wf[i][ks][0]), wlo = *reinterpret_cast<const bf16x8*>(&wf[i][ks][1]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt][ks], acc[i][mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt][ks], acc[i][mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt][ks], acc[i][mt], 0, 0, 0);
+    }
+  }
+  if constexpr (MODE == HS_GLU) {
+    // tiles 0 1 = value, 2 3 = gate of chunk w: gated channels 32 w + 16 j + 4 fg + r
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = tile0 + MT * fi + mt;
+      if (m < a.M) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 hv = acc[j][mt], hg = acc[2 + j][mt];
+          st4(a.y + (long long)m * F + 32 * w + 16 * j + 4 * fg,
+              make_float4(hv[0] * sigmoid_f(hg[0]), hv[1] * sigmoid_f(hg[1]), hv[2] * sigmoid_f(hg[2]), hv[3] * sigmoid_f(hg[3])));
+        }
+      }
+    }
+  } else if constexpr (MODE == HS_QKV) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = tile0 + MT * fi + mt;
+      if (m < a.M) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+          const f32x4 v = acc[i][mt];
+          st4(a.y + (long long)m * a.ldy + 16 * (NTW * w + i) + 4 * fg, make_float4(v[0], v[1], v[2], v[3]));
+        }
+      }
+    }
+  } else {
+    // ---- folded output projection for the pooled rows of this lane's frames, output tiles 2w, 2w+1 ----
+    float4 bov[NTW], lov[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      bov[t] = ld4(a.bo + 16 * (NTW * w + t) + 4 * fg);
+      lov[t] = ld4(a.lso + 16 * (NTW * w + t) + 4 * fg);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = tile0 + MT * fi + mt;
+      bf16x8 oh[KS], ol[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 p = orow[mt][ks][0], q = orow[mt][ks][1];
+        const float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const __bf16 hh = (__bf16)v[e];
+          oh[ks][e] = hh;
+          ol[ks][e] = (__bf16)(v[e] - (float)hh);
+        }
+      }
+      f32x4 pa[NTW];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) pa[t] = (f32x4){bov[t].x, bov[t].y, bov[t].z, bov[t].w};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&wo[t][ks][0]), wlo = *reinterpret_cast<const bf16x8*>(&wo[t][ks][1]);
+          pa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, oh[ks], pa[t], 0, 0, 0);
+          pa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ol[ks], pa[t], 0, 0, 0);
+          pa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, oh[ks], pa[t], 0, 0, 0);
+        }
+      if (m < a.M) {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const int ch = 16 * (NTW * w + t) + 4 * fg;
+          const float4 xr = ld4(a.res + (long long)m * F + ch);
+          const float4 ar = make_float4(pa[t][0] * lov[t].x, pa[t][1] * lov[t].y, pa[t][2] * lov[t].z, pa[t][3] * lov[t].w);
+          const f32x4 g = acc[t][mt];
+          st4(a.y + (long long)m * F + ch, make_float4(fmaf(sigmoid_f(g[0]), ar.x, xr.x), fmaf(sigmoid_f(g[1]), ar.y, xr.y),
+                                                       fmaf(sigmoid_f(g[2]), ar.z, xr.z), fmaf(sigmoid_f(g[3]), ar.w, xr.w)));
+        }
+      }
+    }
+  }
+}
+
+// frame tiles per wave (2 / 4: 32- / 64-frame workgroup tiles) of the output-split head forms for a launch of M rows, 0 = not taken
+// (SEPR_CF_HEAD_HS=0 switches them off)
+static int head_hs_tiles(int M, int cus) {
+  static const bool on = [] {
+    const char* e = getenv("SEPR_CF_HEAD_HS");
+    return !(e && e[0] == '0');
+  }();
+  if (!on) return 0;
+  if ((M + 31) / 32 <= cus) return 2;
+  if ((M + 63) / 64 <= cus) return 4;
+  return 0;
+}
+
 // small launches (round 6): when even the 64-frame tiles of the MT = 1 instantiations leave workgroup slots free (cap = two per CU), a launch's
 // duration is one workgroup's dependent chain - halve it.  SEPR_CF_SMALL=<max 64-frame tiles> overrides the bound (0: never; A/B).
 static bool small_launch(int M, int cap) {
@@ -789,6 +973,10 @@ int launch_cla_head(const ClaFusedArgs& a, int F, int site, hipStream_t stream) 
   const bool timed = prof_begin(site, stream, &slot);
   const int ntiles = (a.M + 127) / 128;
   const int cap = persistent_grid();
+  const int hs = F == 128 ? head_hs_tiles(a.M, cap / 2) : 0;
+  if (hs == 2) hipLaunchKernelGGL((cla_head_hs_kernel<HS_GLU, 2>), dim3((a.M + 31) / 32), dim3(256), 0, stream, a);
+  else if (hs == 4) hipLaunchKernelGGL((cla_head_hs_kernel<HS_GLU, 4>), dim3((a.M + 63) / 64), dim3(256), 0, stream, a);
+  else
   if (F == 256) hipLaunchKernelGGL((cla_head_kernel<256, false>), dim3(ntiles < cap / 2 ? ntiles : cap / 2), dim3(CF_NT), 0, stream, a);   // one workgroup per CU
   else if (small_launch(a.M, cap)) hipLaunchKernelGGL((cla_head_kernel<128, false, 1>), dim3((a.M + 63) / 64), dim3(CF_NT), 0, stream, a);
   else hipLaunchKernelGGL((cla_head_kernel<128, false>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
@@ -806,6 +994,10 @@ int launch_ega_gate(const ClaFusedArgs& a, int F, int site, hipStream_t stream) 
   const bool timed = prof_begin(site, stream, &slot);
   const int ntiles = (a.M + 127) / 128;
   const int cap = persistent_grid();
+  const int hs = (F == 128 && a.o) ? head_hs_tiles(a.M, cap / 2) : 0;
+  if (hs == 2) hipLaunchKernelGGL((cla_head_hs_kernel<HS_GATE, 2>), dim3((a.M + 31) / 32), dim3(256), 0, stream, a);
+  else if (hs == 4) hipLaunchKernelGGL((cla_head_hs_kernel<HS_GATE, 4>), dim3((a.M + 63) / 64), dim3(256), 0, stream, a);
+  else
   if (F == 256) hipLaunchKernelGGL((cla_head_kernel<256, true>), dim3(ntiles < cap / 2 ? ntiles : cap / 2), dim3(CF_NT), 0, stream, a);
   else if (small_launch(a.M, cap)) hipLaunchKernelGGL((cla_head_kernel<128, true, 1>), dim3((a.M + 63) / 64), dim3(CF_NT), 0, stream, a);
   else hipLaunchKernelGGL((cla_head_kernel<128, true>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);
@@ -822,6 +1014,16 @@ int launch_ega_qkv(const ClaFusedArgs& a, int F, int site, hipStream_t stream) {
   const bool timed = prof_begin(site, stream, &slot);
   const int ntiles = (a.M + 127) / 128;
   const int cap = persistent_grid();
+  // (the output-split form of this launch - cla_head_hs_kernel<HS_QKV, .>, SEPR_CF_QKV_HS=1 - measured 19.1 us against 13.4 us for the three
+  //  workgroups per tile below: 32 workgroups at 1000 pooled rows, each wave repeating the pooled loads; profiles/r06_gcfn_hidden_split.txt (8))
+  static const bool qkv_hs = [] {
+    const char* e = getenv("SEPR_CF_QKV_HS");
+    return e && e[0] == '1';
+  }();
+  const int hs = qkv_hs ? head_hs_tiles(a.M, cap / 2) : 0;
+  if (hs == 2) hipLaunchKernelGGL((cla_head_hs_kernel<HS_QKV, 2>), dim3((a.M + 31) / 32), dim3(256), 0, stream, a);
+  else if (hs == 4) hipLaunchKernelGGL((cla_head_hs_kernel<HS_QKV, 4>), dim3((a.M + 63) / 64), dim3(256), 0, stream, a);
+  else
   if (small_launch(3 * a.M, cap)) hipLaunchKernelGGL((cla_head_kernel<128, true, 1, true>), dim3((a.M + 63) / 64, 3), dim3(CF_NT), 0, stream, a);
   else if (small_launch(a.M, cap)) hipLaunchKernelGGL((cla_head_kernel<128, true, 1, true>), dim3((a.M + 63) / 64), dim3(CF_NT), 0, stream, a);
   else hipLaunchKernelGGL((cla_head_kernel<128, true, CF_MT, true>), dim3(ntiles < cap ? ntiles : cap), dim3(CF_NT), 0, stream, a);

@@ -517,19 +517,20 @@ def test_gcfn_hidden_split_bitwise():
     (SEPR_GF_HS=0, read once per process -> own processes) for the GCFN block at every tile size (30 / 46 / 62 frames, boundaries included) and
     for a whole batch-1 forward (SpkSplit / OutputLayer GLU-MLP: the PLAIN instantiations); the CLA block's tail has the same form
     (cla_tail_hs_kernel, SEPR_CF_HS=0 = cla_tail_kernel), and so has the speaker attention (spk_hs_kernel, SEPR_SPK_HS=0 = spk_fused_kernel; its
-    agreement with the oracle is test_blocks' and the end-to-end tests').  Every GCFN / CLA case also agrees with the oracle."""
+    agreement with the oracle is test_blocks' and the end-to-end tests'), and the CLA head, the EGA gate and the q / k / v launch have the
+    output-split form cla_head_hs_kernel (SEPR_CF_HEAD_HS=0 = cla_head_kernel).  Every GCFN / CLA case also agrees with the oracle."""
     import subprocess
     import sys
     outs = []
     for hs in ("0", ""):
-        env = dict(os.environ, SEPR_GF_HS=hs, SEPR_CF_HS=hs, SEPR_SPK_HS=hs)
+        env = dict(os.environ, SEPR_GF_HS=hs, SEPR_CF_HS=hs, SEPR_SPK_HS=hs, SEPR_CF_HEAD_HS=hs)
         if not hs:
-            for k in ("SEPR_GF_HS", "SEPR_CF_HS", "SEPR_SPK_HS"):
+            for k in ("SEPR_GF_HS", "SEPR_CF_HS", "SEPR_SPK_HS", "SEPR_CF_HEAD_HS"):
                 env.pop(k)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r6_hs_check.py")], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("gcfn ", "cla ", "spk ", "model "))]
-        assert len(lines) >= 39, r.stdout[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("gcfn ", "cla ", "ega ", "spk ", "model "))]
+        assert len(lines) >= 48, r.stdout[-2000:]
         for ln in lines:
             if ln.startswith(("gcfn ", "cla ")):
                 assert float(ln.split()[3]) >= 80.0, ln

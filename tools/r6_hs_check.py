@@ -40,6 +40,12 @@ for n, T in ((1, 1), (2, 37), (1, 32), (1, 33), (3, 300), (1, 2000), (1, 8192), 
     print(f"cla {n} {T} {db:.1f} {hashlib.sha256(y.numpy().tobytes()).hexdigest()[:16]}", flush=True)
 
 
+# the EGA block (output-split q / k / v and gate launches; pooling factors 1 .. 16; boundaries 8192 / 16384 rows)
+for n, T, Tp in ((1, 25, 25), (2, 50, 25), (1, 2000, 250), (1, 8000, 1000), (1, 8192, 512), (1, 8208, 513), (2, 8000, 1000), (1, 16384, 1024), (1, 16400, 1025)):
+    x = rnd(n, T, m.cfg.feat, seed=T + 3)
+    y = eng.ega(x.cuda(), eng.pk.enc_stages[0]["g"][0][0], n, T, Tp).cpu()
+    print(f"ega {n} {T} {Tp} {hashlib.sha256(y.numpy().tobytes()).hexdigest()[:16]}", flush=True)
+
 # the speaker attention (spk_hs_kernel: 16- / 32-frame tiles; boundaries 4096 / 8192 frames); n = mixtures x 2 speakers
 w_att = eng.pk.dec_stages[0]["spk"][0][0]
 for n, T in ((2, 1), (4, 33), (2, 4096), (2, 4097), (4, 2500), (2, 8000), (2, 8193)):
