@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SEPR_VERSION 411 /* minor*100 + patch ("ABI 4.11").  Any struct-layout or context-size change bumps the MINOR number
+#define SEPR_VERSION 412 /* minor*100 + patch ("ABI 4.12").  Any struct-layout or context-size change bumps the MINOR number
                             (3.01 -> 3.03 grew sepr_ega_w under a patch bump: a caller built against 3.01 would have passed a short
                             struct).  A binding must compare sepr_version() with the SEPR_VERSION it was written against before its
                             first call: sepreformer_amd/lib.py refuses to load a library whose version differs. */
@@ -197,7 +197,8 @@ const char* sepr_build_info(void);
  * the environment (tests that flip a switch inside one process call it between whole forward + backward runs, never inside one). */
 enum { SEPR_KNOB_X3_WIDE = 0 /* 0 / 1 (default) / 2: sepr_gemm_x3.hip */, SEPR_KNOB_TRAIN_GCFN_PLANES /* default 1 */,
        SEPR_KNOB_TRAIN_ATTN_ONE /* default 1 */, SEPR_KNOB_TRAIN_CLA16 /* default 1 */,
-       SEPR_KNOB_FOLD_HEAD /* default 1: main OutputLayer + AudioDecoder as one launch when sepr_out_w.fold_* are set */, SEPR_KNOB_COUNT };
+       SEPR_KNOB_FOLD_HEAD /* default 1: main OutputLayer + AudioDecoder as one launch when sepr_out_w.fold_* are set */,
+       SEPR_KNOB_TN16 /* default 1: weight-gradient contractions of two bf16 operands on the LDS-DMA + transposing-read kernel */, SEPR_KNOB_COUNT };
 int sepr_knob(int id);
 void sepr_knobs_reload(void);
 /* text of the last HIP error seen by the calling thread ("" if none) */
@@ -503,6 +504,10 @@ int sepr_front_bwd(const float* wav, const float* enc, const float* dout, float*
 size_t sepr_linear_wgrad_workspace(int M, int N, int K);
 int sepr_linear_wgrad(const float* A, const float* B, float* G, float* colsum, int M, int N, int K, int accumulate, int x3, void* ws,
                       size_t ws_bytes, sepr_stream_t stream);
+/* the same for two bf16 operands A16 [M][lda], B16 [M][ldb] (leading dimensions in elements), as the plain-bf16 training precision stores the
+ * large intermediates of the GCFN / CLA backward (ABI 4.12); one bf16 MFMA per product, fp32 accumulate */
+int sepr_linear_wgrad_bf16(const void* A16, int lda, const void* B16, int ldb, float* G, float* colsum, int M, int N, int K, int accumulate,
+                           void* ws, size_t ws_bytes, sepr_stream_t stream);
 /* the same with the normalisation prologue of a projection behind a LayerNorm: B'[m][k] = (B[m][k] - stats[2m]) * stats[2m+1] */
 int sepr_linear_wgrad_norm(const float* A, const float* B, const float* stats, float* G, float* colsum, int M, int N, int K,
                            int accumulate, int x3, void* ws, size_t ws_bytes, sepr_stream_t stream);

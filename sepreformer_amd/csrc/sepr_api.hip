@@ -109,7 +109,7 @@ int g_knobs[SEPR_KNOB_COUNT];
 std::mutex g_knobs_mu;
 void knobs_read() {
   static const struct { const char* name; int dflt; } tab[SEPR_KNOB_COUNT] = {
-      {"SEPR_X3_WIDE", 1}, {"SEPR_TRAIN_GCFN_PLANES", 1}, {"SEPR_TRAIN_ATTN_ONE", 1}, {"SEPR_TRAIN_CLA16", 1}, {"SEPR_FOLD_HEAD", 1}};
+      {"SEPR_X3_WIDE", 1}, {"SEPR_TRAIN_GCFN_PLANES", 1}, {"SEPR_TRAIN_ATTN_ONE", 1}, {"SEPR_TRAIN_CLA16", 1}, {"SEPR_FOLD_HEAD", 1}, {"SEPR_TN16", 1}};
   for (int i = 0; i < SEPR_KNOB_COUNT; ++i) {
     const char* e = getenv(tab[i].name);
     g_knobs[i] = (e && e[0]) ? atoi(e) : tab[i].dflt;

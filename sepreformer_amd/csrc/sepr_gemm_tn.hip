@@ -363,6 +363,138 @@ __global__ __launch_bounds__(TN_THREADS, MD == 2 ? SEPR_TN_ONE_WPE : 2) void gem
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// gemm_tn16_kernel (round 6): the contraction for TWO bf16 operands [M][ld] (the plain-bf16 precision stores dh1, g, x^ and dropout(dy)
+// of every GCFN block and the CLA intermediates as bf16) with N and K multiples of 128 - the largest contractions of a training step.
+// gemm_tn_kernel stages its slabs through registers (8-byte loads, widen, transpose on the VALU, 16-byte LDS stores) with ONE slab in
+// flight per workgroup, and its load phase and MFMA phase do not overlap (profiles/r03_v3_gemm_tn_ablation.txt): 3.0 TB/s on the
+// 256 000-row launches.  Here no VALU instruction touches the operands:
+//   * slabs of 32 rows x (128 + 128) columns go global -> LDS by LDS-DMA (16 B per lane, 128 contiguous bytes per row and instruction:
+//     whole cache lines), into a ring of TN16_NS stages - three slabs (48 KB) in flight per workgroup while one multiplies, two
+//     workgroups per CU; the copies are inline asm with counted vmcnt waits and one raw barrier per slab (sepr_common.h glds16_asm);
+//   * the MFMA contraction index is the ROW index, so a lane needs 8 rows of one column: ds_read_b64_tr_b16, gfx950's transposing LDS
+//     read, delivers 4 rows x 1 column per lane from a row-major image (two reads per fragment).  The slot of fragment element e of lane
+//     group fg is row 16 (e >> 2) + 4 fg + (e & 3) of the slab for BOTH operands (any bijection works: the contraction sums over it);
+//   * LDS image: one copy instruction = [8 rows][64 columns] = 64 slots of 16 B; the slot of (row r, 16-byte chunk c) is
+//     8 r + (c ^ (((r >> 1) & 3) << 1)), which makes the 32 lanes the LDS serves together (rows 0-7 x 32 B of one 16-column tile) hit 16
+//     distinct 16-byte bank windows - the copy's per-lane source address carries the permutation, the image itself is lane-linear;
+//   * column sums of A (bias gradients): 4 extra MFMAs per slab against an all-ones B fragment in the k0 == 0 tiles.
+// Partial tiles and their fixed-order reduction (tn_reduce_kernel) are those of gemm_tn_kernel: same plan, same workspace.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TN16_NS = 4;                 // ring stages (one multiplying, TN16_NS - 1 in flight)
+constexpr int TN16_ROWS = 32;              // rows per slab = one MFMA K step
+constexpr int TN16_STAGE_B = 2 * TN16_ROWS * TN_T * 2;   // A + B images of one slab: 16 KB
+typedef short tn_s16x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn16_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part, float* __restrict__ cpart) {
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[TN16_NS * TN16_STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int gq = gridDim.x >> 3, gr = gridDim.x & 7, bx = blockIdx.x & 7;     // XCD-aware walk: see gemm_tn_kernel
+  const int vb = bx * gq + (bx < gr ? bx : gr) + (blockIdx.x >> 3);
+  const int tile = vb % (p.tn * p.tk), split = vb / (p.tn * p.tk);
+  const int n0 = (tile / p.tk) * TN_T, k0 = (tile % p.tk) * TN_T;
+  const int m_beg = split * p.rows_per_split;
+  const int m_end = min(a.M, m_beg + p.rows_per_split);
+  const int nslab = m_end > m_beg ? (m_end - m_beg + TN16_ROWS - 1) / TN16_ROWS : 0;
+  const bool csum_tile = cpart != nullptr && k0 == 0;
+
+  // ---- copy role: wave w issues 4 copies per slab - column group w & 1, row groups 2 (w >> 1) and 2 (w >> 1) + 1, of A and of B ----
+  // lane l of a copy writes slot l = (row r8 = l >> 3, position l & 7), i.e. reads chunk c = (l & 7) ^ (((r8 >> 1) & 3) << 1) of its row
+  const int r8 = lane >> 3, cch = (lane & 7) ^ (((r8 >> 1) & 3) << 1);
+  const int g64 = wid & 1, rg0 = 2 * (wid >> 1);
+  const unsigned colA = (unsigned)(n0 + 64 * g64 + 8 * cch) * 2u, colB = (unsigned)(k0 + 64 * g64 + 8 * cch) * 2u;
+  const unsigned ldaB = (unsigned)a.lda * 2u, ldbB = (unsigned)a.ldb * 2u;
+  const unsigned ring_lds = lds_addr(ring);
+  auto issue = [&](int s) {
+    const int mb = m_beg + s * TN16_ROWS;
+    const unsigned stage = ring_lds + (unsigned)((s % TN16_NS) * TN16_STAGE_B);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int m = mb + 8 * (rg0 + h) + r8;
+      m = m < a.M ? m : a.M - 1;            // (rows past the tensor: a valid row, zeroed in LDS before the slab multiplies; slabs past the slice: never read)
+      const unsigned blk = (unsigned)((g64 * 4 + rg0 + h) * 1024);
+      glds16_asm(a.A, (unsigned)m * ldaB + colA, __builtin_amdgcn_readfirstlane(stage + blk));
+      glds16_asm(a.B, (unsigned)m * ldbB + colB, __builtin_amdgcn_readfirstlane(stage + (unsigned)(TN16_ROWS * TN_T * 2) + blk));
+    }
+  };
+
+  f32x4 acc[4][4], accs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // fragment read addresses inside a stage: lane (fg, i = fi) of the read h supplies row 16 h + 4 fg + (i >> 2), columns 16 t + 4 (i & 3) .. + 3
+  // of its operand's column group: block (g, row group 2 h + (fg >> 1)), row r = 4 (fg & 1) + (i >> 2) of the block, chunk c = 2 t + ((i & 3) >> 1)
+  const int rr = 4 * (fg & 1) + (fi >> 2), sw = ((rr >> 1) & 3) << 1;
+  unsigned fa[4], fb[4];                      // byte offsets of tile t's first read (h = 0); h = 1: + 2 KB (two row groups further)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const unsigned slot = (unsigned)(8 * rr + ((2 * t + ((fi & 3) >> 1)) ^ sw));
+    const unsigned in_blk = slot * 16u + (unsigned)(fi & 1) * 8u + (unsigned)(fg >> 1) * 1024u;
+    fa[t] = (unsigned)(wm * 4) * 1024u + in_blk;
+    fb[t] = (unsigned)(TN16_ROWS * TN_T * 2) + (unsigned)(wn * 4) * 1024u + in_blk;
+  }
+  typedef __bf16 tn16_bf16x8 __attribute__((ext_vector_type(8)));
+  const tn16_bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+
+#pragma unroll
+  for (int s = 0; s < TN16_NS - 1; ++s) issue(s);
+  for (int s = 0; s < nslab; ++s) {
+    // this wave's copies of slab s have landed (4 copies per wave and slab, issued in order: the 4 (NS - 2) behind them may still fly) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (TN16_NS - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();             // ... and everybody's have; every wave is done reading slab s - 1
+    asm volatile("" ::: "memory");
+    issue(s + TN16_NS - 1);                   // into the stage slab s - 1 occupied (always issued: the counted wait above stays a constant)
+    unsigned char* const stg = ring + (s % TN16_NS) * TN16_STAGE_B;
+    if (m_beg + (s + 1) * TN16_ROWS > a.M) {  // the tensor ends inside this slab (last slice only): rows past it multiply as zeros
+      for (int q = tid; q < 512; q += TN_THREADS) {               // A image: 8 blocks x 64 slots
+        const int blk = q >> 6, r = 8 * (blk & 3) + ((q & 63) >> 3);
+        if (m_beg + s * TN16_ROWS + r >= a.M) *reinterpret_cast<uint4*>(stg + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+      }
+      __syncthreads();
+    }
+    tn16_bf16x8 af[4], bf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      tn_s16x4 lo, hi;
+      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(stg + fa[t]));
+      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(stg + fa[t] + 2048));
+      af[t] = __builtin_bit_cast(tn16_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(stg + fb[t]));
+      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(stg + fb[t] + 2048));
+      bf[t] = __builtin_bit_cast(tn16_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bf[kt], acc[nt][kt], 0, 0, 0);
+    if (csum_tile && wn == 0) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) accs[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], ones, accs[nt], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the copies issued past the slice's end)
+
+  float* pt = part + (long long)split * a.N * a.K;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = k0 + wn * 64 + kt * 16 + fi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pt[(long long)(n0 + wm * 64 + nt * 16 + 4 * fg + r) * a.K + k] = acc[nt][kt][r];
+    }
+  if (csum_tile && wn == 0 && fi == 0) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cpart[(long long)split * a.N + n0 + wm * 64 + nt * 16 + 4 * fg + r] = accs[nt][r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // tn_smallk_kernel (round 4): G[N][16] (+)= sum_m A[m][n] * B'[m][k] for the two filter gradients of the waveform ends - the
 // ConvTranspose1d decoder weights (5 heads) and the Conv1d encoder weights: K = 16 taps, N = 256 basis channels, M = sequences x
 // frames (256 000 rows at batch 16), B' = 16 consecutive samples of the frame's window (row map: seq * seq_stride + r * ldb).
@@ -514,7 +646,12 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   // (A packed-row kernel for two bf16 operands - v_perm transpose, v_dot2 column sums, two slabs in flight, 5x fewer staging VALU
   //  instructions, bit-identical G - was built and measured in round 4: 182.55 vs 182.55 utt/s, no gain; git history 'gemm_tn16'.
   //  The contraction is not bound by its staging arithmetic.)
-  if (x3 == 2) SEPR_TN_LAUNCH(2);
+  // two bf16 operands, whole 128 x 128 tiles: the LDS-DMA + transposing-read kernel (gemm_tn16_kernel; SEPR_TN16=0 keeps the register-staged form)
+  const bool tn16 = x3 == 2 && !gen && !a.stats && a.a16 && a.b16 && a.N % TN_T == 0 && a.K % TN_T == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 &&
+                    (long long)a.M * a.lda * 2 < (1LL << 32) && (long long)a.M * a.ldb * 2 < (1LL << 32) &&
+                    ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0 && knob(SEPR_KNOB_TN16) != 0;
+  if (tn16) hipLaunchKernelGGL(gemm_tn16_kernel, dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp);
+  else if (x3 == 2) SEPR_TN_LAUNCH(2);
   else if (x3) SEPR_TN_LAUNCH(1);
   else SEPR_TN_LAUNCH(0);
 #undef SEPR_TN_LAUNCH

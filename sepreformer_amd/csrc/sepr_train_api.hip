@@ -817,6 +817,18 @@ extern "C" int sepr_linear_wgrad(const float* A, const float* B, float* G, float
   return wgrad(A, N, B, K, nullptr, G, colsum, M, N, K, accumulate, x3 < 0 || x3 > 2 ? 1 : x3, ws, ws_bytes, SEPR_ST);
 }
 
+extern "C" int sepr_linear_wgrad_bf16(const void* A16, int lda, const void* B16, int ldb, float* G, float* colsum, int M, int N, int K,
+                                      int accumulate, void* ws, size_t ws_bytes, sepr_stream_t stream) {
+  if (!A16 || !B16 || !G || M <= 0 || lda < N || ldb < K) return SEPR_EINVAL;
+  TnArgs t = tn_args_zero();
+  t.M = M; t.N = N; t.K = K;
+  t.A = static_cast<const float*>(A16); t.lda = lda; t.a16 = 1;
+  t.B = static_cast<const float*>(B16); t.ldb = ldb; t.b16 = 1;
+  t.G = G; t.ldg = K; t.accumulate = accumulate;
+  t.colsum = colsum; t.colsum_accumulate = accumulate;
+  return launch_gemm_tn(t, 2, ws, ws_bytes, SEPR_ST);
+}
+
 extern "C" int sepr_linear_wgrad_norm(const float* A, const float* B, const float* stats, float* G, float* colsum, int M, int N, int K,
                                       int accumulate, int x3, void* ws, size_t ws_bytes, sepr_stream_t stream) {
   if (!A || !B || !stats || !G || M <= 0) return SEPR_EINVAL;

@@ -118,7 +118,7 @@ FrontGrad = _tstruct("FrontGrad", ["w_enc", "gn_g", "gn_b", "proj_w"])
 (TOP_GCFN, TOP_CLA, TOP_EGA, TOP_SPKATTN, TOP_DOWN, TOP_SPLIT, TOP_FUSE, TOP_OUT, TOP_FRONT, TOP_GCFN_FUSED, TOP_EGA_X3,
  TOP_GCFN_FUSED16) = range(12)
 
-KNOB_X3_WIDE, KNOB_TRAIN_GCFN_PLANES, KNOB_TRAIN_ATTN_ONE, KNOB_TRAIN_CLA16, KNOB_FOLD_HEAD = range(5)
+KNOB_X3_WIDE, KNOB_TRAIN_GCFN_PLANES, KNOB_TRAIN_ATTN_ONE, KNOB_TRAIN_CLA16, KNOB_FOLD_HEAD, KNOB_TN16 = range(6)
 
 # name -> (restype, argtypes); must list every symbol include/sepr.h declares (tests check this)
 SIGNATURES = {
@@ -172,6 +172,7 @@ SIGNATURES = {
     "sepr_linear_wgrad_workspace": (_sz, [_i, _i, _i]),
     "sepr_linear_wgrad": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _sz, _fp]),
     "sepr_linear_wgrad_norm": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _sz, _fp]),
+    "sepr_linear_wgrad_bf16": (_i, [_fp, _i, _fp, _i, _fp, _fp, _i, _i, _i, _i, _fp, _sz, _fp]),
     "sepr_train_pack_lin": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _fp]),
     "sepr_train_fold_bias": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp]),
     "sepr_train_defer_begin": (_i, [_fp, _sz]),
@@ -196,7 +197,7 @@ _lib: Optional[C.CDLL] = None
 _lock = threading.Lock()
 
 
-ABI_VERSION = 411          # include/sepr.h SEPR_VERSION this binding mirrors (tests/test_boundary_cpu.py keeps the two equal)
+ABI_VERSION = 412          # include/sepr.h SEPR_VERSION this binding mirrors (tests/test_boundary_cpu.py keeps the two equal)
 
 
 class SeprLibraryError(RuntimeError):
