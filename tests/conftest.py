@@ -38,7 +38,7 @@ def golden():
 
 # A/B switches the library latches once per process (include/sepr.h SEPR_KNOB_*): a test that flips one with monkeypatch.setenv gets the
 # library's copy refreshed right away, and restored together with the environment when the test ends.
-_KNOBS = {"SEPR_X3_WIDE", "SEPR_TRAIN_GCFN_PLANES", "SEPR_TRAIN_ATTN_ONE", "SEPR_TRAIN_CLA16"}
+_KNOBS = {"SEPR_X3_WIDE", "SEPR_TRAIN_GCFN_PLANES", "SEPR_TRAIN_ATTN_ONE", "SEPR_TRAIN_CLA16", "SEPR_FOLD_HEAD", "SEPR_TN16"}
 
 
 def _knobs_reload():

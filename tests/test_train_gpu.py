@@ -175,6 +175,46 @@ def test_wgrad_core(M, N, K, x3):
     soft.done()
 
 
+@pytest.mark.parametrize("M,N,K,lda,ldb", [(256, 128, 128, 128, 128), (4099, 768, 128, 768, 128), (8191, 128, 384, 128, 384), (33, 128, 128, 128, 128),
+                                           (31, 256, 128, 256, 128), (1000, 128, 128, 384, 256), (70000, 768, 128, 768, 128), (256000, 128, 384, 128, 384),
+                                           (5000, 192, 128, 192, 128)])
+def test_wgrad_bf16_operands(M, N, K, lda, ldb, monkeypatch):
+    """The contraction of two bf16 operands (sepr_linear_wgrad_bf16: what the plain-bf16 precision runs for the GCFN / CLA weight gradients)
+    on gemm_tn16_kernel - LDS-DMA ring, transposing LDS reads, column sums on the matrix pipe - against fp64 of the same bf16 values: whole
+    and ragged last slabs (M % 32), a tensor shorter than one slab, strided operands (lda > N), 500 row slices; and against the
+    register-staged kernel (SEPR_TN16=0: exactly the same products, fp32 sums in another order).  N = 192 is not a whole tile: that launch
+    stays on the register-staged kernel whatever the switch says."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, lda, generator=g) * (1 + torch.arange(lda) % 7)).to(torch.bfloat16)
+    b = (torch.randn(M, ldb, generator=g) + 0.25).to(torch.bfloat16)
+    ad, bd = a.cuda(), b.cuda()
+    want = (a[:, :N].double().t() @ b[:, :K].double()).float()
+    want_cs = a[:, :N].double().sum(0).float()
+    ws = torch.empty(int(lib.sepr_linear_wgrad_workspace(M, N, K)) + 256, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    soft = Soft(f"wgrad_bf16.{M}x{N}x{K}")
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SEPR_TN16", mode)
+        G = torch.full((N, K), 7.0, device="cuda")
+        cs = torch.full((N,), -3.0, device="cuda")
+        L.check(lib.sepr_linear_wgrad_bf16(ad.data_ptr(), lda, bd.data_ptr(), ldb, G.data_ptr(), cs.data_ptr(), M, N, K, 0, ws.data_ptr(), ws.numel(), st), "wgrad_bf16")
+        soft.agree(f"G.tn16={mode}", G, want, 110.0)           # the bf16 values are the inputs here: only the fp32 summation order is left
+        soft.agree(f"colsum.tn16={mode}", cs, want_cs, 110.0)
+        G2 = G.clone()
+        cs2 = cs.clone()
+        L.check(lib.sepr_linear_wgrad_bf16(ad.data_ptr(), lda, bd.data_ptr(), ldb, G2.data_ptr(), cs2.data_ptr(), M, N, K, 1, ws.data_ptr(), ws.numel(), st), "wgrad_bf16")
+        soft.agree(f"G_accumulated.tn16={mode}", G2, 2 * want, 110.0)
+        soft.agree(f"colsum_accumulated.tn16={mode}", cs2, 2 * want_cs, 110.0)
+        G3 = torch.empty_like(G)
+        L.check(lib.sepr_linear_wgrad_bf16(ad.data_ptr(), lda, bd.data_ptr(), ldb, G3.data_ptr(), None, M, N, K, 0, ws.data_ptr(), ws.numel(), st), "wgrad_bf16")
+        assert torch.equal(G3, G)                              # no atomics: bitwise repeatable
+        res[mode] = G
+    soft.agree("G.tn16_vs_staged", res["1"], res["0"], 110.0)
+    soft.done()
+
+
 @pytest.mark.parametrize("x3", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(64000, 768, 128), (20000, 256, 128), (300000, 128, 128), (777, 384, 128)])
 def test_wgrad_norm_full_size(M, N, K, x3):
@@ -1563,6 +1603,9 @@ def test_gcfn_bf16_plane_staged_backward_equals_register_staged(variant, n, T, m
     x, dy = rnd(n, T, F, seed=T).cuda(), rnd(n, T, F, seed=T + 7).cuda()
     outs = []
     pfx = "separator.enc_stages.0.g_block_1.block.gcfn"
+    # (both forms on the register-staged contraction: gemm_tn16_kernel - which form (b) runs by default - sums the same products in another order;
+    #  test_bf16_blocks_tn16_contraction_agrees_with_register_staged compares the two contractions)
+    monkeypatch.setenv("SEPR_TN16", "0")
     for planes in ("0", "1"):
         monkeypatch.setenv("SEPR_TRAIN_GCFN_PLANES", planes)
         gb = GradBuffer(cfg, dev)
@@ -1636,6 +1679,7 @@ def test_cla_bf16_stored_intermediates_equal_fp32_stored(n, T, monkeypatch):
     x, dy = rnd(n, T, F, seed=T).cuda(), rnd(n, T, F, seed=T + 7).cuda()
     pfx = "separator.enc_stages.0.l_block_1.block.cla"
     outs = []
+    monkeypatch.setenv("SEPR_TN16", "0")          # (see test_gcfn_bf16_plane_staged_backward_equals_register_staged)
     for mode in ("0", "1"):
         monkeypatch.setenv("SEPR_TRAIN_CLA16", mode)
         sdd = {k: v.to(dev) for k, v in sd.items()}
@@ -1661,6 +1705,44 @@ def test_cla_bf16_stored_intermediates_equal_fp32_stored(n, T, monkeypatch):
                 assert orc.agreement_db(b_.cpu(), a_.cpu()) >= 45.0, (k, orc.agreement_db(b_.cpu(), a_.cpu()))
         else:
             assert torch.equal(a_, b_), (k, int((a_ != b_).sum()), float((a_ - b_).abs().max()), float(a_.abs().max()))
+
+
+@pytest.mark.parametrize("kind,n,T", [("gcfn", 3, 1201), ("gcfn", 4, 8000), ("cla", 3, 1201), ("cla", 4, 8000)])
+def test_bf16_blocks_tn16_contraction_agrees_with_register_staged(kind, n, T, monkeypatch):
+    """Plain-bf16 precision, GCFN and CLA blocks with dropout live: the weight-gradient contractions of two bf16 operands on gemm_tn16_kernel
+    (default) vs on the register-staged gemm_tn_kernel (SEPR_TN16=0).  Nothing else changes, so block output and input gradient are bitwise
+    equal; the parameter gradients are the same bf16 products summed in fp32 in another order."""
+    from sepreformer_amd.train_engine import TrainEngine
+    from sepreformer_amd.train_pack import GradBuffer, TrainPack
+    cfg = dataclasses.replace(VARIANTS["SepReformer_Base_WSJ0"], dropout=0.3)
+    sd = synth_state_dict(cfg, 0)
+    dev = torch.device("cuda:0")
+    F = cfg.feat
+    x, dy = rnd(n, T, F, seed=T).cuda(), rnd(n, T, F, seed=T + 7).cuda()
+    pfx = "separator.enc_stages.0." + ("g_block_1.block.gcfn" if kind == "gcfn" else "l_block_1.block.cla")
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SEPR_TN16", mode)
+        sdd = {k: v.to(dev) for k, v in sd.items()}
+        gb = GradBuffer(cfg, dev)
+        tp = TrainPack(cfg, sdd, gb, "bf16")
+        eng = TrainEngine(cfg, dev)
+        y, rec = eng.block_fwd(kind, x, (tp.gcfn if kind == "gcfn" else tp.cla)[0], n, T, 0, 0.3, 4242)
+        dx = eng.block_bwd(rec, dy)
+        torch.cuda.synchronize()
+        outs.append((y.clone(), dx.clone(), {k[len(pfx) + 1:]: gb.view(k).clone() for k in sd if k.startswith(pfx + ".") and k in gb.offsets}))
+    assert torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    scale = max(float(v.abs().max()) for v in outs[0][2].values())
+    differ = 0
+    for k, a_ in outs[0][2].items():
+        b_ = outs[1][2][k]
+        differ += int(not torch.equal(a_, b_))
+        if float(a_.abs().max()) <= 3e-2 * scale and k == "linear2.bias":
+            continue                                           # (structural zero in front of the train-mode BatchNorm: rounding noise in both)
+        if float(a_.abs().max()) > 0:
+            assert orc.agreement_db(b_.cpu(), a_.cpu()) >= 95.0, (k, orc.agreement_db(b_.cpu(), a_.cpu()))
+    assert differ > 0          # the switch reached the library (the two kernels do not sum in the same order)
 
 
 @pytest.mark.parametrize("variant,n,T,Tp", [("SepReformer_Base_WSJ0", 4, 2000, 500), ("SepReformer_Large_DM_WHAMR", 2, 520, 130)])
