@@ -550,6 +550,13 @@ int sepr_train_pack_gcfn_fused(const void* const* w1, const void* const* b1, con
  * is per host thread (thread-local state); without one the entry points behave exactly as before. */
 int sepr_train_defer_begin(void* arena, size_t arena_bytes);
 int sepr_train_defer_flush(int close, sepr_stream_t stream);
+/* Riding reductions (ABI 4.12).  Every weight-gradient contraction is followed by the fixed-order reduction of its row-slice partial tiles:
+ * ~300 launches of 5-7 us per step, launch latency again.  With a double buffer registered on an open window (parts: 256-byte aligned device
+ * scratch, 2 x 40 MB covers every contraction of the shipped configurations; NULL unregisters), a contraction whose outputs live in the
+ * window's arena writes its partial tiles into one half of it and its reduction runs in blocks appended to the NEXT contraction's launch on
+ * the same stream (or on its own at the flush) - same arithmetic, bit-identical gradients, ~290 launches fewer.  A contraction that does not
+ * fit a half keeps the immediate form.  The registration ends with the window (flush(close = 1)) or the next sepr_train_defer_begin. */
+int sepr_train_defer_parts(void* parts, size_t parts_bytes);
 
 /* ---- weight-gradient side stream (ABI 4.10) ----------------------------------------------------------------------------------
  * Nothing inside a backward walk reads what the weight-gradient contractions write (parameter gradients, or the arena slots of deferred

@@ -61,6 +61,45 @@ inline TnPlan tn_plan(int M, int N, int K) {
   return p;
 }
 
+// The split-M reduction of ONE contraction, as a job: tn_reduce_kernel runs it on its own; a contraction kernel runs the job of the PREVIOUS
+// contraction in blocks appended to its grid (blockIdx.x >= ngrid; launch_gemm_tn "riding reduction").  Block = 64 output elements x 4 lanes
+// over the slices (fixed order inside a lane, lanes combined in a fixed order): the same arithmetic wherever it runs.
+struct TnRed {
+  const float* part;
+  const float* cpart;
+  int nsplit, N, K;
+  float* G;
+  int ldg, accumulate;
+  float* colsum;
+  int colsum_acc;
+  int nblocks;          // 0: no job
+};
+__device__ __forceinline__ void tn_reduce_block(const TnRed& r, int blk, float* sh /* [4][64] */) {
+  const long long total = (long long)r.N * r.K;
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long long i = (long long)blk * 64 + el;
+  float s = 0.f;
+  if (i < total) {
+#pragma unroll 4
+    for (int sp = sl; sp < r.nsplit; sp += 4) s += r.part[(long long)sp * total + i];
+  } else if (i < total + r.N && r.colsum) {
+#pragma unroll 4
+    for (int sp = sl; sp < r.nsplit; sp += 4) s += r.cpart[(long long)sp * r.N + (i - total)];
+  }
+  sh[sl * 64 + el] = s;
+  __syncthreads();
+  if (sl != 0) return;
+  s = (sh[el] + sh[64 + el]) + (sh[128 + el] + sh[192 + el]);
+  if (i < total) {
+    const int n = (int)(i / r.K), k = (int)(i - (long long)n * r.K);
+    float* g = r.G + (long long)n * r.ldg + k;
+    *g = r.accumulate ? *g + s : s;
+  } else if (i < total + r.N && r.colsum) {
+    const int n = (int)(i - total);
+    r.colsum[n] = r.colsum_acc ? r.colsum[n] + s : s;
+  }
+}
+
 // MD: 0 = exact f32 MFMA, 1 = bf16x3 split arithmetic, 2 = plain bf16 operands (hi planes only, one MFMA per product).
 // GEN: the general B prologue (row maps, index tables, two-source concat, per-sequence statistics, masked A rows) - the fusion
 //      conv, the output heads, the encoder / projector: a handful of launches per step.  !GEN: B is a plain [M][ldb] tensor,
@@ -73,7 +112,7 @@ inline TnPlan tn_plan(int M, int N, int K) {
 #endif
 template <int MD, bool GEN, bool STATS>
 __global__ __launch_bounds__(TN_THREADS, MD == 2 ? SEPR_TN_ONE_WPE : 2) void gemm_tn_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part,
-                                                               float* __restrict__ cpart) {
+                                                               float* __restrict__ cpart, const int ngrid, const TnRed red) {
   // x3: [A_hi, A_lo, B_hi, B_lo][128][72] bf16 = 73 728 B;  plain bf16: [A_hi, B_hi] = 36 864 B;  f32: [A, B][64][132] fp32 = 67 584 B
   // (the plain-bf16 form stays at two workgroups per CU all the same: 208 VGPRs - profiles/r05_v4_wgrad_3waves.txt)
   constexpr bool X3 = MD != 0, ONE = MD == 2;
@@ -86,13 +125,17 @@ __global__ __launch_bounds__(TN_THREADS, MD == 2 ? SEPR_TN_ONE_WPE : 2) void gem
   // ~500 cycles of MFMAs).  The code path is kept behind the constant for the day the accumulator tile shrinks.
   constexpr bool DBUF = false;
   __shared__ float2 st_s[DBUF ? 2 : 1][TN_SLAB];          // (mean, rstd) of the slab's rows (!GEN && STATS)
+  if ((int)blockIdx.x >= ngrid) {          // riding reduction: the previous contraction's partial tiles (launch_gemm_tn)
+    tn_reduce_block(red, (int)blockIdx.x - ngrid, reinterpret_cast<float*>(smem));
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int fi = lane & 15, fg = lane >> 4;
   // XCD-aware walk: hardware block b runs on XCD b % 8, and each XCD has its own L2.  The tiles of one row slice share an operand
   // (B for the tn tiles of a k column, A for the tk tiles of an n row), so they get CONSECUTIVE virtual ids on ONE XCD - the shared
   // slab is fetched from HBM once per slice instead of once per tile (PMC, round 3: 1.67 x the algorithmic bytes before).
-  const int gq = gridDim.x >> 3, gr = gridDim.x & 7, bx = blockIdx.x & 7;
+  const int gq = ngrid >> 3, gr = ngrid & 7, bx = blockIdx.x & 7;
   const int vb = bx * gq + (bx < gr ? bx : gr) + (blockIdx.x >> 3);
   const int tile = vb % (p.tn * p.tk), split = vb / (p.tn * p.tk);
   const int n0 = (tile / p.tk) * TN_T, k0 = (tile % p.tk) * TN_T;
@@ -363,59 +406,88 @@ __global__ __launch_bounds__(TN_THREADS, MD == 2 ? SEPR_TN_ONE_WPE : 2) void gem
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// gemm_tn16_kernel (round 6): the contraction for TWO bf16 operands [M][ld] (the plain-bf16 precision stores dh1, g, x^ and dropout(dy)
-// of every GCFN block and the CLA intermediates as bf16) with N and K multiples of 128 - the largest contractions of a training step.
+// gemm_tnd_kernel (round 6): the plain-bf16 contraction with its operands staged by LDS-DMA - for plain [M][ld] operands (no row map, no
+// normalisation prologue) with N and K multiples of 128: the largest contractions of a training step (the plain-bf16 precision stores dh1,
+// g, x^ and dropout(dy) of every GCFN block and the CLA intermediates as bf16: A16 / B16; every other projection hands over fp32 rows).
 // gemm_tn_kernel stages its slabs through registers (8-byte loads, widen, transpose on the VALU, 16-byte LDS stores) with ONE slab in
 // flight per workgroup, and its load phase and MFMA phase do not overlap (profiles/r03_v3_gemm_tn_ablation.txt): 3.0 TB/s on the
-// 256 000-row launches.  Here no VALU instruction touches the operands:
-//   * slabs of 32 rows x (128 + 128) columns go global -> LDS by LDS-DMA (16 B per lane, 128 contiguous bytes per row and instruction:
-//     whole cache lines), into a ring of TN16_NS stages - three slabs (48 KB) in flight per workgroup while one multiplies, two
-//     workgroups per CU; the copies are inline asm with counted vmcnt waits and one raw barrier per slab (sepr_common.h glds16_asm);
-//   * the MFMA contraction index is the ROW index, so a lane needs 8 rows of one column: ds_read_b64_tr_b16, gfx950's transposing LDS
-//     read, delivers 4 rows x 1 column per lane from a row-major image (two reads per fragment).  The slot of fragment element e of lane
-//     group fg is row 16 (e >> 2) + 4 fg + (e & 3) of the slab for BOTH operands (any bijection works: the contraction sums over it);
-//   * LDS image: one copy instruction = [8 rows][64 columns] = 64 slots of 16 B; the slot of (row r, 16-byte chunk c) is
-//     8 r + (c ^ (((r >> 1) & 3) << 1)), which makes the 32 lanes the LDS serves together (rows 0-7 x 32 B of one 16-column tile) hit 16
-//     distinct 16-byte bank windows - the copy's per-lane source address carries the permutation, the image itself is lane-linear;
+// 256 000-row launches.  Here:
+//   * slabs of 32 rows x (128 + 128) columns go global -> LDS by LDS-DMA (16 B per lane; 128 B of a bf16 row / 256 B of an fp32 row per
+//     instruction: whole cache lines), into a ring of TND_NS stages - three slabs in flight per workgroup while one multiplies (two bf16
+//     operands: 16 KB stages, two workgroups per CU; fp32 operands: 24 / 32 KB stages, one workgroup per CU); the copies are inline asm with
+//     counted vmcnt waits and one raw barrier per slab (sepr_common.h glds16_asm);
+//   * the MFMA contraction index is the ROW index, so a lane needs 8 rows of one column.  bf16 image: ds_read_b64_tr_b16, gfx950's
+//     transposing LDS read, delivers 4 rows x 1 column per lane from a row-major image (two reads per fragment, no VALU at all); the slot
+//     of fragment element e of lane group fg is row 16 (e >> 2) + 4 fg + (e & 3).  fp32 image: ds_read2st64_b32 (two rows, 256 B apart,
+//     per instruction: four per fragment) and the same round-to-nearest conversion gemm_tn_kernel<2> applies while staging; element e
+//     of lane group fg is row 8 fg + e.  (Any bijection works as long as both operands of a launch use the same one - the contraction sums
+//     over it - so a mixed launch reads its bf16 image with the fp32 image's map, through plain 2-byte reads.)
+//   * LDS images, lane-linear per copy instruction (the copy's per-lane SOURCE address carries the permutation):
+//       bf16: [8 rows][64 columns] = 64 slots of 16 B; slot of (row r, chunk c) = 8 r + (c ^ (((r >> 1) & 3) << 1)): the 32 lanes the LDS
+//             serves together (rows 0-7 x 32 B of one 16-column tile) hit 16 distinct 16-byte bank windows;
+//       fp32: [4 rows][64 columns] = 64 slots; slot of (row r, chunk c) = 16 r + (c ^ 4 (row group bit 1)): lane groups fg = 0 / 1 (row
+//             groups 2 fg + h) read bank halves 16 floats apart;
 //   * column sums of A (bias gradients): 4 extra MFMAs per slab against an all-ones B fragment in the k0 == 0 tiles.
 // Partial tiles and their fixed-order reduction (tn_reduce_kernel) are those of gemm_tn_kernel: same plan, same workspace.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int TN16_NS = 4;                 // ring stages (one multiplying, TN16_NS - 1 in flight)
-constexpr int TN16_ROWS = 32;              // rows per slab = one MFMA K step
-constexpr int TN16_STAGE_B = 2 * TN16_ROWS * TN_T * 2;   // A + B images of one slab: 16 KB
+constexpr int TND_NS = 4;                  // ring stages (one multiplying, TND_NS - 1 in flight)
+constexpr int TND_ROWS = 32;               // rows per slab = one MFMA K step
 typedef short tn_s16x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn16_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part, float* __restrict__ cpart) {
-  __shared__ __attribute__((aligned(1024))) unsigned char ring[TN16_NS * TN16_STAGE_B];
+typedef __bf16 tnd_bf16x8 __attribute__((ext_vector_type(8)));
+template <bool A32, bool B32>
+__global__ __launch_bounds__(TN_THREADS, (A32 || B32) ? 1 : 2) void gemm_tnd_kernel(const TnArgs a, const TnPlan p, float* __restrict__ part,
+                                                                                float* __restrict__ cpart, const int ngrid, const TnRed red) {
+  constexpr bool MIXED = A32 != B32;
+  constexpr int IMG_A = TND_ROWS * TN_T * (A32 ? 4 : 2), IMG_B = TND_ROWS * TN_T * (B32 ? 4 : 2), STAGE_B = IMG_A + IMG_B;
+  constexpr int NIA = A32 ? 4 : 2, NIB = B32 ? 4 : 2, NI = NIA + NIB;      // copies per wave and slab
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[TND_NS * STAGE_B];
+  if ((int)blockIdx.x >= ngrid) {          // riding reduction: the previous contraction's partial tiles (launch_gemm_tn)
+    tn_reduce_block(red, (int)blockIdx.x - ngrid, reinterpret_cast<float*>(ring));
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
   const int fi = lane & 15, fg = lane >> 4;
-  const int gq = gridDim.x >> 3, gr = gridDim.x & 7, bx = blockIdx.x & 7;     // XCD-aware walk: see gemm_tn_kernel
+  const int gq = ngrid >> 3, gr = ngrid & 7, bx = blockIdx.x & 7;             // XCD-aware walk: see gemm_tn_kernel
   const int vb = bx * gq + (bx < gr ? bx : gr) + (blockIdx.x >> 3);
   const int tile = vb % (p.tn * p.tk), split = vb / (p.tn * p.tk);
   const int n0 = (tile / p.tk) * TN_T, k0 = (tile % p.tk) * TN_T;
   const int m_beg = split * p.rows_per_split;
   const int m_end = min(a.M, m_beg + p.rows_per_split);
-  const int nslab = m_end > m_beg ? (m_end - m_beg + TN16_ROWS - 1) / TN16_ROWS : 0;
+  const int nslab = m_end > m_beg ? (m_end - m_beg + TND_ROWS - 1) / TND_ROWS : 0;
   const bool csum_tile = cpart != nullptr && k0 == 0;
 
-  // ---- copy role: wave w issues 4 copies per slab - column group w & 1, row groups 2 (w >> 1) and 2 (w >> 1) + 1, of A and of B ----
-  // lane l of a copy writes slot l = (row r8 = l >> 3, position l & 7), i.e. reads chunk c = (l & 7) ^ (((r8 >> 1) & 3) << 1) of its row
-  const int r8 = lane >> 3, cch = (lane & 7) ^ (((r8 >> 1) & 3) << 1);
-  const int g64 = wid & 1, rg0 = 2 * (wid >> 1);
-  const unsigned colA = (unsigned)(n0 + 64 * g64 + 8 * cch) * 2u, colB = (unsigned)(k0 + 64 * g64 + 8 * cch) * 2u;
-  const unsigned ldaB = (unsigned)a.lda * 2u, ldbB = (unsigned)a.ldb * 2u;
+  // ---- copy role: wave w copies column group w & 1 (64 columns) of both operands: bf16 - row groups (8 rows) 2 (w >> 1) + {0, 1};
+  //      fp32 - row groups (4 rows) 4 (w >> 1) + {0 .. 3}.  Lane l writes slot l of its copy's 1 KB block ----
+  const int g64 = wid & 1, wq = wid >> 1;
+  const int r8 = lane >> 3, c8 = (lane & 7) ^ (((r8 >> 1) & 3) << 1);       // bf16 block: row, source chunk (8 columns)
+  const int r4 = lane >> 4, p4 = lane & 15;                                  // fp32 block: row, slot position (source chunk = p4 ^ 4 (rg bit 1))
+  const unsigned ldaB = (unsigned)a.lda * (A32 ? 4u : 2u), ldbB = (unsigned)a.ldb * (B32 ? 4u : 2u);
   const unsigned ring_lds = lds_addr(ring);
-  auto issue = [&](int s) {
-    const int mb = m_beg + s * TN16_ROWS;
-    const unsigned stage = ring_lds + (unsigned)((s % TN16_NS) * TN16_STAGE_B);
+  auto copy16 = [&](const float* src, unsigned ldB, int col0, unsigned img, int mb) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      int m = mb + 8 * (rg0 + h) + r8;
+      const int rg = 2 * wq + h;
+      int m = mb + 8 * rg + r8;
       m = m < a.M ? m : a.M - 1;            // (rows past the tensor: a valid row, zeroed in LDS before the slab multiplies; slabs past the slice: never read)
-      const unsigned blk = (unsigned)((g64 * 4 + rg0 + h) * 1024);
-      glds16_asm(a.A, (unsigned)m * ldaB + colA, __builtin_amdgcn_readfirstlane(stage + blk));
-      glds16_asm(a.B, (unsigned)m * ldbB + colB, __builtin_amdgcn_readfirstlane(stage + (unsigned)(TN16_ROWS * TN_T * 2) + blk));
+      glds16_asm(src, (unsigned)m * ldB + (unsigned)(col0 + 64 * g64 + 8 * c8) * 2u, __builtin_amdgcn_readfirstlane(img + (unsigned)((g64 * 4 + rg) * 1024)));
     }
+  };
+  auto copy32 = [&](const float* src, unsigned ldB, int col0, unsigned img, int mb) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int rg = 4 * wq + h;
+      int m = mb + 4 * rg + r4;
+      m = m < a.M ? m : a.M - 1;
+      const int c4 = p4 ^ (((rg >> 1) & 1) << 2);
+      glds16_asm(src, (unsigned)m * ldB + (unsigned)(col0 + 64 * g64 + 4 * c4) * 4u, __builtin_amdgcn_readfirstlane(img + (unsigned)((g64 * 8 + rg) * 1024)));
+    }
+  };
+  auto issue = [&](int s) {
+    const int mb = m_beg + s * TND_ROWS;
+    const unsigned stage = ring_lds + (unsigned)((s % TND_NS) * STAGE_B);
+    if constexpr (A32) copy32(a.A, ldaB, n0, stage, mb); else copy16(a.A, ldaB, n0, stage, mb);
+    if constexpr (B32) copy32(a.B, ldbB, k0, stage + IMG_A, mb); else copy16(a.B, ldbB, k0, stage + IMG_A, mb);
   };
 
   f32x4 acc[4][4], accs[4];
@@ -425,46 +497,63 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn16_kernel(const TnArgs a
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  // fragment read addresses inside a stage: lane (fg, i = fi) of the read h supplies row 16 h + 4 fg + (i >> 2), columns 16 t + 4 (i & 3) .. + 3
-  // of its operand's column group: block (g, row group 2 h + (fg >> 1)), row r = 4 (fg & 1) + (i >> 2) of the block, chunk c = 2 t + ((i & 3) >> 1)
+  // ---- fragment reads ----
+  // bf16 image, transposing read h of tile t: lane (fg, i = fi) supplies row 16 h + 4 fg + (i >> 2), columns 16 t + 4 (i & 3) .. + 3 of its
+  // wave's column group g: block (g, row group 2 h + (fg >> 1)), row 4 (fg & 1) + (i >> 2) of the block, chunk 2 t + ((i & 3) >> 1)
   const int rr = 4 * (fg & 1) + (fi >> 2), sw = ((rr >> 1) & 3) << 1;
-  unsigned fa[4], fb[4];                      // byte offsets of tile t's first read (h = 0); h = 1: + 2 KB (two row groups further)
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  auto frag16 = [&](const unsigned char* img, int g, int t) -> tnd_bf16x8 {
     const unsigned slot = (unsigned)(8 * rr + ((2 * t + ((fi & 3) >> 1)) ^ sw));
-    const unsigned in_blk = slot * 16u + (unsigned)(fi & 1) * 8u + (unsigned)(fg >> 1) * 1024u;
-    fa[t] = (unsigned)(wm * 4) * 1024u + in_blk;
-    fb[t] = (unsigned)(TN16_ROWS * TN_T * 2) + (unsigned)(wn * 4) * 1024u + in_blk;
-  }
-  typedef __bf16 tn16_bf16x8 __attribute__((ext_vector_type(8)));
-  const tn16_bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    const unsigned char* q = img + (unsigned)(g * 4 + (fg >> 1)) * 1024u + slot * 16u + (unsigned)(fi & 1) * 8u;
+    const tn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(q));
+    const tn_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(q + 2048));
+    return __builtin_bit_cast(tnd_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  // fp32 image: element e = row 8 fg + e, column 16 t + fi of column group g: block (g, row group 2 fg + (e >> 2)), row e & 3, chunk 4 t + (fi >> 2)
+  auto frag32 = [&](const unsigned char* img, int g, int t) -> tnd_bf16x8 {
+    const float* q = reinterpret_cast<const float*>(img + (unsigned)(g * 8 + 2 * fg) * 1024u + (unsigned)(((4 * t + (fi >> 2)) ^ ((fg & 1) << 2)) * 16 + (fi & 3) * 4));
+    tnd_bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)q[(e >> 2) * 256 + (e & 3) * 64];      // (row stride 256 B, row-group stride 1 KB)
+    return v;
+  };
+  // bf16 image through the fp32 image's row map (mixed launches): 2-byte reads, rows 8 fg + e
+  auto frag16m = [&](const unsigned char* img, int g, int t) -> tnd_bf16x8 {
+    tnd_bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = 8 * fg + e, rb = r & 7;          // block (g, r >> 3), row rb, chunk c = 2 t + (fi >> 3), element fi & 7
+      const unsigned slot = (unsigned)(8 * rb + ((2 * t + (fi >> 3)) ^ (((rb >> 1) & 3) << 1)));
+      v[e] = *reinterpret_cast<const __bf16*>(img + (unsigned)(g * 4 + (r >> 3)) * 1024u + slot * 16u + (unsigned)(fi & 7) * 2u);
+    }
+    return v;
+  };
+  const tnd_bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
 
 #pragma unroll
-  for (int s = 0; s < TN16_NS - 1; ++s) issue(s);
+  for (int s = 0; s < TND_NS - 1; ++s) issue(s);
   for (int s = 0; s < nslab; ++s) {
-    // this wave's copies of slab s have landed (4 copies per wave and slab, issued in order: the 4 (NS - 2) behind them may still fly) ...
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (TN16_NS - 2)) : "memory");
+    // this wave's copies of slab s have landed (NI copies per wave and slab, issued in order: the NI (NS - 2) behind them may still fly) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (TND_NS - 2)) : "memory");
     __builtin_amdgcn_s_barrier();             // ... and everybody's have; every wave is done reading slab s - 1
     asm volatile("" ::: "memory");
-    issue(s + TN16_NS - 1);                   // into the stage slab s - 1 occupied (always issued: the counted wait above stays a constant)
-    unsigned char* const stg = ring + (s % TN16_NS) * TN16_STAGE_B;
-    if (m_beg + (s + 1) * TN16_ROWS > a.M) {  // the tensor ends inside this slab (last slice only): rows past it multiply as zeros
-      for (int q = tid; q < 512; q += TN_THREADS) {               // A image: 8 blocks x 64 slots
-        const int blk = q >> 6, r = 8 * (blk & 3) + ((q & 63) >> 3);
-        if (m_beg + s * TN16_ROWS + r >= a.M) *reinterpret_cast<uint4*>(stg + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+    issue(s + TND_NS - 1);                    // into the stage slab s - 1 occupied (always issued: the counted wait above stays a constant)
+    unsigned char* const stg = ring + (s % TND_NS) * STAGE_B;
+    if (m_beg + (s + 1) * TND_ROWS > a.M) {   // the tensor ends inside this slab (last slice only): rows of A past it multiply as zeros
+      for (int q = tid; q < IMG_A / 16; q += TN_THREADS) {
+        const int blk = q >> 6, r = A32 ? 4 * (blk & 7) + ((q & 63) >> 4) : 8 * (blk & 3) + ((q & 63) >> 3);
+        if (m_beg + s * TND_ROWS + r >= a.M) *reinterpret_cast<uint4*>(stg + q * 16) = make_uint4(0u, 0u, 0u, 0u);
       }
       __syncthreads();
     }
-    tn16_bf16x8 af[4], bf[4];
+    tnd_bf16x8 af[4], bf[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      tn_s16x4 lo, hi;
-      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(stg + fa[t]));
-      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(stg + fa[t] + 2048));
-      af[t] = __builtin_bit_cast(tn16_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(stg + fb[t]));
-      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(stg + fb[t] + 2048));
-      bf[t] = __builtin_bit_cast(tn16_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      if constexpr (A32) af[t] = frag32(stg, wm, t);
+      else if constexpr (MIXED) af[t] = frag16m(stg, wm, t);
+      else af[t] = frag16(stg, wm, t);
+      if constexpr (B32) bf[t] = frag32(stg + IMG_A, wn, t);
+      else if constexpr (MIXED) bf[t] = frag16m(stg + IMG_A, wn, t);
+      else bf[t] = frag16(stg + IMG_A, wn, t);
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -556,34 +645,9 @@ __global__ __launch_bounds__(256) void tn_smallk_kernel(const TnArgs a, const Tn
   }
 }
 
-// block = 64 output elements x 4 lanes over the slices (fixed order inside a lane, lanes combined in a fixed order)
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart, int nsplit,
-                                                       int N, int K, float* __restrict__ G, int ldg, int accumulate,
-                                                       float* __restrict__ colsum, int colsum_acc) {
-  __shared__ float sh[4][64];
-  const long long total = (long long)N * K;
-  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const long long i = (long long)blockIdx.x * 64 + el;
-  float s = 0.f;
-  if (i < total) {
-#pragma unroll 4
-    for (int sp = sl; sp < nsplit; sp += 4) s += part[(long long)sp * total + i];
-  } else if (i < total + N && colsum) {
-#pragma unroll 4
-    for (int sp = sl; sp < nsplit; sp += 4) s += cpart[(long long)sp * N + (i - total)];
-  }
-  sh[sl][el] = s;
-  __syncthreads();
-  if (sl != 0) return;
-  s = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
-  if (i < total) {
-    const int n = (int)(i / K), k = (int)(i - (long long)n * K);
-    float* g = G + (long long)n * ldg + k;
-    *g = accumulate ? *g + s : s;
-  } else if (i < total + N && colsum) {
-    const int n = (int)(i - total);
-    colsum[n] = colsum_acc ? colsum[n] + s : s;
-  }
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const TnRed r) {
+  __shared__ float sh[4 * 64];
+  tn_reduce_block(r, (int)blockIdx.x, sh);
 }
 }  // namespace
 
@@ -591,6 +655,46 @@ size_t tn_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const TnPlan p = tn_plan(M, N, K);
   return align_up((size_t)p.nsplit * ((size_t)N * K + N) * sizeof(float));
+}
+
+// ---- riding reduction (round 6) -------------------------------------------------------------------------------------------------------
+// A training step runs ~300 contractions, each followed by its split-M reduction: a 5-7 us launch of which ~5 us are launch latency and the
+// drain of the contraction's tail.  While a deferred-finisher window is open (sepr_train.h) nothing reads a contraction's G / colsum before
+// the window's flush when they live in the window's arena, so the reduction need not run right behind its contraction: its job is kept
+// PENDING and runs in blocks appended to the grid of the NEXT contraction on the same stream (stream order: the partial tiles are complete;
+// the extra blocks are over long before the contraction's own) - or on its own at the flush.  The partial tiles of such a job live in one half
+// of a caller-provided double buffer (sepr_train_defer_parts) instead of the block's workspace, which the next block call carves differently:
+// contraction i writes half i % 2 while the riding blocks read half (i - 1) % 2.  Same reduction arithmetic, same results.
+namespace {
+struct TnPending {
+  bool valid = false;
+  TnRed job;
+  hipStream_t stream = nullptr;
+};
+struct TnParts {
+  char* base = nullptr;
+  size_t half = 0;
+  int toggle = 0;
+  bool used = false;
+  hipStream_t stream = nullptr;     // the stream of the window's riding launches (another stream: that launch keeps the immediate form)
+};
+thread_local TnPending g_pend;
+thread_local TnParts g_parts;
+const TnRed kNoRed = {nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0};
+}  // namespace
+int tn_flush_pending() {
+  if (!g_pend.valid) return SEPR_OK;
+  g_pend.valid = false;
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3(g_pend.job.nblocks), dim3(256), 0, g_pend.stream, g_pend.job);
+  SEPR_CHECK_LAUNCH("tn_reduce_kernel");
+  return SEPR_OK;
+}
+void tn_parts_set(void* parts, size_t bytes) {
+  g_parts.base = static_cast<char*>(parts);
+  g_parts.half = parts ? (bytes / 2) / 256 * 256 : 0;
+  g_parts.toggle = 0;
+  g_parts.used = false;
+  g_parts.stream = nullptr;
 }
 
 int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream_t s_main) {
@@ -603,7 +707,18 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   // contraction + its split-M reduction run on the registered weight-gradient side stream when there is one (sepr_train.h wgrad_stream):
   // nothing in a backward walk consumes their output before the window's join
   hipStream_t s = wgrad_stream(s_main);
+  // this contraction's reduction can wait for the next contraction (see above): outputs in the window's arena, partial tiles in a buffer half
+  bool defer_red = g_parts.base != nullptr && s == s_main && need <= g_parts.half && fin_defers(a.G) && (!a.colsum || fin_defers(a.colsum)) &&
+                   (!g_parts.used || g_parts.stream == s);
+  // a pending job rides on this launch when it was issued on this stream; otherwise it runs on its own now
+  if (g_pend.valid && g_pend.stream != s) SEPR_TRY(tn_flush_pending());
   float* part = static_cast<float*>(ws);
+  if (defer_red) {
+    part = reinterpret_cast<float*>(g_parts.base + (size_t)g_parts.toggle * g_parts.half);
+    g_parts.toggle ^= 1;
+    g_parts.used = true;
+    g_parts.stream = s;
+  }
   float* cpart = part + (size_t)p.nsplit * a.N * a.K;
   const int grid = p.tn * p.tk * p.nsplit;
   // test switch (tools/probe/tn_fault.py, tests; read once, never set in the product): SEPR_TN_FORCE_GEN=1 routes every launch through the
@@ -611,27 +726,41 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   static const bool force_gen = [] { const char* e = getenv("SEPR_TN_FORCE_GEN"); return e && e[0] == '1'; }();
   const bool gen = force_gen || a.rows_out > 0 || a.B2 != nullptr || a.idx != nullptr || a.mask_a != 0 || a.stat_seq != 0;
   if (gen && (a.a16 || a.b16)) return SEPR_EINVAL;      // (checked before the profiling slot opens)
-  long long slot = -1;
-  const bool timed = prof_begin(SEPR_SITE_WGRAD, s, &slot);
   // the filter gradients of the waveform ends (K = 16 taps, exact arithmetic, windowed-frame row map): one pass over A on the VALU
   static const bool smallk_off = [] {
     const char* e = getenv("SEPR_TN_SMALLK");
     return e && e[0] == '0';
   }();
-  if (x3 == 0 && a.K == 16 && a.N <= 256 && a.rows_out > 0 && !a.B2 && !a.idx && !a.stats && !a.mask_a && a.b_shift == 0 && !a.colsum &&
-      !a.a16 && !a.b16 && p.tn * p.tk <= 2 && !smallk_off) {
+  const bool smallk = x3 == 0 && a.K == 16 && a.N <= 256 && a.rows_out > 0 && !a.B2 && !a.idx && !a.stats && !a.mask_a && a.b_shift == 0 && !a.colsum &&
+                      !a.a16 && !a.b16 && p.tn * p.tk <= 2 && !smallk_off;
+  if (smallk) SEPR_TRY(tn_flush_pending());             // (its kernel carries no riding blocks)
+  long long slot = -1;
+  const bool timed = prof_begin(SEPR_SITE_WGRAD, s, &slot);
+  TnRed mine;                                           // this contraction's reduction
+  mine.part = part; mine.cpart = cpart; mine.nsplit = p.nsplit; mine.N = a.N; mine.K = a.K;
+  mine.G = a.G; mine.ldg = a.ldg; mine.accumulate = a.accumulate;
+  mine.colsum = a.colsum; mine.colsum_acc = a.colsum_accumulate;
+  mine.nblocks = (int)(((long long)a.N * a.K + a.N + 63) / 64);
+  if (smallk) {
     hipLaunchKernelGGL(tn_smallk_kernel, dim3(p.nsplit), dim3(256), 0, s, a, p, part);
     if (timed) {
       prof_end(slot, 2.0 * (double)a.M * (double)a.N * (double)a.K, s);
       prof_bytes((double)a.M * ((double)a.N * 4.0 + 64.0));
     }
-    const long long total_e = (long long)a.N * a.K;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)((total_e + 63) / 64)), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
-                       (float*)nullptr, 0);
+    mine.colsum = nullptr;
+    mine.nblocks = (int)(((long long)a.N * a.K + 63) / 64);
+    if (defer_red) {
+      g_pend.valid = true; g_pend.job = mine; g_pend.stream = s;
+    } else {
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3(mine.nblocks), dim3(256), 0, s, mine);
+    }
     SEPR_CHECK_LAUNCH("tn_smallk_kernel");
     return SEPR_OK;
   }
   float* cp = a.colsum ? cpart : nullptr;
+  const TnRed red = g_pend.valid ? g_pend.job : kNoRed;
+  const int gridr = grid + red.nblocks;                 // the pending job's blocks ride behind this contraction's
+  g_pend.valid = false;
   // (Rounds 3-4 ran the general loader at ONE workgroup per CU behind a 16 KB LDS pad: with two co-resident workgroups its bf16
   //  instantiations returned wrong, run-to-run different values in the even columns of the upper half of every B tile.  Round 5 found the
   //  cause - the packed-f32 op_sel fault described in sepr_common.h, triggered by the normalisation's v_pk_mul_f32 op_sel:[0,1] while the
@@ -639,18 +768,25 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
   //  test_general_loader_two_workgroups_per_cu.)
 #define SEPR_TN_LAUNCH(MD)                                                                                                   \
   do {                                                                                                                       \
-    if (gen) hipLaunchKernelGGL((gemm_tn_kernel<MD, true, false>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp);      \
-    else if (a.stats) hipLaunchKernelGGL((gemm_tn_kernel<MD, false, true>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp); \
-    else hipLaunchKernelGGL((gemm_tn_kernel<MD, false, false>), dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp);         \
+    if (gen) hipLaunchKernelGGL((gemm_tn_kernel<MD, true, false>), dim3(gridr), dim3(TN_THREADS), 0, s, a, p, part, cp, grid, red);      \
+    else if (a.stats) hipLaunchKernelGGL((gemm_tn_kernel<MD, false, true>), dim3(gridr), dim3(TN_THREADS), 0, s, a, p, part, cp, grid, red); \
+    else hipLaunchKernelGGL((gemm_tn_kernel<MD, false, false>), dim3(gridr), dim3(TN_THREADS), 0, s, a, p, part, cp, grid, red);         \
   } while (0)
   // (A packed-row kernel for two bf16 operands - v_perm transpose, v_dot2 column sums, two slabs in flight, 5x fewer staging VALU
   //  instructions, bit-identical G - was built and measured in round 4: 182.55 vs 182.55 utt/s, no gain; git history 'gemm_tn16'.
   //  The contraction is not bound by its staging arithmetic.)
-  // two bf16 operands, whole 128 x 128 tiles: the LDS-DMA + transposing-read kernel (gemm_tn16_kernel; SEPR_TN16=0 keeps the register-staged form)
-  const bool tn16 = x3 == 2 && !gen && !a.stats && a.a16 && a.b16 && a.N % TN_T == 0 && a.K % TN_T == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 &&
-                    (long long)a.M * a.lda * 2 < (1LL << 32) && (long long)a.M * a.ldb * 2 < (1LL << 32) &&
-                    ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0 && knob(SEPR_KNOB_TN16) != 0;
-  if (tn16) hipLaunchKernelGGL(gemm_tn16_kernel, dim3(grid), dim3(TN_THREADS), 0, s, a, p, part, cp);
+  // plain operands, whole 128 x 128 tiles, plain-bf16 arithmetic: the LDS-DMA kernel (gemm_tnd_kernel; SEPR_TN16=0 keeps the register-staged form,
+  // SEPR_TN16=1 (default) takes launches with two bf16 operands only, 2 fp32 / mixed operands too - measured not faster, profiles/r06_wgrad_dma.txt)
+  const int tnd_knob = knob(SEPR_KNOB_TN16);
+  const bool tnd = x3 == 2 && !gen && !a.stats && a.N % TN_T == 0 && a.K % TN_T == 0 && a.lda % (a.a16 ? 8 : 4) == 0 && a.ldb % (a.b16 ? 8 : 4) == 0 &&
+                   (long long)a.M * a.lda * (a.a16 ? 2 : 4) < (1LL << 32) && (long long)a.M * a.ldb * (a.b16 ? 2 : 4) < (1LL << 32) &&
+                   ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0 && (tnd_knob >= 2 || (tnd_knob == 1 && a.a16 && a.b16));
+  if (tnd) {
+    if (a.a16 && a.b16) hipLaunchKernelGGL((gemm_tnd_kernel<false, false>), dim3(gridr), dim3(TN_THREADS), 0, s, a, p, part, cp, grid, red);
+    else if (a.a16) hipLaunchKernelGGL((gemm_tnd_kernel<false, true>), dim3(gridr), dim3(TN_THREADS), 0, s, a, p, part, cp, grid, red);
+    else if (a.b16) hipLaunchKernelGGL((gemm_tnd_kernel<true, false>), dim3(gridr), dim3(TN_THREADS), 0, s, a, p, part, cp, grid, red);
+    else hipLaunchKernelGGL((gemm_tnd_kernel<true, true>), dim3(gridr), dim3(TN_THREADS), 0, s, a, p, part, cp, grid, red);
+  }
   else if (x3 == 2) SEPR_TN_LAUNCH(2);
   else if (x3) SEPR_TN_LAUNCH(1);
   else SEPR_TN_LAUNCH(0);
@@ -660,10 +796,11 @@ int launch_gemm_tn(const TnArgs& a, int x3, void* ws, size_t ws_bytes, hipStream
     // both operands once (bf16 sources: 2 bytes per element) + the statistics: what a contraction over M rows has to read
     prof_bytes((double)a.M * ((double)a.N * (a.a16 ? 2.0 : 4.0) + (double)a.K * (a.b16 ? 2.0 : 4.0) + (a.stats ? 8.0 : 0.0)));
   }
-  const long long total = (long long)a.N * a.K + a.N;
-  const int rgrid = (int)((total + 63) / 64);
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, cpart, p.nsplit, a.N, a.K, a.G, a.ldg, a.accumulate,
-                     a.colsum, a.colsum_accumulate);
+  if (defer_red) {
+    g_pend.valid = true; g_pend.job = mine; g_pend.stream = s;
+  } else {
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(mine.nblocks), dim3(256), 0, s, mine);
+  }
   SEPR_CHECK_LAUNCH("gemm_tn_kernel");
   return SEPR_OK;
 }

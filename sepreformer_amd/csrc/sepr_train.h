@@ -204,6 +204,12 @@ int launch_finish_linear_ls(const float* Gr, const float* s, const float* W, con
 // table travels by value in the kernel arguments).  fin_alloc hands out arena slots for G / s; inputs anywhere else keep the immediate launch.
 float* fin_alloc(size_t count);      // nullptr: no window open on this thread, or the arena is full
 int fin_flush(hipStream_t st);       // launches and empties the queue (the window stays open)
+bool fin_defers(const void* p);      // p lives in the open window's arena: nothing reads it before the flush
+// Riding reduction (sepr_gemm_tn.hip): the split-M reduction of a contraction whose outputs live in the window's arena waits for the next
+// contraction's launch; tn_flush_pending runs a waiting one on its own (every flush does), tn_parts_set registers / clears the double buffer
+// of partial tiles (include/sepr.h sepr_train_defer_parts)
+int tn_flush_pending();
+void tn_parts_set(void* parts, size_t bytes);
 
 // Weight-gradient side stream (round 6; include/sepr.h sepr_train_wgrad_stream).  Nothing in a backward walk reads what the weight-gradient
 // contractions write (parameter gradients, or arena slots of the deferred finishers), so while a side stream is registered on the calling

@@ -1553,6 +1553,7 @@ bool fin_in_arena(const void* p) {
   return g_fin.open && c >= g_fin.arena && c < g_fin.arena + g_fin.bytes;
 }
 }  // namespace
+bool fin_defers(const void* p) { return fin_in_arena(p); }
 float* fin_alloc(size_t count) {
   if (!g_fin.open) return nullptr;
   const size_t o = align_up(g_fin.off), n = count * sizeof(float);
@@ -1566,6 +1567,7 @@ int fin_flush(hipStream_t st) {
   // earlier job it clashes with.  Every destination therefore sees its additions in the immediate form's order - bit-identical gradients.
   // The last batch that writes each destination is tracked over the WHOLE queue (round 6; rounds 5's 16-job look-back would have let two
   // accumulations into one tensor more than 16 jobs apart - a tied weight, a block reused across levels - share a launch).
+  SEPR_TRY(tn_flush_pending());        // the last contraction's reduction (riding reduction, sepr_gemm_tn.hip): the finishers read its G
   const size_t nj = g_fin.jobs.size();
   std::unordered_map<const float*, int> last_batch;      // destination -> batch of the last queued job that accumulates into it
   std::vector<int> batch_of(nj, 0), fill;
@@ -1707,6 +1709,15 @@ extern "C" int sepr_train_defer_begin(void* arena, size_t arena_bytes) {
   g_fin.bytes = arena_bytes;
   g_fin.off = 0;
   g_fin.jobs.clear();
+  tn_parts_set(nullptr, 0);
+  return SEPR_OK;
+}
+extern "C" int sepr_train_defer_parts(void* parts, size_t parts_bytes) {
+  using namespace sepr;
+  if (!g_fin.open) return SEPR_EINVAL;                 // (the double buffer belongs to a window: sepr_train_defer_begin first)
+  if (parts && (parts_bytes < 4096 || ((uintptr_t)parts & 255))) return SEPR_EINVAL;
+  SEPR_TRY(tn_flush_pending());
+  tn_parts_set(parts, parts ? parts_bytes : 0);
   return SEPR_OK;
 }
 extern "C" int sepr_train_defer_flush(int close, sepr_stream_t stream) {
@@ -1714,6 +1725,9 @@ extern "C" int sepr_train_defer_flush(int close, sepr_stream_t stream) {
   wgrad_join(static_cast<hipStream_t>(stream));      // the queued finishers read what the side stream's reductions wrote
   if (!g_fin.open) return SEPR_OK;
   const int rc = fin_flush(static_cast<hipStream_t>(stream));
-  if (close) g_fin.open = false;
+  if (close) {
+    g_fin.open = false;
+    tn_parts_set(nullptr, 0);
+  }
   return rc;
 }

@@ -177,6 +177,7 @@ SIGNATURES = {
     "sepr_train_fold_bias": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp]),
     "sepr_train_defer_begin": (_i, [_fp, _sz]),
     "sepr_train_defer_flush": (_i, [_i, _fp]),
+    "sepr_train_defer_parts": (_i, [_fp, _sz]),
     "sepr_train_wgrad_stream": (_i, [_fp]),
     "sepr_train_wgrad_join": (_i, [_fp]),
     "sepr_train_wgrad_mark": (_i, [_i]),

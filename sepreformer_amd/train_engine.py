@@ -41,6 +41,11 @@ class TrainEngine:
         self._sizes: Dict[tuple, int] = {}      # sepr_train_ctx_bytes / sepr_train_ws_bytes per (kind, op, shape): one C call each, ever
         self._fin_arena: Optional[torch.Tensor] = None      # deferred-finisher arena (backward)
         self._defer = os.environ.get("SEPR_TRAIN_DEFER", "1") != "0"           # A/B switch of the deferred finishers
+        # riding reductions (include/sepr.h sepr_train_defer_parts; needs the deferred finishers): built, bit-identical, measured NOT faster - the
+        # appended blocks occupy full workgroup slots of the contraction kernel and a reduction is 33 MB of traffic wherever it runs
+        # (profiles/r06_wgrad_dma.txt) - off by default, SEPR_TRAIN_RIDE=1 enables
+        self._ride = os.environ.get("SEPR_TRAIN_RIDE", "0") == "1"
+        self._parts: Optional[torch.Tensor] = None          # double buffer of partial tiles (riding reductions)
         # Weight-gradient side stream (round 6, include/sepr.h sepr_train_wgrad_stream; SEPR_TRAIN_WGRAD_STREAM=1, OFF by default): inside backward()
         # the contractions run on a second stream beside the input-gradient chain; two workspaces alternate between consecutive block calls (a
         # call's workspace is still read by its side-stream contractions after it returns).  Bit-identical gradients, all 149 training tests
@@ -367,6 +372,12 @@ class TrainEngine:
             self._fin_arena = torch.empty(int(1.25 * 4 * n_par) + (8 << 20), dtype=torch.uint8, device=self.device)
         st_ = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.sepr_train_defer_begin(self._fin_arena.data_ptr(), self._fin_arena.numel()), "sepr_train_defer_begin")
+        if self._ride and not self._wg_on:
+            # riding reductions (include/sepr.h sepr_train_defer_parts): the partial tiles of a contraction wait in one half of this double
+            # buffer for the next contraction's launch, which runs their reduction in appended blocks (~290 launches fewer per step)
+            if self._parts is None:
+                self._parts = torch.empty(2 * (40 << 20), dtype=torch.uint8, device=self.device)
+            L.check(self.lib.sepr_train_defer_parts(self._parts.data_ptr(), self._parts.numel()), "sepr_train_defer_parts")
         try:
             self._backward_walk(tape, dims, d_wav, d_aux, tp, p_drop, on_decoder_done)
         except BaseException:

@@ -2023,11 +2023,18 @@ def test_deferred_finishers_equal_immediate(precision):
     g_def = grads()
     eng = m.__dict__["_train_engine"]
     assert eng._fin_arena is not None and eng._fin_arena.numel() > (32 << 20)
+    eng._ride = True                      # (off by default - measured not faster; the deferred runs below exercise it)
+    g_def = grads()
     big = eng._fin_arena
     eng._fin_arena = torch.empty(4096, dtype=torch.uint8, device=dev)          # no slot fits: every finisher launches immediately
     g_imm = grads()
     eng._fin_arena = big
     g_def2 = grads()
-    bad = [k for k in g_def if not (torch.equal(g_def[k], g_imm[k]) and torch.equal(g_def[k], g_def2[k]))]
+    # round 6, riding reductions (sepr_train_defer_parts): in the deferred runs above the split-M reduction of a contraction ran in blocks appended
+    # to the next contraction's launch; switched off, every reduction is its own launch again - the same arithmetic either way
+    assert eng._ride and eng._parts is not None
+    eng._ride = False
+    g_noride = grads()
+    bad = [k for k in g_def if not (torch.equal(g_def[k], g_imm[k]) and torch.equal(g_def[k], g_def2[k]) and torch.equal(g_def[k], g_noride[k]))]
     assert not bad, bad[:8]
     assert all(torch.isfinite(v).all() for v in g_def.values())
