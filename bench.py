@@ -174,7 +174,7 @@ PMC_KERNEL_RE = "gcfn_fused3_kernel<[0-9]+, [0-9], [0-9], 0, false, false, [0-9]
 
 
 LARGE_KERNEL_RE = "gcfn_fused3_kernel<256, 2, 4, 0, false, false, 0>"       # Large: the fused F = 256 GCFN (round 6; before: gemm_x3w?_kernel<1, 7, 1>)
-TN_KERNEL_RE = "gemm_tn_kernel"      # every instantiation of the weight-gradient contraction (the training line's roofline kernel)
+TN_KERNEL_RE = "gemm_tnd?_kernel"    # every instantiation of the weight-gradient contraction, register-staged and LDS-DMA (the training line's roofline kernel)
 
 
 def measure_pmc_traffic(budget_s=90.0, kernel_re=None, sub_args=None):
@@ -723,7 +723,7 @@ def main():
                         roof["traffic"] = round(pm["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"])
                         roof["traffic_over_algorithmic"] = pm["traffic_over_algorithmic"]
                         roof["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) over the "
-                                                  f"{pm['launches']} gemm_tn launches of an eager sub-run at the same batch and arithmetic; FETCH_SIZE x2 (gfx950 correction of "
+                                                  f"{pm['launches']} gemm_tn / gemm_tnd launches of an eager sub-run at the same batch and arithmetic; FETCH_SIZE x2 (gfx950 correction of "
                                                   f"MI355X_MICROARCH.md), KiB units; fetch {pm['fetch_bytes_per_launch']} + write {pm['write_bytes_per_launch']} B per launch "
                                                   f"there = {pm['traffic_over_algorithmic']} x the algorithmic operand bytes (the write side is the split-M partial tiles)")
                     else:

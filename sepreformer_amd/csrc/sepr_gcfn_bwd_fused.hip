@@ -51,6 +51,43 @@ __device__ __forceinline__ void gb_wait_vm2(gb_u32x4& a, gb_u32x4& b) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 
+#ifndef SEPR_GB_PL_WGS
+#define SEPR_GB_PL_WGS 3   // workgroups per CU the plane-staged (PL) middle kernel is compiled and launched for
+#endif
+#ifndef SEPR_GB_REGEPI
+#define SEPR_GB_REGEPI 0   // 0 (product): the row-window epilogue of gcfn_bwd_mid_kernel through LDS tiles (rounds 2-5); 1: in registers (round 6, second session:
+                           // built, bit-identical outputs, measured equal at two workgroups per CU and slower at three - hipcc spills 50-60 registers into
+                           // the 168 of the three-workgroup regime; tools/variants.mk gbepi2w / gbepi3w, profiles/r06_gcfn_bwd_regepi.txt)
+#endif
+// slab row s = mt * 16 + fi of the middle kernel holds frame 4 fi + mt of the tile (REGEPI) - so that frame neighbours are a lane's own
+// accumulator tiles or one DPP row shift away - or frame s (LDS epilogue)
+__device__ __forceinline__ int gb_frame(int s) { return SEPR_GB_REGEPI ? 4 * (s & 15) + (s >> 4) : s; }
+// DPP row shifts (16-lane rows): lane i <- lane i - 1 / i + 1; the lane without a source gets 0
+__device__ __forceinline__ float gb_shr1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float gb_shl1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float2 ld2g(const float* p) { return *reinterpret_cast<const float2*>(p); }
+// two fp32 -> one bf16x2 word (round to nearest even, the conversion gb_store4 applies): low half = a
+__device__ __forceinline__ unsigned gb_pack2(float a, float b) {
+  typedef __bf16 gb_bf16x2 __attribute__((ext_vector_type(2)));
+  const gb_bf16x2 h = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float4 gb_shr4(float4 v) { return make_float4(gb_shr1(v.x), gb_shr1(v.y), gb_shr1(v.z), gb_shr1(v.w)); }
+__device__ __forceinline__ float4 gb_shl4(float4 v) { return make_float4(gb_shl1(v.x), gb_shl1(v.y), gb_shl1(v.z), gb_shl1(v.w)); }
+// inclusive scan over the 16 lanes of a DPP row (row_shr 1, 2, 4, 8; lanes shifted in from outside the row add 0): lane 15 holds the row's sum
+__device__ __forceinline__ float gb_row_total(float v) {
+#pragma clang fp contract(off)
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false));
+  return v;
+}
+
 namespace {
 template <bool V>
 struct gb_bool { static constexpr bool value = V; };
@@ -131,18 +168,19 @@ struct GcfnBwdArgs {
 // tile-ahead prefetch: the kernel fits three workgroups per CU (51 KB of LDS each), which cover the DMA latency a tile now pays at its
 // start (the slab buffers alias the epilogue tiles, so the next tile's slabs cannot fly under the epilogue).
 template <int PLANES, int NSL, bool PL = false>
-__global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(const GcfnBwdArgs a) {
+__global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_mid_kernel(const GcfnBwdArgs a) {
   constexpr bool ONE = PLANES == 1;
   static_assert(!PL || ONE, "plane staging exists for the plain-bf16 arithmetic");
   constexpr int NP = ONE ? 1 : 2;                              // bf16 planes per LDS buffer
   constexpr int PLANE_E = GB_BM * GB_LDK;                      // elements of one plane
   constexpr int DMA_PER_WAVE = GB_BM * 128 / 1024 / 4;                  // PL: LDS-DMA instructions per wave and slab (2)
   constexpr size_t SLAB_B = PL ? (size_t)2 * NSL * GB_BM * 128 : sizeof(unsigned short) * 2 * NP * PLANE_E;
-  constexpr size_t TILE_B = sizeof(float) * GB_BM * (GB_HS + GB_DS);
+  // (the LDS epilogue's tiles, or the register epilogue's 6 parked 16-byte chunks per thread, alias the slab buffers)
+  constexpr size_t TILE_B = SEPR_GB_REGEPI ? (size_t)6 * GB_THREADS * 16 : sizeof(float) * GB_BM * (GB_HS + GB_DS);
   __shared__ __attribute__((aligned(16))) unsigned char smem[SLAB_B > TILE_B ? SLAB_B : TILE_B];
   unsigned short* const slab = reinterpret_cast<unsigned short*>(smem);
-  float* const Hs = reinterpret_cast<float*>(smem);            // [64][GB_HS]: h1 (+ b1), later dc   (aliases the slab buffers)
-  float* const Ds = Hs + GB_BM * GB_HS;                        // [64][GB_DS]: dgd, later the reduction scratch
+  [[maybe_unused]] float* const Hs = reinterpret_cast<float*>(smem);            // [64][GB_HS]: h1 (+ b1), later dc   (aliases the slab buffers)
+  [[maybe_unused]] float* const Ds = Hs + GB_BM * GB_HS;                        // [64][GB_DS]: dgd, later the reduction scratch
 
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int fi = lane & 15, fg = lane >> 4;
@@ -187,7 +225,7 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
 #pragma unroll
       for (int i = 0; i < DMA_PER_WAVE; ++i) {
         const int pos = (wn * DMA_PER_WAVE + i) * 64 + lane, row = pos >> 3, c = (pos & 7) ^ (row & 7);
-        int msn = mb_ * GB_OUT - 2 + row;
+        int msn = mb_ * GB_OUT - 2 + gb_frame(row);
         msn = msn < 0 ? 0 : (msn > a.M - 1 ? a.M - 1 : msn);
         const unsigned off = (unsigned)msn * (unsigned)(2 * F) + (unsigned)(c * 16);     // M * F * 2 < 2^32 (checked by the launcher)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(plane + off),
@@ -197,7 +235,7 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
   };
   auto load_tile = [&](int mb_) {
     if constexpr (PL) return;
-    const int msn = mb_ * GB_OUT - 2 + srow;
+    const int msn = mb_ * GB_OUT - 2 + gb_frame(srow);
     const long long row = (msn >= 0 && msn < a.M) ? msn : 0;
     const float* px = a.x + row * F + kq;
     const float* pd = a.dy + row * F + kq;
@@ -215,7 +253,8 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
   if (tile < ntiles) load_tile(mb);
   while (tile < ntiles) {
     const int m0 = mb * GB_OUT;
-    const int ms = m0 - 2 + srow;                              // the row this thread stages
+    const int sfr = gb_frame(srow);                            // frame (of the tile) in slab row srow
+    const int ms = m0 - 2 + sfr;                               // the row this thread stages
     const bool svalid = ms >= 0 && ms < a.M;
     const float mean = rst.x, rstd = rst.y;
     auto store_slab = [&](int q) {
@@ -237,7 +276,7 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
             v[e + 1] = (d >> 16) >= a.drop_thr ? v[e + 1] * a.drop_scale : 0.f;
           }
           // one column block writes dropout1(dy) for the weight-gradient contraction of net2.2 (output rows only)
-          if (a.dyq && nb == 0 && srow >= 2 && srow < 2 + GB_OUT && svalid) {
+          if (a.dyq && nb == 0 && sfr >= 2 && sfr < 2 + GB_OUT && svalid) {
             float* o = a.dyq + (long long)ms * F + f0c;
 #pragma unroll
             for (int j = 0; j < 4; ++j) st4(o + 4 * j, make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]));
@@ -387,6 +426,188 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
         if (q + 2 < 2 * nsl) load_wq(q + 2, wset[q & 1]);      // this step's fragment registers are free again
       }
     }
+#if SEPR_GB_REGEPI
+    // ---- epilogue in registers (round 6) -------------------------------------------------------------------------------------------
+    // The accumulators already hold what the row window needs: lane (fi, fg) of wave wn has, per slab-row tile mt, the 4 hidden channels
+    // 64 nb + 16 wn + 4 fg + r of ONE frame - value, gate and dgd.  With slab row mt * 16 + fi holding frame 4 fi + mt (the copy's row map,
+    // gb_frame), the previous / next frame of a lane's tile mt is its own tile mt -+ 1; across the 4-frame seams it is the neighbouring lane's
+    // tile 3 / tile 0 - ONE DPP row shift, and the two lanes without a neighbour (fi = 0 / 15) are the two halo frames at the tile's ends whose
+    // dc is never used.  So the h1 / dgd / dc tiles, their 5 barriers, ~260 KB of LDS traffic per tile and the 64 ds_bpermute of the partial
+    // sums are gone (rounds 2-5 form: -DSEPR_GB_REGEPI=0, tools/variants.mk gbepi0); the depthwise partial sums reduce over the 16 frame lanes of
+    // a DPP row (each wave owns its own 16 channel pairs: no cross-wave step).  Element arithmetic unchanged (same fmaf order as the LDS form).
+    // Register diet (the plane-staged kernel has 168 per lane at three workgroups per CU): the 4 channels of a lane are walked as two PAIRS -
+    // taps, dc values and partial sums of one pair live at a time (a pair is also one dropout word and one packed bf16x2 output register).
+    // the next tile of this workgroup (register-staged forms: its activation slabs go in flight now, under the epilogue below)
+    // The second channel pair's inputs wait in LDS - the slab buffers are dead once every wave has left the MFMA phase; each lane parks and
+    // later re-reads ITS OWN 24 values (6 conflict-free 16-byte chunks, chunk j of thread t at (256 j + t) x 16 B): no exchange, no further barrier
+    __syncthreads();
+    {
+      float4* const pk = reinterpret_cast<float4*>(smem) + tid;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) pk[256 * mt] = make_float4(hv[mt][2], hv[mt][3], hg[mt][2], hg[mt][3]);
+      pk[256 * 4] = make_float4(dd[0][2], dd[0][3], dd[1][2], dd[1][3]);
+      pk[256 * 5] = make_float4(dd[2][2], dd[2][3], dd[3][2], dd[3][3]);
+    }
+    int nxt = tile + gridDim.x, mb_n = 0, nb_n = 0;
+    while (nxt < ntiles && !decode(nxt, mb_n, nb_n)) nxt += gridDim.x;
+    if (nxt < ntiles) load_tile(mb_n);
+    const int cl = wn * 16 + 4 * fg, hc = 64 * nb + cl;          // hidden value channel of accumulator element 0 (gate: C3 + hc)
+    const int C6 = 2 * C3;
+    const int lo_t = (m0 >= 1) ? (m0 - 1) % a.T : 0;
+    const bool edge_tile = !(m0 >= 2 && lo_t >= 1 && lo_t + 62 <= a.T - 2 && m0 + GB_BM - 2 <= a.M);
+    constexpr bool as16 = ONE;            // (the launcher stores g / dh1 as bf16 exactly for the plain-bf16 arithmetic and checks it: out16 == ONE)
+    auto passes = [&](auto edge_c) {
+#pragma clang fp contract(off)
+      constexpr bool EDGE = decltype(edge_c)::value;
+      // outputs of the lane's 4 frames x 4 channels, held until both pairs are done (8- / 16-byte stores): bf16x2 words (as16) or floats
+      [[maybe_unused]] unsigned gP[4][2], ovP[4][2], ogP[4][2];
+      [[maybe_unused]] float gF[4][4], ovF[4][4], ogF[4][4];
+      float f0s[4], f2s[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        f0s[mt] = 1.f;
+        f2s[mt] = 1.f;
+        if constexpr (EDGE) {                                  // zero padding at the sequence ends (tiles that touch one: ~1 in 130)
+          const int m = m0 - 2 + 4 * fi + mt, t = (m >= 0 ? m : 0) % a.T;
+          f0s[mt] = t > 0 ? 1.f : 0.f;
+          f2s[mt] = t < a.T - 1 ? 1.f : 0.f;
+        }
+      }
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {                          // channels hc + 2 pr, hc + 2 pr + 1
+        asm volatile("" ::: "memory");                         // (keeps the second pair's tap loads behind the first pair's work: registers)
+        __builtin_amdgcn_sched_barrier(0);
+        const int hp = hc + 2 * pr;
+        const float2 bv = ld2g(a.b1 + hp), bg = ld2g(a.b1 + C3 + hp);
+        const float2 wv0 = ld2g(a.dw_w + hp), wv1 = ld2g(a.dw_w + C6 + hp), wv2 = ld2g(a.dw_w + 2 * C6 + hp);
+        const float2 wg0 = ld2g(a.dw_w + C3 + hp), wg1 = ld2g(a.dw_w + C6 + C3 + hp), wg2 = ld2g(a.dw_w + 2 * C6 + C3 + hp);
+        const float2 cbv = ld2g(a.dw_b + hp), cbg = ld2g(a.dw_b + C3 + hp);
+        float Hv[4][2], Hg[4][2], Dd[4][2];
+        if (pr == 0) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            Hv[mt][0] = hv[mt][0] + bv.x; Hv[mt][1] = hv[mt][1] + bv.y;
+            Hg[mt][0] = hg[mt][0] + bg.x; Hg[mt][1] = hg[mt][1] + bg.y;
+            Dd[mt][0] = dd[mt][0]; Dd[mt][1] = dd[mt][1];
+          }
+        } else {
+          const float4* const pk = reinterpret_cast<const float4*>(smem) + tid;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const float4 q = pk[256 * mt];
+            Hv[mt][0] = q.x + bv.x; Hv[mt][1] = q.y + bv.y;
+            Hg[mt][0] = q.z + bg.x; Hg[mt][1] = q.w + bg.y;
+          }
+          const float4 q4 = pk[256 * 4], q5 = pk[256 * 5];
+          Dd[0][0] = q4.x; Dd[0][1] = q4.y; Dd[1][0] = q4.z; Dd[1][1] = q4.w;
+          Dd[2][0] = q5.x; Dd[2][1] = q5.y; Dd[3][0] = q5.z; Dd[3][1] = q5.w;
+        }
+        float dcv[4][2], dcg[4][2], acc[2][8];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[e][k] = 0.f;
+        const float pv0[2] = {gb_shr1(Hv[3][0]), gb_shr1(Hv[3][1])}, pg0[2] = {gb_shr1(Hg[3][0]), gb_shr1(Hg[3][1])};   // frame 4 fi - 1
+        const float nv3[2] = {gb_shl1(Hv[0][0]), gb_shl1(Hv[0][1])}, ng3[2] = {gb_shl1(Hg[0][0]), gb_shl1(Hg[0][1])};   // frame 4 fi + 4
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int fo = 4 * fi + mt, m = m0 - 2 + fo;
+          const bool has_dc = fo >= 1 && fo <= GB_BM - 2 && m >= 0 && m < a.M;
+          const bool own = fo >= 2 && fo < 2 + GB_OUT && m < a.M;      // rows this tile outputs
+          float keep[2] = {1.f, 1.f};
+          if (drop) {                                          // network.py:55: mask of the gated tensor, element (m, hp + e)
+            const unsigned d0 = sepr_drop_word(dk0, (unsigned)m, (unsigned)(hp >> 1));
+            keep[0] = (d0 & 0xffffu) >= a.drop_thr ? a.drop_scale : 0.f;
+            keep[1] = (d0 >> 16) >= a.drop_thr ? a.drop_scale : 0.f;
+          }
+          float gd[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float w0v = e ? wv0.y : wv0.x, w1v = e ? wv1.y : wv1.x, w2v = e ? wv2.y : wv2.x, cbvv = e ? cbv.y : cbv.x;
+            const float w0g = e ? wg0.y : wg0.x, w1g = e ? wg1.y : wg1.x, w2g = e ? wg2.y : wg2.x, cbgg = e ? cbg.y : cbg.x;
+            float hvm = mt > 0 ? Hv[mt > 0 ? mt - 1 : 0][e] : pv0[e], hgm = mt > 0 ? Hg[mt > 0 ? mt - 1 : 0][e] : pg0[e];
+            float hvp = mt < 3 ? Hv[mt < 3 ? mt + 1 : 3][e] : nv3[e], hgp = mt < 3 ? Hg[mt < 3 ? mt + 1 : 3][e] : ng3[e];
+            const float hvc = Hv[mt][e], hgc = Hg[mt][e];
+            if constexpr (EDGE) {
+              hvm *= f0s[mt]; hgm *= f0s[mt];
+              hvp *= f2s[mt]; hgp *= f2s[mt];
+            }
+            const float cv = fmaf(w2v, hvp, fmaf(w1v, hvc, fmaf(w0v, hvm, cbvv)));
+            const float cg = fmaf(w2g, hgp, fmaf(w1g, hgc, fmaf(w0g, hgm, cbgg)));
+            const float sg = sigmoid_f(cg);
+            gd[e] = cv * sg * keep[e];
+            const float d = Dd[mt][e] * keep[e];
+            const float dv_ = d * sg, dg_ = d * cv * sg * (1.f - sg);
+            dcv[mt][e] = has_dc ? dv_ : 0.f;
+            dcg[mt][e] = has_dc ? dg_ : 0.f;
+            if (own) {
+              acc[e][0] = fmaf(dv_, hvm, acc[e][0]); acc[e][1] = fmaf(dv_, hvc, acc[e][1]);
+              acc[e][2] = fmaf(dv_, hvp, acc[e][2]); acc[e][3] += dv_;
+              acc[e][4] = fmaf(dg_, hgm, acc[e][4]); acc[e][5] = fmaf(dg_, hgc, acc[e][5]);
+              acc[e][6] = fmaf(dg_, hgp, acc[e][6]); acc[e][7] += dg_;
+            }
+          }
+          if constexpr (as16) gP[mt][pr] = gb_pack2(gd[0], gd[1]);
+          else { gF[mt][2 * pr] = gd[0]; gF[mt][2 * pr + 1] = gd[1]; }
+          __builtin_amdgcn_sched_barrier(0);                   // (one frame at a time: hipcc otherwise interleaves all eight and spills)
+        }
+        // ---- transpose of the conv: dh[t] = w0 dc[t+1] + w1 dc[t] + w2 dc[t-1]   (frames of OTHER sequences do not contribute: f0 / f2) ----
+        const float qv0[2] = {gb_shr1(dcv[3][0]), gb_shr1(dcv[3][1])}, qg0[2] = {gb_shr1(dcg[3][0]), gb_shr1(dcg[3][1])};
+        const float rv3[2] = {gb_shl1(dcv[0][0]), gb_shl1(dcv[0][1])}, rg3[2] = {gb_shl1(dcg[0][0]), gb_shl1(dcg[0][1])};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const float f0 = f0s[mt], f2 = f2s[mt];
+          float ov[2], og[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float w0v = e ? wv0.y : wv0.x, w1v = e ? wv1.y : wv1.x, w2v = e ? wv2.y : wv2.x;
+            const float w0g = e ? wg0.y : wg0.x, w1g = e ? wg1.y : wg1.x, w2g = e ? wg2.y : wg2.x;
+            const float pv = mt > 0 ? dcv[mt > 0 ? mt - 1 : 0][e] : qv0[e], pg = mt > 0 ? dcg[mt > 0 ? mt - 1 : 0][e] : qg0[e];
+            const float nv = mt < 3 ? dcv[mt < 3 ? mt + 1 : 3][e] : rv3[e], ng = mt < 3 ? dcg[mt < 3 ? mt + 1 : 3][e] : rg3[e];
+            ov[e] = fmaf(w0v * f2, nv, fmaf(w1v, dcv[mt][e], (w2v * f0) * pv));
+            og[e] = fmaf(w0g * f2, ng, fmaf(w1g, dcg[mt][e], (w2g * f0) * pg));
+          }
+          if constexpr (as16) { ovP[mt][pr] = gb_pack2(ov[0], ov[1]); ogP[mt][pr] = gb_pack2(og[0], og[1]); }
+          else { ovF[mt][2 * pr] = ov[0]; ovF[mt][2 * pr + 1] = ov[1]; ogF[mt][2 * pr] = og[0]; ogF[mt][2 * pr + 1] = og[1]; }
+        }
+        // depthwise gradient partials of this tile and pair: sum over the 16 lanes (frames) of each DPP row - an inclusive scan, lane 15 ends up
+        // with the row's total - and one 64-byte store per row: part[mb][pair hp + e][8]
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[e][k] = gb_row_total(acc[e][k]);
+        if (fi == 15) {
+          float* po = reinterpret_cast<float*>(reinterpret_cast<char*>(a.part) + ((unsigned)mb * (unsigned)C3 + (unsigned)hp) * 32u);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            st4(po + 8 * e, make_float4(acc[e][0], acc[e][1], acc[e][2], acc[e][3]));
+            st4(po + 8 * e + 4, make_float4(acc[e][4], acc[e][5], acc[e][6], acc[e][7]));
+          }
+        }
+      }
+      // ---- the lane's output rows: g [M][3F], dh1 [M][6F] (value half, gate half); 32-bit byte offsets from the (scalar) tensor bases - the
+      //      launcher checks M * 6F * 4 < 2^32 - so that no 64-bit per-lane address is formed early and kept alive (or spilled) ----
+      char* const gB = static_cast<char*>(a.g);
+      char* const hB = static_cast<char*>(a.dh1);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int fo = 4 * fi + mt, m = m0 - 2 + fo;
+        if (!(fo >= 2 && fo < 2 + GB_OUT && m < a.M)) continue;
+        if constexpr (as16) {
+          const unsigned og_ = ((unsigned)m * (unsigned)C3 + (unsigned)hc) * 2u, oh_ = ((unsigned)m * (unsigned)C6 + (unsigned)hc) * 2u;
+          *reinterpret_cast<uint2*>(gB + og_) = make_uint2(gP[mt][0], gP[mt][1]);
+          *reinterpret_cast<uint2*>(hB + oh_) = make_uint2(ovP[mt][0], ovP[mt][1]);
+          *reinterpret_cast<uint2*>(hB + oh_ + (unsigned)C3 * 2u) = make_uint2(ogP[mt][0], ogP[mt][1]);
+        } else {
+          const unsigned og_ = ((unsigned)m * (unsigned)C3 + (unsigned)hc) * 4u, oh_ = ((unsigned)m * (unsigned)C6 + (unsigned)hc) * 4u;
+          *reinterpret_cast<float4*>(gB + og_) = make_float4(gF[mt][0], gF[mt][1], gF[mt][2], gF[mt][3]);
+          *reinterpret_cast<float4*>(hB + oh_) = make_float4(ovF[mt][0], ovF[mt][1], ovF[mt][2], ovF[mt][3]);
+          *reinterpret_cast<float4*>(hB + oh_ + (unsigned)C3 * 4u) = make_float4(ogF[mt][0], ogF[mt][1], ogF[mt][2], ogF[mt][3]);
+        }
+      }
+    };
+    if (edge_tile) passes(gb_bool<true>{}); else passes(gb_bool<false>{});
+#else
     __syncthreads();   // every wave is done with the slab buffers: they become the h1 / dgd tiles
 
     // ---- stage h1 (+ bias) and dgd: row = frame, a lane holds 4 consecutive channels of one frame per accumulator ----
@@ -553,6 +774,7 @@ __global__ __launch_bounds__(GB_THREADS, PL ? 3 : 2) void gcfn_bwd_mid_kernel(co
         po[o] = (d[0] + d[16 * GB_RS]) + (d[32 * GB_RS] + d[48 * GB_RS]);
       }
     }
+#endif
     tile = nxt;
     mb = mb_n;
     nb = nb_n;
@@ -632,11 +854,12 @@ int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, i
   long long slot = -1;
   const bool timed = prof_begin(SEPR_SITE_GCFN_BWD, st, &slot);
   const bool one = w->up.planes == 1;
+  if (SEPR_GB_REGEPI && ((out16 != 0) != one || M * 6LL * F * 4 >= (1LL << 32))) return SEPR_EINVAL;   // (the register epilogue: bf16 outputs <=> plain-bf16 arithmetic; 32-bit store offsets)
   a.xh16 = static_cast<const unsigned short*>(xh16);
   a.dy16 = static_cast<const unsigned short*>(dy16);
   const bool pl = one && xh16 && dy16;
   if (pl) {
-    const int g3 = (ntiles < cap / 2 * 3) ? ntiles : cap / 2 * 3;   // three workgroups per CU
+    const int g3 = (ntiles < cap / 2 * SEPR_GB_PL_WGS) ? ntiles : cap / 2 * SEPR_GB_PL_WGS;   // SEPR_GB_PL_WGS workgroups per CU
     if (F == 128) hipLaunchKernelGGL((gcfn_bwd_mid_kernel<1, 2, true>), dim3(g3), dim3(GB_THREADS), 0, st, a);
     else hipLaunchKernelGGL((gcfn_bwd_mid_kernel<1, 1, true>), dim3(g3), dim3(GB_THREADS), 0, st, a);
   } else if (F == 128) {

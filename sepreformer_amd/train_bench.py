@@ -243,7 +243,7 @@ def run(variant, precision, B, steps, warmup, rank, world, dev, share, graphs=Tr
             # The contraction over M = batch x frames rows reads both operands once for a [N,K] result with N, K <= 1024: at
             # 2 N K / (4 (N + K)) = 50-130 FLOP per byte it sits under the ridge of the bf16 MFMA (312 FLOP/B) - HBM is its roofline.
             # achieved = algorithmic bytes of the timed launches / their hipEvent durations; the matrix-pipe view rides along.
-            "roofline": {"kernel": "gemm_tn_kernel (weight-gradient contraction G[N][K] = sum_m dY[m][n] X[m][k], all 299 projections of a step)",
+            "roofline": {"kernel": "gemm_tn_kernel / gemm_tnd_kernel (weight-gradient contraction G[N][K] = sum_m dY[m][n] X[m][k], all 299 projections of a step; two bf16 operands: LDS-DMA ring + ds_read_b64_tr_b16)",
                          "bound": "hbm", "achieved": round(algo_bytes / 1e9 / sec, 1) if sec > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(algo_bytes / 1e9 / sec / HBM_PEAK_GBS, 4) if sec > 0 else 0.0,
                          "algorithmic_tflops": round(algo_tf, 2), "mfma_pipe_frac": round(mult * algo_tf / peak, 4),

@@ -69,3 +69,8 @@ VARIANT_gfnofence = -DSEPR_GF3_FENCE256=0
 VARIANT_hsa512 = -DSEPR_GF_ABL=512
 VARIANT_hsa1024 = -DSEPR_GF_ABL=1024
 VARIANT_hsa1536 = -DSEPR_GF_ABL=1536
+# round 6, second session: row-window epilogue of gcfn_bwd_mid_kernel - gbepi0 = through LDS tiles (the rounds 2-5 form), gbepi2w / gbepi3w = in registers with the
+# plane-staged kernel compiled and launched for two / three workgroups per CU (profiles/r06_gcfn_bwd_regepi.txt)
+VARIANT_gbepi0 = -DSEPR_GB_REGEPI=0 -DSEPR_GB_PL_WGS=3
+VARIANT_gbepi2w = -DSEPR_GB_REGEPI=1 -DSEPR_GB_PL_WGS=2
+VARIANT_gbepi3w = -DSEPR_GB_REGEPI=1 -DSEPR_GB_PL_WGS=3
