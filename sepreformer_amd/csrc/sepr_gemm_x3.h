@@ -29,6 +29,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef SEPR_ABL_NOLOAD
 #define SEPR_ABL_NOLOAD 0
 #endif
+#ifndef SEPR_X3_DEEP16
+#define SEPR_X3_DEEP16 1   // fp32 source rows on the single-plane arithmetic (training precision "bf16"): two slabs in flight (0: one; tools/variants.mk x3deep0)
+#endif
 #ifndef SEPR_X3_RAW16
 #define SEPR_X3_RAW16 1   // bf16 source rows on the single-plane arithmetic: raw staging, two slabs in flight (0: the widened one-slab form; tools/variants.mk x3raw0)
 #endif
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
       wbase[nt] = ok ? (unsigned)t16 * (unsigned)kst * 128u : 0u;   // 2 planes x 64 lanes per K step
     }
   };
-  auto load_slab = [&](int s) {
+  auto load_slab_to = [&](int s, float4 (&ra)[8]) {
 #if SEPR_ABL_NOLOAD
     if (s > 0 || blockIdx.x != (unsigned)a.M) return;   // timing ablation
 #endif
@@ -147,10 +150,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
 #pragma unroll
     for (int j = 0; j < 8; ++j) ra[j] = ld4(src + 4 * j);
   };
+  auto load_slab = [&](int s) { load_slab_to(s, ra); };
   // RAW (bf16 source rows on the single-plane arithmetic: the [rows, 6F] input-gradient operand of the plain-bf16 GCFN backward, K = 6F = 12
   // slabs): the slab's bf16 values ARE the LDS plane - no widening, no conversion - so a slab is 4 x 16 bytes per thread and TWO slabs are
   // kept in flight in the registers ONE widened slab took (round 6; SEPR_X3_RAW16=0: the widened one-slab form)
   constexpr bool RAW = A16 && ONE && PRO == PRO_PLAIN && (SEPR_X3_RAW16 != 0);
+  // DEEP (every other single-plane instantiation, i.e. the plain-bf16 TRAINING precision only): the same two-slabs-in-flight schedule with two
+  // fp32 register sets (+32 registers), conversion at the LDS store as before (SEPR_X3_DEEP16=0: one slab; tools/variants.mk x3deep0)
+  constexpr bool DEEP = ONE && !RAW && (SEPR_X3_DEEP16 != 0);
+  [[maybe_unused]] float4 rb[8];
   [[maybe_unused]] uint4 rq0[4], rq1[4];      // (two named sets: a runtime-indexed array would live in scratch)
   [[maybe_unused]] auto load_raw = [&](int s, uint4 (&r)[4]) {
     const unsigned short* src16 = reinterpret_cast<const unsigned short*>(a.A) + pa + (s * X3_BKS + kh);
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(hi + 8 * j) = ok ? r[j] : make_uint4(0u, 0u, 0u, 0u);
   };
-  auto store_slab = [&](int buf) {
+  auto store_slab_from = [&](int buf, const float4 (&ra)[8]) {
 #pragma clang fp contract(off)
     unsigned short* hi = smem + (buf * 2 + 0) * X3_PLANE + srow * X3_LDK + kh;
     unsigned short* lo = smem + (buf * 2 + 1) * X3_PLANE + srow * X3_LDK + kh;
@@ -183,6 +191,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
       if (!ONE) *reinterpret_cast<bf16x8*>(lo + 4 * j) = l;
     }
   };
+  auto store_slab = [&](int buf) { store_slab_from(buf, ra); };
   // weight fragments of K step ks (global, fragment order: one coalesced 1 KiB load per tile and plane)
   auto load_w = [&](int ks, uint4 (&wh)[2], uint4 (&wl)[2]) {
 #if SEPR_ABL_NOW
@@ -271,44 +280,52 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
   if (tile >= ntiles) return;
   setup(m0, nb);
   uint4 wh[2], wl[2], wh2[2], wl2[2];
-  if constexpr (RAW) {
+  if constexpr (RAW || DEEP) {
     // two slabs in flight: slab s + 2 is requested before slab s multiplies and written to LDS two barriers later.  The weight fragments of BOTH K
     // steps of the next slab are requested in front of it (vmcnt retires in order: waiting for them must not wait for the slab behind them)
     uint4 wh3[2], wh4[2];
     load_w(0, wh, wl);
     load_w(1, wh2, wl2);
-    load_raw(0, rq0);
-    if (nslab > 1) load_raw(1, rq1);
+    auto ld2 = [&](int s, auto& set) {
+      if constexpr (RAW) load_raw(s, set); else load_slab_to(s, set);
+    };
+    auto st2 = [&](int buf, const auto& set) {
+      if constexpr (RAW) store_raw(buf, set); else store_slab_from(buf, set);
+    };
+    auto& set0 = [&]() -> auto& { if constexpr (RAW) return rq0; else return ra; }();
+    auto& set1 = [&]() -> auto& { if constexpr (RAW) return rq1; else return rb; }();
+    ld2(0, set0);
+    if (nslab > 1) ld2(1, set1);
     // one slab: `mine` held slab s (in LDS since the barrier that opened this step) and takes slab s + 2, `other` holds slab s + 1
-    auto step = [&](int s, uint4 (&mine)[4], uint4 (&other)[4]) {
+    auto step = [&](int s, auto& mine, auto& other) {
       const int cur = s & 1;
       const unsigned short* ph = smem + (cur * 2 + 0) * X3_PLANE;
       if (s + 1 < nslab) {                                      // (wl / wl2 are never read in the single-plane arithmetic)
         load_w(2 * s + 2, wh3, wl);
         load_w(2 * s + 3, wh4, wl2);
       }
-      if (s + 2 < nslab) load_raw(s + 2, mine);
+      if (s + 2 < nslab) ld2(s + 2, mine);
       mma_half(ph, ph, 0, 0, wh, wl);
       mma_half(ph, ph, 0, 1, wh, wl);
       mma_half(ph, ph, 1, 0, wh2, wl2);
       mma_half(ph, ph, 1, 1, wh2, wl2);
       if (s + 1 < nslab) {
-        store_raw(cur ^ 1, other);
+        st2(cur ^ 1, other);
         wh[0] = wh3[0]; wh[1] = wh3[1];                         // the next slab's fragments (K steps 2 s + 2, 2 s + 3)
         wh2[0] = wh4[0]; wh2[1] = wh4[1];
       }
       __syncthreads();
     };
     while (true) {
-      store_raw(0, rq0);
+      st2(0, set0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       __syncthreads();
       for (int s = 0; s < nslab; s += 2) {
-        step(s, rq0, rq1);
-        if (s + 1 < nslab) step(s + 1, rq1, rq0);
+        step(s, set0, set1);
+        if (s + 1 < nslab) step(s + 1, set1, set0);
       }
       const int m0c = m0, nbc = nb;
       int nxt = tile + gridDim.x;
@@ -318,8 +335,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3_kernel(const GemmArgs
         setup(m0, nb);
         load_w(0, wh, wl);
         load_w(1, wh2, wl2);
-        load_raw(0, rq0);
-        if (nslab > 1) load_raw(1, rq1);
+        ld2(0, set0);
+        if (nslab > 1) ld2(1, set1);
       }
       epilogue(m0c, nbc);
       if (!more) break;

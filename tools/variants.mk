@@ -76,3 +76,4 @@ VARIANT_gbepi2w = -DSEPR_GB_REGEPI=1 -DSEPR_GB_PL_WGS=2
 VARIANT_gbepi3w = -DSEPR_GB_REGEPI=1 -DSEPR_GB_PL_WGS=3
 # round 6, second session: bf16-source projections of the plain-bf16 step (GCFN input gradient) with the widened one-slab staging of rounds 4-5 (A/B of the raw two-slab form)
 VARIANT_x3raw0 = -DSEPR_X3_RAW16=0
+VARIANT_x3deep0 = -DSEPR_X3_DEEP16=0
