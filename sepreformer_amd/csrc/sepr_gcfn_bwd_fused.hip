@@ -21,6 +21,7 @@
 // m0-2 .. m0+61 are computed per tile (two halo frames on each side: dh1[t] needs dc[t+-1], which needs h1[t+-2]).
 // PLANES = 3: bf16x3 split arithmetic; PLANES = 1: plain bf16 operands (the "bf16" training precision).
 #include "sepr_train.h"
+#include <stdlib.h>
 
 namespace sepr {
 
@@ -154,6 +155,10 @@ struct GcfnBwdArgs {
   // (sepr_gcfn_fused.hip xhat16), dy16 = bf16(dropout1(dy)) written by gcfn_dyplane_kernel below - and are staged by LDS-DMA
   const unsigned short* xh16;
   const unsigned short* dy16;
+  // 1: the launch is a persistent grid in which every workgroup keeps ONE column block (grid a multiple of 8 NB, more tiles than workgroups): the depthwise
+  // partials of a workgroup's tiles are summed in two registers per thread and leave ONCE, as row (first tile's mb) of part - grid / NB partial rows instead of
+  // one per row tile (4 267 at 256 000 rows), no per-tile store, a 30x smaller reduction behind the kernel (round 6)
+  int acc_part;
 };
 
 // NSL = F / 64 slabs per operand.  All 2 * NSL activation slabs of a tile (x, then dy) are requested TOGETHER, one tile ahead:
@@ -251,6 +256,9 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
   int tile = blockIdx.x, mb = 0, nb = 0;
   while (tile < ntiles && !decode(tile, mb, nb)) tile += gridDim.x;
   if (tile < ntiles) load_tile(mb);
+  [[maybe_unused]] float wacc[2] = {0.f, 0.f};                 // acc_part: this thread's two of the workgroup's 512 partial sums
+  [[maybe_unused]] const int mb_first = mb, nb_first = nb;
+  [[maybe_unused]] const bool any_tile = tile < ntiles;
   while (tile < ntiles) {
     const int m0 = mb * GB_OUT;
     const int sfr = gb_frame(srow);                            // frame (of the tile) in slab row srow
@@ -771,7 +779,9 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
       for (int h = 0; h < 2; ++h) {
         const int o = tid + GB_THREADS * h;                    // (q, slot) = (o / 32, o % 32)
         const float* d = Ds + (o >> 5) * GB_RS + (o & 31);
-        po[o] = (d[0] + d[16 * GB_RS]) + (d[32 * GB_RS] + d[48 * GB_RS]);
+        const float t = (d[0] + d[16 * GB_RS]) + (d[32 * GB_RS] + d[48 * GB_RS]);
+        if (a.acc_part) wacc[h] += t;
+        else po[o] = t;
       }
     }
 #endif
@@ -779,6 +789,13 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
     mb = mb_n;
     nb = nb_n;
   }
+#if !SEPR_GB_REGEPI
+  if (a.acc_part && any_tile) {
+    float* po = a.part + ((long long)mb_first * C3 + 64 * nb_first) * 8;
+    po[tid] = wacc[0];
+    po[tid + GB_THREADS] = wacc[1];
+  }
+#endif
 }
 }  // namespace
 
@@ -858,8 +875,15 @@ int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, i
   a.xh16 = static_cast<const unsigned short*>(xh16);
   a.dy16 = static_cast<const unsigned short*>(dy16);
   const bool pl = one && xh16 && dy16;
+  a.acc_part = 0;
+  int nslots = MB;                                                     // rows of `part` the reduction walks
   if (pl) {
     const int g3 = (ntiles < cap / 2 * SEPR_GB_PL_WGS) ? ntiles : cap / 2 * SEPR_GB_PL_WGS;   // SEPR_GB_PL_WGS workgroups per CU
+    static const bool acc_off = [] { const char* e = getenv("SEPR_GB_ACC"); return e && e[0] == '0'; }();     // (A/B switch, read once)
+    if (!SEPR_GB_REGEPI && !acc_off && ntiles > g3 && g3 % (8 * NB) == 0) {   // every workgroup keeps its column block: tile b + k g3 -> nb = (b >> 3) % NB
+      a.acc_part = 1;
+      nslots = g3 / NB;                                                // first tiles' mb = 0 .. g3 / NB - 1, all below MB (ntiles > g3)
+    }
     if (F == 128) hipLaunchKernelGGL((gcfn_bwd_mid_kernel<1, 2, true>), dim3(g3), dim3(GB_THREADS), 0, st, a);
     else hipLaunchKernelGGL((gcfn_bwd_mid_kernel<1, 1, true>), dim3(g3), dim3(GB_THREADS), 0, st, a);
   } else if (F == 128) {
@@ -878,7 +902,7 @@ int launch_gcfn_bwd_fused(const float* x, const float* stats, const float* dy, i
   }
   SEPR_CHECK_LAUNCH("gcfn_bwd_mid_kernel");
   float* scratch = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)MB * 3 * F * 8 * sizeof(float)));
-  return launch_gcfn_mid_reduce(a.part, MB, 3 * F, dw_g, db_g, scratch, st);
+  return launch_gcfn_mid_reduce(a.part, nslots, 3 * F, dw_g, db_g, scratch, st);
 }
 
 }  // namespace sepr

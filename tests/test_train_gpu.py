@@ -1651,6 +1651,10 @@ def test_gcfn_bf16_plane_staged_backward_equals_register_staged(variant, n, T, m
             # the one place the two forms round differently: the column sums of dropout(dy) (bias gradient of net2.2, and through it
             # the LayerScale gradient) ride in the contraction's staging registers - fp32 values in form (a), the bf16 rows in form (b)
             assert orc.agreement_db(b_.cpu(), a_.cpu()) >= 45.0, (k, orc.agreement_db(b_.cpu(), a_.cpu()))
+        elif k.startswith("depthwise."):
+            # round 6: form (b) sums the depthwise partials of a workgroup's row tiles in registers when the launch has more tiles than
+            # workgroups (n * T = 20 000 here), form (a) keeps one partial row per tile: the same per-tile sums, added in another order
+            assert orc.agreement_db(b_.cpu(), a_.cpu()) >= 100.0, (k, orc.agreement_db(b_.cpu(), a_.cpu()))
         else:
             assert torch.equal(a_, b_), (k, int((a_ != b_).sum()), float((a_ - b_).abs().max()))
 
