@@ -65,7 +65,7 @@ def test_summary_is_last_key_and_small():
     consumer that keeps only the tail of the ~17 KB line still sees them.  Checked on the committed line of the round."""
     import json
     import bench
-    path = os.path.join(ROOT, "profiles", "r06_v7_bench.json")
+    path = os.path.join(ROOT, "profiles", "r06_v8_bench.json")
     line = open(path).read().strip().split("\n")[-1]
     rec = json.loads(line)
     assert list(rec)[-1] == "summary"
