@@ -314,81 +314,104 @@ int launch_gcfn_mid_bwd(const float* h1, const float* dg, float* dh1, int n, int
 namespace {
 constexpr int WG_TC = 64, WG_CB = 64, WG_KMAX = 129;   // (64 + 128 + 16 + 64) x 64 x 4 B = 68 KB of LDS at most
 
+// nc (round 6): a block walks nc consecutive 64-frame chunks of its sequence with the tap accumulators kept in registers and writes ONE partial
+// row - a quarter of the partial rows (and of the pre-reduction behind the kernel) at nc = 4.  The launcher only asks for nc > 1 when every thread
+// has at most one left-over tap (K % 64 < 4) and at most two 64-tap passes (K < 192): K = 65, every shipped configuration.
 __global__ __launch_bounds__(TPB) void dwconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int T, int C,
-                                                          int K, int nchunk, float* __restrict__ part) {
+                                                          int K, int nchunk, float* __restrict__ part, int nc, int ngrp) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int pad = K / 2;
   const int rows_x = WG_TC + K - 1 + 16;   // + 16 zero rows: the window of the last full tap group reads one group ahead
   float* xs = sm;                       // [rows_x][64]
   float* ds = sm + rows_x * WG_CB;      // [WG_TC][64]
-  const int seq = blockIdx.x / nchunk, chunk = blockIdx.x - seq * nchunk;
+  const int seq = blockIdx.x / ngrp, grp = blockIdx.x - seq * ngrp;
   const int c0 = blockIdx.y * WG_CB;
-  const int t0 = chunk * WG_TC;
   const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
   const float* xq = x + (long long)seq * T * C;
   const float* dq = dy + (long long)seq * T * C;
-  for (int i = threadIdx.x; i < rows_x * (WG_CB / 4); i += TPB) {   // C % 4 == 0: a float4 is inside or outside the channel range
-    const int r = i >> 4, cc = (i & 15) * 4;
-    const int t = t0 - pad + r;
-    const bool in = r < WG_TC + K - 1 && t >= 0 && t < T && c0 + cc < C;
-    st4(xs + r * WG_CB + cc, in ? ld4(xq + (long long)t * C + c0 + cc) : zero4());
-  }
-  for (int i = threadIdx.x; i < WG_TC * (WG_CB / 4); i += TPB) {
-    const int r = i >> 4, cc = (i & 15) * 4;
-    const int t = t0 + r;
-    st4(ds + r * WG_CB + cc, (t < T && c0 + cc < C) ? ld4(dq + (long long)t * C + c0 + cc) : zero4());
-  }
-  __syncthreads();
-  float* p = part + (long long)blockIdx.x * (K + 1) * C;
   const bool cok = c0 + cl < C;
   const int npass = K / 64;
   typedef float f2 __attribute__((ext_vector_type(2)));
-  for (int ps = 0; ps < npass; ++ps) {
-    const int k0 = 64 * ps + 16 * kl;
-    const float* xk = xs + k0 * WG_CB + cl;               // xk[q * 64] = x~[q]: the x value tap k0 + j meets at frame q - j
-    // Packed FMAs want (tap 2m, tap 2m + 1) operand PAIRS in adjacent registers, and the window slides by one value per frame, so
-    // two rings of pairs are kept: E[p] = (x~[2p], x~[2p+1]) serves even frames, O[p] = (x~[2p+1], x~[2p+2]) odd frames.
-    // (A single 16-value ring compiled to 3 register moves per packed FMA - slower than the two-reads-per-FMA version.)
-    f2 acc[8], E[8], O[8];
+  const bool keep = nc > 1;             // accumulate over the block's chunks (at most two passes, one left-over tap per thread)
+  f2 accP[2][8];
+  float accL = 0.f;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      acc[m] = (f2){0.f, 0.f};
-      E[m] = (f2){xk[(2 * m) * WG_CB], xk[(2 * m + 1) * WG_CB]};
-      O[m] = (f2){xk[(2 * m + 1) * WG_CB], xk[(2 * m + 2) * WG_CB]};
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) accP[q][m] = (f2){0.f, 0.f};
+  float* p = part + (long long)blockIdx.x * (K + 1) * C;
+  const int ch_end = min(nchunk, (grp + 1) * nc);
+  for (int chunk = grp * nc; chunk < ch_end; ++chunk) {
+    const int t0 = chunk * WG_TC;
+    if (chunk != grp * nc) __syncthreads();                 // every wave is done with the previous chunk's tiles
+    for (int i = threadIdx.x; i < rows_x * (WG_CB / 4); i += TPB) {   // C % 4 == 0: a float4 is inside or outside the channel range
+      const int r = i >> 4, cc = (i & 15) * 4;
+      const int t = t0 - pad + r;
+      const bool in = r < WG_TC + K - 1 && t >= 0 && t < T && c0 + cc < C;
+      st4(xs + r * WG_CB + cc, in ? ld4(xq + (long long)t * C + c0 + cc) : zero4());
     }
-#pragma unroll 1
-    for (int u0 = 0; u0 < WG_TC / 2; u0 += 8) {
-#pragma unroll
-      for (int uu = 0; uu < 8; ++uu) {                    // frames 2u, 2u + 1; slot uu holds E[u], O[u]
-        const int u = u0 + uu;
-        const float d0 = ds[(2 * u) * WG_CB + cl], d1 = ds[(2 * u + 1) * WG_CB + cl];
-        const f2 dd0 = (f2){d0, d0}, dd1 = (f2){d1, d1};
-#pragma unroll
-        for (int m = 0; m < 8; ++m) acc[m] = __builtin_elementwise_fma(dd0, E[(uu + m) & 7], acc[m]);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) acc[m] = __builtin_elementwise_fma(dd1, O[(uu + m) & 7], acc[m]);
-        const float n1 = xk[(2 * u + 17) * WG_CB], n2 = xk[(2 * u + 18) * WG_CB];
-        E[uu] = (f2){O[(uu + 7) & 7].y, n1};              // E[u + 8] = (x~[2u+16], x~[2u+17])
-        O[uu] = (f2){n1, n2};                             // O[u + 8]
-      }
+    for (int i = threadIdx.x; i < WG_TC * (WG_CB / 4); i += TPB) {
+      const int r = i >> 4, cc = (i & 15) * 4;
+      const int t = t0 + r;
+      st4(ds + r * WG_CB + cc, (t < T && c0 + cc < C) ? ld4(dq + (long long)t * C + c0 + cc) : zero4());
     }
-    if (cok)
+    __syncthreads();
+    const bool last = chunk + 1 == ch_end;
+    // one 64-tap pass; `acc` is the pass's accumulator set (zero at the start of a chunk unless the block keeps them across its chunks)
+    auto pass = [&](int ps, f2 (&acc)[8]) {
+      const int k0 = 64 * ps + 16 * kl;
+      const float* xk = xs + k0 * WG_CB + cl;               // xk[q * 64] = x~[q]: the x value tap k0 + j meets at frame q - j
+      // Packed FMAs want (tap 2m, tap 2m + 1) operand PAIRS in adjacent registers, and the window slides by one value per frame, so
+      // two rings of pairs are kept: E[p] = (x~[2p], x~[2p+1]) serves even frames, O[p] = (x~[2p+1], x~[2p+2]) odd frames.
+      // (A single 16-value ring compiled to 3 register moves per packed FMA - slower than the two-reads-per-FMA version.)
+      f2 E[8], O[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
-        p[(long long)(k0 + 2 * m) * C + c0 + cl] = acc[m].x;
-        p[(long long)(k0 + 2 * m + 1) * C + c0 + cl] = acc[m].y;
+        if (!keep) acc[m] = (f2){0.f, 0.f};
+        E[m] = (f2){xk[(2 * m) * WG_CB], xk[(2 * m + 1) * WG_CB]};
+        O[m] = (f2){xk[(2 * m + 1) * WG_CB], xk[(2 * m + 2) * WG_CB]};
       }
-  }
-  for (int k = 64 * npass + kl; k <= K; k += 4) {          // left-over taps; k == K: the bias column
-    float acc = 0.f;
-    if (k < K) {
-#pragma unroll 8
-      for (int r = 0; r < WG_TC; ++r) acc = fmaf(ds[r * WG_CB + cl], xs[(r + k) * WG_CB + cl], acc);
+#pragma unroll 1
+      for (int u0 = 0; u0 < WG_TC / 2; u0 += 8) {
+#pragma unroll
+        for (int uu = 0; uu < 8; ++uu) {                    // frames 2u, 2u + 1; slot uu holds E[u], O[u]
+          const int u = u0 + uu;
+          const float d0 = ds[(2 * u) * WG_CB + cl], d1 = ds[(2 * u + 1) * WG_CB + cl];
+          const f2 dd0 = (f2){d0, d0}, dd1 = (f2){d1, d1};
+#pragma unroll
+          for (int m = 0; m < 8; ++m) acc[m] = __builtin_elementwise_fma(dd0, E[(uu + m) & 7], acc[m]);
+#pragma unroll
+          for (int m = 0; m < 8; ++m) acc[m] = __builtin_elementwise_fma(dd1, O[(uu + m) & 7], acc[m]);
+          const float n1 = xk[(2 * u + 17) * WG_CB], n2 = xk[(2 * u + 18) * WG_CB];
+          E[uu] = (f2){O[(uu + 7) & 7].y, n1};              // E[u + 8] = (x~[2u+16], x~[2u+17])
+          O[uu] = (f2){n1, n2};                             // O[u + 8]
+        }
+      }
+      if (cok && (last || !keep))
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          p[(long long)(k0 + 2 * m) * C + c0 + cl] = acc[m].x;
+          p[(long long)(k0 + 2 * m + 1) * C + c0 + cl] = acc[m].y;
+        }
+    };
+    if (keep) {
+      if (npass > 0) pass(0, accP[0]);
+      if (npass > 1) pass(1, accP[1]);
     } else {
-#pragma unroll 8
-      for (int r = 0; r < WG_TC; ++r) acc += ds[r * WG_CB + cl];
+      for (int ps = 0; ps < npass; ++ps) pass(ps, accP[0]);
     }
-    if (cok) p[(long long)k * C + c0 + cl] = acc;
+    for (int k = 64 * npass + kl; k <= K; k += 4) {          // left-over taps; k == K: the bias column
+      float acc = keep ? accL : 0.f;
+      if (k < K) {
+#pragma unroll 8
+        for (int r = 0; r < WG_TC; ++r) acc = fmaf(ds[r * WG_CB + cl], xs[(r + k) * WG_CB + cl], acc);
+      } else {
+#pragma unroll 8
+        for (int r = 0; r < WG_TC; ++r) acc += ds[r * WG_CB + cl];
+      }
+      accL = acc;
+      if (cok && (last || !keep)) p[(long long)k * C + c0 + cl] = acc;
+    }
   }
 }
 __global__ __launch_bounds__(TPB) void dwconv_wgrad_reduce_kernel(const float* __restrict__ part, int nblk, int C, int K,
@@ -419,10 +442,17 @@ int launch_dwconv_wgrad(const float* x, const float* dy, int n, int T, int C, in
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (attr != hipSuccess) return SEPR_EINVAL;
   }
-  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(n * nchunk, (C + WG_CB - 1) / WG_CB), dim3(TPB), shm, s, x, dy, T, C, K, nchunk, part);
+  // chunks per block (see the kernel): up to 4 while the launch keeps ~4 blocks per CU; SEPR_DWWG_NC=1: one chunk per block (rounds 2-5)
+  static const int nc_max = [] { const char* e = getenv("SEPR_DWWG_NC"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+  const int cblk = (C + WG_CB - 1) / WG_CB;
+  int nc = 1;
+  if (K % 64 < 4 && K / 64 <= 2)
+    while (nc < nc_max && (long long)n * ((nchunk + 2 * nc - 1) / (2 * nc)) * cblk >= 1024) nc *= 2;
+  const int ngrp = (nchunk + nc - 1) / nc;
+  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(n * ngrp, cblk), dim3(TPB), shm, s, x, dy, T, C, K, nchunk, part, nc, ngrp);
   float* scratch = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)n * nchunk * (K + 1) * C * sizeof(float)));
   const float* rows = nullptr;
-  const int nrows = prereduce(part, n * nchunk, (K + 1) * C, scratch, &rows, s);
+  const int nrows = prereduce(part, n * ngrp, (K + 1) * C, scratch, &rows, s);
   hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3(((K + 1) * C + TPB - 1) / TPB), dim3(TPB), 0, s, rows, nrows, C, K, dw_g, db_g);
   SEPR_CHECK_LAUNCH("dwconv_wgrad_kernel");
   return SEPR_OK;
