@@ -60,6 +60,24 @@ __device__ __forceinline__ void gb_wait_vm2(gb_u32x4& a, gb_u32x4& b) {
                            // built, bit-identical outputs, measured equal at two workgroups per CU and slower at three - hipcc spills 50-60 registers into
                            // the 168 of the three-workgroup regime; tools/variants.mk gbepi2w / gbepi3w, profiles/r06_gcfn_bwd_regepi.txt)
 #endif
+#ifndef SEPR_GB_ONEBAR
+#define SEPR_GB_ONEBAR 0   // PL form: 0 = a counted wait + barrier in front of every slab's MFMAs (slab q multiplies while slabs q+1.. land); 1 = ONE wait for all
+                           // the tile's slabs and one barrier in front of step 0, steps >= 1 wait for their own weight fragments only (round 6, last session:
+                           // tools/variants.mk gbonebar)
+#endif
+#ifndef SEPR_GB_TOPWAIT
+#define SEPR_GB_TOPWAIT 0
+#endif
+#ifndef SEPR_GB_CONSTLDS
+#define SEPR_GB_CONSTLDS 1  // PL form, persistent launches in which a workgroup keeps ONE column block (acc_part): the block's depthwise taps / biases (8 float4 per
+                           // column quad) and up-projection biases (2 x 64) are parked in 2.5 KB of LDS once per workgroup instead of being fetched from L2 by every
+                           // tile right in front of their use (two exposed L2 latencies per tile); 53 760 B per workgroup, still three per CU
+#endif
+#ifndef SEPR_GB_SLIDE
+#define SEPR_GB_SLIDE 2     // (bit mask: 1 = pass A, 2 = pass B) LDS epilogue, interior tiles: a thread's 4 consecutive rows share their conv windows - pass A reads each h1 row of its 6-row window once
+                           // (12 ds_read_b128 instead of 24), pass B takes the neighbour rows of dc from its own registers (4 reads instead of 16); bit-identical
+#endif
+constexpr int GB_CONST_B = SEPR_GB_CONSTLDS ? (8 * 16 + 32) * 16 : 0;
 // slab row s = mt * 16 + fi of the middle kernel holds frame 4 fi + mt of the tile (REGEPI) - so that frame neighbours are a lane's own
 // accumulator tiles or one DPP row shift away - or frame s (LDS epilogue)
 __device__ __forceinline__ int gb_frame(int s) { return SEPR_GB_REGEPI ? 4 * (s & 15) + (s >> 4) : s; }
@@ -182,7 +200,9 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
   constexpr size_t SLAB_B = PL ? (size_t)2 * NSL * GB_BM * 128 : sizeof(unsigned short) * 2 * NP * PLANE_E;
   // (the LDS epilogue's tiles, or the register epilogue's 6 parked 16-byte chunks per thread, alias the slab buffers)
   constexpr size_t TILE_B = SEPR_GB_REGEPI ? (size_t)6 * GB_THREADS * 16 : sizeof(float) * GB_BM * (GB_HS + GB_DS);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SLAB_B > TILE_B ? SLAB_B : TILE_B];
+  constexpr size_t MAIN_B = SLAB_B > TILE_B ? SLAB_B : TILE_B;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_B + (PL ? GB_CONST_B : 0)];
+  [[maybe_unused]] float* const Cs = reinterpret_cast<float*>(smem + MAIN_B);   // CONSTLDS: [8 taps / biases][16 column quads][4], then [value | gate][16 quads][4] of b1
   unsigned short* const slab = reinterpret_cast<unsigned short*>(smem);
   [[maybe_unused]] float* const Hs = reinterpret_cast<float*>(smem);            // [64][GB_HS]: h1 (+ b1), later dc   (aliases the slab buffers)
   [[maybe_unused]] float* const Ds = Hs + GB_BM * GB_HS;                        // [64][GB_DS]: dgd, later the reduction scratch
@@ -256,6 +276,25 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
   int tile = blockIdx.x, mb = 0, nb = 0;
   while (tile < ntiles && !decode(tile, mb, nb)) tile += gridDim.x;
   if (tile < ntiles) load_tile(mb);
+  [[maybe_unused]] const bool cl_on = SEPR_GB_CONSTLDS && PL && a.acc_part != 0;    // (acc_part: nb is the same for every tile of this workgroup)
+  if constexpr (SEPR_GB_CONSTLDS && PL) {
+    if (cl_on && tile < ntiles) {
+      const int C3_ = 3 * a.F, C6_ = 6 * a.F;
+      if (tid < 128) {
+        const int k = tid >> 4, q = tid & 15;                    // k: wv0 wv1 wv2 wg0 wg1 wg2 cbv cbg
+        const int hc_ = 64 * nb + 4 * q;
+        const float* src = k < 6 ? a.dw_w + (k % 3) * C6_ + (k >= 3 ? C3_ : 0) + hc_ : a.dw_b + (k == 7 ? C3_ : 0) + hc_;
+        st4(Cs + (k * 16 + q) * 4, ld4(src));
+      } else if (tid < 160) {
+        const int j = tid - 128;                                 // 0..15 value quads, 16..31 gate quads
+        st4(Cs + (128 + j) * 4, ld4(a.b1 + (j >= 16 ? C3_ : 0) + 64 * nb + 4 * (j & 15)));
+      }
+      // (visible to every wave behind the first tile's barriers)
+    }
+  }
+#if SEPR_GB_TOPWAIT == 2
+  if constexpr (PL) __builtin_amdgcn_s_waitcnt(0x0F70);       // (experiment: the wait once, in front of the tile loop)
+#endif
   [[maybe_unused]] float wacc[2] = {0.f, 0.f};                 // acc_part: this thread's two of the workgroup's 512 partial sums
   [[maybe_unused]] const int mb_first = mb, nb_first = nb;
   [[maybe_unused]] const bool any_tile = tile < ntiles;
@@ -330,6 +369,9 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
     }
     const int tv = 4 * nb + wn, tg = C3 / 16 + 4 * nb + wn;     // this wave's value / gate tile of W1, tv also its W2^T tile
 
+#if SEPR_GB_TOPWAIT == 1
+    if constexpr (PL) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), a wait hipcc's own bookkeeping sees (see SEPR_GB_TOPWAIT above)
+#endif
     __syncthreads();   // the previous tile's epilogue is done with the LDS tiles that alias the slab buffers
     gb_u32x4 wset[2][2][2][2];                                 // [q & 1][a | b][K step of the slab][plane]; a: value (or W2^T), b: gate
     auto load_wq = [&](int q, gb_u32x4 (&ws_)[2][2][2]) {
@@ -366,6 +408,31 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
         static_assert(NQ < 2 || C1 == gb_pl_outstanding(1, NSL, DMA_PER_WAVE), "vmcnt of step 1 does not match the issue order");
         static_assert(NQ < 3 || C2 == gb_pl_outstanding(2, NSL, DMA_PER_WAVE), "vmcnt of step 2 does not match the issue order");
         static_assert(NQ < 4 || gb_pl_outstanding(3, NSL, DMA_PER_WAVE) == 0, "steps >= 3 wait vmcnt(0): nothing may be issued behind W3");
+        if constexpr (SEPR_GB_ONEBAR) {
+          // every copy and both prologue fragment sets were issued before step 0: one vmcnt(0) covers D0 .. D(NQ-1), W0, W1.  Steps q >= 2 wait for
+          // W(q) with W(q+1) - issued behind step q-1's MFMAs - still in flight.
+          if (q == 0) {
+            gb_wait_vm4<0>(wset[0][0][0][0], wset[0][0][1][0], wset[0][1][0][0], wset[0][1][1][0]);
+            if constexpr (NQ > 1) {
+              if constexpr (1 < NSL) gb_wait_vm4<0>(wset[1][0][0][0], wset[1][0][1][0], wset[1][1][0][0], wset[1][1][1][0]);
+              else gb_wait_vm2<0>(wset[1][0][0][0], wset[1][0][1][0]);
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+          } else if (q >= 2) {
+            constexpr int NXT4 = 4, NXT2 = 2;
+            const bool more = q + 1 < NQ, more_up = q + 1 < NSL;
+            if (up) {
+              if (more && more_up) gb_wait_vm4<NXT4>(wa[0][0], wa[1][0], wb[0][0], wb[1][0]);
+              else if (more) gb_wait_vm4<NXT2>(wa[0][0], wa[1][0], wb[0][0], wb[1][0]);
+              else gb_wait_vm4<0>(wa[0][0], wa[1][0], wb[0][0], wb[1][0]);
+            } else {
+              if (more && more_up) gb_wait_vm2<NXT4>(wa[0][0], wa[1][0]);
+              else if (more) gb_wait_vm2<NXT2>(wa[0][0], wa[1][0]);
+              else gb_wait_vm2<0>(wa[0][0], wa[1][0]);
+            }
+          }
+        } else {
         if (up) {
           if (q == 0) gb_wait_vm4<C0>(wa[0][0], wa[1][0], wb[0][0], wb[1][0]);
           else if (q == 1) gb_wait_vm4<C1>(wa[0][0], wa[1][0], wb[0][0], wb[1][0]);
@@ -381,6 +448,7 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
         // slabs with it).  What the barrier must order is exactly what the counted wait above covers: this wave's share of slab q.
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        }
       } else {
         load_wq(q, wset[q & 1]);
         store_slab(q);
@@ -621,7 +689,8 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
     // ---- stage h1 (+ bias) and dgd: row = frame, a lane holds 4 consecutive channels of one frame per accumulator ----
     {
       const int cl = wn * 16 + 4 * fg;
-      const float4 bv = ld4(a.b1 + 64 * nb + cl), bg = ld4(a.b1 + C3 + 64 * nb + cl);
+      const float4 bv = cl_on ? ld4(Cs + (128 + (cl >> 2)) * 4) : ld4(a.b1 + 64 * nb + cl);
+      const float4 bg = cl_on ? ld4(Cs + (144 + (cl >> 2)) * 4) : ld4(a.b1 + C3 + 64 * nb + cl);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         float* hr = Hs + (mt * 16 + fi) * GB_HS;
@@ -640,9 +709,16 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
     const int q4 = tid & 15, strip = tid >> 4;
     const int c4 = 4 * q4, hc = 64 * nb + c4;                    // hidden value channel of column 0 (gate: C3 + hc)
     const int C6 = 2 * C3;
-    const float4 wv0 = ld4(a.dw_w + hc), wv1 = ld4(a.dw_w + C6 + hc), wv2 = ld4(a.dw_w + 2 * C6 + hc);
-    const float4 wg0 = ld4(a.dw_w + C3 + hc), wg1 = ld4(a.dw_w + C6 + C3 + hc), wg2 = ld4(a.dw_w + 2 * C6 + C3 + hc);
-    const float4 cbv = ld4(a.dw_b + hc), cbg = ld4(a.dw_b + C3 + hc);
+    float4 wv0, wv1, wv2, wg0, wg1, wg2, cbv, cbg;
+    if (cl_on) {
+      const float* cq = Cs + 4 * q4;
+      wv0 = ld4(cq); wv1 = ld4(cq + 64); wv2 = ld4(cq + 128); wg0 = ld4(cq + 192); wg1 = ld4(cq + 256); wg2 = ld4(cq + 320);
+      cbv = ld4(cq + 384); cbg = ld4(cq + 448);
+    } else {
+      wv0 = ld4(a.dw_w + hc); wv1 = ld4(a.dw_w + C6 + hc); wv2 = ld4(a.dw_w + 2 * C6 + hc);
+      wg0 = ld4(a.dw_w + C3 + hc); wg1 = ld4(a.dw_w + C6 + C3 + hc); wg2 = ld4(a.dw_w + 2 * C6 + C3 + hc);
+      cbv = ld4(a.dw_b + hc); cbg = ld4(a.dw_b + C3 + hc);
+    }
     float acc8[4][8];                                          // [column][w0 w1 w2 b of the value, then of the gate]
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -656,18 +732,37 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
     auto passes = [&](auto edge_c) {
     constexpr bool EDGE = decltype(edge_c)::value;
     float4 dcv[4], dcg[4];
+    constexpr bool SLIDE = (SEPR_GB_SLIDE & 1) && !EDGE;        // pass A
+    constexpr bool SLIDE_B = (SEPR_GB_SLIDE & 2) && !EDGE;      // pass B
     {
 #pragma clang fp contract(off)
+      // SLIDE: rows r - 1, r of the window, carried from row to row (rows outside the tile are clamped: the rows that would use them are skipped)
+      [[maybe_unused]] float4 wvm, wgm, wvc, wgc;
+      if constexpr (SLIDE) {
+        const float* h0 = Hs + (4 * strip) * GB_HS + c4;
+        const float* hm = strip > 0 ? h0 - GB_HS : h0;
+        wvm = ld4(hm); wgm = ld4(hm + 64);
+        wvc = ld4(h0); wgc = ld4(h0 + 64);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * strip + i;
         const int m = m0 - 2 + r;
         dcv[i] = zero4();
         dcg[i] = zero4();
+        float4 hvc, hgc, hvm, hgm, hvp, hgp;
+        if constexpr (SLIDE) {
+          const float* hp = Hs + (r + 1 < GB_BM ? r + 1 : GB_BM - 1) * GB_HS + c4;
+          hvp = ld4(hp); hgp = ld4(hp + 64);
+          hvm = wvm; hgm = wgm; hvc = wvc; hgc = wgc;
+          wvm = wvc; wgm = wgc; wvc = hvp; wgc = hgp;
+        }
         if (r < 1 || r > GB_BM - 2 || m < 0 || m >= a.M) continue;
         const float* hr = Hs + r * GB_HS + c4;
-        const float4 hvc = ld4(hr), hgc = ld4(hr + 64);
-        float4 hvm = ld4(hr - GB_HS), hgm = ld4(hr - GB_HS + 64), hvp = ld4(hr + GB_HS), hgp = ld4(hr + GB_HS + 64);
+        if constexpr (!SLIDE) {
+          hvc = ld4(hr); hgc = ld4(hr + 64);
+          hvm = ld4(hr - GB_HS); hgm = ld4(hr - GB_HS + 64); hvp = ld4(hr + GB_HS); hgp = ld4(hr + GB_HS + 64);
+        }
         if constexpr (EDGE) {                                  // zero padding at the sequence ends (tiles that touch one: ~1 in 130)
           const int t = m % a.T;
           const float f0 = t > 0 ? 1.f : 0.f, f2 = t < a.T - 1 ? 1.f : 0.f;
@@ -755,7 +850,15 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
           f2 = t < a.T - 1 ? 1.f : 0.f;
         }
         const float* hr = Hs + r * GB_HS + c4;
-        const float4 pv = ld4(hr - GB_HS), pg = ld4(hr - GB_HS + 64), nv = ld4(hr + GB_HS), ng = ld4(hr + GB_HS + 64);
+        float4 pv, pg, nv, ng;
+        if constexpr (SLIDE_B) {                               // the neighbour rows inside the thread's own strip are its own registers (what it stored above)
+          if (i > 0) { pv = dcv[i > 0 ? i - 1 : 0]; pg = dcg[i > 0 ? i - 1 : 0]; }
+          else { pv = ld4(hr - GB_HS); pg = ld4(hr - GB_HS + 64); }
+          if (i < 3) { nv = dcv[i < 3 ? i + 1 : 3]; ng = dcg[i < 3 ? i + 1 : 3]; }
+          else { nv = ld4(hr + GB_HS); ng = ld4(hr + GB_HS + 64); }
+        } else {
+          pv = ld4(hr - GB_HS); pg = ld4(hr - GB_HS + 64); nv = ld4(hr + GB_HS); ng = ld4(hr + GB_HS + 64);
+        }
         // dh[t] = w0 dc[t+1] + w1 dc[t] + w2 dc[t-1]   (frames of OTHER sequences do not contribute: f0 / f2)
         float4 ov, og;
         ov.x = fmaf(wv0.x * f2, nv.x, fmaf(wv1.x, dcv[i].x, (wv2.x * f0) * pv.x));

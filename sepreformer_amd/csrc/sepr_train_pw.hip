@@ -315,7 +315,7 @@ namespace {
 constexpr int WG_TC = 64, WG_CB = 64, WG_KMAX = 129;   // (64 + 128 + 16 + 64) x 64 x 4 B = 68 KB of LDS at most
 
 // nc (round 6): a block walks nc consecutive 64-frame chunks of its sequence with the tap accumulators kept in registers and writes ONE partial
-// row - a quarter of the partial rows (and of the pre-reduction behind the kernel) at nc = 4.  The launcher only asks for nc > 1 when every thread
+// row - an eighth of the partial rows (and of the pre-reduction behind the kernel) at nc = 8.  The launcher only asks for nc > 1 when every thread
 // has at most one left-over tap (K % 64 < 4) and at most two 64-tap passes (K < 192): K = 65, every shipped configuration.
 __global__ __launch_bounds__(TPB) void dwconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int T, int C,
                                                           int K, int nchunk, float* __restrict__ part, int nc, int ngrp) {
@@ -442,8 +442,9 @@ int launch_dwconv_wgrad(const float* x, const float* dy, int n, int T, int C, in
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (attr != hipSuccess) return SEPR_EINVAL;
   }
-  // chunks per block (see the kernel): up to 4 while the launch keeps ~4 blocks per CU; SEPR_DWWG_NC=1: one chunk per block (rounds 2-5)
-  static const int nc_max = [] { const char* e = getenv("SEPR_DWWG_NC"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+  // chunks per block (see the kernel): up to 8 while the launch keeps ~4 blocks per CU (4 -> 8: 71.6 -> 71.3 ms per bf16 step in one call,
+  // profiles/r06_dwwg_nc_ab.txt); SEPR_DWWG_NC=1: one chunk per block (rounds 2-5)
+  static const int nc_max = [] { const char* e = getenv("SEPR_DWWG_NC"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();
   const int cblk = (C + WG_CB - 1) / WG_CB;
   int nc = 1;
   if (K % 64 < 4 && K / 64 <= 2)

@@ -77,3 +77,17 @@ VARIANT_gbepi3w = -DSEPR_GB_REGEPI=1 -DSEPR_GB_PL_WGS=3
 # round 6, second session: bf16-source projections of the plain-bf16 step (GCFN input gradient) with the widened one-slab staging of rounds 4-5 (A/B of the raw two-slab form)
 VARIANT_x3raw0 = -DSEPR_X3_RAW16=0
 VARIANT_x3deep0 = -DSEPR_X3_DEEP16=0
+# round 6, last session: plane-staged GCFN backward middle kernel with ONE wait + barrier for all of a tile's slabs instead of one per slab
+VARIANT_gbonebar = -DSEPR_GB_ONEBAR=1
+# ... the same kernel with a compiler-visible vmcnt(0) at the top of a tile: hipcc otherwise puts its own vmcnt(0) BETWEEN the tile's copies (in front of the first write of a
+# register that a store of the previous tile still reads), which serialises two memory latencies per tile (tools/isa_trace.py)
+VARIANT_gbtopwait = -DSEPR_GB_TOPWAIT=1
+VARIANT_gbtopone = -DSEPR_GB_TOPWAIT=1 -DSEPR_GB_ONEBAR=1
+# ... and with the column block's depthwise taps / biases parked in LDS once per persistent workgroup (SEPR_GB_CONSTLDS)
+VARIANT_gbconst = -DSEPR_GB_TOPWAIT=1 -DSEPR_GB_CONSTLDS=1
+VARIANT_gbconstone = -DSEPR_GB_TOPWAIT=1 -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_ONEBAR=1
+# ... constants in LDS without the top wait; + the sliding conv windows of the LDS epilogue (SEPR_GB_SLIDE), with and without the top wait
+VARIANT_gbcs0 = -DSEPR_GB_CONSTLDS=0
+VARIANT_gbcss = -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_SLIDE=3
+VARIANT_gbslide = -DSEPR_GB_TOPWAIT=1 -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_SLIDE=3
+VARIANT_gbcsb = -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_SLIDE=2
