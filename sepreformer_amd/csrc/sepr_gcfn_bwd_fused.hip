@@ -73,6 +73,9 @@ __device__ __forceinline__ void gb_wait_vm2(gb_u32x4& a, gb_u32x4& b) {
                            // column quad) and up-projection biases (2 x 64) are parked in 2.5 KB of LDS once per workgroup instead of being fetched from L2 by every
                            // tile right in front of their use (two exposed L2 latencies per tile); 53 760 B per workgroup, still three per CU
 #endif
+#ifndef SEPR_GB_REDERIVE
+#define SEPR_GB_REDERIVE 1   // (product; 0 = rounds 4-6 form: 168 registers + 10 spilled, profiles/r06_gcfn_bwd_waits.txt call 4)
+#endif
 #ifndef SEPR_GB_SLIDE
 #define SEPR_GB_SLIDE 2     // (bit mask: 1 = pass A, 2 = pass B) LDS epilogue, interior tiles: a thread's 4 consecutive rows share their conv windows - pass A reads each h1 row of its 6-row window once
                            // (12 ds_read_b128 instead of 24), pass B takes the neighbour rows of dc from its own registers (4 reads instead of 16); bit-identical
@@ -207,8 +210,13 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
   [[maybe_unused]] float* const Hs = reinterpret_cast<float*>(smem);            // [64][GB_HS]: h1 (+ b1), later dc   (aliases the slab buffers)
   [[maybe_unused]] float* const Ds = Hs + GB_BM * GB_HS;                        // [64][GB_DS]: dgd, later the reduction scratch
 
+#if SEPR_GB_REDERIVE
+  int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;      // re-derived at the top of every tile (see SEPR_GB_REDERIVE)
+  int fi = lane & 15, fg = lane >> 4;
+#else
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int fi = lane & 15, fg = lane >> 4;
+#endif
   const int F = a.F, C3 = 3 * F;
   const int NB = C3 / 64;
   const int MB = (a.M + GB_OUT - 1) / GB_OUT;
@@ -299,6 +307,12 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
   [[maybe_unused]] const int mb_first = mb, nb_first = nb;
   [[maybe_unused]] const bool any_tile = tile < ntiles;
   while (tile < ntiles) {
+#if SEPR_GB_REDERIVE
+    if constexpr (PL) {                                        // an opaque copy of the thread index: everything derived from it (LDS addresses, lane roles) is recomputed
+      asm volatile("" : "+v"(tid));                            // per tile instead of being hoisted out of the loop and kept (or spilled) across all of its phases
+      lane = tid & 63; wn = tid >> 6; fi = lane & 15; fg = lane >> 4;
+    }
+#endif
     const int m0 = mb * GB_OUT;
     const int sfr = gb_frame(srow);                            // frame (of the tile) in slab row srow
     const int ms = m0 - 2 + sfr;                               // the row this thread stages

@@ -79,6 +79,10 @@ struct bool_c { static constexpr bool value = V; };
 #ifndef SEPR_GF3_RING
 #define SEPR_GF3_RING 2
 #endif
+#ifndef SEPR_GF3_REDERIVE
+#define SEPR_GF3_REDERIVE 0   // bit 1: the thread index made opaque at the top of every tile, bit 2: again in front of the epilogue - what is derived from it is then
+                              // recomputed there instead of being computed once, hoisted and kept alive (or spilled) across the chunk loop
+#endif
 #ifndef SEPR_GF3_UPFIRST
 #define SEPR_GF3_UPFIRST 1   // 1: both up-projections before both convolutions (the next chunk copy gets one more conv to land; ~1 %)
 #endif
@@ -164,14 +168,23 @@ __global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128 || MT > 2) ? (NW > 4 ?
   const uint4* w2s = wl + (LAT > 0 ? W1_U4 : W1F_U4);
   uint4* csl = wl + (LAT > 0 ? W1F_U4 : W1F_U4 + W2_U4);
 
+#if SEPR_GF3_REDERIVE
+  int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;       // re-derived from an opaque copy at the top of every tile and in front of the epilogue (SEPR_GF3_REDERIVE)
+  int fi = lane & 15, fg = lane >> 4;
+#else
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fi = lane & 15, fg = lane >> 4;
+#endif
   const int ntiles = FOLD ? a.fold_nseq * a.fold_tps : (a.M + GF_TILE - 1) / GF_TILE;
   const uint4* const W1g = static_cast<const uint4*>(a.w1p);
   const uint4* const W2g = static_cast<const uint4*>(a.w2p);
 
   // ---- weight chunks: global -> LDS by LDS-DMA, 1 KiB per wave instruction ---------------------------
+#if SEPR_GF3_REDERIVE
+  [[maybe_unused]] int ws = __builtin_amdgcn_readfirstlane(w);         // the wave index as a scalar
+#else
   [[maybe_unused]] const int ws = __builtin_amdgcn_readfirstlane(w);   // the wave index as a scalar
+#endif
   auto dma = [&](const uint4* gbase, uint4* lbase, int nblk) {   // nblk 1 KiB blocks, dealt round-robin to the waves
     unsigned loff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(loff));
@@ -295,6 +308,12 @@ __global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128 || MT > 2) ? (NW > 4 ?
       for (int i = 0; i < a.stagger; i += 100) __builtin_amdgcn_s_sleep(100);
   }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#if SEPR_GF3_REDERIVE
+    if constexpr ((SEPR_GF3_REDERIVE & 1) != 0) {
+      asm volatile("" : "+v"(tid));
+      lane = tid & 63; w = tid >> 6; fi = lane & 15; fg = lane >> 4; ws = __builtin_amdgcn_readfirstlane(w);
+    }
+#endif
     // chunk 0 of the weights is requested first: it lands under the frame loads and the LayerNorm below
     __syncthreads();   // the previous tile's epilogue staging is fully consumed
     if constexpr (LAT > 0) {
@@ -627,6 +646,12 @@ __global__ __launch_bounds__(64 * NW, (LAT > 0 || F > 128 || MT > 2) ? (NW > 4 ?
       continue;   // (the next tile starts on a barrier: the staging is consumed before the weight copies overwrite it)
     }
     // ---- epilogue: y = x + ls * (acc + b2), two waves at a time through LDS ---------------------------------
+#if SEPR_GF3_REDERIVE
+    if constexpr ((SEPR_GF3_REDERIVE & 2) != 0) {              // the epilogue's per-thread addresses are derived HERE, not in front of the chunk loop
+      asm volatile("" : "+v"(tid));
+      lane = tid & 63; w = tid >> 6; fi = lane & 15; fg = lane >> 4;
+    }
+#endif
     float* const Os = reinterpret_cast<float*>(wl);
     constexpr int WPP = 64 / (16 * MT);   // waves per 64-frame epilogue pass
     constexpr int Q = F / 4;                 // float4 per row

@@ -77,17 +77,27 @@ VARIANT_gbepi3w = -DSEPR_GB_REGEPI=1 -DSEPR_GB_PL_WGS=3
 # round 6, second session: bf16-source projections of the plain-bf16 step (GCFN input gradient) with the widened one-slab staging of rounds 4-5 (A/B of the raw two-slab form)
 VARIANT_x3raw0 = -DSEPR_X3_RAW16=0
 VARIANT_x3deep0 = -DSEPR_X3_DEEP16=0
-# round 6, last session: plane-staged GCFN backward middle kernel with ONE wait + barrier for all of a tile's slabs instead of one per slab
-VARIANT_gbonebar = -DSEPR_GB_ONEBAR=1
-# ... the same kernel with a compiler-visible vmcnt(0) at the top of a tile: hipcc otherwise puts its own vmcnt(0) BETWEEN the tile's copies (in front of the first write of a
-# register that a store of the previous tile still reads), which serialises two memory latencies per tile (tools/isa_trace.py)
-VARIANT_gbtopwait = -DSEPR_GB_TOPWAIT=1
-VARIANT_gbtopone = -DSEPR_GB_TOPWAIT=1 -DSEPR_GB_ONEBAR=1
-# ... and with the column block's depthwise taps / biases parked in LDS once per persistent workgroup (SEPR_GB_CONSTLDS)
-VARIANT_gbconst = -DSEPR_GB_TOPWAIT=1 -DSEPR_GB_CONSTLDS=1
-VARIANT_gbconstone = -DSEPR_GB_TOPWAIT=1 -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_ONEBAR=1
-# ... constants in LDS without the top wait; + the sliding conv windows of the LDS epilogue (SEPR_GB_SLIDE), with and without the top wait
-VARIANT_gbcs0 = -DSEPR_GB_CONSTLDS=0
-VARIANT_gbcss = -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_SLIDE=3
-VARIANT_gbslide = -DSEPR_GB_TOPWAIT=1 -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_SLIDE=3
-VARIANT_gbcsb = -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_SLIDE=2
+# round 6, last session: plane-staged GCFN backward middle kernel (profiles/r06_gcfn_bwd_waits.txt).  Switches (sepr_gcfn_bwd_fused.hip): SEPR_GB_TOPWAIT = a
+# compiler-visible vmcnt(0) at the top of a tile (hipcc otherwise puts its own vmcnt(0) BETWEEN the tile's copies, tools/isa_trace.py), SEPR_GB_ONEBAR = one wait +
+# barrier for all of a tile's slabs, SEPR_GB_CONSTLDS = the column block's depthwise taps / biases parked in LDS once per persistent workgroup (product: 1),
+# SEPR_GB_SLIDE = conv windows shared between a thread's rows (bit 1 pass A, bit 2 pass B; product: 2).  Every variant spells all four out.
+GB0 = -DSEPR_GB_TOPWAIT=0 -DSEPR_GB_ONEBAR=0 -DSEPR_GB_CONSTLDS=0 -DSEPR_GB_SLIDE=0
+VARIANT_gbcs0 = $(GB0)
+VARIANT_gbonebar = $(GB0) -USEPR_GB_ONEBAR -DSEPR_GB_ONEBAR=1
+VARIANT_gbtopwait = $(GB0) -USEPR_GB_TOPWAIT -DSEPR_GB_TOPWAIT=1
+VARIANT_gbtopone = -DSEPR_GB_TOPWAIT=1 -DSEPR_GB_ONEBAR=1 -DSEPR_GB_CONSTLDS=0 -DSEPR_GB_SLIDE=0
+VARIANT_gbconst = -DSEPR_GB_TOPWAIT=1 -DSEPR_GB_ONEBAR=0 -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_SLIDE=0
+VARIANT_gbconstone = -DSEPR_GB_TOPWAIT=1 -DSEPR_GB_ONEBAR=1 -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_SLIDE=0
+VARIANT_gbcs = -DSEPR_GB_TOPWAIT=0 -DSEPR_GB_ONEBAR=0 -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_SLIDE=0
+VARIANT_gbcss = -DSEPR_GB_TOPWAIT=0 -DSEPR_GB_ONEBAR=0 -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_SLIDE=3
+VARIANT_gbslide = -DSEPR_GB_TOPWAIT=1 -DSEPR_GB_ONEBAR=0 -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_SLIDE=3
+VARIANT_gbcsb = -DSEPR_GB_TOPWAIT=0 -DSEPR_GB_ONEBAR=0 -DSEPR_GB_CONSTLDS=1 -DSEPR_GB_SLIDE=2
+# SEPR_GB_REDERIVE = the thread index made opaque at the top of every tile, so the per-thread LDS addresses / lane roles derived from it are recomputed per tile instead of
+# being hoisted out of the tile loop and kept alive (or spilled) across all phases: 168 registers + 10 spilled -> 157, none spilled
+VARIANT_gbred = -DSEPR_GB_REDERIVE=1
+VARIANT_gbred3 = -DSEPR_GB_REDERIVE=1 -DSEPR_GB_SLIDE=3
+VARIANT_gbredepi = -DSEPR_GB_REDERIVE=1 -DSEPR_GB_REGEPI=1 -DSEPR_GB_PL_WGS=3
+# round 6, last session: fused GCFN forward with the thread index made opaque per tile (1), in front of the epilogue (2), both (3): 256 registers + 7 spilled -> 245 / 241, none spilled
+VARIANT_gfred1 = -DSEPR_GF3_REDERIVE=1
+VARIANT_gfred2 = -DSEPR_GF3_REDERIVE=2
+VARIANT_gfred3 = -DSEPR_GF3_REDERIVE=3
