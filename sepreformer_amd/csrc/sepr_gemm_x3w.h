@@ -19,6 +19,9 @@
 #pragma once
 #include "sepr_gemm_x3.h"
 
+#ifndef SEPR_XW_REDERIVE
+#define SEPR_XW_REDERIVE 1   // product (0: rounds 4-6 form, 4-20 spilled registers per instantiation; profiles/r06_gcfn_bwd_waits.txt, last block)
+#endif
 namespace sepr {
 
 constexpr int XW_BKS = 32;                       // K extent of one LDS slab = one MFMA K step
@@ -39,12 +42,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_kernel(const GemmArg
   __shared__ __attribute__((aligned(16))) unsigned char smem_b[SMEM_B];
   unsigned short* const smem = reinterpret_cast<unsigned short*>(smem_b);
 
+#if SEPR_XW_REDERIVE
+  int tid = threadIdx.x;                   // re-derived from an opaque copy at the top of every tile (SEPR_XW_REDERIVE): hipcc then recomputes the per-thread LDS / global
+  int lane = tid & 63;                     // offsets per tile instead of hoisting them out of the tile loop and spilling them
+  int wn = tid >> 6;
+  int fi = lane & 15, fg = lane >> 4;
+  int srow = tid >> 1;
+  int kh = (tid & 1) * 16;
+#else
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wn = tid >> 6;                 // 4 waves side by side: 32 (value/gate: 16 + 16) columns of EACH 128-column half
   const int fi = lane & 15, fg = lane >> 4;
   const int srow = tid >> 1;               // staging: one row per thread pair,
   const int kh = (tid & 1) * 16;           //          half a slab (16 k = 4 float4) per thread
+#endif
 
   const int NB = GLU ? (a.N / 2 + 63) / 64 : (a.N + GEMM_BN - 1) / GEMM_BN;     // 128-column tiles of the narrow core
   const int NB2 = (NB + 1) / 2;                                                 // wide tiles
@@ -221,6 +233,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_kernel(const GemmArg
   load_wp(0, 0, wh);
   load_slab(0);
   while (true) {
+#if SEPR_XW_REDERIVE
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63; wn = tid >> 6; fi = lane & 15; fg = lane >> 4; srow = tid >> 1; kh = (tid & 1) * 16;
+#endif
     store_slab(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)

@@ -101,3 +101,5 @@ VARIANT_gbredepi = -DSEPR_GB_REDERIVE=1 -DSEPR_GB_REGEPI=1 -DSEPR_GB_PL_WGS=3
 VARIANT_gfred1 = -DSEPR_GF3_REDERIVE=1
 VARIANT_gfred2 = -DSEPR_GF3_REDERIVE=2
 VARIANT_gfred3 = -DSEPR_GF3_REDERIVE=3
+# round 6, last session: wide projection core (Large) with the thread index made opaque per tile: every instantiation spill-free except <1,7,1> (20 -> 3 spilled registers)
+VARIANT_xwred = -DSEPR_XW_REDERIVE=1
