@@ -74,7 +74,7 @@ __device__ __forceinline__ void gb_wait_vm2(gb_u32x4& a, gb_u32x4& b) {
                            // tile right in front of their use (two exposed L2 latencies per tile); 53 760 B per workgroup, still three per CU
 #endif
 #ifndef SEPR_GB_REDERIVE
-#define SEPR_GB_REDERIVE 1   // (product; 0 = rounds 4-6 form: 168 registers + 10 spilled, profiles/r06_gcfn_bwd_waits.txt call 4)
+#define SEPR_GB_REDERIVE 3   // product: bit 1 the plane-staged form, bit 2 the register-staged forms too (0 = rounds 4-6: 168 registers + 10 spilled / 256 + 9-13; profiles/r06_gcfn_bwd_waits.txt)
 #endif
 #ifndef SEPR_GB_SLIDE
 #define SEPR_GB_SLIDE 2     // (bit mask: 1 = pass A, 2 = pass B) LDS epilogue, interior tiles: a thread's 4 consecutive rows share their conv windows - pass A reads each h1 row of its 6-row window once
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(GB_THREADS, PL ? SEPR_GB_PL_WGS : 2) void gcfn_bwd_
   [[maybe_unused]] const bool any_tile = tile < ntiles;
   while (tile < ntiles) {
 #if SEPR_GB_REDERIVE
-    if constexpr (PL) {                                        // an opaque copy of the thread index: everything derived from it (LDS addresses, lane roles) is recomputed
+    if constexpr (PL || (SEPR_GB_REDERIVE & 2) != 0) {         // an opaque copy of the thread index: everything derived from it (LDS addresses, lane roles) is recomputed
       asm volatile("" : "+v"(tid));                            // per tile instead of being hoisted out of the loop and kept (or spilled) across all of its phases
       lane = tid & 63; wn = tid >> 6; fi = lane & 15; fg = lane >> 4;
     }

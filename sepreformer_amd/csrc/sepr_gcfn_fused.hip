@@ -80,7 +80,7 @@ struct bool_c { static constexpr bool value = V; };
 #define SEPR_GF3_RING 2
 #endif
 #ifndef SEPR_GF3_REDERIVE
-#define SEPR_GF3_REDERIVE 0   // bit 1: the thread index made opaque at the top of every tile, bit 2: again in front of the epilogue - what is derived from it is then
+#define SEPR_GF3_REDERIVE 1   // bit 1: the thread index made opaque at the top of every tile, bit 2: again in front of the epilogue - what is derived from it is then
                               // recomputed there instead of being computed once, hoisted and kept alive (or spilled) across the chunk loop
 #endif
 #ifndef SEPR_GF3_UPFIRST

@@ -103,3 +103,6 @@ VARIANT_gfred2 = -DSEPR_GF3_REDERIVE=2
 VARIANT_gfred3 = -DSEPR_GF3_REDERIVE=3
 # round 6, last session: wide projection core (Large) with the thread index made opaque per tile: every instantiation spill-free except <1,7,1> (20 -> 3 spilled registers)
 VARIANT_xwred = -DSEPR_XW_REDERIVE=1
+# ... REDERIVE for the register-staged (bf16x3 / fp32-source) middle kernels too (bit 2), and together with the fused forward's per-tile switch (the bf16x3 training step's two spilling kernels)
+VARIANT_gbredall = -DSEPR_GB_REDERIVE=3
+VARIANT_x3train = -DSEPR_GB_REDERIVE=3 -DSEPR_GF3_REDERIVE=1
