@@ -24,6 +24,19 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _cpu_threads():
+    """The oracle's CPU forward / autograd decides the device suite's wall time (458 - 736 s over the boxes of round 6 for the same code).  On many-core hosts
+    torch defaults to one thread per core, which is several times SLOWER than 16 threads for these small ops (bench.py's cpu_baseline sweep on the 128-core
+    GPU hosts: 8 threads 0.91 s, 16: 0.73 s, 32: 1.02 s per 4 s forward; all cores ~6x slower).  SEPR_TEST_THREADS overrides; small hosts are left alone."""
+    want = os.environ.get("SEPR_TEST_THREADS")
+    if want:
+        torch.set_num_threads(max(1, int(want)))
+    elif (os.cpu_count() or 1) > 32 and torch.get_num_threads() > 16:
+        torch.set_num_threads(16)
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}
