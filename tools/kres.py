@@ -15,8 +15,9 @@ READELF = os.path.join(os.path.dirname(OBJDUMP), "llvm-readelf")
 FILT = shutil.which("c++filt") or "c++filt"
 
 
-def main(argv):
-    path, pat = argv[0], re.compile(argv[1] if len(argv) > 1 else ".")
+def resources(path, pattern="."):
+    """[{name, vgpr, agpr, sgpr, spill, scratch, lds}] of the kernels in `path` whose demangled name matches `pattern`."""
+    pat, out = re.compile(pattern), []
     with tempfile.TemporaryDirectory() as tmp:
         base = os.path.join(tmp, os.path.basename(path))
         shutil.copy(path, base)
@@ -29,9 +30,14 @@ def main(argv):
                 dem = subprocess.run([FILT, name], stdout=subprocess.PIPE, text=True).stdout.strip()
                 if not pat.search(dem):
                     continue
-                agpr = blk.split("\n", 1)[0].strip()
-                print(f"vgpr {g('vgpr_count'):>4} agpr {agpr:>3} sgpr {g('sgpr_count'):>4} spill {g('vgpr_spill_count'):>4} scratch {g('private_segment_fixed_size'):>5} "
-                      f"lds {g('group_segment_fixed_size'):>6}  {dem[:150]}")
+                out.append({"name": dem, "vgpr": g("vgpr_count"), "agpr": blk.split("\n", 1)[0].strip(), "sgpr": g("sgpr_count"), "spill": g("vgpr_spill_count"),
+                            "scratch": g("private_segment_fixed_size"), "lds": g("group_segment_fixed_size")})
+    return out
+
+
+def main(argv):
+    for r in resources(argv[0], argv[1] if len(argv) > 1 else "."):
+        print(f"vgpr {r['vgpr']:>4} agpr {r['agpr']:>3} sgpr {r['sgpr']:>4} spill {r['spill']:>4} scratch {r['scratch']:>5} lds {r['lds']:>6}  {r['name'][:150]}")
 
 
 if __name__ == "__main__":
